@@ -1,0 +1,144 @@
+"""ctypes binding of libftmi355.so (C ABI: include/ftmi355.h).
+
+The library is the product path: there is NO fallback.  If the shared object is missing or a symbol
+is absent, importing callers get a RuntimeError telling them to build it (``python -m
+finetrainers_amd.csrc.build``).  PyTorch appears here only as the owner of device memory and of the
+HIP stream the kernels are enqueued on.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libftmi355.so")
+
+FTMI_ERR_INVALID = -1
+FTMI_ERR_UNSUPPORTED = -2
+FTMI_ERR_LAUNCH = -3
+
+EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU = 0, 1, 2, 3
+
+
+class AttnDesc(Structure):
+    _fields_ = [
+        ("B", c_int), ("H", c_int), ("Sq", c_int), ("Sk", c_int), ("d", c_int),
+        ("q_strides", c_long * 3), ("k_strides", c_long * 3), ("v_strides", c_long * 3), ("o_strides", c_long * 3),
+        ("do_strides", c_long * 3), ("dq_strides", c_long * 3), ("dk_strides", c_long * 3), ("dv_strides", c_long * 3),
+        ("scale", c_float),
+    ]
+
+
+class LtxConfig(Structure):
+    _fields_ = [
+        ("B", c_int), ("S", c_int), ("T", c_int),
+        ("D", c_int), ("H", c_int), ("L", c_int),
+        ("C_in", c_int), ("C_out", c_int),
+        ("D_ff", c_int), ("D_cap", c_int),
+        ("r", c_int),
+        ("lora_scale", c_float), ("eps_norm", c_float), ("eps_qk", c_float),
+        ("gemm_variant", c_int),
+    ]
+
+
+LTX_WEIGHT_FIELDS = [
+    "proj_in_w", "proj_in_b", "time_l1_w", "time_l1_b", "time_l2_w", "time_l2_b", "time_lin_w", "time_lin_b",
+    "cap_l1_w", "cap_l1_b", "cap_l2_w", "cap_l2_b", "tables", "table_out", "proj_out_w", "proj_out_b", "proj_out_w_t",
+    "w_qkv", "b_qkv", "w_qkv_t", "norm_q", "norm_k", "w_o", "b_o", "w_o_t", "w_q2", "b_q2", "w_q2_t", "w_kv2", "b_kv2",
+    "norm_q2", "norm_k2", "w_o2", "b_o2", "w_o2_t", "w_ff1", "b_ff1", "w_ff1_t", "w_ff2", "b_ff2", "w_ff2_t",
+    "lora_a", "lora_at", "lora_b", "lora_bt", "lora_at_qkv", "rope_cos", "rope_sin",
+]
+
+
+class LtxWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in LTX_WEIGHT_FIELDS]
+
+
+_SIGS = {
+    "ftmi_version": (c_int, []),
+    "ftmi_last_error": (c_int, [c_char_p, c_size_t]),
+    "ftmi_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ftmi_attn_bwd": (c_int, [POINTER(AttnDesc)] + [c_void_p] * 12),
+    "ftmi_linear_lora_fwd": (c_int, [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 7 + [c_int, c_void_p]),
+    "ftmi_gemm_nt": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p, c_long, c_int,
+                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "ftmi_gemm_tn": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_float, c_void_p]),
+    "ftmi_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ftmi_ltx_workspace_bytes": (c_size_t, [POINTER(LtxConfig)]),
+    "ftmi_ltx_workspace_offset": (c_int, [POINTER(LtxConfig), c_char_p, c_int, POINTER(c_size_t)]),
+    "ftmi_ltx_forward": (c_int, [POINTER(LtxConfig), POINTER(LtxWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_size_t, c_void_p]),
+    "ftmi_ltx_backward": (c_int, [POINTER(LtxConfig), POINTER(LtxWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "ftmi_ltx_noise_pack": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ftmi_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p]),
+    "ftmi_clip_adamw_step": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 6 + [c_int, c_void_p, c_void_p, c_void_p]),
+    "ftmi_lora_refresh": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib_available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def load() -> ctypes.CDLL:
+    """Load libftmi355.so and bind every symbol of include/ftmi355.h.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libftmi355.so not found at {LIB_PATH}: the MI355X backend has no fallback path. "
+            "Build it with `python -m finetrainers_amd.csrc.build` (needs hipcc, --offload-arch=gfx950)."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"libftmi355.so does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = ctypes.create_string_buffer(512)
+    load().ftmi_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = f"{what}: {last_error()} (code {rc})"
+    if rc in (FTMI_ERR_INVALID, FTMI_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live in GPU memory (the MI355X backend has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")

@@ -1,0 +1,197 @@
+// extern "C" surface of libftmi355 (declared in include/ftmi355.h): argument checking, translation of the
+// plain-pointer C structs into the internal launch arguments, error reporting.
+#include <mutex>
+#include <string.h>
+
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace ftmi {
+
+static std::mutex g_err_mu;
+static char g_err[512] = "";
+
+int set_error(int code, const char* msg) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    strncpy(g_err, msg, sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    char buf[400];
+    snprintf(buf, sizeof(buf), "%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return set_error(FTMI_ERR_LAUNCH, buf);
+}
+
+size_t ltx_workspace_bytes(const ftmi_ltx_config& c);
+int ltx_workspace_offset(const ftmi_ltx_config& c, const char* name, int layer, size_t* off);
+int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* x_t, const bf16_t* text, const float* key_bias,
+                const float* sigma, bf16_t* pred, void* ws, size_t ws_bytes, hipStream_t st);
+int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* text, const float* key_bias, const bf16_t* dpred,
+                 float* grad_a, float* grad_b, void* ws, size_t ws_bytes, hipStream_t st);
+
+static int fill_attn(const ftmi_attn_desc* d, AttnArgs& a) {
+    if (!d) return set_error(FTMI_ERR_INVALID, "attention: null descriptor");
+    if (d->d != 64) return set_error(FTMI_ERR_UNSUPPORTED, "attention: head_dim must be 64");
+    a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Sk = d->Sk; a.scale = d->scale;
+    a.q_sb = d->q_strides[0]; a.q_sh = d->q_strides[1]; a.q_ss = d->q_strides[2];
+    a.k_sb = d->k_strides[0]; a.k_sh = d->k_strides[1]; a.k_ss = d->k_strides[2];
+    a.v_sb = d->v_strides[0]; a.v_sh = d->v_strides[1]; a.v_ss = d->v_strides[2];
+    a.o_sb = d->o_strides[0]; a.o_sh = d->o_strides[1]; a.o_ss = d->o_strides[2];
+    a.do_sb = d->do_strides[0]; a.do_sh = d->do_strides[1]; a.do_ss = d->do_strides[2];
+    a.dq_sb = d->dq_strides[0]; a.dq_sh = d->dq_strides[1]; a.dq_ss = d->dq_strides[2];
+    a.dk_sb = d->dk_strides[0]; a.dk_sh = d->dk_strides[1]; a.dk_ss = d->dk_strides[2];
+    a.dv_sb = d->dv_strides[0]; a.dv_sh = d->dv_strides[1]; a.dv_ss = d->dv_strides[2];
+    return 0;
+}
+
+}  // namespace ftmi
+
+using namespace ftmi;
+
+extern "C" {
+
+int ftmi_version(void) { return 100; }
+
+int ftmi_last_error(char* buf, size_t len) {
+    if (!buf || len == 0) return FTMI_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    strncpy(buf, g_err, len - 1);
+    buf[len - 1] = 0;
+    return 0;
+}
+
+int ftmi_attn_fwd(const ftmi_attn_desc* desc, const void* q, const void* k, const void* v, void* out, float* lse, const float* key_bias,
+                  ftmi_stream stream) {
+    AttnArgs a;
+    int rc = fill_attn(desc, a);
+    if (rc) return rc;
+    if (!q || !k || !v || !out) return set_error(FTMI_ERR_INVALID, "ftmi_attn_fwd: null tensor");
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)out; a.lse2 = lse; a.kbias = key_bias;
+    return attn_fwd(a, (hipStream_t)stream);
+}
+
+int ftmi_attn_bwd(const ftmi_attn_desc* desc, const void* q, const void* k, const void* v, const void* out, const float* lse,
+                  const void* dout, void* dq, void* dk, void* dv, float* delta_ws, const float* key_bias, ftmi_stream stream) {
+    AttnArgs a;
+    int rc = fill_attn(desc, a);
+    if (rc) return rc;
+    if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv || !delta_ws) return set_error(FTMI_ERR_INVALID, "ftmi_attn_bwd: null tensor");
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)out; a.lse2 = (float*)lse; a.kbias = key_bias;
+    a.dout = (const bf16_t*)dout; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.delta = delta_ws;
+    return attn_bwd(a, (hipStream_t)stream);
+}
+
+int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha, void* out, long ldo,
+                 int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch, const void* aux, int variant,
+                 ftmi_stream stream) {
+    if (!x || !w || !out) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_nt: null tensor");
+    if (epilogue < 0 || epilogue > 3) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_nt: bad epilogue");
+    if (epilogue == EPI_RESID && !resid) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_nt: residual epilogue without residual");
+    if (epilogue == EPI_DGELU && !aux) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_nt: gelu' epilogue without pre-activation");
+    GemmNtArgs a;
+    a.X = (const bf16_t*)x; a.ldx = ldx; a.W = (const bf16_t*)w; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
+    a.bias = (const bf16_t*)bias; a.alpha = alpha; a.out = (bf16_t*)out; a.ldo = ldo; a.epi = epilogue;
+    a.out2 = (bf16_t*)out2; a.ldo2 = ldo; a.resid = (const bf16_t*)resid; a.ldr = ldo;
+    a.gate = (const bf16_t*)gate; a.gate_bstride = N; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    a.aux = (const bf16_t*)aux; a.ldaux = ldo; a.variant = variant;
+    return gemm_nt(a, (hipStream_t)stream);
+}
+
+int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, long ldv, float* c, long ldc, float scale, ftmi_stream stream) {
+    if (!u || !v || !c) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_tn: null tensor");
+    GemmTnArgs a;
+    a.U = (const bf16_t*)u; a.ldu = ldu; a.V = (const bf16_t*)v; a.ldv = ldv; a.C = c; a.ldc = ldc; a.M = M; a.P = P; a.Q = Q; a.scale = scale;
+    return gemm_tn(a, (hipStream_t)stream);
+}
+
+int ftmi_transpose_bf16(const void* in, void* out, int rows, int cols, ftmi_stream stream) {
+    if (!in || !out) return set_error(FTMI_ERR_INVALID, "ftmi_transpose_bf16: null tensor");
+    return transpose_bf16((const bf16_t*)in, (bf16_t*)out, rows, cols, (hipStream_t)stream);
+}
+
+int ftmi_linear_lora_fwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* w, const void* bias, const void* a_bf,
+                         const void* b_bf, void* y, void* xa_out, int variant, ftmi_stream stream) {
+    if (!x || !w || !y) return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_fwd: null tensor");
+    if (r > 0 && (!a_bf || !b_bf || !xa_out)) return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_fwd: LoRA tensors missing");
+    if (r < 0 || (r % 64)) return set_error(FTMI_ERR_UNSUPPORTED, "ftmi_linear_lora_fwd: rank must be 0 or a multiple of 64");
+    hipStream_t st = (hipStream_t)stream;
+    GemmNtArgs a;
+    a.X = (const bf16_t*)x; a.ldx = K; a.W = (const bf16_t*)w; a.ldw = K; a.M = M; a.N = N; a.K = K;
+    a.bias = (const bf16_t*)bias; a.out = (bf16_t*)y; a.ldo = N; a.variant = variant;
+    if (r > 0) {
+        GemmNtArgs d;
+        d.X = (const bf16_t*)x; d.ldx = K; d.W = (const bf16_t*)a_bf; d.ldw = K; d.M = M; d.N = r; d.K = K; d.alpha = lora_scale;
+        d.out = (bf16_t*)xa_out; d.ldo = r; d.variant = variant;
+        int rc = gemm_nt(d, st);
+        if (rc) return rc;
+        a.X2 = (const bf16_t*)xa_out; a.ldx2 = r; a.W2 = (const bf16_t*)b_bf; a.ldw2 = r; a.K2 = r;
+    }
+    return gemm_nt(a, st);
+}
+
+size_t ftmi_ltx_workspace_bytes(const ftmi_ltx_config* cfg) { return cfg ? ltx_workspace_bytes(*cfg) : 0; }
+
+int ftmi_ltx_workspace_offset(const ftmi_ltx_config* cfg, const char* name, int layer, size_t* offset) {
+    if (!cfg || !name || !offset) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_workspace_offset: null argument");
+    return ltx_workspace_offset(*cfg, name, layer, offset);
+}
+
+int ftmi_ltx_forward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* x_t, const void* text, const float* key_bias,
+                     const float* sigma, void* pred, void* ws, size_t ws_bytes, ftmi_stream stream) {
+    if (!cfg || !w || !x_t || !text || !sigma || !pred || !ws) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_forward: null argument");
+    if (cfg->r > 0 && (!w->lora_a || !w->lora_b)) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_forward: LoRA working copies missing");
+    return ltx_forward(*cfg, *w, (const bf16_t*)x_t, (const bf16_t*)text, key_bias, sigma, (bf16_t*)pred, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ftmi_ltx_backward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias, const void* dpred,
+                      float* grad_a, float* grad_b, void* ws, size_t ws_bytes, ftmi_stream stream) {
+    if (!cfg || !w || !dpred || !ws) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_backward: null argument");
+    if (cfg->r > 0 && (!grad_a || !grad_b || !w->lora_at || !w->lora_bt || !w->lora_at_qkv))
+        return set_error(FTMI_ERR_INVALID, "ftmi_ltx_backward: LoRA gradient buffers / working copies missing");
+    return ltx_backward(*cfg, *w, (const bf16_t*)text, key_bias, (const bf16_t*)dpred, grad_a, grad_b, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int ftmi_ltx_noise_pack(const void* latents, const void* noise, const float* mean, const float* std_, const float* sigma,
+                        const float* sigma_first, int first_frame_tokens, void* x_t, void* target, int B, int C, int S, ftmi_stream stream) {
+    if (!latents || !noise || !mean || !std_ || !sigma || !x_t || !target) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_noise_pack: null argument");
+    return noise_pack((const bf16_t*)latents, (const bf16_t*)noise, mean, std_, sigma, sigma_first, first_frame_tokens, (bf16_t*)x_t,
+                      (bf16_t*)target, B, C, S, (hipStream_t)stream);
+}
+
+int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample, float grad_scale,
+                  ftmi_stream stream) {
+    if (!pred || !target || !loss) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");
+    return mse_loss_fwd_bwd((const bf16_t*)pred, (const bf16_t*)target, weight, loss, (bf16_t*)dpred, B, per_sample, grad_scale, (hipStream_t)stream);
+}
+
+int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int step, float* scratch, float* grad_norm_out, ftmi_stream stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !scratch) return set_error(FTMI_ERR_INVALID, "ftmi_clip_adamw_step: null argument");
+    if (step < 1) return set_error(FTMI_ERR_INVALID, "ftmi_clip_adamw_step: step counts from 1");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0, 2 * sizeof(float), st) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "ftmi_clip_adamw_step: memset failed");
+    int rc = sumsq(grads, n, scratch, st);
+    if (rc) return rc;
+    return adamw_clip_step(params, grads, exp_avg, exp_avg_sq, n, scratch, max_norm, lr, beta1, beta2, eps, weight_decay, step, grad_norm_out, st);
+}
+
+int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a, void* lora_at, void* lora_b, void* lora_bt, void* lora_at_qkv,
+                      int L, int r, int D, ftmi_stream stream) {
+    if (!a_f32 || !b_f32 || !lora_a || !lora_at || !lora_b || !lora_bt || !lora_at_qkv) return set_error(FTMI_ERR_INVALID, "ftmi_lora_refresh: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long per = (long)r * D;
+    int rc = lora_refresh(a_f32, (bf16_t*)lora_a, (bf16_t*)lora_at, r, D, L * 8, per, per, per, st);
+    if (rc) return rc;
+    rc = lora_refresh(b_f32, (bf16_t*)lora_b, (bf16_t*)lora_bt, D, r, L * 8, per, per, per, st);
+    if (rc) return rc;
+    // [A_q;A_k;A_v] (3r x D, contiguous inside a block's 8 adapters) -> (D x 3r)
+    rc = lora_refresh(a_f32, nullptr, (bf16_t*)lora_at_qkv, 3 * r, D, L, 8 * per, 0, 3 * per, st);
+    if (rc) return rc;
+    return 0;
+}
+
+}  // extern "C"

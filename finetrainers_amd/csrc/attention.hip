@@ -1,0 +1,504 @@
+// Fused (flash-style) scaled-dot-product attention for gfx950, head_dim 64, bf16 in / fp32 softmax.
+// Non-causal, optional additive per-key bias (the text mask of LTX's cross-attention).
+//
+// Replaces: torch.nn.functional.scaled_dot_product_attention as installed by the reference's
+// attention_dispatch (finetrainers/models/attention_dispatch.py:405-447, native provider :938-962)
+// and its autograd backward.
+//
+// Layout trick used throughout (see common.hip.h): with D = A.B on v_mfma_f32_32x32x16_bf16 the lane
+// owns one COLUMN of D.  Computing S^T = K.Q^T makes a lane own one query row, so the online-softmax
+// statistics are per-lane scalars (one cross-half shuffle per reduction), and the C-layout registers
+// of P are directly a valid B-slot operand for O^T = V^T.P^T -- no LDS round trip for P.  Operands
+// whose reduction index is the token index (V^T, K^T, Q^T, dO^T) are transposed while the tile is
+// written to LDS (16-bit stores into a padded [64 d][64 tok] image, read back with 8-byte loads).
+//
+// Three kernels: forward (O, LSE), backward dK/dV (one workgroup per 128 keys, loops over queries),
+// backward dQ (one workgroup per 128 queries, loops over keys).  Scores are recomputed in both
+// backward kernels, so no atomics are needed and results are deterministic.
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace ftmi {
+
+static constexpr float kLog2e = 1.4426950408889634f;
+
+FTMI_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// 256 threads load one [64 tok][64 d] bf16 tile as 2 x 16-byte chunks per thread.  A wave instruction
+// covers 16 rows x 64 contiguous bytes.  slot = wave + 4*it : rows (slot&3)*16.., chunks (slot>>2)*4..
+struct TileCoord {
+    int row, chunk;
+};
+FTMI_DEVICE TileCoord tile_coord(int tid, int it) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int slot = wave + 4 * it;
+    TileCoord c;
+    c.row = (slot & 3) * 16 + (lane & 15);
+    c.chunk = (slot >> 2) * 4 + (lane >> 4);
+    return c;
+}
+
+FTMI_DEVICE void load_tile(s16x8 (&r)[2], const bf16_t* base, long row_stride, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        TileCoord c = tile_coord(tid, it);
+        int gr = min(row0 + c.row, nrows - 1);
+        r[it] = *reinterpret_cast<const s16x8*>(base + (long)gr * row_stride + c.chunk * 8);
+    }
+}
+FTMI_DEVICE void store_tile_rm(const s16x8 (&r)[2], char* lds, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        TileCoord c = tile_coord(tid, it);
+        *reinterpret_cast<s16x8*>(lds + lds_rm_off(c.row, c.chunk)) = r[it];
+    }
+}
+FTMI_DEVICE void store_tile_tr(const s16x8 (&r)[2], char* lds, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        TileCoord c = tile_coord(tid, it);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<short*>(lds + (c.chunk * 8 + e) * FTMI_TS + c.row * 2) = r[it][e];
+    }
+}
+// A-slot fragment from a transposed image: row d, token offsets tok0 + {4g..4g+3, 8+4g..8+4g+3}
+FTMI_DEVICE s16x8 read_tr_frag(const char* lds, int d, int tok0, int g) {
+    const char* p = lds + d * FTMI_TS + (tok0 + 4 * g) * 2;
+    s16x4 lo = *reinterpret_cast<const s16x4*>(p);
+    s16x4 hi = *reinterpret_cast<const s16x4*>(p + 16);
+    s16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
+    s16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (short)f2bf(v[hh * 8 + e]);
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+static constexpr int kFwdLds = 8192 + 64 * FTMI_TS + 256;
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ks = smem;
+    char* vts = smem + 8192;
+    float* kb = reinterpret_cast<float*>(smem + 8192 + 64 * FTMI_TS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int i = blockIdx.x * 128 + wave * 32 + li;
+    const int ic = min(i, a.Sq - 1);
+    const float sl = a.scale * kLog2e;
+
+    const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
+    s16x8 qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+
+    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
+    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.Sk : nullptr;
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+
+    const int nt = (a.Sk + 63) / 64;
+    s16x8 kr[2], vr[2];
+    float kbr = 0.f;
+    auto gload = [&](int t) {
+        load_tile(kr, kbase, a.k_ss, t * 64, a.Sk, tid);
+        load_tile(vr, vbase, a.v_ss, t * 64, a.Sk, tid);
+        if (tid < 64) {
+            int j = t * 64 + tid;
+            kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;
+        }
+    };
+    auto lwrite = [&]() {
+        store_tile_rm(kr, ks, tid);
+        store_tile_tr(vr, vts, tid);
+        if (tid < 64) kb[tid] = kbr;
+    };
+
+    gload(0);
+    lwrite();
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) gload(t + 1);
+
+        f32x16 st[2];
+#pragma unroll
+        for (int js = 0; js < 2; ++js) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s16x8 kf = *reinterpret_cast<const s16x8*>(ks + lds_rm_off(js * 32 + li, c * 2 + g));
+                st[js] = mfma32(kf, qf[c], st[js]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int js = 0; js < 2; ++js)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = st[js][r] * sl + kb[js * 32 + crow(r, g)];
+                st[js][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int js = 0; js < 2; ++js)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = fast_exp2(st[js][r] - m_new);
+                st[js][r] = p;
+                rs += p;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+
+#pragma unroll
+        for (int js = 0; js < 2; ++js)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                s16x8 pf = pack_frag(st[js], hh);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    s16x8 vf = read_tr_frag(vts, dt * 32 + li, js * 32 + hh * 16, g);
+                    oacc[dt] = mfma32(vf, pf, oacc[dt]);
+                }
+            }
+        __syncthreads();
+        if (t + 1 < nt) lwrite();
+        __syncthreads();
+    }
+
+    if (i < a.Sq) {
+        const float inv = 1.0f / l_run;
+        bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)i * a.o_ss;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 pk;
+                pk[0] = pack2bf(oacc[dt][rq * 4 + 0] * inv, oacc[dt][rq * 4 + 1] * inv);
+                pk[1] = pack2bf(oacc[dt][rq * 4 + 2] * inv, oacc[dt][rq * 4 + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + dt * 32 + rq * 8 + 4 * g) = pk;
+            }
+        if (g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
+    }
+}
+
+int attn_fwd(const AttnArgs& a, hipStream_t st) {
+    if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_fwd: empty problem");
+    if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 4))
+        return set_error(FTMI_ERR_INVALID, "attn_fwd: token strides must keep 16-byte alignment");
+    dim3 grid((a.Sq + 127) / 128, a.H, a.B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), kFwdLds, st, a);
+    return check_launch("attn_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: delta = rowsum(dO * O)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
+    const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);  // 8 lanes per (b,h,i) row
+    const int sub = threadIdx.x & 7;
+    const long nrows = (long)a.B * a.H * a.Sq;
+    float s = 0.f;
+    if (row < nrows) {
+        const int i = (int)(row % a.Sq);
+        const long bh = row / a.Sq;
+        const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+        const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)i * a.o_ss + sub * 8;
+        const bf16_t* dp = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)i * a.do_ss + sub * 8;
+        s16x8 ov = *reinterpret_cast<const s16x8*>(op);
+        s16x8 dv = *reinterpret_cast<const s16x8*>(dp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += bf2f((bf16_t)ov[e]) * bf2f((bf16_t)dv[e]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (row < nrows && sub == 0) a.delta[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dK, dV
+// ------------------------------------------------------------------------------------------------
+static constexpr int kDkvLds = 2 * 8192 + 2 * 64 * FTMI_TS + 512;
+
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* qs = smem;
+    char* dos = smem + 8192;
+    char* qts = smem + 16384;
+    char* dots = qts + 64 * FTMI_TS;
+    float* lses = reinterpret_cast<float*>(dots + 64 * FTMI_TS);
+    float* dels = lses + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int j = blockIdx.x * 128 + wave * 32 + li;
+    const int jc = min(j, a.Sk - 1);
+    const float sl = a.scale * kLog2e;
+
+    const bf16_t* kp = a.k + (long)b * a.k_sb + (long)h * a.k_sh + (long)jc * a.k_ss;
+    const bf16_t* vp = a.v + (long)b * a.v_sb + (long)h * a.v_sh + (long)jc * a.v_ss;
+    s16x8 kf[4], vf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        kf[c] = *reinterpret_cast<const s16x8*>(kp + c * 16 + g * 8);
+        vf[c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
+    }
+    const float bias_j = a.kbias ? a.kbias[(long)b * a.Sk + jc] * kLog2e : 0.f;
+
+    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
+    const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
+    const float* lsebase = a.lse2 + ((long)b * a.H + h) * a.Sq;
+    const float* delbase = a.delta + ((long)b * a.H + h) * a.Sq;
+
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dkt[dt][r] = 0.f;
+            dvt[dt][r] = 0.f;
+        }
+
+    const int ni = (a.Sq + 63) / 64;
+    s16x8 qr[2], dor[2];
+    float lser = 0.f, delr = 0.f;
+    auto gload = [&](int t) {
+        load_tile(qr, qbase, a.q_ss, t * 64, a.Sq, tid);
+        load_tile(dor, dobase, a.do_ss, t * 64, a.Sq, tid);
+        if (tid < 64) {
+            int i = t * 64 + tid;
+            lser = (i < a.Sq) ? lsebase[i] : INFINITY;  // +inf => p = 0 for padded query rows
+            delr = (i < a.Sq) ? delbase[i] : 0.f;
+        }
+    };
+    auto lwrite = [&]() {
+        store_tile_rm(qr, qs, tid);
+        store_tile_tr(qr, qts, tid);
+        store_tile_rm(dor, dos, tid);
+        store_tile_tr(dor, dots, tid);
+        if (tid < 64) {
+            lses[tid] = lser;
+            dels[tid] = delr;
+        }
+    };
+
+    gload(0);
+    lwrite();
+    __syncthreads();
+    for (int t = 0; t < ni; ++t) {
+        if (t + 1 < ni) gload(t + 1);
+#pragma unroll
+        for (int is = 0; is < 2; ++is) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = 0.f;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s16x8 qf = *reinterpret_cast<const s16x8*>(qs + lds_rm_off(is * 32 + li, c * 2 + g));
+                s = mfma32(qf, kf[c], s);
+                s16x8 dof = *reinterpret_cast<const s16x8*>(dos + lds_rm_off(is * 32 + li, c * 2 + g));
+                dp = mfma32(dof, vf[c], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int il = is * 32 + crow(r, g);
+                float p = fast_exp2(s[r] * sl + bias_j - lses[il]);
+                float ds = p * (dp[r] - dels[il]);
+                s[r] = p;
+                dp[r] = ds;
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                s16x8 pf = pack_frag(s, hh);
+                s16x8 dsf = pack_frag(dp, hh);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    s16x8 dotf = read_tr_frag(dots, dt * 32 + li, is * 32 + hh * 16, g);
+                    dvt[dt] = mfma32(dotf, pf, dvt[dt]);
+                    s16x8 qtf = read_tr_frag(qts, dt * 32 + li, is * 32 + hh * 16, g);
+                    dkt[dt] = mfma32(qtf, dsf, dkt[dt]);
+                }
+            }
+        }
+        __syncthreads();
+        if (t + 1 < ni) lwrite();
+        __syncthreads();
+    }
+
+    if (j < a.Sk) {
+        bf16_t* dkp = a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh + (long)j * a.dk_ss;
+        bf16_t* dvp = a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh + (long)j * a.dv_ss;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 pk;
+                pk[0] = pack2bf(dkt[dt][rq * 4 + 0] * a.scale, dkt[dt][rq * 4 + 1] * a.scale);
+                pk[1] = pack2bf(dkt[dt][rq * 4 + 2] * a.scale, dkt[dt][rq * 4 + 3] * a.scale);
+                *reinterpret_cast<u32x2*>(dkp + dt * 32 + rq * 8 + 4 * g) = pk;
+                pk[0] = pack2bf(dvt[dt][rq * 4 + 0], dvt[dt][rq * 4 + 1]);
+                pk[1] = pack2bf(dvt[dt][rq * 4 + 2], dvt[dt][rq * 4 + 3]);
+                *reinterpret_cast<u32x2*>(dvp + dt * 32 + rq * 8 + 4 * g) = pk;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dQ
+// ------------------------------------------------------------------------------------------------
+static constexpr int kDqLds = 2 * 8192 + 64 * FTMI_TS + 256;
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ks = smem;
+    char* vs = smem + 8192;
+    char* kts = smem + 16384;
+    float* kb = reinterpret_cast<float*>(kts + 64 * FTMI_TS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int i = blockIdx.x * 128 + wave * 32 + li;
+    const int ic = min(i, a.Sq - 1);
+    const float sl = a.scale * kLog2e;
+
+    const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
+    const bf16_t* dop = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)ic * a.do_ss;
+    s16x8 qf[4], dof[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+        dof[c] = *reinterpret_cast<const s16x8*>(dop + c * 16 + g * 8);
+    }
+    const float lse_i = a.lse2[((long)b * a.H + h) * a.Sq + ic];
+    const float del_i = a.delta[((long)b * a.H + h) * a.Sq + ic];
+
+    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
+    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.Sk : nullptr;
+
+    f32x16 dqt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[dt][r] = 0.f;
+
+    const int nt = (a.Sk + 63) / 64;
+    s16x8 kr[2], vr[2];
+    float kbr = 0.f;
+    auto gload = [&](int t) {
+        load_tile(kr, kbase, a.k_ss, t * 64, a.Sk, tid);
+        load_tile(vr, vbase, a.v_ss, t * 64, a.Sk, tid);
+        if (tid < 64) {
+            int j = t * 64 + tid;
+            kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;  // -inf => p = 0 for padded keys
+        }
+    };
+    auto lwrite = [&]() {
+        store_tile_rm(kr, ks, tid);
+        store_tile_tr(kr, kts, tid);
+        store_tile_rm(vr, vs, tid);
+        if (tid < 64) kb[tid] = kbr;
+    };
+
+    gload(0);
+    lwrite();
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) gload(t + 1);
+#pragma unroll
+        for (int js = 0; js < 2; ++js) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = 0.f;
+                dp[r] = 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s16x8 kf = *reinterpret_cast<const s16x8*>(ks + lds_rm_off(js * 32 + li, c * 2 + g));
+                s = mfma32(kf, qf[c], s);
+                s16x8 vf = *reinterpret_cast<const s16x8*>(vs + lds_rm_off(js * 32 + li, c * 2 + g));
+                dp = mfma32(vf, dof[c], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = fast_exp2(s[r] * sl + kb[js * 32 + crow(r, g)] - lse_i);
+                dp[r] = p * (dp[r] - del_i);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                s16x8 dsf = pack_frag(dp, hh);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    s16x8 ktf = read_tr_frag(kts, dt * 32 + li, js * 32 + hh * 16, g);
+                    dqt[dt] = mfma32(ktf, dsf, dqt[dt]);
+                }
+            }
+        }
+        __syncthreads();
+        if (t + 1 < nt) lwrite();
+        __syncthreads();
+    }
+
+    if (i < a.Sq) {
+        bf16_t* dqp = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh + (long)i * a.dq_ss;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                u32x2 pk;
+                pk[0] = pack2bf(dqt[dt][rq * 4 + 0] * a.scale, dqt[dt][rq * 4 + 1] * a.scale);
+                pk[1] = pack2bf(dqt[dt][rq * 4 + 2] * a.scale, dqt[dt][rq * 4 + 3] * a.scale);
+                *reinterpret_cast<u32x2*>(dqp + dt * 32 + rq * 8 + 4 * g) = pk;
+            }
+    }
+}
+
+int attn_bwd(const AttnArgs& a, hipStream_t st) {
+    if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_bwd: empty problem");
+    if (!a.lse2 || !a.delta || !a.dout || !a.o) return set_error(FTMI_ERR_INVALID, "attn_bwd: missing lse/delta/dout/out");
+    if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8) || (a.do_ss % 8) || (a.dq_ss % 4) || (a.dk_ss % 4) || (a.dv_ss % 4))
+        return set_error(FTMI_ERR_INVALID, "attn_bwd: token strides must keep 16-byte alignment");
+    const long nrows = (long)a.B * a.H * a.Sq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
+    int rc = check_launch("attn_delta");
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), kDkvLds, st, a);
+    rc = check_launch("attn_bwd_dkdv");
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), kDqLds, st, a);
+    return check_launch("attn_bwd_dq");
+}
+
+}  // namespace ftmi

@@ -1,0 +1,100 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of libftmi355.
+// One MFMA shape is used everywhere: v_mfma_f32_32x32x16_bf16.
+//   A-slot (32 x 16): lane l holds row (l & 31), k-group (l >> 5): 8 consecutive bf16
+//   B-slot (16 x 32): lane l holds col (l & 31), k-group (l >> 5): 8 consecutive bf16
+//   C/D    (32 x 32): lane l holds col (l & 31); register r holds row (r&3) + 8*(r>>2) + 4*(l>>5)
+// The reduction index is a dummy: A-slot element (g, e) is multiplied with B-slot element (g, e),
+// so any k-assignment is valid as long as both operands use the same one.  The attention kernels
+// rely on this to feed C-layout registers (softmax probabilities) straight back in as an operand.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define FTMI_DEVICE __device__ __forceinline__
+
+FTMI_DEVICE float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (same as torch's .to(torch.bfloat16))
+FTMI_DEVICE bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// round an fp32 value through bf16 (a torch op boundary in the reference's eager bf16 graph)
+FTMI_DEVICE float rbf(float f) { return bf2f(f2bf(f)); }
+
+FTMI_DEVICE uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+FTMI_DEVICE f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// C-layout row of register r for lane-group g (= lane >> 5)
+FTMI_DEVICE int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+// ---- row-major [rows][64] bf16 LDS tile (128-byte rows), 16-byte chunks XOR-swizzled so that the
+// ---- ds_read_b128 of 16 lanes reading 16 different rows at one k-chunk is bank-conflict free.
+FTMI_DEVICE int lds_rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ---- transposed [64 rows][cols] bf16 LDS tile with padded rows (TS bytes, TS % 8 == 0, TS/4 odd*2)
+#define FTMI_TS 136  // 64 bf16 + 8 bytes pad: 8-byte reads of 32 lanes hit 64 distinct banks
+
+FTMI_DEVICE float gelu_tanh_f(float x) {
+    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
+    const float kKappa = 0.044715f;
+    float inner = kBeta * (x + kKappa * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+// torch's gelu_backward(approximate="tanh") in fp32
+FTMI_DEVICE float gelu_tanh_grad_f(float x) {
+    const float kBeta = 0.7978845608028654f;
+    const float kKappa = 0.044715f;
+    float x_sq = x * x;
+    float x_cube = x_sq * x;
+    float inner = kBeta * (x + kKappa * x_cube);
+    float tanh_inner = tanhf(inner);
+    float left = 0.5f * x;
+    float right = 1.0f + tanh_inner;
+    float left_derivative = 0.5f * right;
+    float tanh_derivative = 1.0f - tanh_inner * tanh_inner;
+    float inner_derivative = kBeta * (1.0f + 3.0f * kKappa * x_sq);
+    float right_derivative = left * tanh_derivative * inner_derivative;
+    return left_derivative + right_derivative;
+}
+
+FTMI_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+FTMI_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+FTMI_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware, bijective remap of a 1-D block id: blocks that share an operand panel land on the
+// same XCD (block b is observed to run on XCD b % 8; used for speed only, never correctness).
+FTMI_DEVICE int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, idx = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}

@@ -1,0 +1,425 @@
+// bf16 MFMA GEMMs of the LTX-Video LoRA SFT step (gfx950).
+//
+//  gemm_nt   : C[M,N] = X[M,K] . W[N,K]^T (+ X2[M,K2] . W2[N,K2]^T)  -- every Linear forward, every dgrad
+//              (dgrad uses the pre-transposed frozen weight, so it is the same K-contiguous shape),
+//              with the LoRA up-projection fused as a K-extension and the elementwise tail of the
+//              reference graph (bias, GELU, gate * residual, GELU') fused into the epilogue.  The
+//              epilogue rounds through bf16 at exactly the points where the reference's eager bf16
+//              graph materialises a tensor, so fusion does not move rounding points.
+//  gemm_tn   : C[P,Q] += U[M,P]^T . V[M,Q]  (fp32 atomics) -- LoRA weight gradients dA / dB; the token
+//              dimension is the reduction, tiles are transposed while being written to LDS.
+//
+// Replaces: torch.nn.functional.linear / peft lora.Linear.forward and their autograd backward as
+// launched by the reference step (SURVEY 2c K6,K7,K10,K14,K15,K17,K18,K19,K21).
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace ftmi {
+
+// ------------------------------------------------------------------------------------------------
+// NT GEMM
+// ------------------------------------------------------------------------------------------------
+
+template <int BM, int BN, int WM, int WN, bool GLDS>
+struct NtTile {
+    static constexpr int TM = BM / WM / 32;
+    static constexpr int TN = BN / WN / 32;
+    static constexpr int XCH = BM * 8 / 256;
+    static constexpr int WCH = BN * 8 / 256;
+    static constexpr int STAGE = (BM + BN) * 128;
+};
+
+template <int BM, int BN, int WM, int WN, bool GLDS>
+FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                          int m0, int M, const bf16_t* __restrict__ W, long ldw, int n0, int nk, int tid) {
+    using T = NtTile<BM, BN, WM, WN, GLDS>;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+
+    s16x8 xr[T::XCH], wr[T::WCH];
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < T::XCH; ++i) {
+            int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            int gr = min(m0 + row, M - 1);
+            xr[i] = *reinterpret_cast<const s16x8*>(X + (long)gr * ldx + kt * 64 + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < T::WCH; ++i) {
+            int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            wr[i] = *reinterpret_cast<const s16x8*>(W + (long)(n0 + row) * ldw + kt * 64 + c * 8);
+        }
+    };
+    auto swrite = [&](int buf) {
+        char* xs = smem + buf * T::STAGE;
+        char* ws = xs + BM * 128;
+#pragma unroll
+        for (int i = 0; i < T::XCH; ++i) {
+            int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            *reinterpret_cast<s16x8*>(xs + lds_rm_off(row, c)) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < T::WCH; ++i) {
+            int q = tid + 256 * i, row = q >> 3, c = q & 7;
+            *reinterpret_cast<s16x8*>(ws + lds_rm_off(row, c)) = wr[i];
+        }
+    };
+    // direct global -> LDS (LDS destination is wave-linear: base + lane*16; the swizzle is applied by
+    // permuting the per-lane SOURCE address, the read side applies the same involution)
+    auto gl2lds = [&](int kt, int buf) {
+        char* xs = smem + buf * T::STAGE;
+        char* ws = xs + BM * 128;
+        constexpr int XI = BM * 128 / 1024 / 4;  // 1 KiB wave-instructions per wave
+        constexpr int WI = BN * 128 / 1024 / 4;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            int blk = wave * XI + i;  // 8 rows per block
+            int row = blk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
+            int gr = min(m0 + row, M - 1);
+            const bf16_t* src = X + (long)gr * ldx + kt * 64 + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + blk * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            int blk = wave * WI + i;
+            int row = blk * 8 + (lane >> 3);
+            int c = (lane & 7) ^ ((row >> 1) & 7);
+            const bf16_t* src = W + (long)(n0 + row) * ldw + kt * 64 + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ws + blk * 1024), 16, 0, 0);
+        }
+    };
+
+    if (GLDS) {
+        gl2lds(0, 0);
+    } else {
+        gload(0);
+        swrite(0);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            if (GLDS)
+                gl2lds(kt + 1, cur ^ 1);
+            else
+                gload(kt + 1);
+        }
+        const char* xs = smem + cur * T::STAGE;
+        const char* ws = xs + BM * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s16x8 wf[T::TN], xf[T::TM];
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) {
+                int row = (wn * T::TN + tn) * 32 + li;
+                wf[tn] = *reinterpret_cast<const s16x8*>(ws + lds_rm_off(row, kk * 2 + g));
+            }
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) {
+                int row = (wm * T::TM + tm) * 32 + li;
+                xf[tm] = *reinterpret_cast<const s16x8*>(xs + lds_rm_off(row, kk * 2 + g));
+            }
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[tn], xf[tm], acc[tn][tm]);
+        }
+        if (!GLDS && kt + 1 < nk) swrite(cur ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
+    using T = NtTile<BM, BN, WM, WN, GLDS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+    const int t = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (t % ntm) * BM, n0 = (t / ntm) * BN;
+
+    f32x16 acc[T::TN][T::TM];
+#pragma unroll
+    for (int a = 0; a < T::TN; ++a)
+#pragma unroll
+        for (int b = 0; b < T::TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    {
+        const bf16_t* X = p.X;
+        if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
+        nt_run_k<BM, BN, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / 64, tid);
+    }
+
+    bool bias_done = false;
+    if (p.K2 > 0) {
+        // reference: result = base(x) [rounded to bf16]; result = result + lora (fp32) -> rounded to bf16
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + (wn * T::TN + tn) * 32 + rq * 8 + 4 * g;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+                    bv[0] = bf2f((bf16_t)(raw[0] & 0xffff));
+                    bv[1] = bf2f((bf16_t)(raw[0] >> 16));
+                    bv[2] = bf2f((bf16_t)(raw[1] & 0xffff));
+                    bv[3] = bf2f((bf16_t)(raw[1] >> 16));
+                }
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[tn][tm][rq * 4 + j] = rbf(acc[tn][tm][rq * 4 + j] * p.alpha + bv[j]);
+            }
+        bias_done = true;
+        const bf16_t* X2 = p.X2;
+        if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
+        nt_run_k<BM, BN, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / 64, tid);
+    }
+
+    // ---------------- epilogue ----------------
+#pragma unroll
+    for (int tm = 0; tm < T::TM; ++tm) {
+        const int m = m0 + (wm * T::TM + tm) * 32 + li;
+        if (m >= p.M) continue;
+        const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + (wn * T::TN + tn) * 32 + rq * 8 + 4 * g;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][rq * 4 + j];
+                if (!bias_done) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                    if (p.bias) {
+                        u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+                        v[0] += bf2f((bf16_t)(raw[0] & 0xffff));
+                        v[1] += bf2f((bf16_t)(raw[0] >> 16));
+                        v[2] += bf2f((bf16_t)(raw[1] & 0xffff));
+                        v[3] += bf2f((bf16_t)(raw[1] >> 16));
+                    }
+                }
+                float o[4];
+                if (p.epi == EPI_STORE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = v[j];
+                } else if (p.epi == EPI_GELU) {
+                    float z[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        z[j] = rbf(v[j]);
+                        o[j] = gelu_tanh_f(z[j]);
+                    }
+                    if (p.out2) {  // pre-activation stash
+                        u32x2 pk;
+                        pk[0] = pack2bf(z[0], z[1]);
+                        pk[1] = pack2bf(z[2], z[3]);
+                        *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = pk;
+                    }
+                } else if (p.epi == EPI_RESID) {
+                    u32x2 rr = *reinterpret_cast<const u32x2*>(p.resid + (long)m * p.ldr + n);
+                    float rv[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)), bf2f((bf16_t)(rr[1] & 0xffff)),
+                                   bf2f((bf16_t)(rr[1] >> 16))};
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = rbf(v[j]);
+                    if (p.gate) {
+                        u32x2 gg = *reinterpret_cast<const u32x2*>(p.gate + (long)b * p.gate_bstride + n);
+                        float gv[4] = {bf2f((bf16_t)(gg[0] & 0xffff)), bf2f((bf16_t)(gg[0] >> 16)), bf2f((bf16_t)(gg[1] & 0xffff)),
+                                       bf2f((bf16_t)(gg[1] >> 16))};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = rbf(y[j] * gv[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = rv[j] + y[j];
+                } else {  // EPI_DGELU: grad_in = grad_out * gelu'(z)
+                    u32x2 zz = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
+                    float zv[4] = {bf2f((bf16_t)(zz[0] & 0xffff)), bf2f((bf16_t)(zz[0] >> 16)), bf2f((bf16_t)(zz[1] & 0xffff)),
+                                   bf2f((bf16_t)(zz[1] >> 16))};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = rbf(v[j]) * gelu_tanh_grad_f(zv[j]);
+                }
+                u32x2 pk;
+                pk[0] = pack2bf(o[0], o[1]);
+                pk[1] = pack2bf(o[2], o[3]);
+                *reinterpret_cast<u32x2*>(p.out + (long)m * p.ldo + n) = pk;
+            }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool GLDS>
+static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
+    using T = NtTile<BM, BN, WM, WN, GLDS>;
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+    const size_t smem = 2 * T::STAGE;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, GLDS>), dim3(ntm * ntn), dim3(256), smem, st, a);
+    return check_launch("gemm_nt");
+}
+
+int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.K % 64 != 0 || a.K2 % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: K and K2 must be multiples of 64");
+    if (a.N % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: N must be a multiple of 64");
+    if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 4) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
+        return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
+    const bool glds = a.variant == 1;
+    if (a.N % 128 == 0 && !(a.xk_grp_n > 0 && a.xk_grp_n % 128 != 0) && !(a.x2_grp_n > 0 && a.x2_grp_n % 128 != 0)) {
+        return glds ? launch_nt<128, 128, 2, 2, true>(a, st) : launch_nt<128, 128, 2, 2, false>(a, st);
+    }
+    if ((a.xk_grp_n > 0 && a.xk_grp_n % 64 != 0) || (a.x2_grp_n > 0 && a.x2_grp_n % 64 != 0))
+        return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
+    return glds ? launch_nt<128, 64, 2, 2, true>(a, st) : launch_nt<128, 64, 2, 2, false>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN GEMM (token-dimension reduction):  C[p][q] += scale * sum_m U[m][p] * V[m][q]
+// ------------------------------------------------------------------------------------------------
+
+template <int BP, int BQ>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
+    constexpr int WP = 2, WQ = 2;
+    constexpr int TP = BP / WP / 32, TQ = BQ / WQ / 32;
+    constexpr int UIT = BP / 32, VIT = BQ / 32;  // (16 rows x 4 chunks) load slots per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ut = smem;             // [BP][64 m] row-major swizzled
+    char* vt = smem + BP * 128;  // [BQ][64 m]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave / WQ, wq = wave % WQ;
+    const int li = lane & 31, g = lane >> 5;
+
+    const int ntp = a.P / BP, ntq = a.Q / BQ;
+    int bid = blockIdx.x;
+    const int split = bid / (ntp * ntq);
+    bid -= split * ntp * ntq;
+    const int p0 = (bid / ntq) * BP, q0 = (bid % ntq) * BQ;
+    const int nsteps_total = (a.M + 63) / 64;
+    const int s_begin = split * a.msteps_per_split;
+    const int s_end = min(nsteps_total, s_begin + a.msteps_per_split);
+    if (s_begin >= s_end) return;
+
+    const bf16_t* U = a.U + p0;
+    const bf16_t* V = a.V + q0;
+    if (a.v_grp_p > 0) V += (long)(p0 / a.v_grp_p) * a.v_grp_stride;
+
+    f32x16 acc[TP][TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    s16x8 ur[UIT], vr[VIT];
+    const int m_l = lane & 15, c_l = lane >> 4;
+    auto gload = [&](int s) {
+        const int mbase = s * 64;
+#pragma unroll
+        for (int it = 0; it < UIT; ++it) {
+            int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, pc = (sidx >> 2) * 4 + c_l;
+            s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            ur[it] = (mbase + m < a.M) ? *reinterpret_cast<const s16x8*>(U + (long)(mbase + m) * a.ldu + pc * 8) : z;
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, qc = (sidx >> 2) * 4 + c_l;
+            s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            vr[it] = (mbase + m < a.M) ? *reinterpret_cast<const s16x8*>(V + (long)(mbase + m) * a.ldv + qc * 8) : z;
+        }
+    };
+    auto twrite = [&]() {
+#pragma unroll
+        for (int it = 0; it < UIT; ++it) {
+            int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, pc = (sidx >> 2) * 4 + c_l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int row = pc * 8 + e;
+                *reinterpret_cast<short*>(ut + lds_rm_off(row, m >> 3) + (m & 7) * 2) = ur[it][e];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, qc = (sidx >> 2) * 4 + c_l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int row = qc * 8 + e;
+                *reinterpret_cast<short*>(vt + lds_rm_off(row, m >> 3) + (m & 7) * 2) = vr[it][e];
+            }
+        }
+    };
+
+    gload(s_begin);
+    for (int s = s_begin; s < s_end; ++s) {
+        twrite();
+        __syncthreads();
+        if (s + 1 < s_end) gload(s + 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s16x8 uf[TP], vf[TQ];
+#pragma unroll
+            for (int i = 0; i < TP; ++i) uf[i] = *reinterpret_cast<const s16x8*>(ut + lds_rm_off((wp * TP + i) * 32 + li, kk * 2 + g));
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) vf[j] = *reinterpret_cast<const s16x8*>(vt + lds_rm_off((wq * TQ + j) * 32 + li, kk * 2 + g));
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) acc[i][j] = mfma32(uf[i], vf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const int q = q0 + (wq * TQ + j) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = p0 + (wp * TP + i) * 32 + crow(r, g);
+                atomicAdd(a.C + (long)pp * a.ldc + q, acc[i][j][r] * a.scale);
+            }
+        }
+}
+
+int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
+    GemmTnArgs a = a0;
+    if (a.M <= 0) return 0;
+    if (a.P % 64 || a.Q % 64) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: P and Q must be multiples of 64");
+    if ((a.ldu % 8) || (a.ldv % 8)) return set_error(FTMI_ERR_INVALID, "gemm_tn: leading dimensions must keep 16-byte row alignment");
+    const int nsteps = (a.M + 63) / 64;
+    const bool wideP = (a.P % 128 == 0) && (a.P >= a.Q);
+    const bool wideQ = !wideP && (a.Q % 128 == 0);
+    const int bp = wideP ? 128 : 64, bq = wideP ? 64 : (wideQ ? 128 : 64);
+    if (a.v_grp_p > 0 && a.v_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: group width vs tile");
+    const int tiles = (a.P / bp) * (a.Q / bq);
+    int want = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
+    if (want < 1) want = 1;
+    int per = (nsteps + want - 1) / want;
+    if (per < 1) per = 1;
+    a.msteps_per_split = per;
+    const int nsplit = (nsteps + per - 1) / per;
+    const dim3 grid(tiles * nsplit);
+    if (wideP)
+        hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), (128 + 64) * 128, st, a);
+    else if (wideQ)
+        hipLaunchKernelGGL((gemm_tn_kernel<64, 128>), grid, dim3(256), (128 + 64) * 128, st, a);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, dim3(256), (64 + 64) * 128, st, a);
+    return check_launch("gemm_tn");
+}
+
+}  // namespace ftmi

@@ -1,0 +1,147 @@
+// Internal (C++) launcher interface of libftmi355.  The public C ABI is include/ftmi355.h; this
+// header is what api.hip and the DiT orchestrator (ltx_dit.hip) use to launch the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ftmi355.h"
+
+namespace ftmi {
+
+typedef uint16_t bf16_t;
+
+int set_error(int code, const char* msg);
+int check_launch(const char* what);
+
+enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3 };
+
+struct GemmNtArgs {
+    const bf16_t* X = nullptr;  // [M, ldx]
+    long ldx = 0;
+    const bf16_t* W = nullptr;  // [N, ldw]   (K-contiguous rows)
+    long ldw = 0;
+    int M = 0, N = 0, K = 0;
+    int xk_grp_n = 0;  // X column offset = (n0 / xk_grp_n) * xk_grp_stride   (grouped dXA of fused q,k,v)
+    long xk_grp_stride = 0;
+    // K-extension (fused LoRA up-projection): acc += X2 . W2^T after the base result was rounded to bf16
+    const bf16_t* X2 = nullptr;
+    long ldx2 = 0;
+    const bf16_t* W2 = nullptr;
+    long ldw2 = 0;
+    int K2 = 0;
+    int x2_grp_n = 0;  // X2 column offset = (n0 / x2_grp_n) * x2_grp_stride   (fused q,k,v: one XA slice per projection)
+    long x2_grp_stride = 0;
+    // epilogue
+    const bf16_t* bias = nullptr;  // [N]
+    float alpha = 1.f;
+    bf16_t* out = nullptr;
+    long ldo = 0;
+    bf16_t* out2 = nullptr;  // EPI_GELU: pre-activation z
+    long ldo2 = 0;
+    const bf16_t* resid = nullptr;  // EPI_RESID
+    long ldr = 0;
+    const bf16_t* gate = nullptr;  // EPI_RESID: gate[b * gate_bstride + n], b = m / rows_per_batch
+    long gate_bstride = 0;
+    int rows_per_batch = 0;
+    const bf16_t* aux = nullptr;  // EPI_DGELU: z
+    long ldaux = 0;
+    int epi = EPI_STORE;
+    int variant = 0;  // 0 = register-staged tiles, 1 = direct global->LDS
+};
+int gemm_nt(const GemmNtArgs& a, hipStream_t st);
+
+struct GemmTnArgs {
+    const bf16_t* U = nullptr;  // [M, ldu], P columns used
+    long ldu = 0;
+    const bf16_t* V = nullptr;  // [M, ldv], Q columns used
+    long ldv = 0;
+    float* C = nullptr;  // [P, ldc] fp32, accumulated with atomics
+    long ldc = 0;
+    int M = 0, P = 0, Q = 0;
+    int v_grp_p = 0;  // V column offset = (p0 / v_grp_p) * v_grp_stride
+    long v_grp_stride = 0;
+    int msteps_per_split = 0;  // filled by the launcher
+    float scale = 1.f;
+};
+int gemm_tn(const GemmTnArgs& a, hipStream_t st);
+
+// ---- attention -----------------------------------------------------------------------------------
+struct AttnArgs {
+    int B = 0, H = 0, Sq = 0, Sk = 0;  // head dim fixed at 64
+    // element strides (d contiguous)
+    const bf16_t* q = nullptr;
+    long q_sb = 0, q_sh = 0, q_ss = 0;
+    const bf16_t* k = nullptr;
+    long k_sb = 0, k_sh = 0, k_ss = 0;
+    const bf16_t* v = nullptr;
+    long v_sb = 0, v_sh = 0, v_ss = 0;
+    bf16_t* o = nullptr;  // forward output / backward input
+    long o_sb = 0, o_sh = 0, o_ss = 0;
+    float* lse2 = nullptr;        // [B, H, Sq] log2-domain log-sum-exp of the scaled scores
+    const float* kbias = nullptr;  // [B, Sk] additive key bias (natural units), may be null
+    float scale = 0.125f;
+    // backward only
+    const bf16_t* dout = nullptr;
+    long do_sb = 0, do_sh = 0, do_ss = 0;
+    float* delta = nullptr;  // [B, H, Sq]
+    bf16_t* dq = nullptr;
+    long dq_sb = 0, dq_sh = 0, dq_ss = 0;
+    bf16_t* dk = nullptr;
+    long dk_sb = 0, dk_sh = 0, dk_ss = 0;
+    bf16_t* dv = nullptr;
+    long dv_sb = 0, dv_sh = 0, dv_ss = 0;
+};
+int attn_fwd(const AttnArgs& a, hipStream_t st);
+int attn_bwd(const AttnArgs& a, hipStream_t st);  // delta pre-pass + dK/dV kernel + dQ kernel
+
+// ---- row-wise / elementwise ------------------------------------------------------------------------
+// ada[l][b][slot][D]: slots 0..5 = table[i] + temb[b][i] (shift_msa, scale_msa, gate_msa, shift_mlp,
+// scale_mlp, gate_mlp), 6 = 1 + scale_msa, 7 = 1 + scale_mlp (all rounded to bf16 like the eager graph)
+int ada_prep(const bf16_t* tables, const bf16_t* temb, bf16_t* ada, int L, int B, int D, hipStream_t st);
+// out table for the final norm: ada_out[b][slot][D]: 0 = shift, 1 = scale, 2 = 1 + scale
+int ada_out_prep(const bf16_t* table2, const bf16_t* emb, bf16_t* ada_out, int B, int D, hipStream_t st);
+
+// y = bf(bf(norm(x)) * onep[b]) + shift[b]   (norm = RMS (no affine) or LayerNorm (no affine))
+int norm_modulate_fwd(const bf16_t* x, const bf16_t* shift, const bf16_t* onep, long mod_bstride, bf16_t* y, int rows,
+                      int rows_per_batch, int D, float eps, int layernorm, hipStream_t st);
+// dx_out = (dres ? dres : 0) + norm_bwd(x, bf(dy * onep[b]))
+int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, long mod_bstride, const bf16_t* dres,
+                      bf16_t* dx, int rows, int rows_per_batch, int D, float eps, int layernorm, hipStream_t st);
+
+// affine RMSNorm over the full width (+ optional interleaved-pair RoPE), x row stride ldx
+int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, bf16_t* y, long ldy,
+                    int rows, int rows_per_batch, int D, float eps, hipStream_t st);
+int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy,
+                    long lddy, bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st);
+
+// out = bf(x * gate[b])
+int mul_gate(const bf16_t* x, const bf16_t* gate, long gate_bstride, bf16_t* out, int rows, int rows_per_batch, int D,
+             hipStream_t st);
+
+// latents [B,C,F*H*W] bf16 -> x_t, target packed [B, S, C]
+int noise_pack(const bf16_t* latents, const bf16_t* noise, const float* mean, const float* std_, const float* sigma,
+               const float* sigma_first, int first_frame_tokens, bf16_t* xt, bf16_t* target, int B, int C, int S,
+               hipStream_t st);
+
+// loss (fp32 scalar, accumulated) and dpred
+int mse_loss_fwd_bwd(const bf16_t* pred, const bf16_t* target, const float* weight, float* loss, bf16_t* dpred, int B,
+                     long per_sample, float grad_scale, hipStream_t st);
+
+// timestep sinusoid (256 channels, flip_sin_to_cos) of t = float(timestep)
+int timestep_sinusoid(const float* tval, bf16_t* out, int B, hipStream_t st);
+// y[r][n] = act_out(sum_k act_in(x[r][k]) W[n][k] + bias[n]);  rows <= 8
+int small_linear(const bf16_t* x, const bf16_t* W, const bf16_t* bias, bf16_t* y, int rows, int N, int K, int silu_in,
+                 int silu_out, hipStream_t st);
+
+// ---- optimiser ---------------------------------------------------------------------------------------
+int sumsq(const float* g, long n, float* out /* zeroed scalar */, hipStream_t st);
+int adamw_clip_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq_in, float max_norm, float lr,
+                    float beta1, float beta2, float eps, float wd, int step, float* grad_norm_out, hipStream_t st);
+// bf16 working copies of a LoRA matrix W [rows, cols] fp32: W_bf [rows, cols] and W^T_bf [cols, rows]
+int lora_refresh(const float* w, bf16_t* w_bf, bf16_t* wt_bf, int rows, int cols, int nmat, long in_bstride, long same_bstride,
+                 long t_bstride, hipStream_t st);
+// plain bf16 transpose [rows, cols] -> [cols, rows]
+int transpose_bf16(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t st);
+
+}  // namespace ftmi

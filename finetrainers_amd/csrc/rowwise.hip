@@ -1,0 +1,610 @@
+// HBM-bound kernels of the LTX-Video LoRA SFT step (gfx950): normalisation + AdaLN modulation,
+// QK-RMSNorm + RoPE, gate multiply, noising/patchify, loss, timestep embedding, and their backward.
+// Every kernel rounds through bf16 exactly where the reference's eager bf16 graph materialises a
+// tensor (each torch op = fp32 internal math, one rounding at its output), so fusing the chain into
+// one pass over HBM does not move rounding points.  All loads/stores are 16-byte vectors; one
+// 64-lane wavefront owns one token row and reduces with cross-lane shuffles (no LDS).
+//
+// Replaces (reference call sites): RMSNorm/LayerNorm + scale/shift of LTXVideoTransformerBlock and the
+// tail of patches/models/ltx_video/patch.py:118-123; patches/dependencies/diffusers/rms_norm.py:17-29;
+// apply_rotary_emb patch.py:23-33; models/ltx_video/base_specification.py:295-320,427-459;
+// functional/diffusion.py:4-11; trainer/sft_trainer/trainer.py:463-481 (loss).
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace ftmi {
+
+static constexpr int kNch = 4;  // 16-byte chunks per lane: row width 64 * 8 * 4 = 2048
+
+FTMI_DEVICE void unpack8(const s16x8& v, float (&f)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = bf2f((bf16_t)v[e]);
+}
+FTMI_DEVICE s16x8 pack8(const float (&f)[8]) {
+    s16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(f[e]);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void ada_prep_kernel(const bf16_t* __restrict__ tables, const bf16_t* __restrict__ temb, bf16_t* __restrict__ ada,
+                                int L, int B, int D) {
+    const long n = (long)L * B * D;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D);
+        const int b = (int)((idx / D) % B);
+        const int l = (int)(idx / ((long)D * B));
+        bf16_t* o = ada + ((long)(l * B + b) * 8) * D + d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float v = rbf(bf2f(tables[((long)l * 6 + i) * D + d]) + bf2f(temb[(long)b * 6 * D + (long)i * D + d]));
+            o[(long)i * D] = f2bf(v);
+            if (i == 1) o[(long)6 * D] = f2bf(1.0f + v);
+            if (i == 4) o[(long)7 * D] = f2bf(1.0f + v);
+        }
+    }
+}
+int ada_prep(const bf16_t* tables, const bf16_t* temb, bf16_t* ada, int L, int B, int D, hipStream_t st) {
+    const long n = (long)L * B * D;
+    hipLaunchKernelGGL(ada_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tables, temb, ada, L, B, D);
+    return check_launch("ada_prep");
+}
+
+__global__ void ada_out_prep_kernel(const bf16_t* __restrict__ table2, const bf16_t* __restrict__ emb, bf16_t* __restrict__ out, int B, int D) {
+    const long n = (long)B * D;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D), b = (int)(idx / D);
+        const float e = bf2f(emb[(long)b * D + d]);
+        const float shift = rbf(bf2f(table2[d]) + e);
+        const float scale = rbf(bf2f(table2[D + d]) + e);
+        bf16_t* o = out + (long)b * 3 * D + d;
+        o[0] = f2bf(shift);
+        o[D] = f2bf(scale);
+        o[2 * D] = f2bf(1.0f + scale);
+    }
+}
+int ada_out_prep(const bf16_t* table2, const bf16_t* emb, bf16_t* ada_out, int B, int D, hipStream_t st) {
+    const long n = (long)B * D;
+    hipLaunchKernelGGL(ada_out_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table2, emb, ada_out, B, D);
+    return check_launch("ada_out_prep");
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_modulate_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ shift,
+                                                                const bf16_t* __restrict__ onep, long mod_bstride,
+                                                                bf16_t* __restrict__ y, int rows, int rows_per_batch, float eps) {
+    constexpr int D = kNch * 512;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / rows_per_batch;
+    const bf16_t* xp = x + (long)row * D;
+    float xv[kNch][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        s16x8 raw = *reinterpret_cast<const s16x8*>(xp + (lane + 64 * it) * 8);
+        unpack8(raw, xv[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1 += xv[it][e];
+            s2 += xv[it][e] * xv[it][e];
+        }
+    }
+    float mean = 0.f, rstd;
+    if (LN) {
+        mean = wave_sum(s1) * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int it = 0; it < kNch; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float c = xv[it][e] - mean;
+                v += c * c;
+            }
+        rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
+    } else {
+        rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+    }
+    const bf16_t* sp = shift + (long)b * mod_bstride;
+    const bf16_t* op = onep + (long)b * mod_bstride;
+    bf16_t* yp = y + (long)row * D;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        const int off = (lane + 64 * it) * 8;
+        float sv[8], ov[8], o[8];
+        unpack8(*reinterpret_cast<const s16x8*>(sp + off), sv);
+        unpack8(*reinterpret_cast<const s16x8*>(op + off), ov);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float n = rbf((xv[it][e] - mean) * rstd);
+            o[e] = rbf(n * ov[e]) + sv[e];
+        }
+        *reinterpret_cast<s16x8*>(yp + off) = pack8(o);
+    }
+}
+int norm_modulate_fwd(const bf16_t* x, const bf16_t* shift, const bf16_t* onep, long mod_bstride, bf16_t* y, int rows,
+                      int rows_per_batch, int D, float eps, int layernorm, hipStream_t st) {
+    if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "norm_modulate: row width must be 2048");
+    dim3 grid((rows + 3) / 4);
+    if (layernorm)
+        hipLaunchKernelGGL(norm_modulate_fwd_kernel<true>, grid, dim3(256), 0, st, x, shift, onep, mod_bstride, y, rows, rows_per_batch, eps);
+    else
+        hipLaunchKernelGGL(norm_modulate_fwd_kernel<false>, grid, dim3(256), 0, st, x, shift, onep, mod_bstride, y, rows, rows_per_batch, eps);
+    return check_launch("norm_modulate_fwd");
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                const bf16_t* __restrict__ onep, long mod_bstride,
+                                                                const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int rows,
+                                                                int rows_per_batch, float eps) {
+    constexpr int D = kNch * 512;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = row / rows_per_batch;
+    const bf16_t* xp = x + (long)row * D;
+    const bf16_t* dyp = dy + (long)row * D;
+    const bf16_t* op = onep + (long)b * mod_bstride;
+    float xv[kNch][8], gv[kNch][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        const int off = (lane + 64 * it) * 8;
+        unpack8(*reinterpret_cast<const s16x8*>(xp + off), xv[it]);
+        float dv[8], ov[8];
+        unpack8(*reinterpret_cast<const s16x8*>(dyp + off), dv);
+        unpack8(*reinterpret_cast<const s16x8*>(op + off), ov);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gv[it][e] = rbf(dv[e] * ov[e]);  // grad w.r.t. the normalised tensor (a bf16 tensor in the eager graph)
+            s1 += xv[it][e];
+            s2 += xv[it][e] * xv[it][e];
+        }
+    }
+    float mean = 0.f, rstd;
+    if (LN) {
+        mean = wave_sum(s1) * (1.0f / D);
+        float v = 0.f;
+#pragma unroll
+        for (int it = 0; it < kNch; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float c = xv[it][e] - mean;
+                v += c * c;
+            }
+        rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
+    } else {
+        rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+    }
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xh = (xv[it][e] - mean) * rstd;
+            c1 += gv[it][e];
+            c2 += gv[it][e] * xh;
+        }
+    c1 = LN ? wave_sum(c1) * (1.0f / D) : 0.f;
+    c2 = wave_sum(c2) * (1.0f / D);
+    bf16_t* dxp = dx + (long)row * D;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        const int off = (lane + 64 * it) * 8;
+        float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8];
+        if (dres) unpack8(*reinterpret_cast<const s16x8*>(dres + (long)row * D + off), rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float xh = (xv[it][e] - mean) * rstd;
+            float d = rstd * (gv[it][e] - c1 - xh * c2);
+            o[e] = dres ? rv[e] + rbf(d) : d;
+        }
+        *reinterpret_cast<s16x8*>(dxp + off) = pack8(o);
+    }
+}
+int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, long mod_bstride, const bf16_t* dres, bf16_t* dx,
+                      int rows, int rows_per_batch, int D, float eps, int layernorm, hipStream_t st) {
+    if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "norm_modulate: row width must be 2048");
+    dim3 grid((rows + 3) / 4);
+    if (layernorm)
+        hipLaunchKernelGGL(norm_modulate_bwd_kernel<true>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps);
+    else
+        hipLaunchKernelGGL(norm_modulate_bwd_kernel<false>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps);
+    return check_launch("norm_modulate_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                              const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                              bf16_t* __restrict__ y, long ldy, int rows, int rows_per_batch, float eps) {
+    constexpr int D = kNch * 512;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int s = row % rows_per_batch;
+    const bf16_t* xp = x + (long)row * ldx;
+    float xv[kNch][8];
+    float s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        unpack8(*reinterpret_cast<const s16x8*>(xp + (lane + 64 * it) * 8), xv[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2 += xv[it][e] * xv[it][e];
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+    bf16_t* yp = y + (long)row * ldy;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        const int ch = lane + 64 * it;
+        float wv[8], n[8], o[8];
+        unpack8(*reinterpret_cast<const s16x8*>(w + ch * 8), wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) n[e] = rbf(xv[it][e] * rstd * wv[e]);
+        if (cos_t) {
+            f32x4 c = *reinterpret_cast<const f32x4*>(cos_t + (long)s * (D / 2) + ch * 4);
+            f32x4 sn = *reinterpret_cast<const f32x4*>(sin_t + (long)s * (D / 2) + ch * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[2 * k] = n[2 * k] * c[k] + (-n[2 * k + 1]) * sn[k];
+                o[2 * k + 1] = n[2 * k + 1] * c[k] + n[2 * k] * sn[k];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = n[e];
+        }
+        *reinterpret_cast<s16x8*>(yp + ch * 8) = pack8(o);
+    }
+}
+int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, bf16_t* y, long ldy,
+                    int rows, int rows_per_batch, int D, float eps, hipStream_t st) {
+    if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
+    if ((ldx % 8) || (ldy % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, y, ldy, rows, rows_per_batch, eps);
+    return check_launch("qknorm_rope_fwd");
+}
+
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                              const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                              const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
+                                                              int rows, int rows_per_batch, float eps) {
+    constexpr int D = kNch * 512;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int s = row % rows_per_batch;
+    const bf16_t* xp = x + (long)row * ldx;
+    const bf16_t* dyp = dy + (long)row * lddy;
+    float xv[kNch][8], gv[kNch][8];
+    float s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        const int ch = lane + 64 * it;
+        unpack8(*reinterpret_cast<const s16x8*>(xp + ch * 8), xv[it]);
+        float dv[8], wv[8], dn[8];
+        unpack8(*reinterpret_cast<const s16x8*>(dyp + ch * 8), dv);
+        unpack8(*reinterpret_cast<const s16x8*>(w + ch * 8), wv);
+        if (cos_t) {
+            f32x4 c = *reinterpret_cast<const f32x4*>(cos_t + (long)s * (D / 2) + ch * 4);
+            f32x4 sn = *reinterpret_cast<const f32x4*>(sin_t + (long)s * (D / 2) + ch * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // autograd of (x.float()*cos + rot(x).float()*sin).to(bf16): each branch's grad is cast to bf16
+                // before the two are accumulated (in bf16) into x's grad
+                dn[2 * k] = rbf(rbf(dv[2 * k] * c[k]) + rbf(dv[2 * k + 1] * sn[k]));
+                dn[2 * k + 1] = rbf(rbf(dv[2 * k + 1] * c[k]) + (-rbf(dv[2 * k] * sn[k])));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dn[e] = dv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gv[it][e] = dn[e] * wv[e];
+            s2 += xv[it][e] * xv[it][e];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+    float c2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c2 += gv[it][e] * (xv[it][e] * rstd);
+    c2 = wave_sum(c2) * (1.0f / D);
+    bf16_t* dxp = dx + (long)row * lddx;
+#pragma unroll
+    for (int it = 0; it < kNch; ++it) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[it][e] - (xv[it][e] * rstd) * c2);
+        *reinterpret_cast<s16x8*>(dxp + (lane + 64 * it) * 8) = pack8(o);
+    }
+}
+int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy, long lddy,
+                    bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st) {
+    if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
+    if ((ldx % 8) || (lddy % 8) || (lddx % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps);
+    return check_launch("qknorm_rope_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void mul_gate_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate, long gate_bstride, bf16_t* __restrict__ out,
+                                long nchunks, int chunks_per_row, int rows_per_batch) {
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long)gridDim.x * blockDim.x) {
+        const long row = c / chunks_per_row;
+        const int ch = (int)(c % chunks_per_row);
+        const int b = (int)(row / rows_per_batch);
+        float xv[8], gv[8], o[8];
+        unpack8(*reinterpret_cast<const s16x8*>(x + c * 8), xv);
+        unpack8(*reinterpret_cast<const s16x8*>(gate + (long)b * gate_bstride + ch * 8), gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = xv[e] * gv[e];
+        *reinterpret_cast<s16x8*>(out + c * 8) = pack8(o);
+    }
+}
+int mul_gate(const bf16_t* x, const bf16_t* gate, long gate_bstride, bf16_t* out, int rows, int rows_per_batch, int D, hipStream_t st) {
+    if (D % 8) return set_error(FTMI_ERR_UNSUPPORTED, "mul_gate: D % 8");
+    const long nchunks = (long)rows * (D / 8);
+    long blocks = (nchunks + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mul_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, gate, gate_bstride, out, nchunks, D / 8, rows_per_batch);
+    return check_launch("mul_gate");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// latents [B][C][S] -> (x_t, target) [B][S][C]:  normalise, flow-match mix, patchify (p = p_t = 1)
+__global__ __launch_bounds__(256) void noise_pack_kernel(const bf16_t* __restrict__ lat, const bf16_t* __restrict__ noise,
+                                                         const float* __restrict__ mean, const float* __restrict__ std_,
+                                                         const float* __restrict__ sigma, const float* __restrict__ sigma_first,
+                                                         int first_frame_tokens, bf16_t* __restrict__ xt, bf16_t* __restrict__ target,
+                                                         int C, int S) {
+    // tile: 64 channels x 64 tokens, LDS pitch 66 (2-byte elements) to spread the column reads
+    __shared__ bf16_t txt[64][66];
+    __shared__ bf16_t ttg[64][66];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, s0 = blockIdx.x * 64;
+    const float sg = sigma[b];
+    const float sgf = sigma_first ? sigma_first[b] : sg;
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int cl = idx >> 6, sl = idx & 63;
+        const int c = c0 + cl, s = s0 + sl;
+        bf16_t vx = 0, vt = 0;
+        if (c < C && s < S) {
+            const long off = ((long)b * C + c) * S + s;
+            const float x0 = rbf((bf2f(lat[off]) - mean[c]) * 1.0f / std_[c]);
+            const float n = bf2f(noise[off]);
+            const float t = (s < first_frame_tokens) ? sgf : sg;
+            vx = f2bf((1.0f - t) * x0 + t * n);
+            vt = f2bf(n - x0);
+        }
+        txt[cl][sl] = vx;
+        ttg[cl][sl] = vt;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+        const int sl = idx >> 6, cl = idx & 63;
+        const int c = c0 + cl, s = s0 + sl;
+        if (c < C && s < S) {
+            const long off = ((long)b * S + s) * C + c;
+            xt[off] = txt[cl][sl];
+            target[off] = ttg[cl][sl];
+        }
+    }
+}
+int noise_pack(const bf16_t* latents, const bf16_t* noise, const float* mean, const float* std_, const float* sigma,
+               const float* sigma_first, int first_frame_tokens, bf16_t* xt, bf16_t* target, int B, int C, int S, hipStream_t st) {
+    dim3 grid((S + 63) / 64, (C + 63) / 64, B);
+    hipLaunchKernelGGL(noise_pack_kernel, grid, dim3(256), 0, st, latents, noise, mean, std_, sigma, sigma_first, first_frame_tokens, xt,
+                       target, C, S);
+    return check_launch("noise_pack");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// loss = mean_b mean_{s,c} w_b (pred - target)^2 ; dpred = bf(2 w_b (pred - target) / (per_sample * B))
+__global__ __launch_bounds__(256) void mse_loss_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ target,
+                                                       const float* __restrict__ weight, float* __restrict__ loss, bf16_t* __restrict__ dpred,
+                                                       long per_sample, float inv_count, float grad_scale) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const float w = weight ? weight[b] : 1.0f;
+    const long nch = per_sample / 8;
+    float acc = 0.f;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += (long)gridDim.x * blockDim.x) {
+        const long off = (long)b * per_sample + c * 8;
+        float pv[8], tv[8], o[8];
+        unpack8(*reinterpret_cast<const s16x8*>(pred + off), pv);
+        unpack8(*reinterpret_cast<const s16x8*>(target + off), tv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = pv[e] - tv[e];
+            acc += w * (d * d);
+            o[e] = (w * (2.0f * d)) * grad_scale;
+        }
+        if (dpred) *reinterpret_cast<s16x8*>(dpred + off) = pack8(o);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+int mse_loss_fwd_bwd(const bf16_t* pred, const bf16_t* target, const float* weight, float* loss, bf16_t* dpred, int B, long per_sample,
+                     float grad_scale, hipStream_t st) {
+    if (per_sample % 8) return set_error(FTMI_ERR_UNSUPPORTED, "mse_loss: per-sample size % 8");
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (e != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "mse_loss: memset failed");
+    long blocks = (per_sample / 8 + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    const float inv_count = 1.0f / ((float)per_sample * (float)B);
+    hipLaunchKernelGGL(mse_loss_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, pred, target, weight, loss, dpred, per_sample, inv_count,
+                       inv_count * grad_scale);
+    return check_launch("mse_loss");
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void timestep_sinusoid_kernel(const float* __restrict__ tval, bf16_t* __restrict__ out, int B) {
+    const int b = blockIdx.x, k = threadIdx.x;  // 256 threads: [cos(128) | sin(128)]
+    if (b >= B) return;
+    const float t = tval[b];
+    const int j = k & 127;
+    const float freq = expf(-9.210340371976184f * (float)j / 128.0f);
+    const float a = t * freq;
+    out[(long)b * 256 + k] = f2bf(k < 128 ? cosf(a) : sinf(a));
+}
+int timestep_sinusoid(const float* tval, bf16_t* out, int B, hipStream_t st) {
+    hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3(B), dim3(256), 0, st, tval, out, B);
+    return check_launch("timestep_sinusoid");
+}
+
+// y[r][n] = bf(sum_k xin[r][k] W[n][k] + bias[n]),  xin = silu_in ? bf(silu(x)) : x ;  rows <= 8, one wave per n
+template <int R>
+__global__ __launch_bounds__(256) void small_linear_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W,
+                                                           const bf16_t* __restrict__ bias, bf16_t* __restrict__ y, int N, int K, int silu_in) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        float wv[8];
+        unpack8(*reinterpret_cast<const s16x8*>(W + (long)n * K + k), wv);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float xv[8];
+            unpack8(*reinterpret_cast<const s16x8*>(x + (long)r * K + k), xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float xin = silu_in ? rbf(silu_f(xv[e])) : xv[e];
+                acc[r] += xin * wv[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float s = wave_sum(acc[r]);
+        if (lane == 0) y[(long)r * N + n] = f2bf(s + (bias ? bf2f(bias[n]) : 0.f));
+    }
+}
+int small_linear(const bf16_t* x, const bf16_t* W, const bf16_t* bias, bf16_t* y, int rows, int N, int K, int silu_in, int silu_out,
+                 hipStream_t st) {
+    (void)silu_out;
+    if (K % 8) return set_error(FTMI_ERR_UNSUPPORTED, "small_linear: K % 8");
+    dim3 grid((N + 3) / 4);
+#define FTMI_SL(R)                                                                                             \
+    case R:                                                                                                    \
+        hipLaunchKernelGGL(small_linear_kernel<R>, grid, dim3(256), 0, st, x, W, bias, y, N, K, silu_in);      \
+        break;
+    switch (rows) {
+        FTMI_SL(1) FTMI_SL(2) FTMI_SL(3) FTMI_SL(4) FTMI_SL(5) FTMI_SL(6) FTMI_SL(7) FTMI_SL(8)
+        default:
+            return set_error(FTMI_ERR_UNSUPPORTED, "small_linear: rows must be 1..8");
+    }
+#undef FTMI_SL
+    return check_launch("small_linear");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// optimiser: global grad-norm clip + AdamW over the flat LoRA buffer (reference: utils/torch.py:99-161 clip,
+// torch.optim.AdamW(fused=False) via optimizer.py:117-125)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long i = n4 * 4; i < n; ++i) acc += g[i] * g[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+int sumsq(const float* g, long n, float* out, hipStream_t st) {
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, out);
+    return check_launch("sumsq");
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, const float* __restrict__ sumsq_in, float max_norm,
+                                                    float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    float* __restrict__ grad_norm_out) {
+    const float total_norm = sqrtf(*sumsq_in);
+    float coef = max_norm / (total_norm + 1e-6f);
+    coef = coef > 1.0f ? 1.0f : coef;
+    if (max_norm <= 0.f) coef = 1.0f;
+    if (grad_norm_out && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm_out = total_norm;
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);  // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+int adamw_clip_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq_in, float max_norm, float lr, float beta1,
+                    float beta2, float eps, float wd, int step, float* grad_norm_out, hipStream_t st) {
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq_in, max_norm, lr, beta1, beta2, eps, wd,
+                       bc1, bc2_sqrt, grad_norm_out);
+    return check_launch("adamw");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transposes (LoRA working copies; frozen-weight transposes for dgrad are made once at load time)
+template <typename TIN>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out_same, bf16_t* __restrict__ out_t,
+                                                             int rows, int cols, long in_bstride, long same_bstride, long t_bstride) {
+    __shared__ bf16_t tile[32][33];
+    in += (long)blockIdx.z * in_bstride;
+    if (out_same) out_same += (long)blockIdx.z * same_bstride;
+    out_t += (long)blockIdx.z * t_bstride;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        bf16_t v = 0;
+        if (r < rows && c < cols) {
+            if constexpr (sizeof(TIN) == 4)
+                v = f2bf((float)in[(long)r * cols + c]);
+            else
+                v = (bf16_t)in[(long)r * cols + c];
+            if (out_same) out_same[(long)r * cols + c] = v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) out_t[(long)c * rows + r] = tile[tx][i];
+    }
+}
+// nmat matrices [rows, cols] fp32 at stride in_bstride -> bf16 copies (same layout, may be null) and transposes
+int lora_refresh(const float* w, bf16_t* w_bf, bf16_t* wt_bf, int rows, int cols, int nmat, long in_bstride, long same_bstride,
+                 long t_bstride, hipStream_t st) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nmat);
+    hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, st, w, w_bf, wt_bf, rows, cols, in_bstride, same_bstride, t_bstride);
+    return check_launch("lora_refresh");
+}
+int transpose_bf16(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t st) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, 1);
+    hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, dim3(256), 0, st, in, (bf16_t*)nullptr, out, rows, cols, 0L, 0L, 0L);
+    return check_launch("transpose_bf16");
+}
+
+}  // namespace ftmi

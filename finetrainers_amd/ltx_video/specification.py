@@ -1,0 +1,173 @@
+"""``MI355XLTXVideoModelSpecification`` -- the ModelSpecification plugin for the MI355X LTX-Video backend.
+
+Mirrors the part of finetrainers' ``ModelSpecification`` interface the SFT step touches
+(finetrainers/models/modeling_utils.py:26-300; LTX implementation finetrainers/models/ltx_video/
+base_specification.py:93-459): ``_resolution_dim_keys``, ``load_diffusion_models``, ``collate_conditions``,
+``collate_latents`` and ``forward`` (same names, argument meaning and return convention).  Everything that
+feeds the step from outside the hot path (VAE / T5 loading, validation pipeline, saving) is out of scope for
+this backend and raises ``NotImplementedError`` -- the reference's own spec stays in charge of those.
+
+``forward`` = base_specification.py:271-345: normalise latents, draw noise, flow-match mix (with the 10 %
+first-frame conditioning branch), pack, timesteps, DiT call, target.  Normalise + mix + pack + target run in one
+gfx950 kernel (``ftmi_ltx_noise_pack``); the DiT runs in ``MI355XLTXVideoTransformer3DModel``.
+"""
+
+from __future__ import annotations
+
+import random
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from .. import ops
+from .transformer import LTXTransformerConfig, MI355XLTXVideoTransformer3DModel
+
+# finetrainers/models/modeling_utils.py:22
+IGNORE_KEYS_FOR_COLLATION = {"height", "width", "num_frames", "frame_rate", "rope_interpolation_scale", "return_dict", "attention_kwargs",
+                             "cross_attention_kwargs", "joint_attention_kwargs", "latents_mean", "latents_std"}
+
+
+class FlowMatchSigmas:
+    """The one thing the step needs from ``FlowMatchEulerDiscreteScheduler``: its sigma table
+    (1000 entries, 1.0 -> 0.001, shift 1.0) and ``config.num_train_timesteps``."""
+
+    class _Cfg:
+        num_train_timesteps = 1000
+
+    config = _Cfg()
+
+    def __init__(self, num_train_timesteps: int = 1000, shift: float = 1.0):
+        t = torch.linspace(1, num_train_timesteps, num_train_timesteps, dtype=torch.float32).flip(0)
+        s = t / num_train_timesteps
+        self.sigmas = shift * s / (1 + (shift - 1) * s)
+        self.config = type("Cfg", (), {"num_train_timesteps": num_train_timesteps})()
+
+
+class MI355XLTXVideoModelSpecification:
+    def __init__(self, transformer_config: Optional[LTXTransformerConfig] = None, transformer_dtype: torch.dtype = torch.bfloat16,
+                 gemm_variant: int = 0, **kwargs) -> None:
+        if transformer_dtype != torch.bfloat16:
+            raise ValueError("the MI355X backend computes in bf16 (fp32 accumulation); transformer_dtype must be torch.bfloat16")
+        self.transformer_dtype = transformer_dtype
+        self.transformer_config = transformer_config or LTXTransformerConfig()
+        self.gemm_variant = gemm_variant
+        self.first_frame_conditioning_p = 0.1  # base_specification.py:282
+        self.min_first_frame_sigma = 0.25      # base_specification.py:283
+
+    # modeling_utils.py:81-86 / ltx base_specification.py:131-133
+    @property
+    def _resolution_dim_keys(self) -> Dict[str, Tuple[int, ...]]:
+        return {"latents": (2, 3, 4)}
+
+    def load_diffusion_models(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, device: Optional[torch.device] = None,
+                              seed: int = 0) -> Dict[str, Any]:
+        """-> {"transformer": nn.Module, "scheduler": ...} (base_specification.py:173-190).  Weights come from a
+        diffusers-format state dict when given, else random init of the production architecture."""
+        transformer = MI355XLTXVideoTransformer3DModel(self.transformer_config, device=device, gemm_variant=self.gemm_variant)
+        if state_dict is not None:
+            transformer.load_diffusers_state_dict(state_dict)
+        else:
+            transformer.init_random_(seed)
+        return {"transformer": transformer, "scheduler": FlowMatchSigmas()}
+
+    def load_condition_models(self):
+        raise NotImplementedError("text encoders are outside the MI355X hot path; use the reference specification")
+
+    def load_latent_models(self):
+        raise NotImplementedError("the VAE is outside the MI355X hot path; use the reference specification")
+
+    @staticmethod
+    def _collate(data: List[Dict[str, Any]]) -> Dict[str, Any]:
+        """modeling_utils.py:156-181."""
+        keys = list(data[0].keys())
+        out = {}
+        for key in keys:
+            if key in IGNORE_KEYS_FOR_COLLATION:
+                out[key] = data[0][key]
+                continue
+            vals = [d[key] for d in data]
+            if isinstance(vals[0], torch.Tensor):
+                vals = torch.cat(vals)
+            out[key] = vals
+        return out
+
+    def collate_conditions(self, data):
+        return self._collate(data)
+
+    def collate_latents(self, data):
+        return self._collate(data)
+
+    def forward(
+        self,
+        transformer: MI355XLTXVideoTransformer3DModel,
+        condition_model_conditions: Dict[str, torch.Tensor],
+        latent_model_conditions: Dict[str, torch.Tensor],
+        sigmas: torch.Tensor,
+        generator: Optional[torch.Generator] = None,
+        compute_posterior: bool = True,
+        noise: Optional[torch.Tensor] = None,
+        first_frame_sigma: Optional[torch.Tensor] = None,
+        force_first_frame_branch: Optional[bool] = None,
+        **kwargs,
+    ) -> Tuple[torch.Tensor, ...]:
+        """Same contract as the reference: returns ``(pred, target, sigmas[B,S,1])``.
+
+        Extra keyword-only hooks for parity runs (the reference draws the branch from Python's global
+        RNG): ``noise`` injects the N(0,1) draw, ``first_frame_sigma`` ([B] fp32) injects the first-frame sigma,
+        ``force_first_frame_branch`` pins the 10 % branch on/off."""
+        if not compute_posterior:
+            raise NotImplementedError("precomputed latents (compute_posterior=True) are the supported SFT path")
+        latents = latent_model_conditions.pop("latents")
+        latents_mean = latent_model_conditions.pop("latents_mean")
+        latents_std = latent_model_conditions.pop("latents_std")
+        num_frames = latent_model_conditions.get("num_frames", latents.shape[2])
+        height = latent_model_conditions.get("height", latents.shape[3])
+        width = latent_model_conditions.get("width", latents.shape[4])
+        dev = latents.device
+        B, C = latents.shape[:2]
+        latents = latents.to(torch.bfloat16)
+        # per-channel statistics broadcast over the batch (evident intent of base_specification.py:427-436; identical
+        # to the reference at B == 1)
+        mean = latents_mean.reshape(-1)[:C].to(device=dev, dtype=torch.float32).contiguous()
+        std = latents_std.reshape(-1)[:C].to(device=dev, dtype=torch.float32).contiguous()
+        if noise is None:
+            noise = torch.zeros_like(latents).normal_(generator=generator)
+        sig = sigmas.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+        if sig.numel() != B:
+            raise ValueError("sigmas must hold one value per sample")
+
+        take_branch = force_first_frame_branch
+        if take_branch is None:
+            take_branch = first_frame_sigma is not None or random.random() < self.first_frame_conditioning_p
+        sig_first = None
+        tokens_first = 0
+        if take_branch:
+            if first_frame_sigma is None:
+                first_frame_sigma = torch.rand_like(sig) * sig
+            sig_first = torch.min(first_frame_sigma.reshape(-1).to(sig), sig.new_full(sig.shape, self.min_first_frame_sigma)).contiguous()
+            tokens_first = height * width  # tokens of latent frame 0 (patch size 1)
+
+        noisy, target = ops.noise_pack(latents, noise.to(torch.bfloat16), mean, std, sig, sig_first, tokens_first)
+        S = noisy.shape[1]
+        sigmas_bs1 = sig.view(-1, 1, 1).expand(-1, S, -1)
+        timesteps = (sig * 1000.0).long()  # one per sample; every token of a sample shares it (:319-320)
+
+        # base_specification.py:324-334
+        frame_rate, temporal_compression_ratio, vae_spatial_compression_ratio = 25, 8, 32
+        rope_interpolation_scale = [1 / (frame_rate / temporal_compression_ratio), vae_spatial_compression_ratio, vae_spatial_compression_ratio]
+
+        pred = transformer(
+            hidden_states=noisy,
+            encoder_hidden_states=condition_model_conditions["encoder_hidden_states"],
+            encoder_attention_mask=condition_model_conditions.get("encoder_attention_mask"),
+            timestep=timesteps,
+            num_frames=num_frames,
+            height=height,
+            width=width,
+            rope_interpolation_scale=rope_interpolation_scale,
+            return_dict=False,
+        )[0]
+        return pred, target, sigmas_bs1
+
+    def validation(self, *a, **k):
+        raise NotImplementedError("inference/validation is outside the MI355X hot path; use the reference specification")

@@ -1,0 +1,412 @@
+"""MI355X-native LTX-Video DiT behind the interface finetrainers' trainer expects of a transformer.
+
+``MI355XLTXVideoTransformer3DModel`` is an ``nn.Module`` whose ``forward`` has the signature of the
+reference's patched ``LTXVideoTransformer3DModel.forward`` (finetrainers/patches/models/ltx_video/
+patch.py:38-50) and whose backward yields LoRA gradients -- but the whole 28-block forward and backward
+run as hand-written gfx950 kernels launched by two C calls (``ftmi_ltx_forward`` / ``ftmi_ltx_backward``).
+
+HBM layout (designed for 288 GB, not ported from the reference's per-module parameters):
+  * frozen bf16 base weights are stacked per kind along a leading layer axis ([L,3D,D] fused q|k|v, ...)
+    and every weight that needs a dgrad also keeps a transposed copy, so forward and dgrad are the same
+    K-contiguous GEMM kernel (costs 1x extra weight memory, 3.6 GB);
+  * the 224 LoRA adapters live in two flat fp32 parameters ``lora_A`` [L,8,r,D] and ``lora_B`` [L,8,D,r]
+    (adapter order q,k,v,out of attn1 then attn2) -> one fused clip+AdamW launch and one contiguous
+    all-reduce; bf16 working copies (A, A^T, B, B^T) are refreshed after each optimiser step;
+  * all activations of a step live in one caller-owned workspace (about 0.37 GB per block at B=2).
+peft/diffusers-compatible names are provided by ``state_dict()`` / ``lora_state_dict()`` views.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+import re
+from dataclasses import dataclass
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from .._lib import LtxConfig, LtxWeights, check, ptr, stream_ptr
+
+bf16 = torch.bfloat16
+
+LORA_ORDER = ("attn1.to_q", "attn1.to_k", "attn1.to_v", "attn1.to_out.0", "attn2.to_q", "attn2.to_k", "attn2.to_v", "attn2.to_out.0")
+# finetrainers/trainer/sft_trainer/config.py:24-26
+DEFAULT_TARGET_MODULES = "(transformer_blocks|single_transformer_blocks).*(to_q|to_k|to_v|to_out.0)"
+
+
+@dataclass
+class LTXTransformerConfig:
+    """Hyper-parameters of LTXVideoTransformer3DModel (reference: tests/models/ltx_video/_test_tp.py:29-59)."""
+
+    in_channels: int = 128
+    out_channels: int = 128
+    patch_size: int = 1
+    patch_size_t: int = 1
+    num_attention_heads: int = 32
+    attention_head_dim: int = 64
+    cross_attention_dim: int = 2048
+    num_layers: int = 28
+    caption_channels: int = 4096
+    norm_eps: float = 1e-6
+    qk_norm_eps: float = 1e-5
+    ff_mult: int = 4
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+
+def ltx_rope_tables(num_frames: int, height: int, width: int, rope_interpolation_scale, dim: int = 2048,
+                    base_num_frames: int = 20, base_height: int = 2048, base_width: int = 2048, patch_size: int = 1,
+                    patch_size_t: int = 1, theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(cos, sin) per rotated pair, fp32 [S, dim/2], for one sample (identical across the batch).
+
+    Same arithmetic as upstream ``LTXVideoRotaryPosEmbed`` (always fp32).  The upstream tables are
+    [B,S,dim] with every frequency repeated for the two members of a pair and ``dim % 6`` leading
+    (cos=1, sin=0) pad columns; since dim % 6 == 2 the pad is exactly pair 0, so one value per pair
+    carries the same information.  Computed once per clip shape on the host and kept resident."""
+    if dim % 6 != 2:
+        raise ValueError("compact RoPE table assumes dim % 6 == 2 (LTX: 2048)")
+    grid_f = torch.arange(num_frames, dtype=torch.float32)
+    grid_h = torch.arange(height, dtype=torch.float32)
+    grid_w = torch.arange(width, dtype=torch.float32)
+    grid = torch.stack(torch.meshgrid(grid_f, grid_h, grid_w, indexing="ij"), dim=0).unsqueeze(0)
+    if rope_interpolation_scale is not None:
+        grid[:, 0:1] = grid[:, 0:1] * rope_interpolation_scale[0] * patch_size_t / base_num_frames
+        grid[:, 1:2] = grid[:, 1:2] * rope_interpolation_scale[1] * patch_size / base_height
+        grid[:, 2:3] = grid[:, 2:3] * rope_interpolation_scale[2] * patch_size / base_width
+    grid = grid.flatten(2, 4).transpose(1, 2)  # [1, S, 3]
+    freqs = theta ** torch.linspace(math.log(1.0, theta), math.log(theta, theta), dim // 6, dtype=torch.float32)
+    freqs = freqs * math.pi / 2.0
+    freqs = freqs * (grid.unsqueeze(-1) * 2 - 1)
+    freqs = freqs.transpose(-1, -2).flatten(2)[0]  # [S, 3 * (dim // 6)]
+    pad_c = torch.ones(freqs.shape[0], 1)
+    pad_s = torch.zeros(freqs.shape[0], 1)
+    cos = torch.cat([pad_c, freqs.cos()], dim=-1).contiguous()
+    sin = torch.cat([pad_s, freqs.sin()], dim=-1).contiguous()
+    return cos, sin
+
+
+class _LTXDiTFunction(torch.autograd.Function):
+    """One autograd node for the whole DiT: Python overhead is O(1) per step."""
+
+    @staticmethod
+    def forward(ctx, module, x_t, text, key_bias, tvals, cos, sin, lora_a, lora_b):
+        B, S, _ = x_t.shape
+        T = text.shape[1]
+        cfg = module._c_config(B, S, T)
+        weights = module._c_weights(cos, sin)
+        lib = _lib.load()
+        ws_bytes = lib.ftmi_ltx_workspace_bytes(ctypes.byref(cfg))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x_t.device)
+        pred = torch.empty((B, S, module.config.out_channels), dtype=bf16, device=x_t.device)
+        check(lib.ftmi_ltx_forward(ctypes.byref(cfg), ctypes.byref(weights), ptr(x_t), ptr(text), ptr(key_bias), ptr(tvals), ptr(pred),
+                                   ptr(ws), ws_bytes, stream_ptr()), "ftmi_ltx_forward")
+        ctx.module, ctx.cfg, ctx.weights, ctx.ws, ctx.ws_bytes = module, cfg, weights, ws, ws_bytes
+        ctx.keep = (x_t, text, key_bias, tvals, cos, sin)
+        module._last_workspace = (cfg, ws)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        module = ctx.module
+        if module.lora_A is None:
+            return (None,) * 9
+        dpred = dpred.contiguous()
+        # one flat fp32 gradient buffer [A | B]: a single contiguous all-reduce and a single clip+AdamW launch downstream
+        n_a = module.lora_A.numel()
+        gflat = torch.zeros(n_a + module.lora_B.numel(), dtype=torch.float32, device=dpred.device)
+        ga = gflat[:n_a].view_as(module.lora_A)
+        gb = gflat[n_a:].view_as(module.lora_B)
+        module._grad_flat = gflat
+        _, text, key_bias, _, _, _ = ctx.keep
+        check(_lib.load().ftmi_ltx_backward(ctypes.byref(ctx.cfg), ctypes.byref(ctx.weights), ptr(text), ptr(key_bias), ptr(dpred),
+                                             ptr(ga), ptr(gb), ptr(ctx.ws), ctx.ws_bytes, stream_ptr()), "ftmi_ltx_backward")
+        ctx.ws = None
+        return None, None, None, None, None, None, None, ga, gb
+
+
+class MI355XLTXVideoTransformer3DModel(nn.Module):
+    _FROZEN = {
+        # name: shape builder (cfg dims) ; filled in __init__
+    }
+
+    def __init__(self, config: Optional[LTXTransformerConfig] = None, device: Optional[torch.device] = None, gemm_variant: int = 0):
+        super().__init__()
+        self.config = config or LTXTransformerConfig()
+        c = self.config
+        if c.inner_dim != 2048 or c.attention_head_dim != 64 or c.patch_size != 1 or c.patch_size_t != 1:
+            raise ValueError("the MI355X kernels are built for LTX-Video's production geometry: width 2048 = 32 heads x 64, patch size 1")
+        self.gemm_variant = gemm_variant
+        self.gradient_checkpointing = False  # accepted for interface parity; activations fit HBM, nothing is recomputed
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        D, L, Dff, Dcap, Cin, Cout = c.inner_dim, c.num_layers, c.inner_dim * c.ff_mult, c.caption_channels, c.in_channels, c.out_channels
+        shapes = {
+            "proj_in_w": (D, Cin), "proj_in_b": (D,),
+            "time_l1_w": (D, 256), "time_l1_b": (D,), "time_l2_w": (D, D), "time_l2_b": (D,),
+            "time_lin_w": (6 * D, D), "time_lin_b": (6 * D,),
+            "cap_l1_w": (D, Dcap), "cap_l1_b": (D,), "cap_l2_w": (D, D), "cap_l2_b": (D,),
+            "tables": (L, 6, D), "table_out": (2, D),
+            "proj_out_w": (Cout, D), "proj_out_b": (Cout,), "proj_out_w_t": (D, Cout),
+            "w_qkv": (L, 3 * D, D), "b_qkv": (L, 3 * D), "w_qkv_t": (L, D, 3 * D),
+            "norm_q": (L, D), "norm_k": (L, D),
+            "w_o": (L, D, D), "b_o": (L, D), "w_o_t": (L, D, D),
+            "w_q2": (L, D, D), "b_q2": (L, D), "w_q2_t": (L, D, D),
+            "w_kv2": (L, 2 * D, D), "b_kv2": (L, 2 * D),
+            "norm_q2": (L, D), "norm_k2": (L, D),
+            "w_o2": (L, D, D), "b_o2": (L, D), "w_o2_t": (L, D, D),
+            "w_ff1": (L, Dff, D), "b_ff1": (L, Dff), "w_ff1_t": (L, D, Dff),
+            "w_ff2": (L, D, Dff), "b_ff2": (L, D), "w_ff2_t": (L, Dff, D),
+        }
+        self._frozen_names = list(shapes.keys())
+        for n, shp in shapes.items():
+            self.register_buffer(n, torch.zeros(shp, dtype=bf16, device=dev), persistent=False)
+        self.lora_A: Optional[nn.Parameter] = None
+        self.lora_B: Optional[nn.Parameter] = None
+        self.lora_rank = 0
+        self.lora_alpha = 0.0
+        self._lora_versions = None
+        self._rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._last_workspace = None
+        self._grad_flat = None
+        self.lora_flat = None
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def device(self) -> torch.device:
+        return self.proj_in_w.device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return bf16
+
+    @torch.no_grad()
+    def init_random_(self, seed: int = 0) -> "MI355XLTXVideoTransformer3DModel":
+        """Random-init weights of the production architecture (nn.Linear default init; tables randn/sqrt(D);
+        norm weights 1).  Used by bench.py / smoke (no checkpoints are reachable offline)."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        D = self.config.inner_dim
+        for n in self._frozen_names:
+            t = getattr(self, n)
+            if n.endswith("_t"):
+                continue
+            if n in ("tables", "table_out"):
+                t.copy_((torch.randn(t.shape, generator=g, device=self.device) / D**0.5).to(bf16))
+            elif n.startswith("norm_"):
+                t.fill_(1.0)
+            else:
+                fan_in = {"b_qkv": D, "b_o": D, "b_q2": D, "b_kv2": D, "b_o2": D, "b_ff1": D, "b_ff2": 4 * D, "proj_in_b": self.config.in_channels,
+                          "time_l1_b": 256, "time_l2_b": D, "time_lin_b": D, "cap_l1_b": self.config.caption_channels, "cap_l2_b": D,
+                          "proj_out_b": D}.get(n, t.shape[-1])
+                bound = 1.0 / math.sqrt(fan_in)
+                # chunked to bound temporary fp32 memory
+                flat = t.view(-1)
+                step = 1 << 26
+                for i in range(0, flat.numel(), step):
+                    m = min(step, flat.numel() - i)
+                    flat[i:i + m] = ((torch.rand(m, generator=g, device=self.device) * 2 - 1) * bound).to(bf16)
+        self._make_transposes()
+        return self
+
+    @torch.no_grad()
+    def _make_transposes(self) -> None:
+        L = self.config.num_layers
+        self.proj_out_w_t.copy_(ops.transpose_bf16(self.proj_out_w))
+        for name in ("w_qkv", "w_o", "w_q2", "w_o2", "w_ff1", "w_ff2"):
+            src, dst = getattr(self, name), getattr(self, name + "_t")
+            for l in range(L):
+                dst[l].copy_(ops.transpose_bf16(src[l]))
+
+    @torch.no_grad()
+    def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Load base weights from a diffusers-style ``LTXVideoTransformer3DModel`` state dict (peft-wrapped
+        ``.base_layer.`` names accepted).  LoRA tensors in ``sd`` are loaded too if an adapter exists."""
+        sd = {k.replace(".base_layer.", "."): v for k, v in sd.items()}
+        dev = self.device
+
+        def cp(dst, key):
+            dst.copy_(sd[key].to(device=dev, dtype=bf16))
+
+        cp(self.proj_in_w, "proj_in.weight"); cp(self.proj_in_b, "proj_in.bias")
+        cp(self.time_l1_w, "time_embed.emb.timestep_embedder.linear_1.weight"); cp(self.time_l1_b, "time_embed.emb.timestep_embedder.linear_1.bias")
+        cp(self.time_l2_w, "time_embed.emb.timestep_embedder.linear_2.weight"); cp(self.time_l2_b, "time_embed.emb.timestep_embedder.linear_2.bias")
+        cp(self.time_lin_w, "time_embed.linear.weight"); cp(self.time_lin_b, "time_embed.linear.bias")
+        cp(self.cap_l1_w, "caption_projection.linear_1.weight"); cp(self.cap_l1_b, "caption_projection.linear_1.bias")
+        cp(self.cap_l2_w, "caption_projection.linear_2.weight"); cp(self.cap_l2_b, "caption_projection.linear_2.bias")
+        cp(self.table_out, "scale_shift_table")
+        cp(self.proj_out_w, "proj_out.weight"); cp(self.proj_out_b, "proj_out.bias")
+        D = self.config.inner_dim
+        for l in range(self.config.num_layers):
+            p = f"transformer_blocks.{l}."
+            cp(self.tables[l], p + "scale_shift_table")
+            for i, t in enumerate(("to_q", "to_k", "to_v")):
+                cp(self.w_qkv[l, i * D:(i + 1) * D], p + f"attn1.{t}.weight")
+                cp(self.b_qkv[l, i * D:(i + 1) * D], p + f"attn1.{t}.bias")
+            cp(self.norm_q[l], p + "attn1.norm_q.weight"); cp(self.norm_k[l], p + "attn1.norm_k.weight")
+            cp(self.w_o[l], p + "attn1.to_out.0.weight"); cp(self.b_o[l], p + "attn1.to_out.0.bias")
+            cp(self.w_q2[l], p + "attn2.to_q.weight"); cp(self.b_q2[l], p + "attn2.to_q.bias")
+            for i, t in enumerate(("to_k", "to_v")):
+                cp(self.w_kv2[l, i * D:(i + 1) * D], p + f"attn2.{t}.weight")
+                cp(self.b_kv2[l, i * D:(i + 1) * D], p + f"attn2.{t}.bias")
+            cp(self.norm_q2[l], p + "attn2.norm_q.weight"); cp(self.norm_k2[l], p + "attn2.norm_k.weight")
+            cp(self.w_o2[l], p + "attn2.to_out.0.weight"); cp(self.b_o2[l], p + "attn2.to_out.0.bias")
+            cp(self.w_ff1[l], p + "ff.net.0.proj.weight"); cp(self.b_ff1[l], p + "ff.net.0.proj.bias")
+            cp(self.w_ff2[l], p + "ff.net.2.weight"); cp(self.b_ff2[l], p + "ff.net.2.bias")
+        self._make_transposes()
+        if self.lora_A is not None and any("lora_A" in k for k in sd):
+            self.load_lora_state_dict({k: v for k, v in sd.items() if "lora_" in k})
+
+    # ------------------------------------------------------------------ LoRA (peft-compatible surface)
+    def add_adapter(self, adapter_config=None, adapter_name: str = "default", *, r: Optional[int] = None, lora_alpha: Optional[float] = None,
+                    target_modules=None) -> None:
+        """Mirror of diffusers ``PeftAdapterMixin.add_adapter(LoraConfig(r, lora_alpha, init_lora_weights=True,
+        target_modules))`` as called at finetrainers/trainer/sft_trainer/trainer.py:121-128: A ~ kaiming-uniform(a=sqrt(5)),
+        B = 0, fp32 parameters."""
+        if adapter_config is not None:
+            r = getattr(adapter_config, "r", r)
+            lora_alpha = getattr(adapter_config, "lora_alpha", lora_alpha)
+            target_modules = getattr(adapter_config, "target_modules", target_modules)
+        if target_modules is not None:
+            pats = [target_modules] if isinstance(target_modules, str) else list(target_modules)
+            names = [f"transformer_blocks.0.{n}" for n in LORA_ORDER]
+            hit = [any(re.fullmatch(p, n) or re.search(p, n) for p in pats) for n in names]
+            if not all(hit):
+                raise ValueError("the MI355X LTX backend fuses LoRA into to_q/to_k/to_v/to_out.0 of attn1+attn2; "
+                                 f"target_modules={target_modules!r} does not cover exactly that set")
+        if r is None or r <= 0 or r % 64 != 0:
+            raise ValueError(f"LoRA rank must be a positive multiple of 64 for the gfx950 kernels, got {r}")
+        if self.lora_A is not None:
+            raise ValueError(f"adapter {adapter_name!r}: an adapter is already attached")
+        L, D = self.config.num_layers, self.config.inner_dim
+        n = L * 8 * r * D
+        # one flat fp32 buffer [A | B]; the two Parameters are views into it
+        self.lora_flat = torch.zeros(2 * n, dtype=torch.float32, device=self.device)
+        bound = math.sqrt(6.0 / ((1 + 5.0) * D))  # kaiming_uniform_(a=sqrt(5)) on [r, D]: bound = sqrt(6/((1+a^2) fan_in))
+        self.lora_flat[:n].uniform_(-bound, bound)
+        self.lora_A = nn.Parameter(self.lora_flat[:n].view(L, 8, r, D))
+        self.lora_B = nn.Parameter(self.lora_flat[n:].view(L, 8, D, r))
+        self.lora_rank, self.lora_alpha = int(r), float(lora_alpha if lora_alpha is not None else r)
+        for n, shp in (("lora_a_bf", (L, 8, r, D)), ("lora_at_bf", (L, 8, D, r)), ("lora_b_bf", (L, 8, D, r)), ("lora_bt_bf", (L, 8, r, D)),
+                       ("lora_at_qkv_bf", (L, D, 3 * r))):
+            self.register_buffer(n, torch.zeros(shp, dtype=bf16, device=self.device), persistent=False)
+        self._lora_versions = None
+
+    def lora_views(self) -> Iterable[Tuple[str, torch.Tensor, torch.Tensor]]:
+        """(module path, A view [r,D], B view [D,r]) for each of the L*8 adapters (views into the flat parameters)."""
+        for l in range(self.config.num_layers):
+            for i, n in enumerate(LORA_ORDER):
+                yield f"transformer_blocks.{l}.{n}", self.lora_A[l, i], self.lora_B[l, i]
+
+    def lora_state_dict(self, adapter_name: Optional[str] = None) -> Dict[str, torch.Tensor]:
+        """peft-format keys (what ``get_peft_model_state_dict`` returns: adapter name stripped)."""
+        out = {}
+        mid = f".{adapter_name}" if adapter_name else ""
+        for path, a, b in self.lora_views():
+            out[f"{path}.lora_A{mid}.weight"] = a
+            out[f"{path}.lora_B{mid}.weight"] = b
+        return out
+
+    @torch.no_grad()
+    def load_lora_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        sd = {k.replace(".default.", "."): v for k, v in sd.items()}
+        for path, a, b in self.lora_views():
+            a.copy_(sd[f"{path}.lora_A.weight"].to(a))
+            b.copy_(sd[f"{path}.lora_B.weight"].to(b))
+        self._lora_versions = None
+
+    def lora_grad_views(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        if self.lora_A is None or self.lora_A.grad is None:
+            return out
+        for l in range(self.config.num_layers):
+            for i, n in enumerate(LORA_ORDER):
+                out[f"transformer_blocks.{l}.{n}.lora_A.weight"] = self.lora_A.grad[l, i]
+                out[f"transformer_blocks.{l}.{n}.lora_B.weight"] = self.lora_B.grad[l, i]
+        return out
+
+    @torch.no_grad()
+    def refresh_lora_copies(self, force: bool = False) -> None:
+        if self.lora_A is None:
+            return
+        ver = (self.lora_A._version, self.lora_B._version, self.lora_A.data_ptr(), self.lora_B.data_ptr())
+        if not force and ver == self._lora_versions:
+            return
+        c = self.config
+        check(_lib.load().ftmi_lora_refresh(ptr(self.lora_A), ptr(self.lora_B), ptr(self.lora_a_bf), ptr(self.lora_at_bf), ptr(self.lora_b_bf),
+                                             ptr(self.lora_bt_bf), ptr(self.lora_at_qkv_bf), c.num_layers, self.lora_rank, c.inner_dim, stream_ptr()),
+              "ftmi_lora_refresh")
+        self._lora_versions = ver
+
+    # ------------------------------------------------------------------ C structs
+    def _c_config(self, B: int, S: int, T: int) -> LtxConfig:
+        c = self.config
+        return LtxConfig(B=B, S=S, T=T, D=c.inner_dim, H=c.num_attention_heads, L=c.num_layers, C_in=c.in_channels, C_out=c.out_channels,
+                         D_ff=c.inner_dim * c.ff_mult, D_cap=c.caption_channels, r=self.lora_rank,
+                         lora_scale=(self.lora_alpha / self.lora_rank) if self.lora_rank else 0.0, eps_norm=c.norm_eps, eps_qk=c.qk_norm_eps,
+                         gemm_variant=self.gemm_variant)
+
+    def _c_weights(self, cos: torch.Tensor, sin: torch.Tensor) -> LtxWeights:
+        w = LtxWeights()
+        for n in self._frozen_names:
+            setattr(w, n, getattr(self, n).data_ptr())
+        if self.lora_A is not None:
+            w.lora_a, w.lora_at = self.lora_a_bf.data_ptr(), self.lora_at_bf.data_ptr()
+            w.lora_b, w.lora_bt = self.lora_b_bf.data_ptr(), self.lora_bt_bf.data_ptr()
+            w.lora_at_qkv = self.lora_at_qkv_bf.data_ptr()
+        w.rope_cos, w.rope_sin = cos.data_ptr(), sin.data_ptr()
+        return w
+
+    def rope_tables(self, num_frames: int, height: int, width: int, rope_interpolation_scale) -> Tuple[torch.Tensor, torch.Tensor]:
+        key = (num_frames, height, width, None if rope_interpolation_scale is None else tuple(float(x) for x in rope_interpolation_scale))
+        if key not in self._rope_cache:
+            cos, sin = ltx_rope_tables(num_frames, height, width, rope_interpolation_scale, dim=self.config.inner_dim)
+            self._rope_cache[key] = (cos.to(self.device), sin.to(self.device))
+        return self._rope_cache[key]
+
+    # ------------------------------------------------------------------ forward (patch.py:38-50 signature)
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, timestep: torch.Tensor,
+                encoder_attention_mask: Optional[torch.Tensor], num_frames: int, height: int, width: int,
+                rope_interpolation_scale=None, return_dict: bool = True, *args, **kwargs):
+        if not hidden_states.is_cuda:
+            raise RuntimeError("MI355XLTXVideoTransformer3DModel runs on the GPU only (no CPU path)")
+        B, S, _ = hidden_states.shape
+        if S != num_frames * height * width:
+            raise ValueError(f"sequence length {S} != num_frames*height*width = {num_frames * height * width}")
+        x_t = hidden_states.to(bf16).contiguous()
+        text = encoder_hidden_states.to(bf16).contiguous()
+        T = text.shape[1]
+        # patch.py:55-57: mask -> additive bias, computed in the activations' dtype
+        if encoder_attention_mask is None:
+            key_bias = None
+        elif encoder_attention_mask.ndim == 2:
+            key_bias = ((1 - encoder_attention_mask.to(bf16)) * -10000.0).float().contiguous()
+        else:
+            key_bias = encoder_attention_mask.reshape(B, T).float().contiguous()
+        # every token of a sample shares its timestep in SFT (base_specification.py:319-320): one row per sample
+        if timestep.ndim == 1:
+            tvals = timestep.float().contiguous()
+        else:
+            tvals = timestep.reshape(B, -1)[:, 0].float().contiguous()
+        cos, sin = self.rope_tables(num_frames, height, width, rope_interpolation_scale)
+        self.refresh_lora_copies()
+        la = self.lora_A if self.lora_A is not None else None
+        lb = self.lora_B if self.lora_B is not None else None
+        out = _LTXDiTFunction.apply(self, x_t, text, key_bias, tvals, cos, sin, la, lb)
+        if not return_dict:
+            return (out,)
+        return {"sample": out}
+
+    # ------------------------------------------------------------------ debugging / tests
+    def workspace_tensor(self, name: str, layer: int, shape, dtype=bf16) -> torch.Tensor:
+        """View of a stashed activation of the most recent forward (tests / debugging only)."""
+        cfg, ws = self._last_workspace
+        off = ctypes.c_size_t(0)
+        check(_lib.load().ftmi_ltx_workspace_offset(ctypes.byref(cfg), name.encode(), layer, ctypes.byref(off)), "ftmi_ltx_workspace_offset")
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        return ws[off.value:off.value + nbytes].view(dtype).view(*shape)

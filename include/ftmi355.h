@@ -1,0 +1,176 @@
+/* libftmi355 -- MI355X (gfx950) native kernels for the finetrainers LTX-Video LoRA SFT step.
+ *
+ * C ABI: plain pointers (device memory unless stated), explicit sizes/strides, a HIP stream, caller-owned
+ * workspaces.  No allocation and no ownership inside the library; every call is stream-ordered (the library
+ * never synchronises the device) and re-entrant.  Return value: 0 = ok, negative = error (see FTMI_ERR_*),
+ * message via ftmi_last_error().
+ *
+ * The reference (a-r-r-o-w/finetrainers, pure Python) has no FFI; the entry points below sit behind its two
+ * plugin surfaces.  Each entry names the reference interface it replaces (paths relative to the reference
+ * tree):
+ *
+ *   ftmi_attn_fwd / ftmi_attn_bwd ...... a provider function of finetrainers/models/attention_dispatch.py:405-447
+ *                                        (contract :295-362; native provider :938-962) and its autograd backward
+ *   ftmi_ltx_forward / ftmi_ltx_backward the transformer call inside LTXVideoModelSpecification.forward
+ *                                        (finetrainers/models/ltx_video/base_specification.py:336-342), i.e.
+ *                                        _patched_LTXVideoTransformer3D_forward (finetrainers/patches/models/
+ *                                        ltx_video/patch.py:38-127) + loss.backward() through it
+ *                                        (finetrainers/trainer/sft_trainer/trainer.py:481)
+ *   ftmi_ltx_noise_pack ................ normalise / noise / flow-match mix / pack / target of
+ *                                        base_specification.py:295-320,343,427-459 + functional/diffusion.py:4-11
+ *   ftmi_mse_loss ...................... trainer/sft_trainer/trainer.py:463-480 (+ d loss / d pred)
+ *   ftmi_clip_adamw_step ............... utils/torch.py:99-161,299-374 (clip_grad_norm_) +
+ *                                        optimizer.py:117-125 (torch.optim.AdamW step) over the flat LoRA buffer
+ *   ftmi_lora_refresh .................. (new) bf16 working copies of the fp32 LoRA matrices after a step
+ *   ftmi_linear_lora_fwd ............... peft lora.Linear.forward over a frozen nn.Linear
+ *                                        (trainer/sft_trainer/trainer.py:121-136 injects them)
+ */
+#ifndef FTMI355_H
+#define FTMI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTMI_OK 0
+#define FTMI_ERR_INVALID (-1)     /* bad argument (ValueError on the Python side) */
+#define FTMI_ERR_UNSUPPORTED (-2) /* shape/dtype outside what the gfx950 kernels cover (ValueError) */
+#define FTMI_ERR_LAUNCH (-3)      /* HIP launch/runtime failure (RuntimeError) */
+
+typedef void* ftmi_stream; /* hipStream_t */
+
+int ftmi_version(void);
+/* Copies the message of the most recent failing call (process-wide slot, not thread-local) */
+int ftmi_last_error(char* buf, size_t len);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Attention provider level.  q,k,v,out,dout,dq,dk,dv: bf16, head_dim 64 contiguous; element (b,h,s,:) lives at
+ * base + b*stride[0] + h*stride[1] + s*stride[2] (strides in elements).  lse: fp32 [B,H,Sq] (log2 domain,
+ * written by fwd, read by bwd).  key_bias: optional fp32 [B,Sk] additive bias per key (attn_mask broadcast over
+ * heads and queries), NULL for none.  Non-causal, no dropout.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, H, Sq, Sk, d;
+    long q_strides[3], k_strides[3], v_strides[3], o_strides[3];
+    long do_strides[3], dq_strides[3], dk_strides[3], dv_strides[3]; /* backward only */
+    float scale;
+} ftmi_attn_desc;
+
+int ftmi_attn_fwd(const ftmi_attn_desc* desc, const void* q, const void* k, const void* v, void* out, float* lse,
+                  const float* key_bias, ftmi_stream stream);
+/* delta_ws: fp32 [B,H,Sq] scratch */
+int ftmi_attn_bwd(const ftmi_attn_desc* desc, const void* q, const void* k, const void* v, const void* out,
+                  const float* lse, const void* dout, void* dq, void* dk, void* dv, float* delta_ws,
+                  const float* key_bias, ftmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Linear (+ LoRA) building block:  y = bf16(x W^T + b) [+ lora_scale * (x A^T) B^T, re-rounded], bf16 operands.
+ * a_bf [r,K], b_bf [N,r] are the bf16 working copies of the fp32 LoRA matrices; xa_out [M,r] receives
+ * bf16(lora_scale * x A^T) (kept for the backward).  r == 0 => plain linear (a_bf, b_bf, xa_out may be NULL).
+ * ------------------------------------------------------------------------------------------------------------ */
+int ftmi_linear_lora_fwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* w, const void* bias,
+                         const void* a_bf, const void* b_bf, void* y, void* xa_out, int variant, ftmi_stream stream);
+
+/* Generic building blocks (exposed for tests / incremental adoption) */
+/* out[M,N] = bf16(alpha * x[M,K] w[N,K]^T + bias) ; epilogue: 0 store, 1 gelu-tanh (out2 <- pre-activation),
+ * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux) */
+int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha,
+                 void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
+                 const void* aux, int variant, ftmi_stream stream);
+/* c[P,Q] (fp32) += scale * u[M,P]^T v[M,Q] */
+int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, long ldv, float* c, long ldc, float scale,
+                 ftmi_stream stream);
+/* out[cols,rows] = in[rows,cols]^T (bf16); used once at load time for the dgrad copies of frozen weights */
+int ftmi_transpose_bf16(const void* in, void* out, int rows, int cols, ftmi_stream stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LTX-Video DiT level
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, S, T;      /* batch, video tokens / sample, text tokens / sample */
+    int D, H, L;      /* width (2048), heads (D/H must be 64), blocks */
+    int C_in, C_out;  /* latent channels (128) */
+    int D_ff, D_cap;  /* 8192, 4096 */
+    int r;            /* LoRA rank: 0 or a multiple of 64 */
+    float lora_scale; /* alpha / r */
+    float eps_norm;   /* 1e-6 (norm1 / norm2 / norm_out) */
+    float eps_qk;     /* 1e-5 (norm_q / norm_k) */
+    int gemm_variant; /* 0 register-staged tiles, 1 direct global->LDS */
+} ftmi_ltx_config;
+
+/* All weights bf16 unless noted.  Per-block tensors are stacked along a leading L dimension.  "*_t" are
+ * transposed copies (made once at load) so that every dgrad is the same K-contiguous GEMM as the forward.
+ * LoRA order inside a block: 0 attn1.to_q, 1 attn1.to_k, 2 attn1.to_v, 3 attn1.to_out.0,
+ *                            4 attn2.to_q, 5 attn2.to_k, 6 attn2.to_v, 7 attn2.to_out.0 */
+typedef struct {
+    const void *proj_in_w, *proj_in_b;                   /* [D,C_in] [D] */
+    const void *time_l1_w, *time_l1_b;                   /* [D,256] [D] */
+    const void *time_l2_w, *time_l2_b;                   /* [D,D] [D] */
+    const void *time_lin_w, *time_lin_b;                 /* [6D,D] [6D] */
+    const void *cap_l1_w, *cap_l1_b;                     /* [D,D_cap] [D] */
+    const void *cap_l2_w, *cap_l2_b;                     /* [D,D] [D] */
+    const void* tables;                                  /* [L,6,D] scale_shift_table of every block */
+    const void* table_out;                               /* [2,D] */
+    const void *proj_out_w, *proj_out_b, *proj_out_w_t;  /* [C_out,D] [C_out] [D,C_out] */
+    const void *w_qkv, *b_qkv, *w_qkv_t;                 /* [L,3D,D] [L,3D] [L,D,3D] */
+    const void *norm_q, *norm_k;                         /* [L,D] */
+    const void *w_o, *b_o, *w_o_t;                       /* [L,D,D] [L,D] [L,D,D] */
+    const void *w_q2, *b_q2, *w_q2_t;                    /* [L,D,D] [L,D] [L,D,D] */
+    const void *w_kv2, *b_kv2;                           /* [L,2D,D] [L,2D] */
+    const void *norm_q2, *norm_k2;                       /* [L,D] */
+    const void *w_o2, *b_o2, *w_o2_t;                    /* [L,D,D] [L,D] [L,D,D] */
+    const void *w_ff1, *b_ff1, *w_ff1_t;                 /* [L,D_ff,D] [L,D_ff] [L,D,D_ff] */
+    const void *w_ff2, *b_ff2, *w_ff2_t;                 /* [L,D,D_ff] [L,D] [L,D_ff,D] */
+    /* bf16 working copies of the LoRA matrices, refreshed by ftmi_lora_refresh */
+    const void* lora_a;      /* [L,8,r,D]  A          */
+    const void* lora_at;     /* [L,8,D,r]  A^T        */
+    const void* lora_b;      /* [L,8,D,r]  B          */
+    const void* lora_bt;     /* [L,8,r,D]  B^T        */
+    const void* lora_at_qkv; /* [L,D,3r]   [A_q;A_k;A_v]^T */
+    const float *rope_cos, *rope_sin; /* fp32 [S, D/2]: one (cos, sin) per rotated pair */
+} ftmi_ltx_weights;
+
+size_t ftmi_ltx_workspace_bytes(const ftmi_ltx_config* cfg);
+/* Byte offset of a named activation inside the workspace (for tests / debugging): global names "hs" (residual
+ * stream [L+1,B*S,D]; layer selects the slice), "e", "emb", "temb", "ada", "ada_out"; per-block names "n1", "qkv",
+ * "qrot", "krot", "o1", "lse1", "xa_qkv", "xa_o", "h1", "q2raw", "q2n", "kv2raw", "k2n", "o2", "lse2", "xa_q2",
+ * "xa_kv2", "xa_o2", "h2", "z". */
+int ftmi_ltx_workspace_offset(const ftmi_ltx_config* cfg, const char* name, int layer, size_t* offset);
+
+/* Forward of the DiT: x_t [B,S,C_in], text [B,T,D_cap], key_bias fp32 [B,T] ((1-mask) * -10000 as the reference
+ * builds it), timestep fp32 [B] (= float(long(sigma*1000)), base_specification.py:320; one per sample) -> pred [B,S,C_out].
+ * Activations needed by the backward are kept in ws. */
+int ftmi_ltx_forward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* x_t, const void* text,
+                     const float* key_bias, const float* timestep, void* pred, void* ws, size_t ws_bytes, ftmi_stream stream);
+
+/* Backward: dpred [B,S,C_out] bf16 -> LoRA gradients ACCUMULATED (+=) into fp32 grad_a [L,8,r,D] and grad_b [L,8,D,r]. */
+int ftmi_ltx_backward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias,
+                      const void* dpred, float* grad_a, float* grad_b, void* ws, size_t ws_bytes, ftmi_stream stream);
+
+/* latents, noise [B,C,F*H*W] bf16; mean,std fp32 [C]; sigma fp32 [B]; sigma_first fp32 [B] or NULL (first-frame
+ * conditioning branch: tokens < first_frame_tokens use it) -> x_t, target [B,S,C] bf16 */
+int ftmi_ltx_noise_pack(const void* latents, const void* noise, const float* mean, const float* std_, const float* sigma,
+                        const float* sigma_first, int first_frame_tokens, void* x_t, void* target, int B, int C, int S,
+                        ftmi_stream stream);
+
+/* loss (device fp32 scalar) = mean_b mean w_b (pred-target)^2 ; dpred = d(loss*grad_scale)/dpred (bf16), may be NULL */
+int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample,
+                  float grad_scale, ftmi_stream stream);
+
+/* Global L2 clip (max_norm <= 0 disables) + AdamW over flat fp32 buffers; scratch: >= 2 floats (device).
+ * grad_norm_out (device fp32, may be NULL) receives the pre-clip total norm. */
+int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, float* grad_norm_out,
+                         ftmi_stream stream);
+
+/* fp32 flat LoRA params (A region [L,8,r,D] then B region [L,8,D,r]) -> the bf16 working copies of ftmi_ltx_weights */
+int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a, void* lora_at, void* lora_b, void* lora_bt,
+                      void* lora_at_qkv, int L, int r, int D, ftmi_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTMI355_H */

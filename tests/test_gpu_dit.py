@@ -1,0 +1,245 @@
+"""End-to-end parity of the MI355X LTX-Video DiT (forward, loss, LoRA gradients, optimiser step) against
+the CPU oracle on identical noised latents + timesteps.  Also dumps every stashed activation's error so a
+failure localises to one kernel.  Run on the MI355X box: pytest -m gpu."""
+
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+# Stated tolerances (bf16 storage, fp32 accumulation; rounding points mirror the eager reference graph):
+LOSS_RTOL = 1e-3          # north_star: loss within 1e-3 relative
+GRAD_REL_L2 = 1e-2        # per-adapter LoRA-gradient relative L2 error (bf16 activations; see DESIGN.md "Parity")
+GRAD_GLOBAL_REL_L2 = 5e-3  # all LoRA gradients taken as one vector
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _oracle_trace(model, inp):
+    """Oracle forward with named intermediates of every block (restated from the oracle's own block forward)."""
+    from oracle import ltx
+
+    tr = {}
+    sig5 = inp.sigmas.view(-1, 1, 1, 1, 1)
+    lat = ltx.normalize_latents(inp.latents, inp.latents_mean, inp.latents_std)
+    if inp.first_frame_sigma is not None:
+        ffs = torch.min(inp.first_frame_sigma.view(-1, 1, 1, 1, 1), sig5.new_full(sig5.shape, 0.25))
+        noisy = torch.cat([ltx.flow_match_xt(lat[:, :, :1], inp.noise[:, :, :1], ffs), ltx.flow_match_xt(lat[:, :, 1:], inp.noise[:, :, 1:], sig5)], 2)
+    else:
+        noisy = ltx.flow_match_xt(lat, inp.noise, sig5)
+    x = ltx.pack_latents(noisy).to(lat)
+    B, S, _ = x.shape
+    F_, H_, W_ = inp.latents.shape[2:]
+    rope = model.rope(x, F_, H_, W_, [1 / (25 / 8), 32, 32])
+    mask = ((1 - inp.encoder_attention_mask.to(x.dtype)) * -10000.0).unsqueeze(1)
+    t = (inp.sigmas.view(-1, 1, 1).expand(-1, S, -1) * 1000.0).long()
+    temb, emb = model.time_embed(t.flatten(), batch_size=B, hidden_dtype=x.dtype)
+    temb, emb = temb.view(B, S, -1), emb.view(B, S, -1)
+    tr["temb"], tr["emb"] = temb[:, 0], emb[:, 0]
+    h = model.proj_in(x)
+    e = model.caption_projection(inp.encoder_hidden_states).view(B, -1, h.size(-1))
+    tr["e"] = e
+    for l, blk in enumerate(model.transformer_blocks):
+        tr[f"{l}.hs"] = h
+        n = blk.norm1(h)
+        ada = blk.scale_shift_table[None, None] + temb.reshape(B, S, 6, -1)
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = ada.unbind(dim=2)
+        n = n * (1 + scale_msa) + shift_msa
+        tr[f"{l}.n1"] = n
+        a1 = blk.attn1
+        qr, kr, vr = a1.to_q(n), a1.to_k(n), a1.to_v(n)
+        tr[f"{l}.qkv"] = torch.cat([qr, kr, vr], dim=-1)
+        q = ltx.apply_rotary_emb(a1.norm_q(qr), rope)
+        k = ltx.apply_rotary_emb(a1.norm_k(kr), rope)
+        tr[f"{l}.qrot"], tr[f"{l}.krot"] = q, k
+        sp = lambda z: z.unflatten(2, (a1.heads, -1)).transpose(1, 2)
+        o = ltx.sdpa_math(sp(q), sp(k), sp(vr), None).transpose(1, 2).flatten(2, 3)
+        tr[f"{l}.o1"] = o
+        h = h + a1.to_out[0](o) * gate_msa
+        tr[f"{l}.h1"] = h
+        a2 = blk.attn2
+        q2r = a2.to_q(h)
+        tr[f"{l}.q2raw"] = q2r
+        q2 = a2.norm_q(q2r)
+        tr[f"{l}.q2n"] = q2
+        k2r, v2r = a2.to_k(e), a2.to_v(e)
+        tr[f"{l}.kv2raw"] = torch.cat([k2r, v2r], dim=-1)
+        k2 = a2.norm_k(k2r)
+        tr[f"{l}.k2n"] = k2
+        am = mask.repeat_interleave(a2.heads, dim=0).view(B, a2.heads, -1, mask.shape[-1])
+        o2 = ltx.sdpa_math(sp(q2), sp(k2), sp(v2r), am).transpose(1, 2).flatten(2, 3)
+        tr[f"{l}.o2"] = o2
+        h = h + a2.to_out[0](o2)
+        tr[f"{l}.h2"] = h
+        n2 = blk.norm2(h) * (1 + scale_mlp) + shift_mlp
+        z = blk.ff.net[0].proj(n2)
+        tr[f"{l}.z"] = z
+        h = h + blk.ff.net[2](torch.nn.functional.gelu(z, approximate="tanh")) * gate_mlp
+    tr[f"{len(model.transformer_blocks)}.hs"] = h
+    return tr
+
+
+def _build(num_layers, B, F_, H_, W_, first_frame, seed):
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
+    from oracle import ltx
+
+    cfg = ltx.LTXConfig.production(num_layers=num_layers)
+    omodel = ltx.build_model(cfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
+    mask_lens = [32, 96][:B]
+    inp = ltx.synth_inputs(cfg, B, F_, H_, W_, seed=seed, mask_lens=mask_lens, sigmas=[0.25, 0.7][:B])
+    inp.latents_mean = torch.randn(cfg.in_channels, generator=torch.Generator().manual_seed(5)) * 0.1
+    inp.latents_std = 1.0 + 0.2 * torch.rand(cfg.in_channels, generator=torch.Generator().manual_seed(6))
+    if first_frame:
+        inp.first_frame_sigma = torch.tensor([0.1, 0.6][:B])
+    spec = MI355XLTXVideoModelSpecification(LTXTransformerConfig(num_layers=num_layers))
+    gmodel = spec.load_diffusion_models(state_dict=omodel.state_dict(), device=_dev())["transformer"]
+    gmodel.add_adapter(r=64, lora_alpha=64)
+    gmodel.load_lora_state_dict({k: v for k, v in omodel.state_dict().items() if "lora_" in k})
+    return cfg, omodel, inp, spec, gmodel
+
+
+def _gpu_forward(spec, gmodel, inp):
+    dev = _dev()
+    pred, target, sig = spec.forward(
+        transformer=gmodel,
+        condition_model_conditions={"encoder_hidden_states": inp.encoder_hidden_states.to(dev), "encoder_attention_mask": inp.encoder_attention_mask.to(dev)},
+        latent_model_conditions={"latents": inp.latents.to(dev), "latents_mean": inp.latents_mean, "latents_std": inp.latents_std,
+                                 "num_frames": inp.latents.shape[2], "height": inp.latents.shape[3], "width": inp.latents.shape[4]},
+        sigmas=inp.sigmas.view(-1, 1, 1, 1, 1).to(dev),
+        noise=inp.noise.to(dev),
+        first_frame_sigma=None if inp.first_frame_sigma is None else inp.first_frame_sigma.to(dev),
+        force_first_frame_branch=inp.first_frame_sigma is not None,
+    )
+    return pred, target, sig
+
+
+CASES = [
+    # layers, B, F, H, W, first_frame
+    (2, 1, 2, 4, 4, False),   # BASELINE config 1 geometry (9x128x128 clip -> 32 tokens), 2 blocks
+    (2, 2, 3, 4, 6, True),    # batch 2, ragged text masks {32, 96}, first-frame conditioning branch
+    (1, 2, 2, 8, 10, False),  # 160 tokens: spans two 128-row GEMM tiles and several attention tiles
+]
+
+
+@pytest.mark.parametrize("num_layers,B,F_,H_,W_,first_frame", CASES)
+def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
+    from finetrainers_amd.trainer import sft_loss
+    from oracle import ltx
+
+    cfg, omodel, inp, spec, gmodel = _build(num_layers, B, F_, H_, W_, first_frame, seed=3)
+    S = F_ * H_ * W_
+    D = 2048
+
+    # ---- oracle ----
+    loss_ref, pred_ref, target_ref = ltx.forward_loss(omodel, inp)
+    loss_ref.backward()
+    grads_ref = {n.replace(".default", ""): p.grad for n, p in ltx.lora_parameters(omodel)}
+    with torch.no_grad():
+        trace = _oracle_trace(omodel, inp)
+
+    # ---- MI355X ----
+    pred, target, sig = _gpu_forward(spec, gmodel, inp)
+    loss = sft_loss(pred, target, sig, "none")
+    loss.backward()
+    torch.cuda.synchronize()
+
+    rows = []
+    T = cfg.text_seq_len
+    shapes = {"n1": (B * S, D), "qkv": (B * S, 3 * D), "qrot": (B * S, D), "krot": (B * S, D), "o1": (B * S, D), "h1": (B * S, D),
+              "q2raw": (B * S, D), "q2n": (B * S, D), "kv2raw": (B * T, 2 * D), "k2n": (B * T, D), "o2": (B * S, D), "h2": (B * S, D),
+              "z": (B * S, 4 * D)}
+    worst = 0.0
+    for name, shp in (("temb", (B, 6 * D)), ("emb", (B, D)), ("e", (B * T, D))):
+        err = rel_l2(gmodel.workspace_tensor(name, 0, shp), trace[name].reshape(shp))
+        rows.append((name, err))
+    for l in range(num_layers):
+        err = rel_l2(gmodel.workspace_tensor("hs", l, (B * S, D)), trace[f"{l}.hs"].reshape(B * S, D))
+        rows.append((f"{l}.hs", err))
+        for name, shp in shapes.items():
+            err = rel_l2(gmodel.workspace_tensor(name, l, shp), trace[f"{l}.{name}"].reshape(shp))
+            rows.append((f"{l}.{name}", err))
+    rows.append((f"{num_layers}.hs", rel_l2(gmodel.workspace_tensor("hs", num_layers, (B * S, D)), trace[f"{num_layers}.hs"].reshape(B * S, D))))
+    for n, e in rows:
+        print(f"[dit-trace] {n:12s} rel_l2={e:.3e}")
+        worst = max(worst, e)
+
+    pred_err = rel_l2(pred, pred_ref)
+    tgt_equal = torch.equal(target.cpu(), target_ref)
+    loss_rel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    print(f"[dit] pred rel_l2={pred_err:.3e} target_equal={tgt_equal} loss={loss.item():.6f} ref={loss_ref.item():.6f} rel={loss_rel:.3e}")
+
+    gv = gmodel.lora_grad_views()
+    per = {}
+    num = den = 0.0
+    for k, gr in grads_ref.items():
+        gg = gv[k].float().cpu()
+        per[k] = rel_l2(gg, gr)
+        num += (gg - gr.float()).pow(2).sum().item()
+        den += gr.float().pow(2).sum().item()
+        print(f"[dit-grad] {k:58s} rel_l2={per[k]:.3e} |g|={gr.norm().item():.3e}")
+    glob = (num / den) ** 0.5
+    print(f"[dit] global LoRA-grad rel_l2={glob:.3e} worst adapter={max(per.values()):.3e}")
+
+    out_dir = os.environ.get("FTMI_REPORT_DIR", "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, f"parity_L{num_layers}_B{B}_S{S}.json"), "w") as f:
+            json.dump({"trace": rows, "pred_rel_l2": pred_err, "loss": loss.item(), "loss_ref": loss_ref.item(), "loss_rel": loss_rel,
+                       "grad_global_rel_l2": glob, "grad_per_adapter": per}, f, indent=1)
+    except OSError:
+        pass
+
+    assert tgt_equal, "flow-match target must be bit-exact"
+    assert worst < 2e-2, f"an activation diverged (worst rel_l2 {worst:.3e})"
+    assert pred_err < 1e-2
+    assert loss_rel < LOSS_RTOL, f"loss {loss.item()} vs oracle {loss_ref.item()}"
+    assert glob < GRAD_GLOBAL_REL_L2, f"global LoRA gradient error {glob:.3e}"
+    assert max(per.values()) < GRAD_REL_L2, f"worst per-adapter LoRA gradient error {max(per.values()):.3e}"
+
+
+def test_full_step_matches_oracle_step():
+    """forward + loss + backward + clip + AdamW: updated LoRA parameters vs the oracle's torch.optim.AdamW step."""
+    from finetrainers_amd.trainer import MI355XSFTStep
+    from oracle import ltx
+
+    cfg, omodel, inp, spec, gmodel = _build(1, 2, 2, 4, 4, False, seed=11)
+    opt = ltx.make_optimizer(omodel, lr=5e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4)
+    before = {n.replace(".default", ""): p.detach().clone() for n, p in ltx.lora_parameters(omodel)}
+    loss_ref, gn_ref, _ = ltx.sft_step(omodel, opt, inp, max_grad_norm=1.0)
+
+    step = MI355XSFTStep(gmodel, spec, lr=5e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, max_grad_norm=1.0)
+    dev = _dev()
+    out = step.step(
+        condition_model_conditions={"encoder_hidden_states": inp.encoder_hidden_states.to(dev), "encoder_attention_mask": inp.encoder_attention_mask.to(dev)},
+        latent_model_conditions={"latents": inp.latents.to(dev), "latents_mean": inp.latents_mean, "latents_std": inp.latents_std},
+        sigmas=inp.sigmas.to(dev), noise=inp.noise.to(dev), force_first_frame_branch=False,
+    )
+    torch.cuda.synchronize()
+    loss, gn = out["loss"].item(), out["grad_norm"].item()
+    print(f"[step] loss {loss:.6f} vs {loss_ref.item():.6f}; grad_norm {gn:.6e} vs {gn_ref.item():.6e}")
+    assert abs(loss - loss_ref.item()) / abs(loss_ref.item()) < LOSS_RTOL
+    assert abs(gn - gn_ref.item()) / gn_ref.item() < 5e-3
+    after = gmodel.lora_state_dict()
+    num = den = 0.0
+    for n, p in ltx.lora_parameters(omodel):
+        k = n.replace(".default", "")
+        d_ref = (p.detach() - before[k]).float()
+        d_got = (after[k].detach().cpu() - before[k]).float()
+        num += (d_got - d_ref).pow(2).sum().item()
+        den += d_ref.pow(2).sum().item()
+    upd = (num / max(den, 1e-30)) ** 0.5
+    print(f"[step] parameter-update rel_l2 = {upd:.3e}")
+    # AdamW's first step is sign-like (m/sqrt(v) = +-1): only gradient entries that are ~0 can flip
+    assert upd < 5e-2
