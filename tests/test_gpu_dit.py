@@ -48,6 +48,8 @@ def _oracle_trace(model, inp):
     temb, emb = model.time_embed(t.flatten(), batch_size=B, hidden_dtype=x.dtype)
     temb, emb = temb.view(B, S, -1), emb.view(B, S, -1)
     tr["temb"], tr["emb"] = temb[:, 0], emb[:, 0]
+    tr["tsin"] = model.time_embed.emb.time_proj(t[:, 0, 0]).to(x.dtype)
+    tr["xt"] = x
     h = model.proj_in(x)
     e = model.caption_projection(inp.encoder_hidden_states).view(B, -1, h.size(-1))
     tr["e"] = e
@@ -161,7 +163,7 @@ def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
               "q2raw": (B * S, D), "q2n": (B * S, D), "kv2raw": (B * T, 2 * D), "k2n": (B * T, D), "o2": (B * S, D), "h2": (B * S, D),
               "z": (B * S, 4 * D)}
     worst = 0.0
-    for name, shp in (("temb", (B, 6 * D)), ("emb", (B, D)), ("e", (B * T, D))):
+    for name, shp in (("tsin", (B, 256)), ("temb", (B, 6 * D)), ("emb", (B, D)), ("e", (B * T, D))):
         err = rel_l2(gmodel.workspace_tensor(name, 0, shp), trace[name].reshape(shp))
         rows.append((name, err))
     for l in range(num_layers):
@@ -175,6 +177,12 @@ def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
         print(f"[dit-trace] {n:12s} rel_l2={e:.3e}")
         worst = max(worst, e)
 
+    from finetrainers_amd import ops as _ops
+    dev = _dev()
+    ffd = None if inp.first_frame_sigma is None else torch.min(inp.first_frame_sigma, torch.full_like(inp.first_frame_sigma, 0.25)).to(dev)
+    xt_g, _ = _ops.noise_pack(inp.latents.to(dev), inp.noise.to(dev), inp.latents_mean.to(dev), inp.latents_std.to(dev), inp.sigmas.to(dev), ffd,
+                              H_ * W_ if ffd is not None else 0)
+    print(f"[dit] x_t equal={torch.equal(xt_g.cpu(), trace['xt'])} rel_l2={rel_l2(xt_g, trace['xt']):.3e}")
     pred_err = rel_l2(pred, pred_ref)
     tgt_equal = torch.equal(target.cpu(), target_ref)
     loss_rel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())

@@ -2,6 +2,7 @@
 # One gpurun call: probes + GPU parity tests, everything logged under gpurun_out/.
 mkdir -p gpurun_out
 export FTMI_REPORT_DIR=gpurun_out
+python -m finetrainers_amd.csrc.build > gpurun_out/build.log 2>&1 || { echo BUILD FAILED; tail -20 gpurun_out/build.log; exit 1; }
 rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 > gpurun_out/rocminfo.txt
 nproc > gpurun_out/nproc.txt
 timeout 60 ./tools/probe_tr16 > gpurun_out/probe_tr16.txt 2>&1
