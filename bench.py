@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- LTX-Video LoRA SFT step on MI355X (BASELINE.json metric: train samples/sec + step ms,
+49x512x768 clip, batch 2 per GPU, rank-64 LoRA, bf16, at 1/2/4/8 GPUs).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full optimisation step of the reference's SFTTrainer._train body on synthetic latents already
+resident in HBM: noise/flow-match mix/pack -> 28-block DiT forward -> weighted MSE -> backward (LoRA grads) ->
+[DP: all-reduce of the flat LoRA gradient over RCCL] -> global-norm clip -> AdamW -> refresh of the bf16 LoRA copies.
+Nothing is skipped or cached between steps; weights are random-init of the production architecture (no checkpoints
+are reachable offline).  Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per sample (multiply-add = 2), SURVEY section 8d / BASELINE.md: no activation recompute
+STEP_TFLOP_PER_SAMPLE = 24.93
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (BASELINE configs[1]: 2)")
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--rank", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=7, help="latent frames  (49 px frames / 8 + 1)")
+    ap.add_argument("--height", type=int, default=16, help="latent height (512 / 32)")
+    ap.add_argument("--width", type=int, default=24, help="latent width  (768 / 32)")
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("FTMI_GEMM_VARIANT", "1")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-layers", type=int, default=2)
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events inside the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The reference path (its CPU restatement, oracle/ltx.py) timed on this box's host cores: one forward+backward+
+    clip+AdamW step at the SAME clip shape and width, batch 1, on a bounded number of DiT blocks, scaled linearly to 28
+    blocks (blocks are identical; embeddings/tail are <1 % of the work)."""
+    from oracle import ltx
+
+    torch.manual_seed(0)
+    nl = args.cpu_baseline_layers
+    cfg = ltx.LTXConfig.production(num_layers=nl)
+    model = ltx.build_model(cfg, seed=0, rank=args.rank, alpha=float(args.rank))
+    opt = ltx.make_optimizer(model)
+    inp = ltx.synth_inputs(cfg, 1, args.frames, args.height, args.width, seed=1, mask_lens=[32], sigmas=[0.7])
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    ltx.sft_step(model, opt, inp)
+    dt = time.time() - t0
+    per_sample_full = dt * (28.0 / nl)
+    return {
+        "value": 1.0 / per_sample_full,
+        "unit": "samples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle (CPU restatement of the reference step, bf16 storage) 1 step, batch 1, clip 49x512x768 "
+                  f"(2688 tokens), {nl} of 28 blocks timed = {dt:.1f} s, scaled x{28 // nl if 28 % nl == 0 else 28 / nl:g} to 28 blocks",
+        "step_s_measured": dt,
+    }
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the MI355X backend has no CPU path)")
+
+    from finetrainers_amd import _lib
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
+    from finetrainers_amd.parallel import DataParallelBackend
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    par = DataParallelBackend()
+    if par.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={par.world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = par.device
+    lib = _lib.load()
+
+    tcfg = LTXTransformerConfig(num_layers=args.layers)
+    spec = MI355XLTXVideoModelSpecification(tcfg, gemm_variant=args.gemm_variant)
+    model = spec.load_diffusion_models(device=dev, seed=0)["transformer"]  # identical weights on every rank
+    model.add_adapter(r=args.rank, lora_alpha=float(args.rank))
+    with torch.no_grad():  # same LoRA init on every rank; B != 0 so every gradient path carries real data
+        g = torch.Generator(device=dev).manual_seed(1)
+        model.lora_flat.copy_(torch.randn(model.lora_flat.shape, generator=g, device=dev) * 0.01)
+    step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, max_grad_norm=1.0, parallel=par,
+                         generator=torch.Generator(device=dev).manual_seed(1234 + par.rank))
+
+    # synthetic batch of the named clip shape, different data per rank (seed + rank), resident in HBM
+    B, C = args.batch, tcfg.in_channels
+    gd = torch.Generator(device=dev).manual_seed(100 + par.rank)
+    latents = torch.randn((B, C, args.frames, args.height, args.width), generator=gd, device=dev).to(torch.bfloat16)
+    text = torch.randn((B, 128, tcfg.caption_channels), generator=gd, device=dev).to(torch.bfloat16)
+    mask = torch.zeros((B, 128), dtype=torch.bfloat16, device=dev)
+    for i in range(B):
+        mask[i, : (32 if i % 2 == 0 else 96)] = 1
+    cond = {"encoder_hidden_states": text, "encoder_attention_mask": mask}
+    lat = {"latents": latents, "latents_mean": torch.zeros(C, device=dev), "latents_std": torch.ones(C, device=dev),
+           "num_frames": args.frames, "height": args.height, "width": args.width}
+
+    def one_step():
+        return step.step(cond, lat)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    par.wait_for_everyone()
+    torch.cuda.synchronize()
+
+    prof = not args.no_prof
+    if prof:
+        for k in range(4):
+            lib.ftmi_prof_summary(k, None, None, None, 1)
+        lib.ftmi_prof_enable(1)
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    par.wait_for_everyone()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if prof:
+        lib.ftmi_prof_enable(0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if par.world_size > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = t.item()
+    loss = out["loss"].item()
+
+    if par.rank == 0:
+        ms = elapsed / args.steps * 1e3
+        samples_per_s = par.world_size * B * args.steps / elapsed
+        S = args.frames * args.height * args.width
+        full_shape = (args.layers == 28 and S == 2688 and args.rank == 64)
+        step_tflop = STEP_TFLOP_PER_SAMPLE * B * (args.layers / 28.0)
+        res = {
+            "metric": "train samples/sec (+ step ms) LTX-Video LoRA 49x512x768 @1/2/4/8 MI355X",
+            "value": samples_per_s,
+            "unit": "samples/s",
+            "n_gpus": par.world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic latents [B,128,7,16,24] + random text embeds, random-init weights of the production LTX-Video DiT",
+            "config": {
+                "workload": "LTX-Video LoRA rank=64 bf16 SFT step, 49x512x768 clip (latents 7x16x24 = 2688 tokens), batch 2 per GPU "
+                            "(BASELINE configs[1])" if full_shape else f"REDUCED: layers={args.layers} tokens={S} rank={args.rank}",
+                "model": "LTX-Video DiT 28 blocks, width 2048, 32x64 heads, 1.923B frozen bf16 params + 58.7M fp32 LoRA params",
+                "global_batch": par.world_size * B,
+                "seq_len": S,
+                "parallelism": f"dp{par.world_size}",
+                "activation_checkpointing": False,
+                "optimizer": "AdamW(lr 5e-5, betas (0.9,0.99), wd 1e-4) + clip 1.0, fused",
+                "gemm_variant": args.gemm_variant,
+            },
+            "step_tflop_algorithmic": step_tflop,
+            "mfma_utilisation_step": step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS,
+            "final_loss": loss,
+        }
+        if prof:
+            classes = {0: "gemm_nt", 1: "gemm_tn", 2: "attn_fwd", 3: "attn_bwd"}
+            kern = {}
+            for k, name in classes.items():
+                tms, n, fl = ctypes.c_double(0), ctypes.c_long(0), ctypes.c_double(0)
+                lib.ftmi_prof_summary(k, ctypes.byref(tms), ctypes.byref(n), ctypes.byref(fl), 1)
+                if n.value:
+                    kern[name] = {"launches_per_step": n.value / args.steps, "ms_per_step": tms.value / args.steps,
+                                  "avg_us": tms.value / n.value * 1e3, "tflops": fl.value / (tms.value * 1e-3) / 1e12}
+            res["kernels"] = kern
+            if "gemm_nt" in kern:
+                g_ = kern["gemm_nt"]
+                res["roofline"] = {
+                    "kernel": "ftmi::gemm_nt_kernel (bf16 MFMA GEMM + fused LoRA/epilogues; every Linear forward and dgrad)",
+                    "bound": "mfma",
+                    "achieved": g_["tflops"],
+                    "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": g_["tflops"] / PEAK_BF16_TFLOPS,
+                    "traffic": None,
+                    "avg_launch_us": g_["avg_us"],
+                    "launches_per_step": g_["launches_per_step"],
+                    "share_of_step": g_["ms_per_step"] / ms,
+                    "note": "achieved = sum of algorithmic FLOPs (2*M*N*(K+K2)) of the launches / sum of their HIP-event durations, "
+                            "events recorded on the launch stream inside the timed region",
+                }
+                if "attn_fwd" in kern and "attn_bwd" in kern:
+                    a_ms = kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["ms_per_step"]
+                    a_fl = kern["attn_fwd"]["tflops"] * kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["tflops"] * kern["attn_bwd"]["ms_per_step"]
+                    res["attention_roofline"] = {"achieved": a_fl / a_ms, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a_fl / a_ms / PEAK_BF16_TFLOPS,
+                                                 "share_of_step": a_ms / ms}
+        if par.world_size == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:  # the baseline must never take the bench line down
+                res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(res))
+    par.destroy()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,8 @@
 // plain-pointer C structs into the internal launch arguments, error reporting.
 #include <mutex>
 #include <string.h>
+#include <utility>
+#include <vector>
 
 #include "common.hip.h"
 #include "kernels.h"
@@ -24,6 +26,46 @@ int check_launch(const char* what) {
     char buf[400];
     snprintf(buf, sizeof(buf), "%s: HIP launch failed: %s", what, hipGetErrorString(e));
     return set_error(FTMI_ERR_LAUNCH, buf);
+}
+
+// ---------------- profiler ----------------
+namespace {
+struct ProfRec {
+    hipEvent_t a, b;
+    int k;
+    double flops;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+hipEvent_t g_prof_open[PROF_NCLASS];
+double g_prof_open_flops[PROF_NCLASS];
+hipEvent_t g_prof_open_b[PROF_NCLASS];
+}  // namespace
+
+bool prof_enabled() { return g_prof_on; }
+
+void prof_begin(int k, double flops, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t a, b;
+    if (!g_prof_pool.empty()) {
+        a = g_prof_pool.back().first;
+        b = g_prof_pool.back().second;
+        g_prof_pool.pop_back();
+    } else {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    }
+    hipEventRecord(a, st);
+    g_prof_open[k] = a;
+    g_prof_open_b[k] = b;
+    g_prof_open_flops[k] = flops;
+}
+
+void prof_end(int k, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEventRecord(g_prof_open_b[k], st);
+    g_prof_recs.push_back(ProfRec{g_prof_open[k], g_prof_open_b[k], k, g_prof_open_flops[k]});
 }
 
 size_t ltx_workspace_bytes(const ftmi_ltx_config& c);
@@ -55,6 +97,39 @@ using namespace ftmi;
 extern "C" {
 
 int ftmi_version(void) { return 100; }
+
+int ftmi_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int ftmi_prof_summary(int kclass, double* total_ms, long* launches, double* total_flops, int reset) {
+    if (kclass < 0 || kclass >= PROF_NCLASS) return set_error(FTMI_ERR_INVALID, "ftmi_prof_summary: bad kernel class");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0, fl = 0;
+    long n = 0;
+    std::vector<ProfRec> keep;
+    for (const ProfRec& r : g_prof_recs) {
+        if (r.k != kclass) {
+            keep.push_back(r);
+            continue;
+        }
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms += t;
+            fl += r.flops;
+            ++n;
+        }
+        if (reset) g_prof_pool.push_back({r.a, r.b});
+        else keep.push_back(r);
+    }
+    if (reset) g_prof_recs.swap(keep);
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (total_flops) *total_flops = fl;
+    return 0;
+}
 
 int ftmi_last_error(char* buf, size_t len) {
     if (!buf || len == 0) return FTMI_ERR_INVALID;

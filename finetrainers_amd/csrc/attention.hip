@@ -212,6 +212,7 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 4))
         return set_error(FTMI_ERR_INVALID, "attn_fwd: token strides must keep 16-byte alignment");
     dim3 grid((a.Sq + 127) / 128, a.H, a.B);
+    ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), kFwdLds, st, a);
     return check_launch("attn_fwd");
 }
@@ -491,6 +492,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8) || (a.do_ss % 8) || (a.dq_ss % 4) || (a.dk_ss % 4) || (a.dv_ss % 4))
         return set_error(FTMI_ERR_INVALID, "attn_bwd: token strides must keep 16-byte alignment");
     const long nrows = (long)a.B * a.H * a.Sq;
+    ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);  // algorithmic: 5 matmuls (2.5x forward)
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
     int rc = check_launch("attn_delta");
     if (rc) return rc;

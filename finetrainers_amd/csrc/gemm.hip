@@ -267,6 +267,7 @@ static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     using T = NtTile<BM, BN, WM, WN, GLDS>;
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
     const size_t smem = 2 * T::STAGE;
+    ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, GLDS>), dim3(ntm * ntn), dim3(256), smem, st, a);
     return check_launch("gemm_nt");
 }
@@ -413,6 +414,7 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     a.msteps_per_split = per;
     const int nsplit = (nsteps + per - 1) / per;
     const dim3 grid(tiles * nsplit);
+    ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q, st);
     if (wideP)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), (128 + 64) * 128, st, a);
     else if (wideQ)

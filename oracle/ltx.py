@@ -567,9 +567,17 @@ def spec_forward(
     generator: Optional[torch.Generator] = None,
     patch_size: int = 1,
     patch_size_t: int = 1,
+    contiguous_hidden_states: bool = False,
 ):
     """Returns (pred, target, sigmas[B,S,1]).  Noise and the 10 % first-frame branch are
-    *injected* rather than drawn (the branch uses Python's global RNG)."""
+    *injected* rather than drawn (the branch uses Python's global RNG).
+
+    ``contiguous_hidden_states``: the reference hands the transformer ``noisy_latents.to(latents)``, a
+    NON-contiguous view (base_specification.py:322).  On the CPU, torch's bf16 ``F.linear`` takes a slower
+    path for non-contiguous inputs that rounds twice (matmul -> bf16, + bias -> bf16) instead of once, which
+    perturbs ~28 % of proj_in's outputs by one bf16 ulp.  That is an artefact of running the reference on the
+    CPU, not part of its algorithm (on a GPU the bias is fused and rounding happens once).  Default False
+    reproduces the reference-on-CPU bit-for-bit (golden fixtures); the GPU parity tests pass True."""
     num_frames, height, width = latents.shape[2:]
     latents = normalize_latents(latents, latents_mean, latents_std)
     if noise is None:
@@ -591,8 +599,11 @@ def spec_forward(
     timesteps = (sig * 1000.0).long()
 
     rope_interpolation_scale = [1 / (25 / 8), 32, 32]
+    hidden = noisy_p.to(latents_p)
+    if contiguous_hidden_states:
+        hidden = hidden.contiguous()
     pred = transformer(
-        hidden_states=noisy_p.to(latents_p),
+        hidden_states=hidden,
         encoder_hidden_states=encoder_hidden_states,
         encoder_attention_mask=encoder_attention_mask,
         num_frames=num_frames,
@@ -722,21 +733,23 @@ def synth_inputs(cfg: LTXConfig, batch: int, frames: int, height: int, width: in
     )
 
 
-def forward_loss(model, inp: StepInputs, flow_weighting_scheme: str = "none"):
+def forward_loss(model, inp: StepInputs, flow_weighting_scheme: str = "none", contiguous_hidden_states: bool = False):
     sig5 = inp.sigmas.view(-1, 1, 1, 1, 1)
     ffs = None if inp.first_frame_sigma is None else inp.first_frame_sigma.view(-1, 1, 1, 1, 1)
     pred, target, sig = spec_forward(
         model, inp.latents.clone(), inp.latents_mean, inp.latents_std, inp.encoder_hidden_states,
         inp.encoder_attention_mask, sig5, noise=inp.noise, first_frame_sigma=ffs,
+        contiguous_hidden_states=contiguous_hidden_states,
     )
     loss = sft_loss(pred, target, sig, flow_weighting_scheme)
     return loss, pred, target
 
 
-def sft_step(model, optimizer, inp: StepInputs, max_grad_norm: float = 1.0, flow_weighting_scheme: str = "none"):
+def sft_step(model, optimizer, inp: StepInputs, max_grad_norm: float = 1.0, flow_weighting_scheme: str = "none",
+             contiguous_hidden_states: bool = False):
     """One optimisation step in the reference's order (trainer.py:436-503).  Returns
     (loss, grad_norm, {name: grad-before-clip})."""
-    loss, _, _ = forward_loss(model, inp, flow_weighting_scheme)
+    loss, _, _ = forward_loss(model, inp, flow_weighting_scheme, contiguous_hidden_states)
     loss.backward()
     grads = {n: p.grad.detach().clone() for n, p in lora_parameters(model)}
     gn = clip_grad_norm_([p for p in model.parameters()], max_grad_norm)
