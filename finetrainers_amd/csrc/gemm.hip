@@ -20,81 +20,99 @@ namespace ftmi {
 // NT GEMM
 // ------------------------------------------------------------------------------------------------
 
-template <int BM, int BN, int WM, int WN, bool GLDS>
+// LDS tile [rows][BK] bf16 (BK*2-byte rows); 16-byte chunks XOR-swizzled so that the ds_read_b128 of 16 lanes reading
+// 16 different rows at one k-chunk is bank-conflict free (BK=64: 2 rows / 256-B bank row; BK=32: 4 rows / bank row).
+template <int BK>
+FTMI_DEVICE int nt_lds_off(int row, int chunk) {
+    if constexpr (BK == 64)
+        return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    else
+        return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
 struct NtTile {
     static constexpr int TM = BM / WM / 32;
     static constexpr int TN = BN / WN / 32;
-    static constexpr int XCH = BM * 8 / 256;
-    static constexpr int WCH = BN * 8 / 256;
-    static constexpr int STAGE = (BM + BN) * 128;
+    static constexpr int CPR = BK / 8;                   // 16-byte chunks per row
+    static constexpr int XCH = BM * CPR / 256;           // chunks per thread
+    static constexpr int WCH = BN * CPR / 256;
+    static constexpr int STAGE = (BM + BN) * BK * 2;     // bytes
+    static constexpr int RPI = 1024 / (BK * 2);          // rows per 1-KiB wave instruction (direct-to-LDS)
 };
 
-template <int BM, int BN, int WM, int WN, bool GLDS>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
 FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
                           int m0, int M, const bf16_t* __restrict__ W, long ldw, int n0, int nk, int tid) {
-    using T = NtTile<BM, BN, WM, WN, GLDS>;
+    using T = NtTile<BM, BN, BK, WM, WN>;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, g = lane >> 5;
 
-    s16x8 xr[T::XCH], wr[T::WCH];
+    s16x8 xr[GLDS ? 1 : T::XCH], wr[GLDS ? 1 : T::WCH];
 
     auto gload = [&](int kt) {
+        if constexpr (!GLDS) {
 #pragma unroll
-        for (int i = 0; i < T::XCH; ++i) {
-            int q = tid + 256 * i, row = q >> 3, c = q & 7;
-            int gr = min(m0 + row, M - 1);
-            xr[i] = *reinterpret_cast<const s16x8*>(X + (long)gr * ldx + kt * 64 + c * 8);
-        }
+            for (int i = 0; i < T::XCH; ++i) {
+                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                int gr = min(m0 + row, M - 1);
+                xr[i] = *reinterpret_cast<const s16x8*>(X + (long)gr * ldx + kt * BK + c * 8);
+            }
 #pragma unroll
-        for (int i = 0; i < T::WCH; ++i) {
-            int q = tid + 256 * i, row = q >> 3, c = q & 7;
-            wr[i] = *reinterpret_cast<const s16x8*>(W + (long)(n0 + row) * ldw + kt * 64 + c * 8);
+            for (int i = 0; i < T::WCH; ++i) {
+                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                wr[i] = *reinterpret_cast<const s16x8*>(W + (long)(n0 + row) * ldw + kt * BK + c * 8);
+            }
         }
     };
     auto swrite = [&](int buf) {
-        char* xs = smem + buf * T::STAGE;
-        char* ws = xs + BM * 128;
+        if constexpr (!GLDS) {
+            char* xs = smem + buf * T::STAGE;
+            char* ws = xs + BM * BK * 2;
 #pragma unroll
-        for (int i = 0; i < T::XCH; ++i) {
-            int q = tid + 256 * i, row = q >> 3, c = q & 7;
-            *reinterpret_cast<s16x8*>(xs + lds_rm_off(row, c)) = xr[i];
-        }
+            for (int i = 0; i < T::XCH; ++i) {
+                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                *reinterpret_cast<s16x8*>(xs + nt_lds_off<BK>(row, c)) = xr[i];
+            }
 #pragma unroll
-        for (int i = 0; i < T::WCH; ++i) {
-            int q = tid + 256 * i, row = q >> 3, c = q & 7;
-            *reinterpret_cast<s16x8*>(ws + lds_rm_off(row, c)) = wr[i];
+            for (int i = 0; i < T::WCH; ++i) {
+                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                *reinterpret_cast<s16x8*>(ws + nt_lds_off<BK>(row, c)) = wr[i];
+            }
         }
     };
     // direct global -> LDS (LDS destination is wave-linear: base + lane*16; the swizzle is applied by
     // permuting the per-lane SOURCE address, the read side applies the same involution)
     auto gl2lds = [&](int kt, int buf) {
         char* xs = smem + buf * T::STAGE;
-        char* ws = xs + BM * 128;
-        constexpr int XI = BM * 128 / 1024 / 4;  // 1 KiB wave-instructions per wave
-        constexpr int WI = BN * 128 / 1024 / 4;
+        char* ws = xs + BM * BK * 2;
+        constexpr int XI = BM * BK * 2 / 1024 / 4;  // 1 KiB wave-instructions per wave
+        constexpr int WI = BN * BK * 2 / 1024 / 4;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
-            int blk = wave * XI + i;  // 8 rows per block
-            int row = blk * 8 + (lane >> 3);
-            int c = (lane & 7) ^ ((row >> 1) & 7);
+            int blk = wave * XI + i;
+            int row = blk * T::RPI + lane / T::CPR;
+            int cs = lane % T::CPR;  // chunk slot in LDS
+            int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
             int gr = min(m0 + row, M - 1);
-            const bf16_t* src = X + (long)gr * ldx + kt * 64 + c * 8;
+            const bf16_t* src = X + (long)gr * ldx + kt * BK + c * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(xs + blk * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             int blk = wave * WI + i;
-            int row = blk * 8 + (lane >> 3);
-            int c = (lane & 7) ^ ((row >> 1) & 7);
-            const bf16_t* src = W + (long)(n0 + row) * ldw + kt * 64 + c * 8;
+            int row = blk * T::RPI + lane / T::CPR;
+            int cs = lane % T::CPR;
+            int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+            const bf16_t* src = W + (long)(n0 + row) * ldw + kt * BK + c * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(ws + blk * 1024), 16, 0, 0);
         }
     };
 
-    if (GLDS) {
+    if constexpr (GLDS) {
         gl2lds(0, 0);
     } else {
         gload(0);
@@ -105,39 +123,44 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            if (GLDS)
+            if constexpr (GLDS)
                 gl2lds(kt + 1, cur ^ 1);
             else
                 gload(kt + 1);
         }
         const char* xs = smem + cur * T::STAGE;
-        const char* ws = xs + BM * 128;
+        const char* ws = xs + BM * BK * 2;
+        constexpr int NKK = BK / 16;
+        s16x8 wf[NKK][T::TN], xf[NKK][T::TM];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            s16x8 wf[T::TN], xf[T::TM];
+        for (int kk = 0; kk < NKK; ++kk) {
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn) {
                 int row = (wn * T::TN + tn) * 32 + li;
-                wf[tn] = *reinterpret_cast<const s16x8*>(ws + lds_rm_off(row, kk * 2 + g));
+                wf[kk][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>(row, kk * 2 + g));
             }
 #pragma unroll
             for (int tm = 0; tm < T::TM; ++tm) {
                 int row = (wm * T::TM + tm) * 32 + li;
-                xf[tm] = *reinterpret_cast<const s16x8*>(xs + lds_rm_off(row, kk * 2 + g));
+                xf[kk][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>(row, kk * 2 + g));
             }
+        }
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[tn], xf[tm], acc[tn][tm]);
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk][tn], xf[kk][tm], acc[tn][tm]);
+        if constexpr (!GLDS) {
+            if (kt + 1 < nk) swrite(cur ^ 1);
         }
-        if (!GLDS && kt + 1 < nk) swrite(cur ^ 1);
         __syncthreads();
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
-    using T = NtTile<BM, BN, WM, WN, GLDS>;
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT>
+__global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmNtArgs p) {
+    using T = NtTile<BM, BN, BK, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -159,11 +182,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        nt_run_k<BM, BN, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / 64, tid);
+        nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
     }
 
-    bool bias_done = false;
-    if (p.K2 > 0) {
+    if constexpr (EXT) {
         // reference: result = base(x) [rounded to bf16]; result = result + lora (fp32) -> rounded to bf16
 #pragma unroll
         for (int tn = 0; tn < T::TN; ++tn)
@@ -183,10 +205,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[tn][tm][rq * 4 + j] = rbf(acc[tn][tm][rq * 4 + j] * p.alpha + bv[j]);
             }
-        bias_done = true;
         const bf16_t* X2 = p.X2;
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
-        nt_run_k<BM, BN, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / 64, tid);
+        nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
     }
 
     // ---------------- epilogue ----------------
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][rq * 4 + j];
-                if (!bias_done) {
+                if constexpr (!EXT) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
                     if (p.bias) {
@@ -215,10 +236,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                     }
                 }
                 float o[4];
-                if (p.epi == EPI_STORE) {
+                if constexpr (EPI == EPI_STORE) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = v[j];
-                } else if (p.epi == EPI_GELU) {
+                } else if constexpr (EPI == EPI_GELU) {
                     float z[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -231,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
                         pk[1] = pack2bf(z[2], z[3]);
                         *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = pk;
                     }
-                } else if (p.epi == EPI_RESID) {
+                } else if constexpr (EPI == EPI_RESID) {
                     u32x2 rr = *reinterpret_cast<const u32x2*>(p.resid + (long)m * p.ldr + n);
                     float rv[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)), bf2f((bf16_t)(rr[1] & 0xffff)),
                                    bf2f((bf16_t)(rr[1] >> 16))};
@@ -262,29 +283,49 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool GLDS>
-static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
-    using T = NtTile<BM, BN, WM, WN, GLDS>;
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT>
+static int launch_nt3(const GemmNtArgs& a, hipStream_t st) {
+    using T = NtTile<BM, BN, BK, WM, WN>;
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
     const size_t smem = 2 * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, GLDS>), dim3(ntm * ntn), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT>), dim3(ntm * ntn), dim3(256), smem, st, a);
     return check_launch("gemm_nt");
 }
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI>
+static int launch_nt2(const GemmNtArgs& a, hipStream_t st) {
+    return a.K2 > 0 ? launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, true>(a, st) : launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, false>(a, st);
+}
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW>
+static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
+    switch (a.epi) {
+        case EPI_STORE: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE>(a, st);
+        case EPI_GELU: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_GELU>(a, st);
+        case EPI_RESID: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_RESID>(a, st);
+        default: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_DGELU>(a, st);
+    }
+}
 
+// variant: 0 = BK64 register-staged, 1 = BK64 direct-to-LDS, 2 = BK32 direct-to-LDS, 3 = BK32 direct-to-LDS sized for 3 waves/SIMD
 int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K % 64 != 0 || a.K2 % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: K and K2 must be multiples of 64");
     if (a.N % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: N must be a multiple of 64");
     if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 4) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
-    const bool glds = a.variant == 1;
-    if (a.N % 128 == 0 && !(a.xk_grp_n > 0 && a.xk_grp_n % 128 != 0) && !(a.x2_grp_n > 0 && a.x2_grp_n % 128 != 0)) {
-        return glds ? launch_nt<128, 128, 2, 2, true>(a, st) : launch_nt<128, 128, 2, 2, false>(a, st);
-    }
-    if ((a.xk_grp_n > 0 && a.xk_grp_n % 64 != 0) || (a.x2_grp_n > 0 && a.x2_grp_n % 64 != 0))
+    const bool wide = a.N % 128 == 0 && !(a.xk_grp_n > 0 && a.xk_grp_n % 128 != 0) && !(a.x2_grp_n > 0 && a.x2_grp_n % 128 != 0);
+    if (!wide && ((a.xk_grp_n > 0 && a.xk_grp_n % 64 != 0) || (a.x2_grp_n > 0 && a.x2_grp_n % 64 != 0)))
         return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
-    return glds ? launch_nt<128, 64, 2, 2, true>(a, st) : launch_nt<128, 64, 2, 2, false>(a, st);
+    if (wide) {
+        switch (a.variant) {
+            case 0: return launch_nt<128, 128, 64, 2, 2, false, 1>(a, st);
+            case 2: return launch_nt<128, 128, 32, 2, 2, true, 1>(a, st);
+            case 3: return launch_nt<128, 128, 32, 2, 2, true, 3>(a, st);
+            default: return launch_nt<128, 128, 64, 2, 2, true, 1>(a, st);
+        }
+    }
+    if (a.variant == 0) return launch_nt<128, 64, 64, 2, 2, false, 1>(a, st);
+    return launch_nt<128, 64, 64, 2, 2, true, 1>(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------
