@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=7, help="latent frames  (49 px frames / 8 + 1)")
     ap.add_argument("--height", type=int, default=16, help="latent height (512 / 32)")
     ap.add_argument("--width", type=int, default=24, help="latent width  (768 / 32)")
-    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("FTMI_GEMM_VARIANT", "1")))
+    ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("FTMI_GEMM_VARIANT", "8")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-layers", type=int, default=2)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events inside the timed region")

@@ -24,6 +24,30 @@ static constexpr float kLog2e = 1.4426950408889634f;
 
 FTMI_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// 1-D grid of ntile * H * B workgroups -> (tile, head, batch).  Block b is observed to run on XCD b % 8 (speed only): all
+// tiles of one (batch, head) are sent to the same XCD so its K/V (forward, dQ) or Q/dO (dK/dV) stream is fetched from the
+// fabric once and re-used out of that XCD's L2 by the other tiles.
+struct AttnBlock {
+    int tile, h, b;
+};
+FTMI_DEVICE AttnBlock attn_block(int bid, int ntile, int H, int B) {
+    AttnBlock r;
+    const int nhb = H * B;
+    int hb, tile;
+    if ((nhb & 7) == 0) {
+        const int xcd = bid & 7, idx = bid >> 3;
+        hb = (idx / ntile) * 8 + xcd;
+        tile = idx % ntile;
+    } else {
+        hb = bid / ntile;
+        tile = bid % ntile;
+    }
+    r.tile = tile;
+    r.h = hb % H;
+    r.b = hb / H;
+    return r;
+}
+
 // 256 threads load one [64 tok][64 d] bf16 tile as 2 x 16-byte chunks per thread.  A wave instruction
 // covers 16 rows x 64 contiguous bytes.  slot = wave + 4*it : rows (slot&3)*16.., chunks (slot>>2)*4..
 struct TileCoord {
@@ -91,8 +115,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int i = blockIdx.x * 128 + wave * 32 + li;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 127) / 128, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int i = blk.tile * 128 + wave * 32 + li;
     const int ic = min(i, a.Sq - 1);
     const float sl = a.scale * kLog2e;
 
@@ -211,7 +236,7 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_fwd: empty problem");
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 4))
         return set_error(FTMI_ERR_INVALID, "attn_fwd: token strides must keep 16-byte alignment");
-    dim3 grid((a.Sq + 127) / 128, a.H, a.B);
+    dim3 grid(((a.Sq + 127) / 128) * a.H * a.B);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), kFwdLds, st, a);
     return check_launch("attn_fwd");
@@ -258,8 +283,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int j = blockIdx.x * 128 + wave * 32 + li;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sk + 127) / 128, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int j = blk.tile * 128 + wave * 32 + li;
     const int jc = min(j, a.Sk - 1);
     const float sl = a.scale * kLog2e;
 
@@ -388,8 +414,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int i = blockIdx.x * 128 + wave * 32 + li;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 127) / 128, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int i = blk.tile * 128 + wave * 32 + li;
     const int ic = min(i, a.Sq - 1);
     const float sl = a.scale * kLog2e;
 
@@ -496,10 +523,10 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
     int rc = check_launch("attn_delta");
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), kDkvLds, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
     rc = check_launch("attn_bwd_dkdv");
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), kDqLds, st, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
     return check_launch("attn_bwd_dq");
 }
 

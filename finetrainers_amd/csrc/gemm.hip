@@ -34,9 +34,11 @@ template <int BM, int BN, int BK, int WM, int WN>
 struct NtTile {
     static constexpr int TM = BM / WM / 32;
     static constexpr int TN = BN / WN / 32;
+    static constexpr int NT = WM * WN * 64;               // threads per workgroup
+    static constexpr int NW = WM * WN;
     static constexpr int CPR = BK / 8;                   // 16-byte chunks per row
-    static constexpr int XCH = BM * CPR / 256;           // chunks per thread
-    static constexpr int WCH = BN * CPR / 256;
+    static constexpr int XCH = BM * CPR / NT;            // chunks per thread
+    static constexpr int WCH = BN * CPR / NT;
     static constexpr int STAGE = (BM + BN) * BK * 2;     // bytes
     static constexpr int RPI = 1024 / (BK * 2);          // rows per 1-KiB wave instruction (direct-to-LDS)
 };
@@ -55,13 +57,13 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
         if constexpr (!GLDS) {
 #pragma unroll
             for (int i = 0; i < T::XCH; ++i) {
-                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                int q = tid + T::NT * i, row = q / T::CPR, c = q % T::CPR;
                 int gr = min(m0 + row, M - 1);
                 xr[i] = *reinterpret_cast<const s16x8*>(X + (long)gr * ldx + kt * BK + c * 8);
             }
 #pragma unroll
             for (int i = 0; i < T::WCH; ++i) {
-                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                int q = tid + T::NT * i, row = q / T::CPR, c = q % T::CPR;
                 wr[i] = *reinterpret_cast<const s16x8*>(W + (long)(n0 + row) * ldw + kt * BK + c * 8);
             }
         }
@@ -72,12 +74,12 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
             char* ws = xs + BM * BK * 2;
 #pragma unroll
             for (int i = 0; i < T::XCH; ++i) {
-                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                int q = tid + T::NT * i, row = q / T::CPR, c = q % T::CPR;
                 *reinterpret_cast<s16x8*>(xs + nt_lds_off<BK>(row, c)) = xr[i];
             }
 #pragma unroll
             for (int i = 0; i < T::WCH; ++i) {
-                int q = tid + 256 * i, row = q / T::CPR, c = q % T::CPR;
+                int q = tid + T::NT * i, row = q / T::CPR, c = q % T::CPR;
                 *reinterpret_cast<s16x8*>(ws + nt_lds_off<BK>(row, c)) = wr[i];
             }
         }
@@ -87,8 +89,8 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
     auto gl2lds = [&](int kt, int buf) {
         char* xs = smem + buf * T::STAGE;
         char* ws = xs + BM * BK * 2;
-        constexpr int XI = BM * BK * 2 / 1024 / 4;  // 1 KiB wave-instructions per wave
-        constexpr int WI = BN * BK * 2 / 1024 / 4;
+        constexpr int XI = BM * BK * 2 / 1024 / T::NW;  // 1 KiB wave-instructions per wave
+        constexpr int WI = BN * BK * 2 / 1024 / T::NW;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             int blk = wave * XI + i;
@@ -131,26 +133,29 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
         const char* xs = smem + cur * T::STAGE;
         const char* ws = xs + BM * BK * 2;
         constexpr int NKK = BK / 16;
-        s16x8 wf[NKK][T::TN], xf[NKK][T::TM];
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
+        // fragments of k-slice kk+1 are fetched from LDS while the MFMAs of slice kk issue (register double buffer)
+        s16x8 wf[2][T::TN], xf[2][T::TM];
+        auto lfrag = [&](int buf, int kk) {
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn) {
                 int row = (wn * T::TN + tn) * 32 + li;
-                wf[kk][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>(row, kk * 2 + g));
+                wf[buf][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>(row, kk * 2 + g));
             }
 #pragma unroll
             for (int tm = 0; tm < T::TM; ++tm) {
                 int row = (wm * T::TM + tm) * 32 + li;
-                xf[kk][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>(row, kk * 2 + g));
+                xf[buf][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>(row, kk * 2 + g));
             }
-        }
+        };
+        lfrag(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk)
+        for (int kk = 0; kk < NKK; ++kk) {
+            if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk][tn], xf[kk][tm], acc[tn][tm]);
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+        }
         if constexpr (!GLDS) {
             if (kt + 1 < nk) swrite(cur ^ 1);
         }
@@ -159,7 +164,7 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT>
-__global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmNtArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs p) {
     using T = NtTile<BM, BN, BK, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -167,9 +172,23 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmNtArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, g = lane >> 5;
 
+    // block b runs on XCD b % 8 (observed; speed only).  XCD (xm, xn) owns a map_rm x map_rn rectangle of tiles and walks
+    // it in column groups of 4 n-tiles, m fastest inside a group: the ~64 tiles resident on an XCD at any time cover
+    // ~16 X-panels x 4 W-panels instead of 64 X-panels x 1 W-panel, cutting fabric -> L2 operand traffic ~3x.
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
-    const int t = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (t % ntm) * BM, n0 = (t / ntm) * BN;
+    int tile_m, tile_n;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xm = xcd / p.map_gn, xn = xcd % p.map_gn;
+        constexpr int GN = 4;
+        const int gsz = p.map_rm * GN;
+        const int grp = idx / gsz, r = idx - grp * gsz;
+        const int cols = min(GN, p.map_rn - grp * GN);
+        tile_m = xm * p.map_rm + r / cols;
+        tile_n = xn * p.map_rn + grp * GN + r % cols;
+    }
+    if (tile_m >= ntm || tile_n >= ntn) return;  // padded grid (whole workgroup exits before any barrier)
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     f32x16 acc[T::TN][T::TM];
 #pragma unroll
@@ -284,12 +303,34 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmNtArgs p) {
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT>
-static int launch_nt3(const GemmNtArgs& a, hipStream_t st) {
+static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
     using T = NtTile<BM, BN, BK, WM, WN>;
-    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+    const int ntm = (a0.M + BM - 1) / BM, ntn = a0.N / BN;
+    GemmNtArgs a = a0;
+    // choose the XCD grid (gm x gn = 8) whose rectangles touch the fewest operand bytes per tile, then pad the launch
+    long best = -1;
+    for (int gm = 1; gm <= 8; gm *= 2) {
+        const int gn = 8 / gm;
+        const int rm = (ntm + gm - 1) / gm, rn = (ntn + gn - 1) / gn;
+        const long panels = (long)rm * BM + (long)rn * BN;         // operand rows streamed per K-slice by one XCD
+        const long waste = (long)rm * rn * 8 - (long)ntm * ntn;    // padded (idle) blocks
+        const long cost = panels * 64 + waste * 256;
+        if (best < 0 || cost < best) {
+            best = cost;
+            a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
+        }
+    }
     const size_t smem = 2 * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT>), dim3(ntm * ntn), dim3(256), smem, st, a);
+        if (smem > 65536) {
+        static bool attr_set = false;  // per instantiation
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT>), dim3(8 * a.map_rm * a.map_rn), dim3(T::NT), smem, st, a);
     return check_launch("gemm_nt");
 }
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI>
@@ -306,7 +347,9 @@ static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     }
 }
 
-// variant: 0 = BK64 register-staged, 1 = BK64 direct-to-LDS, 2 = BK32 direct-to-LDS, 3 = BK32 direct-to-LDS sized for 3 waves/SIMD
+// variant: 0 = 128x128 BK64 register-staged, 1 = 128x128 BK64 direct-to-LDS, 2/3 = 128x128 BK32 direct-to-LDS,
+// 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 128x64 per wave), 6 = 256x256 (8 waves, 64x128 per wave),
+// 7 = 192x128 (4 waves, 96x64 per wave), 8 = auto (7 for M >= 1024 else 1)
 int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K % 64 != 0 || a.K2 % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: K and K2 must be multiples of 64");
@@ -317,10 +360,16 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (!wide && ((a.xk_grp_n > 0 && a.xk_grp_n % 64 != 0) || (a.x2_grp_n > 0 && a.x2_grp_n % 64 != 0)))
         return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
     if (wide) {
-        switch (a.variant) {
+        int variant = a.variant;
+        if (variant == 8) variant = (a.M >= 1024) ? 7 : 1;  // auto: 192x128 tiles fill 256 CUs x 2 WG best at M = 5376 (measured)
+        switch (variant) {
             case 0: return launch_nt<128, 128, 64, 2, 2, false, 1>(a, st);
             case 2: return launch_nt<128, 128, 32, 2, 2, true, 1>(a, st);
             case 3: return launch_nt<128, 128, 32, 2, 2, true, 3>(a, st);
+            case 4: return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
+            case 5: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
+            case 6: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 4, 2, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
+            case 7: return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
             default: return launch_nt<128, 128, 64, 2, 2, true, 1>(a, st);
         }
     }

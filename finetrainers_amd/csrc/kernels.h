@@ -64,7 +64,10 @@ struct GemmNtArgs {
     const bf16_t* aux = nullptr;  // EPI_DGELU: z
     long ldaux = 0;
     int epi = EPI_STORE;
-    int variant = 0;  // 0 = register-staged tiles, 1 = direct global->LDS
+    int variant = 0;  // 0 = register-staged tiles, 1 = direct global->LDS (BK64), 2/3 = BK32 direct-to-LDS
+    // tile -> XCD rasterisation (filled by the launcher): the 8 XCDs form a map_gm x map_gn grid, each owning a
+    // map_rm x map_rn rectangle of output tiles, so the tiles resident on one XCD share few operand panels in its L2
+    int map_gm = 1, map_gn = 8, map_rm = 0, map_rn = 0;
 };
 int gemm_nt(const GemmNtArgs& a, hipStream_t st);
 

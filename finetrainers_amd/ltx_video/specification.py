@@ -45,7 +45,7 @@ class FlowMatchSigmas:
 
 class MI355XLTXVideoModelSpecification:
     def __init__(self, transformer_config: Optional[LTXTransformerConfig] = None, transformer_dtype: torch.dtype = torch.bfloat16,
-                 gemm_variant: int = 0, **kwargs) -> None:
+                 gemm_variant: int = 8, **kwargs) -> None:
         if transformer_dtype != torch.bfloat16:
             raise ValueError("the MI355X backend computes in bf16 (fp32 accumulation); transformer_dtype must be torch.bfloat16")
         self.transformer_dtype = transformer_dtype

@@ -134,7 +134,7 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         # name: shape builder (cfg dims) ; filled in __init__
     }
 
-    def __init__(self, config: Optional[LTXTransformerConfig] = None, device: Optional[torch.device] = None, gemm_variant: int = 0):
+    def __init__(self, config: Optional[LTXTransformerConfig] = None, device: Optional[torch.device] = None, gemm_variant: int = 8):
         super().__init__()
         self.config = config or LTXTransformerConfig()
         c = self.config
