@@ -107,6 +107,7 @@ FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
 // ------------------------------------------------------------------------------------------------
 static constexpr int kFwdLds = 8192 + 64 * FTMI_TS + 256;
 
+template <bool HAS_KB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks = smem;
@@ -171,15 +172,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 st[js] = mfma32(kf, qf[c], st[js]);
             }
         }
+        // scores in the log2 domain: x = s * (scale * log2 e) + bias;  row max / exp2 / row sum per lane (= per query row)
         float mx = -INFINITY;
+        if constexpr (HAS_KB) {
 #pragma unroll
-        for (int js = 0; js < 2; ++js)
+            for (int js = 0; js < 2; ++js)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = st[js][r] * sl + kb[js * 32 + crow(r, g)];
-                st[js][r] = x;
-                mx = fmaxf(mx, x);
-            }
+                for (int rq = 0; rq < 4; ++rq) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = __builtin_fmaf(st[js][rq * 4 + j], sl, b4[j]);
+                        st[js][rq * 4 + j] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int js = 0; js < 2; ++js)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[js][r]);
+            mx *= sl;  // sl > 0
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = fast_exp2(m_run - m_new);
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int js = 0; js < 2; ++js)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = fast_exp2(st[js][r] - m_new);
+                float p = HAS_KB ? fast_exp2(st[js][r] - m_new) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_new));
                 st[js][r] = p;
                 rs += p;
             }
@@ -238,7 +252,10 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
         return set_error(FTMI_ERR_INVALID, "attn_fwd: token strides must keep 16-byte alignment");
     dim3 grid(((a.Sq + 127) / 128) * a.H * a.B);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), kFwdLds, st, a);
+    if (a.kbias || (a.Sk % 64) != 0)
+        hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), kFwdLds, st, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), kFwdLds, st, a);
     return check_launch("attn_fwd");
 }
 
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 static constexpr int kDkvLds = 2 * 8192 + 2 * 64 * FTMI_TS + 512;
 
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* qs = smem;
     char* dos = smem + 8192;
@@ -357,12 +374,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 dp = mfma32(dof, vf[c], dp);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int il = is * 32 + crow(r, g);
-                float p = fast_exp2(s[r] * sl + bias_j - lses[il]);
-                float ds = p * (dp[r] - dels[il]);
-                s[r] = p;
-                dp[r] = ds;
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + is * 32 + rq * 8 + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + is * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = rq * 4 + j;
+                    float p = fast_exp2(__builtin_fmaf(s[r], sl, bias_j - l4[j]));
+                    float ds = p * (dp[r] - d4[j]);
+                    s[r] = p;
+                    dp[r] = ds;
+                }
             }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -480,9 +502,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 dp = mfma32(vf, dof[c], dp);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = fast_exp2(s[r] * sl + kb[js * 32 + crow(r, g)] - lse_i);
-                dp[r] = p * (dp[r] - del_i);
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = rq * 4 + j;
+                    float p = fast_exp2(__builtin_fmaf(s[r], sl, b4[j] - lse_i));
+                    dp[r] = p * (dp[r] - del_i);
+                }
             }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {

@@ -11,6 +11,8 @@
 //
 // Replaces: torch.nn.functional.linear / peft lora.Linear.forward and their autograd backward as
 // launched by the reference step (SURVEY 2c K6,K7,K10,K14,K15,K17,K18,K19,K21).
+#include <stdlib.h>
+
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -347,6 +349,72 @@ static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny NT GEMM (N <= 256: the LoRA down-projections x A^T and dY B): the output has too few tiles to fill 256 CUs with
+// 128-wide tiles and the K loop is latency-bound, so one workgroup owns a 32 x 64 output tile and its 4 waves split K
+// four ways (operands straight from global/L2 into MFMA fragments, no LDS staging), then reduce through LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmNtArgs p) {
+    __shared__ float red[4][2][16][64];  // [wave][n-subtile][acc register][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, g = lane >> 5;
+    const int ntm = (p.M + 31) / 32;
+    const int m0 = (blockIdx.x % ntm) * 32, n0 = (blockIdx.x / ntm) * 64;
+    const bf16_t* X = p.X;
+    if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
+    const int kq = p.K / 4, k0 = wave * kq;
+    const int row = min(m0 + li, p.M - 1);
+    const bf16_t* xp = X + (long)row * p.ldx + k0 + g * 8;
+    const bf16_t* wp0 = p.W + (long)(n0 + li) * p.ldw + k0 + g * 8;
+    const bf16_t* wp1 = wp0 + 32 * p.ldw;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+    }
+#pragma unroll 8
+    for (int k = 0; k < kq; k += 16) {
+        s16x8 xf = *reinterpret_cast<const s16x8*>(xp + k);
+        s16x8 w0 = *reinterpret_cast<const s16x8*>(wp0 + k);
+        s16x8 w1 = *reinterpret_cast<const s16x8*>(wp1 + k);
+        acc0 = mfma32(w0, xf, acc0);
+        acc1 = mfma32(w1, xf, acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[wave][0][r][lane] = acc0[r];
+        red[wave][1][r][lane] = acc1[r];
+    }
+    __syncthreads();
+    const int m = m0 + li;
+    if (m >= p.M) return;
+    // wave w finalises accumulator registers 4w..4w+3 (= 4 consecutive n) of both n-subtiles
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave * 4 + j;
+            v[j] = (red[0][tn][r][lane] + red[1][tn][r][lane]) + (red[2][tn][r][lane] + red[3][tn][r][lane]);
+        }
+        const int n = n0 + tn * 32 + wave * 8 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+        if (p.bias) {
+            u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+            v[0] += bf2f((bf16_t)(raw[0] & 0xffff));
+            v[1] += bf2f((bf16_t)(raw[0] >> 16));
+            v[2] += bf2f((bf16_t)(raw[1] & 0xffff));
+            v[3] += bf2f((bf16_t)(raw[1] >> 16));
+        }
+        u32x2 pk;
+        pk[0] = pack2bf(v[0], v[1]);
+        pk[1] = pack2bf(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(p.out + (long)m * p.ldo + n) = pk;
+    }
+}
+
 // variant: 0 = 128x128 BK64 register-staged, 1 = 128x128 BK64 direct-to-LDS, 2/3 = 128x128 BK32 direct-to-LDS,
 // 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 128x64 per wave), 6 = 256x256 (8 waves, 64x128 per wave),
 // 7 = 192x128 (4 waves, 96x64 per wave), 8 = auto (7 for M >= 1024 else 1)
@@ -356,6 +424,11 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (a.N % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: N must be a multiple of 64");
     if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 4) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
+    if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
+        ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)a.K, st);
+        hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(256), 0, st, a);
+        return check_launch("gemm_nt_skinny");
+    }
     const bool wide = a.N % 128 == 0 && !(a.xk_grp_n > 0 && a.xk_grp_n % 128 != 0) && !(a.x2_grp_n > 0 && a.x2_grp_n % 128 != 0);
     if (!wide && ((a.xk_grp_n > 0 && a.xk_grp_n % 64 != 0) || (a.x2_grp_n > 0 && a.x2_grp_n % 64 != 0)))
         return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
@@ -497,7 +570,14 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     const int bp = wideP ? 128 : 64, bq = wideP ? 64 : (wideQ ? 128 : 64);
     if (a.v_grp_p > 0 && a.v_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: group width vs tile");
     const int tiles = (a.P / bp) * (a.Q / bq);
-    int want = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
+    static int target_wgs = 0;
+    if (target_wgs == 0) {
+        const char* e = getenv("FTMI_TN_TARGET_WGS");
+        target_wgs = e ? atoi(e) : 256;
+        if (target_wgs < 1) target_wgs = 256;
+    }
+    // the split-M partials meet in fp32 atomics: more splits = more parallelism but P*Q atomics per split
+    int want = (target_wgs + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int per = (nsteps + want - 1) / want;
     if (per < 1) per = 1;
