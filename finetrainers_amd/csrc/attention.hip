@@ -96,10 +96,10 @@ FTMI_DEVICE s16x8 read_tr_frag(const char* lds, int d, int tok0, int g) {
     return f;
 }
 FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
-    s16x8 f;
+    u32x4 w;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (short)f2bf(v[hh * 8 + e]);
-    return f;
+    for (int e = 0; e < 4; ++e) w[e] = pack2bf(v[hh * 8 + 2 * e], v[hh * 8 + 2 * e + 1]);
+    return __builtin_bit_cast(s16x8, w);
 }
 
 // ------------------------------------------------------------------------------------------------

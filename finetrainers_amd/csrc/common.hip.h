@@ -24,18 +24,19 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 FTMI_DEVICE float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (same as torch's .to(torch.bfloat16))
-FTMI_DEVICE bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// round-to-nearest-even fp32 -> bf16 (same as torch's .to(torch.bfloat16)); lowers to v_cvt_pk_bf16_f32 on gfx950
+FTMI_DEVICE bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 // round an fp32 value through bf16 (a torch op boundary in the reference's eager bf16 graph)
 FTMI_DEVICE float rbf(float f) { return bf2f(f2bf(f)); }
 
-FTMI_DEVICE uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+FTMI_DEVICE uint32_t pack2bf(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 FTMI_DEVICE f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);

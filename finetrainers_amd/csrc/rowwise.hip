@@ -21,10 +21,10 @@ FTMI_DEVICE void unpack8(const s16x8& v, float (&f)[8]) {
     for (int e = 0; e < 8; ++e) f[e] = bf2f((bf16_t)v[e]);
 }
 FTMI_DEVICE s16x8 pack8(const float (&f)[8]) {
-    s16x8 v;
+    u32x4 w;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(f[e]);
-    return v;
+    for (int e = 0; e < 4; ++e) w[e] = pack2bf(f[2 * e], f[2 * e + 1]);
+    return __builtin_bit_cast(s16x8, w);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,276 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header declares, host logic of the
+ModelSpecification / attention-provider / step mirrors, and the product path's refusal to run without the GPU."""
+
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from finetrainers_amd import _lib
+
+    if not _lib.lib_available():
+        from finetrainers_amd.csrc.build import build
+
+        build()
+    return _lib.load()
+
+
+def test_c_abi_exports_every_declared_symbol(lib):
+    from finetrainers_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "ftmi355.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(ftmi_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"libftmi355.so does not export {name}"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.ftmi_version() >= 100
+
+
+def test_c_abi_error_reporting(lib):
+    """int status + ftmi_last_error, converted to ValueError (invalid / unsupported), without touching a GPU."""
+    import ctypes
+
+    from finetrainers_amd import _lib
+
+    cfg = _lib.LtxConfig(B=2, S=2688, T=128, D=2048, H=32, L=28, C_in=128, C_out=128, D_ff=8192, D_cap=4096, r=64, lora_scale=1.0,
+                         eps_norm=1e-6, eps_qk=1e-5, gemm_variant=8)
+    ws = lib.ftmi_ltx_workspace_bytes(ctypes.byref(cfg))
+    assert 8 * 2**30 < ws < 16 * 2**30  # ~10.4 GB of activations at the headline shape
+    off = ctypes.c_size_t(0)
+    assert lib.ftmi_ltx_workspace_offset(ctypes.byref(cfg), b"qkv", 3, ctypes.byref(off)) == 0 and 0 < off.value < ws
+    rc = lib.ftmi_ltx_workspace_offset(ctypes.byref(cfg), b"no_such_tensor", 0, ctypes.byref(off))
+    assert rc == _lib.FTMI_ERR_INVALID and "unknown name" in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "ftmi_ltx_workspace_offset")
+    # NULL tensors are rejected before any launch
+    rc = lib.ftmi_gemm_nt(128, 128, 64, None, 64, None, 64, None, 1.0, None, 128, 0, None, None, None, 0, None, 0, None)
+    assert rc == _lib.FTMI_ERR_INVALID
+    desc = _lib.AttnDesc(B=1, H=1, Sq=64, Sk=64, d=32, scale=0.1)
+    rc = lib.ftmi_attn_fwd(ctypes.byref(desc), None, None, None, None, None, None, None)
+    assert rc == _lib.FTMI_ERR_UNSUPPORTED and "head_dim" in _lib.last_error()
+
+
+def test_product_path_never_imports_the_oracle():
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "finetrainers_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, f"product code imports the oracle: {bad}"
+
+
+def test_product_path_fails_loudly_without_gpu():
+    from finetrainers_amd import ops
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoTransformer3DModel
+
+    q = torch.zeros(1, 2, 64, 64, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="GPU"):
+        ops.attn_fwd(q, q, q)
+    model = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=1), device=torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="GPU"):
+        model(torch.zeros(1, 32, 128), torch.zeros(1, 128, 4096), torch.tensor([500]), torch.ones(1, 128), 2, 4, 4)
+    with pytest.raises(ValueError, match="production geometry"):
+        MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_attention_heads=4, attention_head_dim=8), device=torch.device("cpu"))
+
+
+def test_adapter_surface_is_peft_compatible():
+    """sft_trainer/trainer.py:121-136: add_adapter(LoraConfig(r, lora_alpha, init_lora_weights=True, target_modules)); fp32 params;
+    names as get_peft_model_state_dict would emit them."""
+    from types import SimpleNamespace
+
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoTransformer3DModel
+    from finetrainers_amd.ltx_video.transformer import DEFAULT_TARGET_MODULES
+
+    model = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=2), device=torch.device("cpu"))
+    with pytest.raises(ValueError):
+        model.add_adapter(r=48, lora_alpha=48)  # rank must be a multiple of 64
+    with pytest.raises(ValueError):
+        model.add_adapter(SimpleNamespace(r=64, lora_alpha=64, target_modules="ff.net.0.proj"))
+    model.add_adapter(SimpleNamespace(r=64, lora_alpha=64, target_modules=DEFAULT_TARGET_MODULES, init_lora_weights=True))
+    params = dict(model.named_parameters())
+    assert set(params) == {"lora_A", "lora_B"} and all(p.dtype == torch.float32 and p.requires_grad for p in params.values())
+    assert params["lora_A"].shape == (2, 8, 64, 2048) and params["lora_B"].shape == (2, 8, 2048, 64)
+    assert params["lora_B"].abs().max() == 0 and params["lora_A"].abs().max() > 0  # B = 0, A kaiming-uniform
+    bound = (6.0 / (6.0 * 2048)) ** 0.5
+    assert params["lora_A"].abs().max() <= bound
+    assert params["lora_A"].data_ptr() == model.lora_flat.data_ptr()  # views into one flat buffer [A | B]
+    assert params["lora_B"].data_ptr() == model.lora_flat.data_ptr() + 4 * params["lora_A"].numel()
+    sd = model.lora_state_dict()
+    assert len(sd) == 2 * 8 * 2
+    assert sd["transformer_blocks.1.attn2.to_out.0.lora_B.weight"].shape == (2048, 64)
+    assert sd["transformer_blocks.0.attn1.to_q.lora_A.weight"].shape == (64, 2048)
+    # 224 adapters / 58 720 256 parameters at the production depth
+    assert 28 * 8 == 224 and 28 * 8 * 2 * 64 * 2048 == 58_720_256
+    with pytest.raises(ValueError):
+        model.add_adapter(r=64, lora_alpha=64)  # already attached
+
+
+def test_rope_tables_match_upstream_formula():
+    from finetrainers_amd.ltx_video.transformer import ltx_rope_tables
+    from oracle import ltx
+
+    scale = [1 / (25 / 8), 32, 32]
+    cos_c, sin_c = ltx_rope_tables(3, 4, 6, scale)
+    rope = ltx.LTXVideoRotaryPosEmbed(dim=2048)
+    cos_f, sin_f = rope(torch.zeros(2, 72, 128), 3, 4, 6, scale)
+    assert torch.equal(cos_f[0], cos_f[1])  # identical across the batch -> one table per clip shape
+    assert torch.equal(cos_f[0, :, 0::2], cos_f[0, :, 1::2]) and torch.equal(sin_f[0, :, 0::2], sin_f[0, :, 1::2])
+    assert torch.equal(cos_c, cos_f[0, :, 0::2]) and torch.equal(sin_c, sin_f[0, :, 0::2])
+
+
+def test_spec_mirror_collation_and_scheduler():
+    from finetrainers_amd.ltx_video import MI355XLTXVideoModelSpecification
+    from finetrainers_amd.ltx_video.specification import FlowMatchSigmas
+    from oracle import ltx
+
+    spec = MI355XLTXVideoModelSpecification()
+    assert spec._resolution_dim_keys == {"latents": (2, 3, 4)}
+    items = [{"latents": torch.ones(1, 128, 2, 4, 4) * i, "latents_mean": torch.zeros(128), "num_frames": 2} for i in range(3)]
+    out = spec.collate_latents(items)
+    assert out["latents"].shape == (3, 128, 2, 4, 4) and out["latents_mean"].shape == (128,) and out["num_frames"] == 2
+    assert torch.equal(FlowMatchSigmas().sigmas, ltx.scheduler_sigmas())
+    with pytest.raises(ValueError):
+        MI355XLTXVideoModelSpecification(transformer_dtype=torch.float16)
+    with pytest.raises(NotImplementedError):
+        spec.load_latent_models()
+
+
+def test_sigma_sampling_mirror_matches_reference(golden):
+    from finetrainers_amd.ltx_video.specification import FlowMatchSigmas
+    from finetrainers_amd.utils import diffusion as D
+
+    sch = FlowMatchSigmas()
+    for scheme in ("none", "logit_normal", "mode"):
+        gen = torch.Generator().manual_seed(21)
+        s = D.prepare_sigmas(sch, sch.sigmas, 16, 1000, flow_weighting_scheme=scheme, generator=gen)
+        assert torch.equal(s, golden[f"sigmas.{scheme}"])
+    sig = torch.tensor([0.25, 0.7])
+    assert torch.equal(D.prepare_loss_weights(sch, sigmas=sig, flow_weighting_scheme="none"), torch.ones(2))
+    torch.testing.assert_close(D.prepare_loss_weights(sch, sigmas=sig, flow_weighting_scheme="sigma_sqrt"), sig**-2.0)
+
+
+def test_attention_provider_registry_semantics():
+    from finetrainers_amd import attention_dispatch as ad
+
+    reg = ad._AttentionProviderRegistry
+    assert ad.AttentionProvider("mi355x") in reg.list_providers()
+    name, fn = reg.get_active_provider()
+    assert name == ad.AttentionProvider.MI355X and fn is ad._mi355x_attention
+    assert not reg.supports_context_parallel(ad.AttentionProvider.MI355X)
+    with pytest.raises(ValueError):
+        with ad.attention_provider(ad.AttentionProvider.MI355X, mesh=object()):
+            pass
+    # constraint checks raise ValueError like the reference's (attention_dispatch.py:460-519)
+    q = torch.zeros(1, 2, 16, 64, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="GPU"):
+        ad._check_device_gpu(query=q, key=q, value=q)
+    with pytest.raises(ValueError, match="bfloat16"):
+        ad._check_qkv_dtype_bf16(query=q.float(), key=q, value=q)
+    with pytest.raises(ValueError, match="head_dim"):
+        ad._check_head_dim_64(query=q[..., :32], key=q, value=q)
+    with pytest.raises(ValueError):
+        ad._check_no_dropout_causal_gqa(is_causal=True)
+    # kwargs the provider does not name are dropped by the dispatcher (attention_dispatch.py:442)
+    seen = {}
+
+    def fake(query, key, value, attn_mask=None):
+        seen.update(attn_mask=attn_mask)
+        return query
+
+    old = reg._providers[ad.AttentionProvider.MI355X], reg._supported_arg_names[ad.AttentionProvider.MI355X]
+    try:
+        reg.register(ad.AttentionProvider.MI355X)(fake)
+        out = ad.attention_dispatch(q, q, q, attn_mask=None, dropout_p=0.0, is_causal=False, scale=0.5, enable_gqa=False,
+                                    attention_kwargs={"unknown_kw": 1})
+        assert out is q and "attn_mask" in seen
+    finally:
+        reg._providers[ad.AttentionProvider.MI355X], reg._supported_arg_names[ad.AttentionProvider.MI355X] = old
+    # LTX's [B, H, 1, T] additive mask -> per-key bias
+    m = ((1 - torch.tensor([[1.0, 1, 0, 0], [1, 0, 0, 0]]).to(torch.bfloat16)) * -10000.0).unsqueeze(1)
+    m4 = m.repeat_interleave(3, dim=0).view(2, 3, 1, 4)
+    kb = ad._key_bias_from_mask(m4, 2, 3, 4)
+    assert kb.shape == (2, 4) and kb[0, 2] == -9984.0 and kb[0, 0] == 0
+    assert ad.register_into_finetrainers() is False  # the reference package is not importable in this image
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from finetrainers_amd.parallel import DataParallelBackend
+
+    par = DataParallelBackend(backend="gloo")
+    try:
+        g = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        par.all_reduce_mean_(g)
+        m = par.reduce_step_metrics(torch.tensor(1.0 + rank), torch.tensor(10.0 * (rank + 1)))
+        w = torch.full((4,), float(rank))
+        par.broadcast_(w, src=0)
+        q.put((rank, g.tolist(), {k: v.item() for k, v in m.items()}, list(par.shard_indices(7)), w.tolist(), par.is_main_process))
+    finally:
+        par.destroy()
+
+
+def test_data_parallel_backend_world_size_2_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g, m, shard, w, main in res:
+        assert g == [1.5 * i for i in range(10)]  # mean of g and 2g
+        assert m["global_avg_loss"] == 1.5 and m["global_max_loss"] == 2.0 and m["grad_norm"] == 15.0
+        assert shard == list(range(rank, 7, 2))
+        assert w == [0.0] * 4
+        assert main == (rank == 0)
+
+
+def test_dp_gradient_average_equals_large_batch_gradient():
+    """The DP contract of the step: averaging per-rank LoRA gradients (each the mean over its own samples) equals the gradient
+    of the global-batch loss -- checked on the oracle (tiny config), world 2 emulated in-process."""
+    from oracle import ltx
+
+    cfg = ltx.LTXConfig.dummy()
+    m = ltx.build_model(cfg, seed=0, rank=4, alpha=4.0, dtype=torch.float32, lora_b_std=0.02)
+    inp = ltx.synth_inputs(cfg, 2, 2, 4, 4, dtype=torch.float32)
+    loss, _, _ = ltx.forward_loss(m, inp)
+    loss.backward()
+    full = {n: p.grad.clone() for n, p in ltx.lora_parameters(m)}
+    per_rank = []
+    for r in range(2):
+        m.zero_grad()
+        sub = ltx.StepInputs(inp.latents[r:r + 1], inp.latents_mean, inp.latents_std, inp.encoder_hidden_states[r:r + 1],
+                             inp.encoder_attention_mask[r:r + 1], inp.sigmas[r:r + 1], inp.noise[r:r + 1])
+        l, _, _ = ltx.forward_loss(m, sub)
+        l.backward()
+        per_rank.append({n: p.grad.clone() for n, p in ltx.lora_parameters(m)})
+    for n in full:
+        torch.testing.assert_close((per_rank[0][n] + per_rank[1][n]) / 2, full[n], rtol=1e-4, atol=1e-7)
+
+
+def test_bench_and_entry_points_exist():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"metric"', '"roofline"', '"cpu_baseline"', '"ms_per_step"', '"vs_baseline"', "--gpus", "--steps", "--warmup"):
+        assert key in src
+    import __graft_entry__ as ge
+
+    assert callable(ge.build) and callable(ge.smoke)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True)
+    assert out.returncode != 0 and "MI355X" in (out.stderr + out.stdout)  # refuses to run without the GPU
