@@ -63,7 +63,8 @@ _SIGS = {
     "ftmi_version": (c_int, []),
     "ftmi_last_error": (c_int, [c_char_p, c_size_t]),
     "ftmi_prof_enable": (c_int, [c_int]),
-    "ftmi_prof_summary": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_long), POINTER(ctypes.c_double), c_int]),
+    "ftmi_prof_summary": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_long), POINTER(ctypes.c_double), POINTER(c_long),
+                                  POINTER(ctypes.c_double), c_int]),
     "ftmi_attn_fwd": (c_int, [POINTER(AttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ftmi_attn_bwd": (c_int, [POINTER(AttnDesc)] + [c_void_p] * 12),
     "ftmi_linear_lora_fwd": (c_int, [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 7 + [c_int, c_void_p]),

@@ -37,6 +37,9 @@ struct ProfRec {
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+int g_prof_stride = 1;
+long g_prof_count[PROF_NCLASS] = {0, 0, 0, 0};     // all launches seen while enabled
+double g_prof_flops[PROF_NCLASS] = {0, 0, 0, 0};   // their algorithmic FLOPs
 std::vector<ProfRec> g_prof_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 hipEvent_t g_prof_open[PROF_NCLASS];
@@ -46,20 +49,24 @@ hipEvent_t g_prof_open_b[PROF_NCLASS];
 
 bool prof_enabled() { return g_prof_on; }
 
-void prof_begin(int k, double flops, hipStream_t st) {
+bool prof_begin(int k, double flops, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    const long n = g_prof_count[k]++;
+    g_prof_flops[k] += flops;
+    if (n % g_prof_stride != 0) return false;  // only every stride-th launch of a class is bracketed by events
     hipEvent_t a, b;
     if (!g_prof_pool.empty()) {
         a = g_prof_pool.back().first;
         b = g_prof_pool.back().second;
         g_prof_pool.pop_back();
     } else {
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
     }
     hipEventRecord(a, st);
     g_prof_open[k] = a;
     g_prof_open_b[k] = b;
     g_prof_open_flops[k] = flops;
+    return true;
 }
 
 void prof_end(int k, hipStream_t st) {
@@ -98,13 +105,15 @@ extern "C" {
 
 int ftmi_version(void) { return 100; }
 
-int ftmi_prof_enable(int on) {
+int ftmi_prof_enable(int stride) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof_on = on != 0;
+    g_prof_on = stride > 0;
+    g_prof_stride = stride > 0 ? stride : 1;
     return 0;
 }
 
-int ftmi_prof_summary(int kclass, double* total_ms, long* launches, double* total_flops, int reset) {
+int ftmi_prof_summary(int kclass, double* total_ms, long* launches, double* total_flops, long* all_launches, double* all_flops,
+                      int reset) {
     if (kclass < 0 || kclass >= PROF_NCLASS) return set_error(FTMI_ERR_INVALID, "ftmi_prof_summary: bad kernel class");
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double ms = 0, fl = 0;
@@ -128,6 +137,12 @@ int ftmi_prof_summary(int kclass, double* total_ms, long* launches, double* tota
     if (total_ms) *total_ms = ms;
     if (launches) *launches = n;
     if (total_flops) *total_flops = fl;
+    if (all_launches) *all_launches = g_prof_count[kclass];
+    if (all_flops) *all_flops = g_prof_flops[kclass];
+    if (reset) {
+        g_prof_count[kclass] = 0;
+        g_prof_flops[kclass] = 0;
+    }
     return 0;
 }
 

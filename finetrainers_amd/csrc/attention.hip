@@ -9,8 +9,9 @@
 // owns one COLUMN of D.  Computing S^T = K.Q^T makes a lane own one query row, so the online-softmax
 // statistics are per-lane scalars (one cross-half shuffle per reduction), and the C-layout registers
 // of P are directly a valid B-slot operand for O^T = V^T.P^T -- no LDS round trip for P.  Operands
-// whose reduction index is the token index (V^T, K^T, Q^T, dO^T) are transposed while the tile is
-// written to LDS (16-bit stores into a padded [64 d][64 tok] image, read back with 8-byte loads).
+// whose reduction index is the token index (V^T, K^T, Q^T, dO^T) come out of the SAME row-major LDS
+// tile as the row fragments, through gfx950's transposing LDS read (ds_read_b64_tr_b16): one swizzled
+// image per operand serves both orientations (common.hip.h: lds_rt_off / lds_tr_frag).
 //
 // Three kernels: forward (O, LSE), backward dK/dV (one workgroup per 128 keys, loops over queries),
 // backward dQ (one workgroup per 128 queries, loops over keys).  Scores are recomputed in both
@@ -74,26 +75,18 @@ FTMI_DEVICE void store_tile_rm(const s16x8 (&r)[2], char* lds, int tid) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         TileCoord c = tile_coord(tid, it);
-        *reinterpret_cast<s16x8*>(lds + lds_rm_off(c.row, c.chunk)) = r[it];
+        *reinterpret_cast<s16x8*>(lds + lds_rt_off(c.row, c.chunk)) = r[it];
     }
 }
-FTMI_DEVICE void store_tile_tr(const s16x8 (&r)[2], char* lds, int tid) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        TileCoord c = tile_coord(tid, it);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) *reinterpret_cast<short*>(lds + (c.chunk * 8 + e) * FTMI_TS + c.row * 2) = r[it][e];
-    }
+// row fragment (non-reduction index = token row) of a [64 tok][64 d] image: lane (row, g) reads d = 16 c + 8 g .. +7
+FTMI_DEVICE s16x8 read_row_frag(const char* lds, int row, int c, int g) {
+    return *reinterpret_cast<const s16x8*>(lds + lds_rt_off(row, c * 2 + g));
 }
-// A-slot fragment from a transposed image: row d, token offsets tok0 + {4g..4g+3, 8+4g..8+4g+3}
-FTMI_DEVICE s16x8 read_tr_frag(const char* lds, int d, int tok0, int g) {
-    const char* p = lds + d * FTMI_TS + (tok0 + 4 * g) * 2;
-    s16x4 lo = *reinterpret_cast<const s16x4*>(p);
-    s16x4 hi = *reinterpret_cast<const s16x4*>(p + 16);
-    s16x8 f;
-    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    return f;
+// transposed fragment (non-reduction index = d = dbase + (lane&31)), reduction over tokens tok0 + {4g..4g+3, 8+4g..8+4g+3}:
+// exactly the token order in which the C-layout registers of P / dS are packed (pack_frag)
+FTMI_DEVICE s16x8 read_tr_frag(const char* lds, int dbase, int tok0, int lane) {
+    const int g = lane >> 5;
+    return lds_tr_frag(lds, dbase, tok0 + 4 * g, tok0 + 8 + 4 * g, lane);
 }
 FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
     u32x4 w;
@@ -105,14 +98,14 @@ FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-static constexpr int kFwdLds = 8192 + 64 * FTMI_TS + 256;
+static constexpr int kFwdLds = 2 * 8192 + 256;
 
 template <bool HAS_KB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks = smem;
-    char* vts = smem + 8192;
-    float* kb = reinterpret_cast<float*>(smem + 8192 + 64 * FTMI_TS);
+    char* vs = smem + 8192;
+    float* kb = reinterpret_cast<float*>(smem + 2 * 8192);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
@@ -151,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     };
     auto lwrite = [&]() {
         store_tile_rm(kr, ks, tid);
-        store_tile_tr(vr, vts, tid);
+        store_tile_rm(vr, vs, tid);
         if (tid < 64) kb[tid] = kbr;
     };
 
@@ -168,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                s16x8 kf = *reinterpret_cast<const s16x8*>(ks + lds_rm_off(js * 32 + li, c * 2 + g));
+                s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
                 st[js] = mfma32(kf, qf[c], st[js]);
             }
         }
@@ -221,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 s16x8 pf = pack_frag(st[js], hh);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    s16x8 vf = read_tr_frag(vts, dt * 32 + li, js * 32 + hh * 16, g);
+                    s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
                     oacc[dt] = mfma32(vf, pf, oacc[dt]);
                 }
             }
@@ -287,15 +280,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward: dK, dV
 // ------------------------------------------------------------------------------------------------
-static constexpr int kDkvLds = 2 * 8192 + 2 * 64 * FTMI_TS + 512;
+static constexpr int kDkvLds = 2 * 8192 + 512;
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* qs = smem;
     char* dos = smem + 8192;
-    char* qts = smem + 16384;
-    char* dots = qts + 64 * FTMI_TS;
-    float* lses = reinterpret_cast<float*>(dots + 64 * FTMI_TS);
+    float* lses = reinterpret_cast<float*>(smem + 2 * 8192);
     float* dels = lses + 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -344,9 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     };
     auto lwrite = [&]() {
         store_tile_rm(qr, qs, tid);
-        store_tile_tr(qr, qts, tid);
         store_tile_rm(dor, dos, tid);
-        store_tile_tr(dor, dots, tid);
         if (tid < 64) {
             lses[tid] = lser;
             dels[tid] = delr;
@@ -368,9 +357,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                s16x8 qf = *reinterpret_cast<const s16x8*>(qs + lds_rm_off(is * 32 + li, c * 2 + g));
+                s16x8 qf = read_row_frag(qs, is * 32 + li, c, g);
                 s = mfma32(qf, kf[c], s);
-                s16x8 dof = *reinterpret_cast<const s16x8*>(dos + lds_rm_off(is * 32 + li, c * 2 + g));
+                s16x8 dof = read_row_frag(dos, is * 32 + li, c, g);
                 dp = mfma32(dof, vf[c], dp);
             }
 #pragma unroll
@@ -392,9 +381,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 s16x8 dsf = pack_frag(dp, hh);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    s16x8 dotf = read_tr_frag(dots, dt * 32 + li, is * 32 + hh * 16, g);
+                    s16x8 dotf = read_tr_frag(dos, dt * 32, is * 32 + hh * 16, lane);
                     dvt[dt] = mfma32(dotf, pf, dvt[dt]);
-                    s16x8 qtf = read_tr_frag(qts, dt * 32 + li, is * 32 + hh * 16, g);
+                    s16x8 qtf = read_tr_frag(qs, dt * 32, is * 32 + hh * 16, lane);
                     dkt[dt] = mfma32(qtf, dsf, dkt[dt]);
                 }
             }
@@ -425,14 +414,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward: dQ
 // ------------------------------------------------------------------------------------------------
-static constexpr int kDqLds = 2 * 8192 + 64 * FTMI_TS + 256;
+static constexpr int kDqLds = 2 * 8192 + 256;
 
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ks = smem;
     char* vs = smem + 8192;
-    char* kts = smem + 16384;
-    float* kb = reinterpret_cast<float*>(kts + 64 * FTMI_TS);
+    float* kb = reinterpret_cast<float*>(smem + 2 * 8192);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
@@ -476,7 +464,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     };
     auto lwrite = [&]() {
         store_tile_rm(kr, ks, tid);
-        store_tile_tr(kr, kts, tid);
         store_tile_rm(vr, vs, tid);
         if (tid < 64) kb[tid] = kbr;
     };
@@ -496,9 +483,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                s16x8 kf = *reinterpret_cast<const s16x8*>(ks + lds_rm_off(js * 32 + li, c * 2 + g));
+                s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
                 s = mfma32(kf, qf[c], s);
-                s16x8 vf = *reinterpret_cast<const s16x8*>(vs + lds_rm_off(js * 32 + li, c * 2 + g));
+                s16x8 vf = read_row_frag(vs, js * 32 + li, c, g);
                 dp = mfma32(vf, dof[c], dp);
             }
 #pragma unroll
@@ -516,7 +503,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 s16x8 dsf = pack_frag(dp, hh);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    s16x8 ktf = read_tr_frag(kts, dt * 32 + li, js * 32 + hh * 16, g);
+                    s16x8 ktf = read_tr_frag(ks, dt * 32, js * 32 + hh * 16, lane);
                     dqt[dt] = mfma32(ktf, dsf, dqt[dt]);
                 }
             }

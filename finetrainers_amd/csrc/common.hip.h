@@ -49,8 +49,36 @@ FTMI_DEVICE int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 // ---- ds_read_b128 of 16 lanes reading 16 different rows at one k-chunk is bank-conflict free.
 FTMI_DEVICE int lds_rm_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// ---- transposed [64 rows][cols] bf16 LDS tile with padded rows (TS bytes, TS % 8 == 0, TS/4 odd*2)
-#define FTMI_TS 136  // 64 bf16 + 8 bytes pad: 8-byte reads of 32 lanes hit 64 distinct banks
+// ---- row-major [tok][64] bf16 LDS tile that is read BOTH ways: as rows (ds_read_b128: fragment with the row as the
+// ---- non-reduction index) and transposed (ds_read_b64_tr_b16: fragment with the COLUMN as the non-reduction index,
+// ---- reduction over rows).  Swizzle f(row) = bit-permutation of (row>>1)&7 whose bit 2 is (row>>1)&1: 16 lanes reading 16
+// ---- rows at one chunk hit 16 distinct 16-byte slots, and the 4 consecutive rows x 64 bytes of one transposing read hit
+// ---- 4 distinct 64-byte windows of the 256-byte bank row.
+FTMI_DEVICE int lds_rt_off(int row, int chunk) {
+    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    return row * 128 + ((chunk ^ f) << 4);
+}
+
+// ds_read_b64_tr_b16 (measured on gfx950, tools/probe_tr16.hip): inside each 16-lane group, lane 4j+q supplies the address
+// of 4 contiguous bf16 = R[j][4q..4q+3] of a 4 x 16 matrix R; lane c receives column c: (R[0][c], R[1][c], R[2][c], R[3][c]).
+FTMI_DEVICE s16x4 lds_tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// Fragment (A- or B-slot) whose non-reduction index is the tile COLUMN c = cbase + (lane & 31) and whose 8 reduction values
+// are the tile ROWS rowa + {0..3} (elements 0..3) and rowb + {0..3} (elements 4..7), from a lds_rt_off image.
+FTMI_DEVICE s16x8 lds_tr_frag(const char* tile, int cbase, int rowa, int rowb, int lane) {
+    const int l16 = lane & 15, grp = (lane >> 4) & 1;
+    const int j = l16 >> 2, q = l16 & 3;
+    const int col = cbase + grp * 16 + 4 * q;
+    const int chunk = col >> 3, within = (col & 7) * 2;
+    s16x4 lo = lds_tr_read(tile + lds_rt_off(rowa + j, chunk) + within);
+    s16x4 hi = lds_tr_read(tile + lds_rt_off(rowb + j, chunk) + within);
+    s16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
 
 FTMI_DEVICE float gelu_tanh_f(float x) {
     const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)

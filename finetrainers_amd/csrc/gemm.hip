@@ -7,7 +7,7 @@
 //              epilogue rounds through bf16 at exactly the points where the reference's eager bf16
 //              graph materialises a tensor, so fusion does not move rounding points.
 //  gemm_tn   : C[P,Q] += U[M,P]^T . V[M,Q]  (fp32 atomics) -- LoRA weight gradients dA / dB; the token
-//              dimension is the reduction, tiles are transposed while being written to LDS.
+//              dimension is the reduction, fragments come from row-major LDS tiles via ds_read_b64_tr_b16.
 //
 // Replaces: torch.nn.functional.linear / peft lora.Linear.forward and their autograd backward as
 // launched by the reference step (SURVEY 2c K6,K7,K10,K14,K15,K17,K18,K19,K21).
@@ -165,7 +165,104 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT>
+template <int N>
+FTMI_DEVICE void wait_vmcnt_barrier() {
+    // counted wait + raw barrier: a __syncthreads() here would drain every direct-to-LDS load in flight (vmcnt(0))
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// 3-stage LDS ring, direct-to-LDS loads issued two K-tiles ahead and retired with a COUNTED vmcnt, so a tile's HBM/L2
+// latency is covered by two tiles of MFMA work instead of one.
+template <int BM, int BN, int BK, int WM, int WN>
+FTMI_DEVICE void nt_run_k_ring(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                               int m0, int M, const bf16_t* __restrict__ W, long ldw, int n0, int nk, int tid) {
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;  // 1 KiB wave-instructions per wave
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;
+    constexpr int LPT = XI + WI;                    // loads per thread per K-tile
+
+    // per-lane source offsets (loop invariant apart from the K advance)
+    const bf16_t* xsrc[XI];
+    const bf16_t* wsrc[WI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        int blk = wave * XI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        int gr = min(m0 + row, M - 1);
+        xsrc[i] = X + (long)gr * ldx + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int blk = wave * WI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        wsrc[i] = W + (long)(n0 + row) * ldw + c * 8;
+    }
+    auto gl2lds = [&](int kt, int buf) {
+        char* xs = smem + buf * T::STAGE;
+        char* ws = xs + BM * BK * 2;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(xs + (wave * XI + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(ws + (wave * WI + i) * 1024), 16, 0, 0);
+    };
+
+    gl2lds(0, 0);
+    if (nk > 1) {
+        gl2lds(1, 1);
+        wait_vmcnt_barrier<LPT>();
+    } else {
+        wait_vmcnt_barrier<0>();
+    }
+    int cur = 0, nxt2 = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) gl2lds(kt + 2, nxt2);
+        const char* xs = smem + cur * T::STAGE;
+        const char* ws = xs + BM * BK * 2;
+        constexpr int NKK = BK / 16;
+        s16x8 wf[2][T::TN], xf[2][T::TM];
+        auto lfrag = [&](int buf, int kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) {
+                int row = (wn * T::TN + tn) * 32 + li;
+                wf[buf][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>(row, kk * 2 + g));
+            }
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) {
+                int row = (wm * T::TM + tm) * 32 + li;
+                xf[buf][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>(row, kk * 2 + g));
+            }
+        };
+        lfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+        }
+        // tile kt+1 (issued one iteration ago) must have landed before anyone reads it; tile kt+2 may stay in flight
+        if (kt + 2 < nk)
+            wait_vmcnt_barrier<LPT>();
+        else
+            wait_vmcnt_barrier<0>();
+        cur = (cur == 2) ? 0 : cur + 1;
+        nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs p) {
     using T = NtTile<BM, BN, BK, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,7 +300,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
+        if constexpr (NSTAGE == 3)
+            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
+        else
+            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
     }
 
     if constexpr (EXT) {
@@ -228,7 +328,10 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             }
         const bf16_t* X2 = p.X2;
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
-        nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
+        if constexpr (NSTAGE == 3)
+            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
+        else
+            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
     }
 
     // ---------------- epilogue ----------------
@@ -304,7 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int NSTAGE>
 static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
     using T = NtTile<BM, BN, BK, WM, WN>;
     const int ntm = (a0.M + BM - 1) / BM, ntn = a0.N / BN;
@@ -322,30 +425,31 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
             a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
         }
     }
-    const size_t smem = 2 * T::STAGE;
+    const size_t smem = NSTAGE * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
         if (smem > 65536) {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, NSTAGE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT>), dim3(8 * a.map_rm * a.map_rn), dim3(T::NT), smem, st, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, NSTAGE>), dim3(8 * a.map_rm * a.map_rn), dim3(T::NT), smem, st, a);
     return check_launch("gemm_nt");
 }
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, int NSTAGE>
 static int launch_nt2(const GemmNtArgs& a, hipStream_t st) {
-    return a.K2 > 0 ? launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, true>(a, st) : launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, false>(a, st);
+    return a.K2 > 0 ? launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, true, NSTAGE>(a, st)
+                    : launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, false, NSTAGE>(a, st);
 }
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int NSTAGE = 2>
 static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     switch (a.epi) {
-        case EPI_STORE: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE>(a, st);
-        case EPI_GELU: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_GELU>(a, st);
-        case EPI_RESID: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_RESID>(a, st);
-        default: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_DGELU>(a, st);
+        case EPI_STORE: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE, NSTAGE>(a, st);
+        case EPI_GELU: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_GELU, NSTAGE>(a, st);
+        case EPI_RESID: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_RESID, NSTAGE>(a, st);
+        default: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_DGELU, NSTAGE>(a, st);
     }
 }
 
@@ -373,8 +477,25 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmNtArgs p) {
         acc0[r] = 0.f;
         acc1[r] = 0.f;
     }
-#pragma unroll 8
-    for (int k = 0; k < kq; k += 16) {
+    // the K loop is a chain of independent (load, load, load, mfma, mfma) steps: issue UN steps of loads before the first
+    // MFMA so ~24 x 1 KiB are in flight per wave (the compiler does not unroll a runtime-bound loop on its own)
+    constexpr int UN = 8;
+    int k = 0;
+    for (; k + 16 * UN <= kq; k += 16 * UN) {
+        s16x8 xf[UN], w0[UN], w1[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            xf[u] = *reinterpret_cast<const s16x8*>(xp + k + 16 * u);
+            w0[u] = *reinterpret_cast<const s16x8*>(wp0 + k + 16 * u);
+            w1[u] = *reinterpret_cast<const s16x8*>(wp1 + k + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc0 = mfma32(w0[u], xf[u], acc0);
+            acc1 = mfma32(w1[u], xf[u], acc1);
+        }
+    }
+    for (; k < kq; k += 16) {
         s16x8 xf = *reinterpret_cast<const s16x8*>(xp + k);
         s16x8 w0 = *reinterpret_cast<const s16x8*>(wp0 + k);
         s16x8 w1 = *reinterpret_cast<const s16x8*>(wp1 + k);
@@ -443,6 +564,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 5: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 6: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 4, 2, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 7: return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
+            case 9: return launch_nt<192, 128, 32, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, BK 32: 60 KB -> 2 WG / CU
+            case 10: return launch_nt<128, 128, 64, 2, 2, true, 1, 3>(a, st);  // 3-stage ring, BK 64: 96 KB -> 1 WG / CU
+            case 11: return launch_nt<128, 128, 32, 2, 2, true, 1, 3>(a, st);  // 3-stage ring, BK 32: 48 KB -> 3 WG / CU
             default: return launch_nt<128, 128, 64, 2, 2, true, 1>(a, st);
         }
     }
@@ -459,9 +583,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     constexpr int WP = 2, WQ = 2;
     constexpr int TP = BP / WP / 32, TQ = BQ / WQ / 32;
     constexpr int UIT = BP / 32, VIT = BQ / 32;  // (16 rows x 4 chunks) load slots per wave
+    // Row-major [64 tok][64 col] sub-tiles (8 KiB each, lds_rt_off swizzle).  Both operands have the token index as the
+    // reduction, so every fragment is fetched with the transposing LDS read (ds_read_b64_tr_b16) -- no transposed copy.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ut = smem;             // [BP][64 m] row-major swizzled
-    char* vt = smem + BP * 128;  // [BQ][64 m]
+    char* ut = smem;                      // BP/64 sub-tiles
+    char* vt = smem + (BP / 64) * 8192;   // BQ/64 sub-tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave / WQ, wq = wave % WQ;
     const int li = lane & 31, g = lane >> 5;
@@ -488,62 +614,72 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    s16x8 ur[UIT], vr[VIT];
+    // The token loop is short (a few 64-row steps per workgroup) and each step depends on a fresh HBM read, so the
+    // loads of up to NB steps are issued together (register-staged) and consumed one step at a time.
+    constexpr int NB = 4;
+    s16x8 ur[NB][UIT], vr[NB][VIT];
     const int m_l = lane & 15, c_l = lane >> 4;
-    auto gload = [&](int s) {
+    auto gload = [&](int b, int s) {
         const int mbase = s * 64;
 #pragma unroll
         for (int it = 0; it < UIT; ++it) {
             int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, pc = (sidx >> 2) * 4 + c_l;
             s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            ur[it] = (mbase + m < a.M) ? *reinterpret_cast<const s16x8*>(U + (long)(mbase + m) * a.ldu + pc * 8) : z;
+            ur[b][it] = (mbase + m < a.M) ? *reinterpret_cast<const s16x8*>(U + (long)(mbase + m) * a.ldu + pc * 8) : z;
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
             int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, qc = (sidx >> 2) * 4 + c_l;
             s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            vr[it] = (mbase + m < a.M) ? *reinterpret_cast<const s16x8*>(V + (long)(mbase + m) * a.ldv + qc * 8) : z;
+            vr[b][it] = (mbase + m < a.M) ? *reinterpret_cast<const s16x8*>(V + (long)(mbase + m) * a.ldv + qc * 8) : z;
         }
     };
-    auto twrite = [&]() {
+    auto twrite = [&](int b) {
 #pragma unroll
         for (int it = 0; it < UIT; ++it) {
             int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, pc = (sidx >> 2) * 4 + c_l;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int row = pc * 8 + e;
-                *reinterpret_cast<short*>(ut + lds_rm_off(row, m >> 3) + (m & 7) * 2) = ur[it][e];
-            }
+            *reinterpret_cast<s16x8*>(ut + (pc >> 3) * 8192 + lds_rt_off(m, pc & 7)) = ur[b][it];
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
             int sidx = wave + 4 * it, m = (sidx & 3) * 16 + m_l, qc = (sidx >> 2) * 4 + c_l;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int row = qc * 8 + e;
-                *reinterpret_cast<short*>(vt + lds_rm_off(row, m >> 3) + (m & 7) * 2) = vr[it][e];
-            }
+            *reinterpret_cast<s16x8*>(vt + (qc >> 3) * 8192 + lds_rt_off(m, qc & 7)) = vr[b][it];
         }
     };
-
-    gload(s_begin);
-    for (int s = s_begin; s < s_end; ++s) {
-        twrite();
-        __syncthreads();
-        if (s + 1 < s_end) gload(s + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
+            const int rowa = kk * 16 + 8 * g, rowb = rowa + 4;  // k-group g reduces over tokens kk*16 + 8g + {0..7}
             s16x8 uf[TP], vf[TQ];
 #pragma unroll
-            for (int i = 0; i < TP; ++i) uf[i] = *reinterpret_cast<const s16x8*>(ut + lds_rm_off((wp * TP + i) * 32 + li, kk * 2 + g));
+            for (int i = 0; i < TP; ++i) {
+                const int pc = (wp * TP + i) * 32;
+                uf[i] = lds_tr_frag(ut + (pc >> 6) * 8192, pc & 63, rowa, rowb, lane);
+            }
 #pragma unroll
-            for (int j = 0; j < TQ; ++j) vf[j] = *reinterpret_cast<const s16x8*>(vt + lds_rm_off((wq * TQ + j) * 32 + li, kk * 2 + g));
+            for (int j = 0; j < TQ; ++j) {
+                const int qc = (wq * TQ + j) * 32;
+                vf[j] = lds_tr_frag(vt + (qc >> 6) * 8192, qc & 63, rowa, rowb, lane);
+            }
 #pragma unroll
             for (int i = 0; i < TP; ++i)
 #pragma unroll
                 for (int j = 0; j < TQ; ++j) acc[i][j] = mfma32(uf[i], vf[j], acc[i][j]);
         }
-        __syncthreads();
+    };
+
+    for (int s = s_begin; s < s_end; s += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (s + b < s_end) gload(b, s + b);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (s + b < s_end) {
+                twrite(b);
+                __syncthreads();
+                compute();
+                __syncthreads();
+            }
     }
 
 #pragma unroll
@@ -586,11 +722,11 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     const dim3 grid(tiles * nsplit);
     ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q, st);
     if (wideP)
-        hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), (128 + 64) * 128, st, a);
+        hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), 3 * 8192, st, a);
     else if (wideQ)
-        hipLaunchKernelGGL((gemm_tn_kernel<64, 128>), grid, dim3(256), (128 + 64) * 128, st, a);
+        hipLaunchKernelGGL((gemm_tn_kernel<64, 128>), grid, dim3(256), 3 * 8192, st, a);
     else
-        hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, dim3(256), (64 + 64) * 128, st, a);
+        hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, dim3(256), 2 * 8192, st, a);
     return check_launch("gemm_tn");
 }
 

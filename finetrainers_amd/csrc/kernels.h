@@ -19,14 +19,14 @@ enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3 };
 // ---- in-stream HIP-event profiler (bench.py's live roofline numbers) ----
 enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_ATTN_FWD = 2, PROF_ATTN_BWD = 3, PROF_NCLASS = 4 };
 bool prof_enabled();
-void prof_begin(int kclass, double flops, hipStream_t st);
+bool prof_begin(int kclass, double flops, hipStream_t st);  // true if this launch is sampled (events recorded)
 void prof_end(int kclass, hipStream_t st);
 struct ProfScope {
     int k;
     hipStream_t st;
     bool on;
-    ProfScope(int kclass, double flops, hipStream_t s) : k(kclass), st(s), on(prof_enabled()) {
-        if (on) prof_begin(k, flops, st);
+    ProfScope(int kclass, double flops, hipStream_t s) : k(kclass), st(s), on(false) {
+        if (prof_enabled()) on = prof_begin(k, flops, st);
     }
     ~ProfScope() {
         if (on) prof_end(k, st);

@@ -46,12 +46,15 @@ int ftmi_version(void);
 /* Copies the message of the most recent failing call (process-wide slot, not thread-local) */
 int ftmi_last_error(char* buf, size_t len);
 
-/* In-stream HIP-event profiler used by bench.py for its live roofline figures: while enabled, every launch of a
- * kernel class is bracketed by two events on the launch stream.  Classes: 0 gemm_nt, 1 gemm_tn, 2 attention forward,
- * 3 attention backward (delta + dK/dV + dQ).  ftmi_prof_summary waits for the recorded events and returns the summed
- * device time, launch count and algorithmic FLOPs of one class (reset != 0 clears its records). */
-int ftmi_prof_enable(int on);
-int ftmi_prof_summary(int kernel_class, double* total_ms, long* launches, double* total_flops, int reset);
+/* In-stream HIP-event profiler used by bench.py for its live roofline figures: while enabled, every stride-th launch of a
+ * kernel class is bracketed by two events on the launch stream (stride 1 = every launch; bracketing all ~1500 launches
+ * of a step costs ~8 % of the step, sampling keeps the measurement inside the timed region at <1 %).  Classes: 0 gemm_nt,
+ * 1 gemm_tn, 2 attention forward, 3 attention backward (delta + dK/dV + dQ).  ftmi_prof_summary waits for the recorded
+ * events and returns, for one class, the summed device time / count / algorithmic FLOPs of the SAMPLED launches and the
+ * count / FLOPs of ALL launches seen (reset != 0 clears the class). */
+int ftmi_prof_enable(int stride);
+int ftmi_prof_summary(int kernel_class, double* sampled_ms, long* sampled_launches, double* sampled_flops, long* all_launches,
+                      double* all_flops, int reset);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Attention provider level.  q,k,v,out,dout,dq,dk,dv: bf16, head_dim 64 contiguous; element (b,h,s,:) lives at
