@@ -51,6 +51,17 @@ def parse():
     return ap.parse_args()
 
 
+def _pmc_traffic(kernel: str):
+    """PMC counters cannot be read from inside the process being measured: the per-launch HBM traffic of the dominant kernel is
+    taken from the committed rocprofv3 --pmc summary of this same command (tools/gpu_traffic.sh); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(args):
     """The reference path (its CPU restatement, oracle/ltx.py) timed on this box's host cores: one forward+backward+
     clip+AdamW step at the SAME clip shape and width, batch 1, on a bounded number of DiT blocks, scaled linearly to 28
@@ -203,7 +214,8 @@ def main():
                     "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s",
                     "frac": g_["tflops"] / PEAK_BF16_TFLOPS,
-                    "traffic": None,
+                    "traffic": _pmc_traffic("gemm_nt_kernel"),
+                    "traffic_unit": "HBM/fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/r01_pmc_traffic.json)",
                     "avg_launch_us": g_["avg_us"],
                     "launches_per_step": g_["launches_per_step"],
                     "share_of_step": g_["ms_per_step"] / ms,
