@@ -262,6 +262,124 @@ FTMI_DEVICE void nt_run_k_ring(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// "Ping-pong" K loop for one 8-wave workgroup per CU (192 x 256 tile, BK = 32, 4-stage LDS ring, direct-to-LDS loads).
+// The two wave rows (wm = 0 / 1; waves i and i+4 share a SIMD) run ONE BARRIER apart: every K-tile is a load segment
+// (issue tile s+3, ds_read the fragments of tile s, counted vmcnt for tile s+1, lgkmcnt(0)) and an MFMA segment, separated
+// by workgroup barriers -- so on every SIMD one wave is always inside its MFMA cluster while the other fetches operands.
+//   barrier index:      B0 | B1      | B2      | B3      | B4 ...
+//   wave row 0:   load_0   | mfma_0  | load_1  | mfma_1  | load_2 ...
+//   wave row 1:   (waits)  | load_0  | mfma_0  | load_1  | mfma_1 ...        (+1 barrier at the end for row 0)
+// Safety (by construction): tile s+1 is read first after B(2s+2); every wave has passed its own counted
+// vmcnt for tile s+1 before that barrier.  Tile s+3 overwrites the buffer of tile s-1 only after B(2s), and every read of
+// tile s-1 has completed (lgkmcnt(0)) before its reader arrived at B(2s) or earlier.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+FTMI_DEVICE void pp_wait_mid() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+FTMI_DEVICE void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int BM, int BN, int WM, int WN>
+FTMI_DEVICE void nt_run_k_pp(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                             int m0, int M, const bf16_t* __restrict__ W, long ldw, int n0, int nk, int tid) {
+    constexpr int BK = 32, NS = 4;
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    static_assert(T::NW == 8, "ping-pong loop is written for 8 waves");
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int NBLK = (BM + BN) * BK * 2 / 1024;  // 1 KiB blocks (16 rows x 64 B) per K-tile, X rows first then W rows
+    constexpr int MAXB = (NBLK + 7) / 8;
+
+    // this wave's blocks: wave, wave + 8, ...; per-lane source pointer of each (K advance added per tile)
+    const bf16_t* src[MAXB];
+    int nblk = 0;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + 8 * i;
+        src[i] = nullptr;
+        if (blk < NBLK) {
+            const int trow = blk * 16 + (lane >> 2);  // row inside [X tile | W tile]
+            const int cs = lane & 3;
+            if (trow < BM) {
+                const int c = cs ^ ((trow >> 2) & 3);
+                src[i] = X + (long)min(m0 + trow, M - 1) * ldx + c * 8;
+            } else {
+                const int r = trow - BM;
+                const int c = cs ^ ((r >> 2) & 3);
+                src[i] = W + (long)(n0 + r) * ldw + c * 8;
+            }
+            nblk = i + 1;
+        }
+    }
+    const bool full = (nblk == MAXB);  // wave-uniform: this wave issues MAXB (else MAXB-1) loads per tile
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & (NS - 1)) * T::STAGE;
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            if (i < MAXB - 1 || full)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
+                                                 (__attribute__((address_space(3))) void*)(st + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+    };
+    // counted wait so that all but the newest `ahead` tiles of this wave have landed, then lgkmcnt(0) + barrier
+    auto wait_mid = [&](int ahead) {
+        if (full) {
+            if (ahead >= 2) pp_wait_mid<2 * MAXB>();
+            else if (ahead == 1) pp_wait_mid<MAXB>();
+            else pp_wait_mid<0>();
+        } else {
+            if (ahead >= 2) pp_wait_mid<2 * (MAXB - 1)>();
+            else if (ahead == 1) pp_wait_mid<MAXB - 1>();
+            else pp_wait_mid<0>();
+        }
+    };
+
+    // prologue: three tiles in flight, tile 0 landed and visible to everyone
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    wait_mid(min(2, nk - 1));   // B0
+    if (wm == 1) pp_barrier();  // wave row 1 runs one barrier behind (joins at B1)
+
+    for (int s = 0; s < nk; ++s) {
+        // ---------------- load segment ----------------
+        if (s + 3 < nk) issue(s + 3);
+        const char* xs = smem + (s & (NS - 1)) * T::STAGE;
+        const char* ws = xs + BM * BK * 2;
+        s16x8 wf[2][T::TN], xf[2][T::TM];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) {
+                int row = (wn * T::TN + tn) * 32 + li;
+                wf[kk][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>(row, kk * 2 + g));
+            }
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) {
+                int row = (wm * T::TM + tm) * 32 + li;
+                xf[kk][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>(row, kk * 2 + g));
+            }
+        }
+        // tile s+1 must have landed (this wave's part); tiles s+2, s+3 may stay in flight
+        wait_mid(min(2, nk - 1 - (s + 1)) < 0 ? 0 : min(2, nk - 1 - (s + 1)));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---------------- MFMA segment ----------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk][tn], xf[kk][tm], acc[tn][tm]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        pp_barrier();
+    }
+    if (wm == 0) pp_barrier();  // re-align the two wave rows
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs p) {
     using T = NtTile<BM, BN, BK, WM, WN>;
@@ -300,7 +418,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        if constexpr (NSTAGE == 3)
+        if constexpr (NSTAGE == 4)
+            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
+        else if constexpr (NSTAGE == 3)
             nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
         else
             nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
@@ -328,7 +448,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             }
         const bf16_t* X2 = p.X2;
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
-        if constexpr (NSTAGE == 3)
+        if constexpr (NSTAGE == 4)
+            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
+        else if constexpr (NSTAGE == 3)
             nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
         else
             nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
@@ -412,14 +534,27 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
     using T = NtTile<BM, BN, BK, WM, WN>;
     const int ntm = (a0.M + BM - 1) / BM, ntn = a0.N / BN;
     GemmNtArgs a = a0;
-    // choose the XCD grid (gm x gn = 8) whose rectangles touch the fewest operand bytes per tile, then pad the launch
+    // Choose the XCD grid gm x gn = 8 by predicted fabric->L2 operand traffic: every XCD streams the X panels of its tile rows
+    // once per round of resident tiles and W panels once per tile column, so traffic ~ gn*|X|*rounds + gm*|W|.  Measured
+    // with rocprofv3 FETCH_SIZE on the step's shapes (profiles/r01_pmc_traffic.json, tools/gpu_map_exp.sh): splitting the
+    // token dimension over all 8 XCDs (gm = 8) moves the fewest bytes whenever M >= N; the launch grid is padded to 8*rm*rn.
     long best = -1;
+    static int force_gm = -1;
+    if (force_gm < 0) {
+        const char* e = getenv("FTMI_MAP_GM");
+        force_gm = e ? atoi(e) : 0;
+    }
     for (int gm = 1; gm <= 8; gm *= 2) {
+        if (force_gm > 0 && gm != force_gm) continue;
         const int gn = 8 / gm;
         const int rm = (ntm + gm - 1) / gm, rn = (ntn + gn - 1) / gn;
-        const long panels = (long)rm * BM + (long)rn * BN;         // operand rows streamed per K-slice by one XCD
-        const long waste = (long)rm * rn * 8 - (long)ntm * ntn;    // padded (idle) blocks
-        const long cost = panels * 64 + waste * 256;
+        const long resident = 64;                                              // tiles an XCD holds at once (32 CUs x 2 WG)
+        const long rounds = ((long)rm * rn + resident - 1) / resident;
+        const long cols_per_round = (rn + rounds - 1) / rounds;                // column groups walked m-fastest
+        const long x_reads = (long)rm * BM * ((rn + cols_per_round - 1) / cols_per_round);  // X rows streamed by one XCD
+        const long w_reads = (long)rn * BN;                                    // W rows streamed by one XCD
+        const long waste = (long)rm * rn * 8 - (long)ntm * ntn;                // padded (idle) blocks
+        const long cost = (x_reads + w_reads) * 8 + waste * 64;
         if (best < 0 || cost < best) {
             best = cost;
             a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
@@ -564,6 +699,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 5: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 6: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 4, 2, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 7: return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
+            case 12: if (a.N % 256 == 0) return launch_nt<192, 256, 32, 2, 4, true, 1, 4>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
             case 9: return launch_nt<192, 128, 32, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, BK 32: 60 KB -> 2 WG / CU
             case 10: return launch_nt<128, 128, 64, 2, 2, true, 1, 3>(a, st);  // 3-stage ring, BK 64: 96 KB -> 1 WG / CU
             case 11: return launch_nt<128, 128, 32, 2, 2, true, 1, 3>(a, st);  // 3-stage ring, BK 32: 48 KB -> 3 WG / CU
@@ -602,8 +738,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     const int s_end = min(nsteps_total, s_begin + a.msteps_per_split);
     if (s_begin >= s_end) return;
 
-    const bf16_t* U = a.U + p0;
-    const bf16_t* V = a.V + q0;
+    const bf16_t* U = a.U + (long)blockIdx.y * a.u_bstride + p0;
+    const bf16_t* V = a.V + (long)blockIdx.y * a.v_bstride + q0;
+    float* C = a.C + (long)blockIdx.y * a.c_bstride;
     if (a.v_grp_p > 0) V += (long)(p0 / a.v_grp_p) * a.v_grp_stride;
 
     f32x16 acc[TP][TQ];
@@ -690,7 +827,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pp = p0 + (wp * TP + i) * 32 + crow(r, g);
-                atomicAdd(a.C + (long)pp * a.ldc + q, acc[i][j][r] * a.scale);
+                atomicAdd(C + (long)pp * a.ldc + q, acc[i][j][r] * a.scale);
             }
         }
 }
@@ -713,14 +850,16 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
         if (target_wgs < 1) target_wgs = 256;
     }
     // the split-M partials meet in fp32 atomics: more splits = more parallelism but P*Q atomics per split
-    int want = (target_wgs + tiles - 1) / tiles;
+    const int nb = a.batch > 0 ? a.batch : 1;
+    // batched launches already fill the GPU with tiles x batch workgroups: split the token loop only as far as needed
+    int want = nb > 1 ? (4 * target_wgs + tiles * nb - 1) / (tiles * nb) : (target_wgs + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int per = (nsteps + want - 1) / want;
     if (per < 1) per = 1;
     a.msteps_per_split = per;
     const int nsplit = (nsteps + per - 1) / per;
-    const dim3 grid(tiles * nsplit);
-    ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q, st);
+    const dim3 grid(tiles * nsplit, nb);
+    ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q * nb, st);
     if (wideP)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), 3 * 8192, st, a);
     else if (wideQ)

@@ -83,6 +83,9 @@ struct GemmTnArgs {
     long v_grp_stride = 0;
     int msteps_per_split = 0;  // filled by the launcher
     float scale = 1.f;
+    // batched form (blockIdx.y = batch index): element strides between consecutive problems (0 = shared operand)
+    int batch = 1;
+    long u_bstride = 0, v_bstride = 0, c_bstride = 0;
 };
 int gemm_tn(const GemmTnArgs& a, hipStream_t st);
 

@@ -22,6 +22,8 @@ struct WsLayout {
     size_t blk0, blk_stride;
     // per-block (offsets relative to the block base)
     size_t n1, qkv, qrot, krot, o1, lse1, xa_qkv, xa_o, h1, q2raw, q2n, kv2raw, k2n, o2, lse2, xa_q2, xa_kv2, xa_o2, h2, z;
+    // per-block backward stash: the dY / dXA operands of the LoRA weight gradients, consumed by batched launches at the end
+    size_t g_o2, g_q2, g_o, g_qkv, g_kv2, dxa_o2, dxa_kv2, dxa_q2, dxa_o, dxa_qkv;
     // scratch
     size_t s_n2, s_g, s_ln, s_dh0, s_dh1, s_d1, s_d2, s_d3, s_dqr, s_dkr, s_dbig, s_dqkv, s_dxa, s_delta, s_dkv2, s_dk2n;
 };
@@ -70,6 +72,16 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.xa_o2 = b.take(M * r * e2);
     w.h2 = b.take(M * D * e2);
     w.z = b.take(M * (size_t)c.D_ff * e2);
+    w.g_o2 = b.take(M * D * e2);
+    w.g_q2 = b.take(M * D * e2);
+    w.g_o = b.take(M * D * e2);
+    w.g_qkv = b.take(M * 3 * D * e2);
+    w.g_kv2 = b.take(Mt * 2 * D * e2);
+    w.dxa_o2 = b.take(M * r * e2);
+    w.dxa_kv2 = b.take(Mt * 2 * r * e2);
+    w.dxa_q2 = b.take(M * r * e2);
+    w.dxa_o = b.take(M * r * e2);
+    w.dxa_qkv = b.take(M * 3 * r * e2);
     w.blk_stride = b.off;
     w.blk0 = g.take(w.blk_stride * c.L);
     w.s_n2 = g.take(M * D * e2);
@@ -325,8 +337,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     bf16_t* dh[2] = {W(ws, L.s_dh0), W(ws, L.s_dh1)};
     bf16_t* d1 = W(ws, L.s_d1);
     bf16_t* d2 = W(ws, L.s_d2);
-    bf16_t* d3 = W(ws, L.s_d3);
-    bf16_t* dxa = W(ws, L.s_dxa);
+    bf16_t* dO = W(ws, L.s_d3);
 
     // ---- tail ----
     FTMI_TRY(linear(dpred, c.C_out, M, P(w.proj_out_w_t, 0), c.C_out, D, c.C_out, nullptr, d1, D, V, st));
@@ -337,25 +348,16 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     }
     int cur = 0;
 
-    // LoRA weight-gradient pair for one adapter: dB += dY^T XA ; dXA = s * dY B ; dA += dXA^T X
-    auto lora_grads = [&](const bf16_t* dY, long lddy, int rows, int nadp, int adp, int l, const bf16_t* XA, const bf16_t* X, long ldX) -> int {
-        // nadp fused adapters starting at index adp (q,k,v -> 3; k2,v2 -> 2; else 1); dY is [rows, nadp*D]
+    // LoRA adapter backward, critical-path half: dXA = s * dY B (needed at once by the dgrad K-extension).  The weight
+    // gradients dB += dY^T XA and dA += dXA^T X only feed the gradient buffer, so dY / dXA are kept per block and all 28
+    // blocks of one adapter are reduced by ONE batched launch after the loop (fills the GPU instead of 28 latency-bound ones).
+    auto lora_dxa = [&](const bf16_t* dY, long lddy, int rows, int nadp, int adp, int l, bf16_t* dxa_out) -> int {
         const bf16_t* lbt = P(w.lora_bt, ((size_t)l * 8 + adp) * r * D);  // [nadp*r][D]
-        float* gB = grad_b + ((size_t)l * 8 + adp) * D * r;               // [nadp*D][r]
-        float* gA = grad_a + ((size_t)l * 8 + adp) * r * D;               // [nadp*r][D]
-        GemmTnArgs t;
-        t.U = dY; t.ldu = lddy; t.V = XA; t.ldv = (long)nadp * r; t.C = gB; t.ldc = r; t.M = rows; t.P = nadp * D; t.Q = r;
-        if (nadp > 1) { t.v_grp_p = D; t.v_grp_stride = r; }
-        FTMI_TRY(gemm_tn(t, st));
         GemmNtArgs a;
         a.X = dY; a.ldx = lddy; a.W = lbt; a.ldw = D; a.M = rows; a.N = nadp * r; a.K = D; a.alpha = s;
         if (nadp > 1) { a.xk_grp_n = r; a.xk_grp_stride = D; }
-        a.out = dxa; a.ldo = (long)nadp * r; a.variant = V;
-        FTMI_TRY(gemm_nt(a, st));
-        GemmTnArgs u;
-        u.U = dxa; u.ldu = (long)nadp * r; u.V = X; u.ldv = ldX; u.C = gA; u.ldc = D; u.M = rows; u.P = nadp * r; u.Q = D;
-        FTMI_TRY(gemm_tn(u, st));
-        return 0;
+        a.out = dxa_out; a.ldo = (long)nadp * r; a.variant = V;
+        return gemm_nt(a, st);
     };
 
     for (int l = c.L - 1; l >= 0; --l) {
@@ -377,14 +379,15 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             FTMI_TRY(gemm_nt(a, st));
         }
         FTMI_TRY(linear(W(ws, L.s_dbig), c.D_ff, M, P(w.w_ff1_t, (size_t)l * D * c.D_ff), c.D_ff, D, c.D_ff, nullptr, d2, D, V, st));
-        FTMI_TRY(norm_modulate_bwd(h2, d2, ada + 7 * D, ab, dhin, d3, M, c.S, D, c.eps_norm, 0, st));  // d3 = dh2
+        bf16_t* d3 = W(blk, L.g_o2);  // dh2: also the dY of attn2.to_out
+        FTMI_TRY(norm_modulate_bwd(h2, d2, ada + 7 * D, ab, dhin, d3, M, c.S, D, c.eps_norm, 0, st));
 
         // ---- cross-attention ----
-        if (r > 0) FTMI_TRY(lora_grads(d3, D, M, 1, 7, l, W(blk, L.xa_o2), W(blk, L.o2), D));
+        if (r > 0) FTMI_TRY(lora_dxa(d3, D, M, 1, 7, l, W(blk, L.dxa_o2)));
         {
             GemmNtArgs a;
             a.X = d3; a.ldx = D; a.W = P(w.w_o2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d1; a.ldo = D; a.variant = V;
-            if (r > 0) { a.X2 = dxa; a.ldx2 = r; a.W2 = lat + 7L * D * r; a.ldw2 = r; a.K2 = r; }
+            if (r > 0) { a.X2 = W(blk, L.dxa_o2); a.ldx2 = r; a.W2 = lat + 7L * D * r; a.ldw2 = r; a.K2 = r; }
             FTMI_TRY(gemm_nt(a, st));  // d1 = dO2
         }
         {
@@ -398,34 +401,36 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             a.delta = WF(ws, L.s_delta);
             a.dq = d2;                    set3(a.dq_sb, a.dq_sh, a.dq_ss, c.S, D);
             a.dk = W(ws, L.s_dk2n);       set3(a.dk_sb, a.dk_sh, a.dk_ss, c.T, D);
-            a.dv = W(ws, L.s_dkv2) + D;   set3(a.dv_sb, a.dv_sh, a.dv_ss, c.T, 2 * D);
+            a.dv = W(blk, L.g_kv2) + D;   set3(a.dv_sb, a.dv_sh, a.dv_ss, c.T, 2 * D);
             FTMI_TRY(attn_bwd(a, st));
         }
         if (r > 0) {
             FTMI_TRY(qknorm_rope_bwd(W(blk, L.kv2raw), 2 * D, P(w.norm_k2, (size_t)l * D), nullptr, nullptr, W(ws, L.s_dk2n), D,
-                                     W(ws, L.s_dkv2), 2 * D, Mt, c.T, D, c.eps_qk, st));
-            FTMI_TRY(lora_grads(W(ws, L.s_dkv2), 2 * D, Mt, 2, 5, l, W(blk, L.xa_kv2), e, D));
+                                     W(blk, L.g_kv2), 2 * D, Mt, c.T, D, c.eps_qk, st));
+            FTMI_TRY(lora_dxa(W(blk, L.g_kv2), 2 * D, Mt, 2, 5, l, W(blk, L.dxa_kv2)));
         }
-        FTMI_TRY(qknorm_rope_bwd(W(blk, L.q2raw), D, P(w.norm_q2, (size_t)l * D), nullptr, nullptr, d2, D, d1, D, M, c.S, D, c.eps_qk, st));  // d1 = dq2raw
-        if (r > 0) FTMI_TRY(lora_grads(d1, D, M, 1, 4, l, W(blk, L.xa_q2), h1, D));
+        bf16_t* gq2 = W(blk, L.g_q2);  // dq2raw
+        FTMI_TRY(qknorm_rope_bwd(W(blk, L.q2raw), D, P(w.norm_q2, (size_t)l * D), nullptr, nullptr, d2, D, gq2, D, M, c.S, D, c.eps_qk, st));
+        if (r > 0) FTMI_TRY(lora_dxa(gq2, D, M, 1, 4, l, W(blk, L.dxa_q2)));
         {
             GemmNtArgs a;
-            a.X = d1; a.ldx = D; a.W = P(w.w_q2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d2; a.ldo = D; a.variant = V;
+            a.X = gq2; a.ldx = D; a.W = P(w.w_q2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d2; a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = d3; a.ldr = D;
-            if (r > 0) { a.X2 = dxa; a.ldx2 = r; a.W2 = lat + 4L * D * r; a.ldw2 = r; a.K2 = r; }
+            if (r > 0) { a.X2 = W(blk, L.dxa_q2); a.ldx2 = r; a.W2 = lat + 4L * D * r; a.ldw2 = r; a.K2 = r; }
             FTMI_TRY(gemm_nt(a, st));  // d2 = dh1
         }
 
         // ---- self-attention ----
-        FTMI_TRY(mul_gate(d2, ada + 2 * D, ab, d1, M, c.S, D, st));  // d1 = d(to_out output)
-        if (r > 0) FTMI_TRY(lora_grads(d1, D, M, 1, 3, l, W(blk, L.xa_o), W(blk, L.o1), D));
+        bf16_t* go = W(blk, L.g_o);  // d(attn1.to_out output)
+        FTMI_TRY(mul_gate(d2, ada + 2 * D, ab, go, M, c.S, D, st));
+        if (r > 0) FTMI_TRY(lora_dxa(go, D, M, 1, 3, l, W(blk, L.dxa_o)));
         {
             GemmNtArgs a;
-            a.X = d1; a.ldx = D; a.W = P(w.w_o_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d3; a.ldo = D; a.variant = V;
-            if (r > 0) { a.X2 = dxa; a.ldx2 = r; a.W2 = lat + 3L * D * r; a.ldw2 = r; a.K2 = r; }
-            FTMI_TRY(gemm_nt(a, st));  // d3 = dO
+            a.X = go; a.ldx = D; a.W = P(w.w_o_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = dO; a.ldo = D; a.variant = V;
+            if (r > 0) { a.X2 = W(blk, L.dxa_o); a.ldx2 = r; a.W2 = lat + 3L * D * r; a.ldw2 = r; a.K2 = r; }
+            FTMI_TRY(gemm_nt(a, st));
         }
-        bf16_t* dqkv = W(ws, L.s_dqkv);
+        bf16_t* dqkv = W(blk, L.g_qkv);
         const bf16_t* qkv = W(blk, L.qkv);
         {
             AttnArgs a = attn_args(c, c.S, c.S);
@@ -434,7 +439,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             a.v = qkv + 2 * D;    set3(a.v_sb, a.v_sh, a.v_ss, c.S, 3 * D);
             a.o = W(blk, L.o1);   set3(a.o_sb, a.o_sh, a.o_ss, c.S, D);
             a.lse2 = WF(blk, L.lse1);
-            a.dout = d3;          set3(a.do_sb, a.do_sh, a.do_ss, c.S, D);
+            a.dout = dO;          set3(a.do_sb, a.do_sh, a.do_ss, c.S, D);
             a.delta = WF(ws, L.s_delta);
             a.dq = W(ws, L.s_dqr); set3(a.dq_sb, a.dq_sh, a.dq_ss, c.S, D);
             a.dk = W(ws, L.s_dkr); set3(a.dk_sb, a.dk_sh, a.dk_ss, c.S, D);
@@ -443,14 +448,41 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         }
         FTMI_TRY(qknorm_rope_bwd(qkv, 3 * D, P(w.norm_q, (size_t)l * D), w.rope_cos, w.rope_sin, W(ws, L.s_dqr), D, dqkv, 3 * D, M, c.S, D, c.eps_qk, st));
         FTMI_TRY(qknorm_rope_bwd(qkv + D, 3 * D, P(w.norm_k, (size_t)l * D), w.rope_cos, w.rope_sin, W(ws, L.s_dkr), D, dqkv + D, 3 * D, M, c.S, D, c.eps_qk, st));
-        if (r > 0) FTMI_TRY(lora_grads(dqkv, 3 * D, M, 3, 0, l, W(blk, L.xa_qkv), W(blk, L.n1), D));
+        if (r > 0) FTMI_TRY(lora_dxa(dqkv, 3 * D, M, 3, 0, l, W(blk, L.dxa_qkv)));
         if (l > 0) {
             GemmNtArgs a;
             a.X = dqkv; a.ldx = 3 * D; a.W = P(w.w_qkv_t, (size_t)l * 3 * D2); a.ldw = 3 * D; a.M = M; a.N = D; a.K = 3 * D; a.out = d1; a.ldo = D; a.variant = V;
-            if (r > 0) { a.X2 = dxa; a.ldx2 = 3 * r; a.W2 = P(w.lora_at_qkv, (size_t)l * D * 3 * r); a.ldw2 = 3 * r; a.K2 = 3 * r; }
+            if (r > 0) { a.X2 = W(blk, L.dxa_qkv); a.ldx2 = 3 * r; a.W2 = P(w.lora_at_qkv, (size_t)l * D * 3 * r); a.ldw2 = 3 * r; a.K2 = 3 * r; }
             FTMI_TRY(gemm_nt(a, st));  // d1 = dn1
             FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st));
             cur ^= 1;
+        }
+    }
+
+    // ---- LoRA weight gradients: one batched launch per adapter group over all L blocks ----
+    if (r > 0) {
+        char* blk0 = reinterpret_cast<char*>(ws) + L.blk0;
+        const long bs = (long)(L.blk_stride / 2);  // block stride in bf16 elements
+        struct G { size_t dy; long lddy; int rows, nadp, adp; size_t xa, dxa; const bf16_t* x; long ldx, x_bs; };
+        const G groups[5] = {
+            {L.g_o2, D, M, 1, 7, L.xa_o2, L.dxa_o2, W(blk0, L.o2), D, bs},
+            {L.g_kv2, 2L * D, Mt, 2, 5, L.xa_kv2, L.dxa_kv2, e, D, 0},
+            {L.g_q2, D, M, 1, 4, L.xa_q2, L.dxa_q2, W(blk0, L.h1), D, bs},
+            {L.g_o, D, M, 1, 3, L.xa_o, L.dxa_o, W(blk0, L.o1), D, bs},
+            {L.g_qkv, 3L * D, M, 3, 0, L.xa_qkv, L.dxa_qkv, W(blk0, L.n1), D, bs},
+        };
+        for (const G& gr : groups) {
+            GemmTnArgs t;  // dB[l] += dY[l]^T XA[l]
+            t.U = W(blk0, gr.dy); t.ldu = gr.lddy; t.V = W(blk0, gr.xa); t.ldv = (long)gr.nadp * r;
+            t.C = grad_b + (size_t)gr.adp * D * r; t.ldc = r; t.M = gr.rows; t.P = gr.nadp * D; t.Q = r;
+            if (gr.nadp > 1) { t.v_grp_p = D; t.v_grp_stride = r; }
+            t.batch = c.L; t.u_bstride = bs; t.v_bstride = bs; t.c_bstride = 8L * D * r;
+            FTMI_TRY(gemm_tn(t, st));
+            GemmTnArgs u;  // dA[l] += dXA[l]^T X[l]
+            u.U = W(blk0, gr.dxa); u.ldu = (long)gr.nadp * r; u.V = gr.x; u.ldv = gr.ldx;
+            u.C = grad_a + (size_t)gr.adp * r * D; u.ldc = D; u.M = gr.rows; u.P = gr.nadp * r; u.Q = D;
+            u.batch = c.L; u.u_bstride = bs; u.v_bstride = gr.x_bs; u.c_bstride = 8L * r * D;
+            FTMI_TRY(gemm_tn(u, st));
         }
     }
     return 0;
