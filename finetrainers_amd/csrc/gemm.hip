@@ -415,15 +415,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // first row of this tile's weight panel (rows may live in strided groups; a tile never straddles a group)
+    const bf16_t* Wt = p.w_grp_n > 0 ? p.W + (long)(n0 / p.w_grp_n) * p.w_grp_stride + (long)(n0 % p.w_grp_n) * p.ldw : p.W + (long)n0 * p.ldw;
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
         if constexpr (NSTAGE == 4)
-            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
+            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
         else if constexpr (NSTAGE == 3)
-            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
+            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
         else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, p.W, p.ldw, n0, p.K / BK, tid);
+            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
     }
 
     if constexpr (EXT) {
@@ -448,12 +450,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             }
         const bf16_t* X2 = p.X2;
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
+        const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
+                                           : p.W2 + (long)n0 * p.ldw2;
         if constexpr (NSTAGE == 4)
-            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
+            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 3)
-            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
+            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
         else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, p.W2, p.ldw2, n0, p.K2 / BK, tid);
+            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
     }
 
     // ---------------- epilogue ----------------
@@ -680,12 +684,14 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (a.N % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: N must be a multiple of 64");
     if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 4) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
-    if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
+    if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && a.w_grp_n == 0 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
         ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)a.K, st);
         hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(256), 0, st, a);
         return check_launch("gemm_nt_skinny");
     }
-    const bool wide = a.N % 128 == 0 && !(a.xk_grp_n > 0 && a.xk_grp_n % 128 != 0) && !(a.x2_grp_n > 0 && a.x2_grp_n % 128 != 0);
+    if ((a.w_grp_n > 0 && a.w_grp_n % 64) || (a.w2_grp_n > 0 && a.w2_grp_n % 64))
+        return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: weight group size must be a multiple of 64");
+    const bool wide = a.N % 128 == 0 && !(a.w_grp_n > 0 && a.w_grp_n % 128 != 0) && !(a.w2_grp_n > 0 && a.w2_grp_n % 128 != 0) && !(a.xk_grp_n > 0 && a.xk_grp_n % 128 != 0) && !(a.x2_grp_n > 0 && a.x2_grp_n % 128 != 0);
     if (!wide && ((a.xk_grp_n > 0 && a.xk_grp_n % 64 != 0) || (a.x2_grp_n > 0 && a.x2_grp_n % 64 != 0)))
         return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
     if (wide) {

@@ -41,6 +41,12 @@ struct GemmNtArgs {
     int M = 0, N = 0, K = 0;
     int xk_grp_n = 0;  // X column offset = (n0 / xk_grp_n) * xk_grp_stride   (grouped dXA of fused q,k,v)
     long xk_grp_stride = 0;
+    // W rows live in groups of w_grp_n consecutive rows, w_grp_stride elements apart (0 = plain [N, ldw]); same for W2.
+    // Lets one launch span the per-block slices of a stacked [L, 8, ...] LoRA tensor (all blocks' text-side K/V projections).
+    int w_grp_n = 0;
+    long w_grp_stride = 0;
+    int w2_grp_n = 0;
+    long w2_grp_stride = 0;
     // K-extension (fused LoRA up-projection): acc += X2 . W2^T after the base result was rounded to bf16
     const bf16_t* X2 = nullptr;
     long ldx2 = 0;
@@ -133,10 +139,11 @@ int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, lon
                       bf16_t* dx, int rows, int rows_per_batch, int D, float eps, int layernorm, hipStream_t st);
 
 // affine RMSNorm over the full width (+ optional interleaved-pair RoPE), x row stride ldx
+// w_rows > 1: row i uses weight row (i % w_rows) of a [w_rows, D] table (rows interleaved over blocks)
 int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, bf16_t* y, long ldy,
-                    int rows, int rows_per_batch, int D, float eps, hipStream_t st);
+                    int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1);
 int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy,
-                    long lddy, bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st);
+                    long lddy, bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1);
 
 // out = bf(x * gate[b])
 int mul_gate(const bf16_t* x, const bf16_t* gate, long gate_bstride, bf16_t* out, int rows, int rows_per_batch, int D,

@@ -19,11 +19,13 @@ namespace {
 struct WsLayout {
     size_t total = 0;
     size_t tsin, t1, emb, temb, ada, ada_out, cap_h, e, hs;
+    // text-side K/V of the cross-attention for ALL blocks (the text stream `e` is block-independent): one launch each
+    size_t kv2_all, k2n_all, xa_kv2_all, g_kv2_all, g_k2n_all, dxa_kv2_all;
     size_t blk0, blk_stride;
     // per-block (offsets relative to the block base)
-    size_t n1, qkv, qrot, krot, o1, lse1, xa_qkv, xa_o, h1, q2raw, q2n, kv2raw, k2n, o2, lse2, xa_q2, xa_kv2, xa_o2, h2, z;
+    size_t n1, qkv, qrot, krot, o1, lse1, xa_qkv, xa_o, h1, q2raw, q2n, o2, lse2, xa_q2, xa_o2, h2, z;
     // per-block backward stash: the dY / dXA operands of the LoRA weight gradients, consumed by batched launches at the end
-    size_t g_o2, g_q2, g_o, g_qkv, g_kv2, dxa_o2, dxa_kv2, dxa_q2, dxa_o, dxa_qkv;
+    size_t g_o2, g_q2, g_o, g_qkv, dxa_o2, dxa_q2, dxa_o, dxa_qkv;
     // scratch
     size_t s_n2, s_g, s_ln, s_dh0, s_dh1, s_d1, s_d2, s_d3, s_dqr, s_dkr, s_dbig, s_dqkv, s_dxa, s_delta, s_dkv2, s_dk2n;
 };
@@ -51,6 +53,12 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.cap_h = g.take(Mt * D * e2);
     w.e = g.take(Mt * D * e2);
     w.hs = g.take((size_t)(c.L + 1) * M * D * e2);
+    w.kv2_all = g.take(Mt * (size_t)c.L * 2 * D * e2);      // [Mt][L*2D]  (k | v per block)
+    w.k2n_all = g.take(Mt * (size_t)c.L * D * e2);          // [Mt][L][D]
+    w.xa_kv2_all = g.take(Mt * (size_t)c.L * 2 * r * e2);   // [Mt][L*2r]
+    w.g_kv2_all = g.take(Mt * (size_t)c.L * 2 * D * e2);
+    w.g_k2n_all = g.take(Mt * (size_t)c.L * D * e2);
+    w.dxa_kv2_all = g.take(Mt * (size_t)c.L * 2 * r * e2);
     Bump b;
     w.n1 = b.take(M * D * e2);
     w.qkv = b.take(M * 3 * D * e2);
@@ -63,12 +71,9 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.h1 = b.take(M * D * e2);
     w.q2raw = b.take(M * D * e2);
     w.q2n = b.take(M * D * e2);
-    w.kv2raw = b.take(Mt * 2 * D * e2);
-    w.k2n = b.take(Mt * D * e2);
     w.o2 = b.take(M * D * e2);
     w.lse2 = b.take((size_t)c.B * c.H * c.S * 4);
     w.xa_q2 = b.take(M * r * e2);
-    w.xa_kv2 = b.take(Mt * 2 * r * e2);
     w.xa_o2 = b.take(M * r * e2);
     w.h2 = b.take(M * D * e2);
     w.z = b.take(M * (size_t)c.D_ff * e2);
@@ -76,9 +81,7 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.g_q2 = b.take(M * D * e2);
     w.g_o = b.take(M * D * e2);
     w.g_qkv = b.take(M * 3 * D * e2);
-    w.g_kv2 = b.take(Mt * 2 * D * e2);
     w.dxa_o2 = b.take(M * r * e2);
-    w.dxa_kv2 = b.take(Mt * 2 * r * e2);
     w.dxa_q2 = b.take(M * r * e2);
     w.dxa_o = b.take(M * r * e2);
     w.dxa_qkv = b.take(M * 3 * r * e2);
@@ -153,7 +156,7 @@ int ltx_workspace_offset(const ftmi_ltx_config& c, const char* name, int layer, 
     const WsLayout L = make_layout(c);
     const size_t M = (size_t)c.B * c.S;
     struct E { const char* n; size_t o; };
-    const E globals[] = {{"e", L.e}, {"emb", L.emb}, {"temb", L.temb}, {"ada", L.ada}, {"ada_out", L.ada_out}, {"tsin", L.tsin}};
+    const E globals[] = {{"kv2_all", L.kv2_all}, {"k2n_all", L.k2n_all}, {"xa_kv2_all", L.xa_kv2_all}, {"e", L.e}, {"emb", L.emb}, {"temb", L.temb}, {"ada", L.ada}, {"ada_out", L.ada_out}, {"tsin", L.tsin}};
     for (const E& g : globals)
         if (!strcmp(name, g.n)) { *off = g.o; return 0; }
     if (!strcmp(name, "hs")) {
@@ -163,8 +166,8 @@ int ltx_workspace_offset(const ftmi_ltx_config& c, const char* name, int layer, 
     }
     const E blocks[] = {{"n1", L.n1}, {"qkv", L.qkv}, {"qrot", L.qrot}, {"krot", L.krot}, {"o1", L.o1}, {"lse1", L.lse1},
                         {"xa_qkv", L.xa_qkv}, {"xa_o", L.xa_o}, {"h1", L.h1}, {"q2raw", L.q2raw}, {"q2n", L.q2n},
-                        {"kv2raw", L.kv2raw}, {"k2n", L.k2n}, {"o2", L.o2}, {"lse2", L.lse2}, {"xa_q2", L.xa_q2},
-                        {"xa_kv2", L.xa_kv2}, {"xa_o2", L.xa_o2}, {"h2", L.h2}, {"z", L.z}};
+                        {"o2", L.o2}, {"lse2", L.lse2}, {"xa_q2", L.xa_q2},
+                        {"xa_o2", L.xa_o2}, {"h2", L.h2}, {"z", L.z}};
     if (layer < 0 || layer >= c.L) return set_error(FTMI_ERR_INVALID, "workspace_offset: layer out of range");
     for (const E& b : blocks)
         if (!strcmp(name, b.n)) { *off = L.blk0 + L.blk_stride * layer + b.o; return 0; }
@@ -198,6 +201,26 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
         FTMI_TRY(linear(W(ws, L.cap_h), D, Mt, P(w.cap_l2_w, 0), D, D, D, P(w.cap_l2_b, 0), W(ws, L.e), D, V, st));
     }
     const bf16_t* e = W(ws, L.e);
+
+    // ---- cross-attention keys/values of EVERY block (the text stream does not change across blocks) ----
+    {
+        const long ldkv = (long)c.L * 2 * D;
+        GemmNtArgs a;
+        a.X = e; a.ldx = D; a.W = P(w.w_kv2, 0); a.ldw = D; a.M = Mt; a.N = c.L * 2 * D; a.K = D;
+        a.bias = P(w.b_kv2, 0); a.out = W(ws, L.kv2_all); a.ldo = ldkv; a.variant = V;
+        if (r > 0) {
+            GemmNtArgs x;  // XA[:, (l,k|v)] = s * e A_{l,k|v}^T : adapters 5,6 of block l are 2r consecutive rows, blocks 8rD apart
+            x.X = e; x.ldx = D; x.W = P(w.lora_a, 5L * r * D); x.ldw = D; x.w_grp_n = 2 * r; x.w_grp_stride = 8L * r * D;
+            x.M = Mt; x.N = c.L * 2 * r; x.K = D; x.alpha = s; x.out = W(ws, L.xa_kv2_all); x.ldo = (long)c.L * 2 * r; x.variant = V;
+            FTMI_TRY(gemm_nt(x, st));
+            a.X2 = W(ws, L.xa_kv2_all); a.ldx2 = (long)c.L * 2 * r; a.x2_grp_n = D; a.x2_grp_stride = r; a.K2 = r;
+            a.W2 = P(w.lora_b, 5L * D * r); a.ldw2 = r; a.w2_grp_n = 2 * D; a.w2_grp_stride = 8L * D * r;
+        }
+        FTMI_TRY(gemm_nt(a, st));
+        // k2 = norm_k(k2raw): rows ordered (token, block): row i = t * L + l reads kv2_all + i * 2D, weight row l
+        FTMI_TRY(qknorm_rope_fwd(W(ws, L.kv2_all), 2 * D, P(w.norm_k2, 0), nullptr, nullptr, W(ws, L.k2n_all), D, Mt * c.L, Mt * c.L, D,
+                                 c.eps_qk, st, c.L));
+    }
 
     for (int l = 0; l < c.L; ++l) {
         char* blk = reinterpret_cast<char*>(ws) + L.blk0 + L.blk_stride * l;
@@ -261,24 +284,12 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             FTMI_TRY(gemm_nt(a, st));
             FTMI_TRY(qknorm_rope_fwd(W(blk, L.q2raw), D, P(w.norm_q2, (size_t)l * D), nullptr, nullptr, W(blk, L.q2n), D, M, c.S, D, c.eps_qk, st));
         }
-        // 8. cross-attention key/value from the text stream
-        {
-            GemmNtArgs a;
-            a.X = e; a.ldx = D; a.W = P(w.w_kv2, (size_t)l * 2 * D2); a.ldw = D; a.M = Mt; a.N = 2 * D; a.K = D;
-            a.bias = P(w.b_kv2, (size_t)l * 2 * D); a.out = W(blk, L.kv2raw); a.ldo = 2 * D; a.variant = V;
-            if (r > 0) {
-                FTMI_TRY(linear(e, D, Mt, la + 5L * r * D, D, 2 * r, D, nullptr, W(blk, L.xa_kv2), 2 * r, V, st, s));
-                a.X2 = W(blk, L.xa_kv2); a.ldx2 = 2 * r; a.W2 = lb + 5L * D * r; a.ldw2 = r; a.K2 = r; a.x2_grp_n = D; a.x2_grp_stride = r;
-            }
-            FTMI_TRY(gemm_nt(a, st));
-            FTMI_TRY(qknorm_rope_fwd(W(blk, L.kv2raw), 2 * D, P(w.norm_k2, (size_t)l * D), nullptr, nullptr, W(blk, L.k2n), D, Mt, c.T, D, c.eps_qk, st));
-        }
         // 9. cross-attention with the text-mask bias
         {
             AttnArgs a = attn_args(c, c.S, c.T);
             a.q = W(blk, L.q2n);          set3(a.q_sb, a.q_sh, a.q_ss, c.S, D);
-            a.k = W(blk, L.k2n);          set3(a.k_sb, a.k_sh, a.k_ss, c.T, D);
-            a.v = W(blk, L.kv2raw) + D;   set3(a.v_sb, a.v_sh, a.v_ss, c.T, 2 * D);
+            a.k = W(ws, L.k2n_all) + (size_t)l * D;              set3(a.k_sb, a.k_sh, a.k_ss, c.T, (long)c.L * D);
+            a.v = W(ws, L.kv2_all) + (size_t)l * 2 * D + D;      set3(a.v_sb, a.v_sh, a.v_ss, c.T, (long)c.L * 2 * D);
             a.o = W(blk, L.o2);           set3(a.o_sb, a.o_sh, a.o_ss, c.S, D);
             a.lse2 = WF(blk, L.lse2);
             a.kbias = key_bias;
@@ -393,21 +404,16 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         {
             AttnArgs a = attn_args(c, c.S, c.T);
             a.q = W(blk, L.q2n);          set3(a.q_sb, a.q_sh, a.q_ss, c.S, D);
-            a.k = W(blk, L.k2n);          set3(a.k_sb, a.k_sh, a.k_ss, c.T, D);
-            a.v = W(blk, L.kv2raw) + D;   set3(a.v_sb, a.v_sh, a.v_ss, c.T, 2 * D);
+            a.k = W(ws, L.k2n_all) + (size_t)l * D;              set3(a.k_sb, a.k_sh, a.k_ss, c.T, (long)c.L * D);
+            a.v = W(ws, L.kv2_all) + (size_t)l * 2 * D + D;      set3(a.v_sb, a.v_sh, a.v_ss, c.T, (long)c.L * 2 * D);
             a.o = W(blk, L.o2);           set3(a.o_sb, a.o_sh, a.o_ss, c.S, D);
             a.lse2 = WF(blk, L.lse2); a.kbias = key_bias;
             a.dout = d1;                  set3(a.do_sb, a.do_sh, a.do_ss, c.S, D);
             a.delta = WF(ws, L.s_delta);
             a.dq = d2;                    set3(a.dq_sb, a.dq_sh, a.dq_ss, c.S, D);
-            a.dk = W(ws, L.s_dk2n);       set3(a.dk_sb, a.dk_sh, a.dk_ss, c.T, D);
-            a.dv = W(blk, L.g_kv2) + D;   set3(a.dv_sb, a.dv_sh, a.dv_ss, c.T, 2 * D);
+            a.dk = W(ws, L.g_k2n_all) + (size_t)l * D;            set3(a.dk_sb, a.dk_sh, a.dk_ss, c.T, (long)c.L * D);
+            a.dv = W(ws, L.g_kv2_all) + (size_t)l * 2 * D + D;    set3(a.dv_sb, a.dv_sh, a.dv_ss, c.T, (long)c.L * 2 * D);
             FTMI_TRY(attn_bwd(a, st));
-        }
-        if (r > 0) {
-            FTMI_TRY(qknorm_rope_bwd(W(blk, L.kv2raw), 2 * D, P(w.norm_k2, (size_t)l * D), nullptr, nullptr, W(ws, L.s_dk2n), D,
-                                     W(blk, L.g_kv2), 2 * D, Mt, c.T, D, c.eps_qk, st));
-            FTMI_TRY(lora_dxa(W(blk, L.g_kv2), 2 * D, Mt, 2, 5, l, W(blk, L.dxa_kv2)));
         }
         bf16_t* gq2 = W(blk, L.g_q2);  // dq2raw
         FTMI_TRY(qknorm_rope_bwd(W(blk, L.q2raw), D, P(w.norm_q2, (size_t)l * D), nullptr, nullptr, d2, D, gq2, D, M, c.S, D, c.eps_qk, st));
@@ -459,14 +465,25 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         }
     }
 
+    // ---- text side of the cross-attention, all blocks at once (nothing upstream of `e` needs a gradient) ----
+    if (r > 0) {
+        // d(k2raw) = RMSNorm backward of d(k2n); rows ordered (token, block) like the forward
+        FTMI_TRY(qknorm_rope_bwd(W(ws, L.kv2_all), 2 * D, P(w.norm_k2, 0), nullptr, nullptr, W(ws, L.g_k2n_all), D, W(ws, L.g_kv2_all), 2 * D,
+                                 Mt * c.L, Mt * c.L, D, c.eps_qk, st, c.L));
+        GemmNtArgs a;  // dXA[:, (l,k|v)] = s * dY[:, (l,k|v) slice] B_{l,k|v}
+        a.X = W(ws, L.g_kv2_all); a.ldx = (long)c.L * 2 * D; a.xk_grp_n = r; a.xk_grp_stride = D;
+        a.W = P(w.lora_bt, 5L * r * D); a.ldw = D; a.w_grp_n = 2 * r; a.w_grp_stride = 8L * r * D;
+        a.M = Mt; a.N = c.L * 2 * r; a.K = D; a.alpha = s; a.out = W(ws, L.dxa_kv2_all); a.ldo = (long)c.L * 2 * r; a.variant = V;
+        FTMI_TRY(gemm_nt(a, st));
+    }
+
     // ---- LoRA weight gradients: one batched launch per adapter group over all L blocks ----
     if (r > 0) {
         char* blk0 = reinterpret_cast<char*>(ws) + L.blk0;
         const long bs = (long)(L.blk_stride / 2);  // block stride in bf16 elements
         struct G { size_t dy; long lddy; int rows, nadp, adp; size_t xa, dxa; const bf16_t* x; long ldx, x_bs; };
-        const G groups[5] = {
+        const G groups[4] = {
             {L.g_o2, D, M, 1, 7, L.xa_o2, L.dxa_o2, W(blk0, L.o2), D, bs},
-            {L.g_kv2, 2L * D, Mt, 2, 5, L.xa_kv2, L.dxa_kv2, e, D, 0},
             {L.g_q2, D, M, 1, 4, L.xa_q2, L.dxa_q2, W(blk0, L.h1), D, bs},
             {L.g_o, D, M, 1, 3, L.xa_o, L.dxa_o, W(blk0, L.o1), D, bs},
             {L.g_qkv, 3L * D, M, 3, 0, L.xa_qkv, L.dxa_qkv, W(blk0, L.n1), D, bs},
@@ -482,6 +499,18 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             u.U = W(blk0, gr.dxa); u.ldu = (long)gr.nadp * r; u.V = gr.x; u.ldv = gr.ldx;
             u.C = grad_a + (size_t)gr.adp * r * D; u.ldc = D; u.M = gr.rows; u.P = gr.nadp * r; u.Q = D;
             u.batch = c.L; u.u_bstride = bs; u.v_bstride = gr.x_bs; u.c_bstride = 8L * r * D;
+            FTMI_TRY(gemm_tn(u, st));
+        }
+        {   // attn2.to_k / to_v: operands are column slices of the all-block arrays (batch stride = one block's columns)
+            GemmTnArgs t;
+            t.U = W(ws, L.g_kv2_all); t.ldu = (long)c.L * 2 * D; t.V = W(ws, L.xa_kv2_all); t.ldv = (long)c.L * 2 * r;
+            t.C = grad_b + 5L * D * r; t.ldc = r; t.M = Mt; t.P = 2 * D; t.Q = r; t.v_grp_p = D; t.v_grp_stride = r;
+            t.batch = c.L; t.u_bstride = 2L * D; t.v_bstride = 2L * r; t.c_bstride = 8L * D * r;
+            FTMI_TRY(gemm_tn(t, st));
+            GemmTnArgs u;
+            u.U = W(ws, L.dxa_kv2_all); u.ldu = (long)c.L * 2 * r; u.V = e; u.ldv = D;
+            u.C = grad_a + 5L * r * D; u.ldc = D; u.M = Mt; u.P = 2 * r; u.Q = D;
+            u.batch = c.L; u.u_bstride = 2L * r; u.v_bstride = 0; u.c_bstride = 8L * r * D;
             FTMI_TRY(gemm_tn(u, st));
         }
     }

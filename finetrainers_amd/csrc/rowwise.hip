@@ -220,12 +220,13 @@ int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, lon
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                              bf16_t* __restrict__ y, long ldy, int rows, int rows_per_batch, float eps) {
+                                                              bf16_t* __restrict__ y, long ldy, int rows, int rows_per_batch, float eps, int w_rows) {
     constexpr int D = kNch * 512;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int s = row % rows_per_batch;
+    if (w_rows > 1) w += (long)(row % w_rows) * D;
     const bf16_t* xp = x + (long)row * ldx;
     float xv[kNch][8];
     float s2 = 0.f;
@@ -260,22 +261,23 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
     }
 }
 int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, bf16_t* y, long ldy,
-                    int rows, int rows_per_batch, int D, float eps, hipStream_t st) {
+                    int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows) {
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
     if ((ldx % 8) || (ldy % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
-    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, y, ldy, rows, rows_per_batch, eps);
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, y, ldy, rows, rows_per_batch, eps, w_rows);
     return check_launch("qknorm_rope_fwd");
 }
 
 __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                               const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
-                                                              int rows, int rows_per_batch, float eps) {
+                                                              int rows, int rows_per_batch, float eps, int w_rows) {
     constexpr int D = kNch * 512;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int s = row % rows_per_batch;
+    if (w_rows > 1) w += (long)(row % w_rows) * D;
     const bf16_t* xp = x + (long)row * ldx;
     const bf16_t* dyp = dy + (long)row * lddy;
     float xv[kNch][8], gv[kNch][8];
@@ -324,10 +326,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
     }
 }
 int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy, long lddy,
-                    bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st) {
+                    bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows) {
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
     if ((ldx % 8) || (lddy % 8) || (lddx % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
-    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps);
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps, w_rows);
     return check_launch("qknorm_rope_bwd");
 }
 

@@ -145,9 +145,9 @@ typedef struct {
 
 size_t ftmi_ltx_workspace_bytes(const ftmi_ltx_config* cfg);
 /* Byte offset of a named activation inside the workspace (for tests / debugging): global names "hs" (residual
- * stream [L+1,B*S,D]; layer selects the slice), "e", "emb", "temb", "ada", "ada_out"; per-block names "n1", "qkv",
- * "qrot", "krot", "o1", "lse1", "xa_qkv", "xa_o", "h1", "q2raw", "q2n", "kv2raw", "k2n", "o2", "lse2", "xa_q2",
- * "xa_kv2", "xa_o2", "h2", "z". */
+ * stream [L+1,B*S,D]; layer selects the slice), "e", "emb", "temb", "ada", "ada_out", "kv2_all" ([B*T, L*2D] text-side k|v of
+ * every block), "k2n_all" ([B*T, L, D]), "xa_kv2_all"; per-block names "n1", "qkv", "qrot", "krot", "o1", "lse1", "xa_qkv",
+ * "xa_o", "h1", "q2raw", "q2n", "o2", "lse2", "xa_q2", "xa_o2", "h2", "z". */
 int ftmi_ltx_workspace_offset(const ftmi_ltx_config* cfg, const char* name, int layer, size_t* offset);
 
 /* Forward of the DiT: x_t [B,S,C_in], text [B,T,D_cap], key_bias fp32 [B,T] ((1-mask) * -10000 as the reference

@@ -163,7 +163,7 @@ def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
     rows = []
     T = cfg.text_seq_len
     shapes = {"n1": (B * S, D), "qkv": (B * S, 3 * D), "qrot": (B * S, D), "krot": (B * S, D), "o1": (B * S, D), "h1": (B * S, D),
-              "q2raw": (B * S, D), "q2n": (B * S, D), "kv2raw": (B * T, 2 * D), "k2n": (B * T, D), "o2": (B * S, D), "h2": (B * S, D),
+              "q2raw": (B * S, D), "q2n": (B * S, D), "o2": (B * S, D), "h2": (B * S, D),
               "z": (B * S, 4 * D)}
     worst = 0.0
     for name, shp in (("tsin", (B, 256)), ("temb", (B, 6 * D)), ("emb", (B, D)), ("e", (B * T, D))):
@@ -175,6 +175,12 @@ def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
         for name, shp in shapes.items():
             err = rel_l2(gmodel.workspace_tensor(name, l, shp), trace[f"{l}.{name}"].reshape(shp))
             rows.append((f"{l}.{name}", err))
+    # text-side K/V of every block live in all-block arrays: kv2_all [B*T, L*2D], k2n_all [B*T, L, D]
+    kv_all = gmodel.workspace_tensor("kv2_all", 0, (B * T, num_layers * 2 * D))
+    k2n_all = gmodel.workspace_tensor("k2n_all", 0, (B * T, num_layers, D))
+    for l in range(num_layers):
+        rows.append((f"{l}.kv2raw", rel_l2(kv_all[:, l * 2 * D:(l + 1) * 2 * D], trace[f"{l}.kv2raw"].reshape(B * T, 2 * D))))
+        rows.append((f"{l}.k2n", rel_l2(k2n_all[:, l], trace[f"{l}.k2n"].reshape(B * T, D))))
     rows.append((f"{num_layers}.hs", rel_l2(gmodel.workspace_tensor("hs", num_layers, (B * S, D)), trace[f"{num_layers}.hs"].reshape(B * S, D))))
     for n, e in rows:
         print(f"[dit-trace] {n:12s} rel_l2={e:.3e}")
