@@ -20,6 +20,10 @@ FLAGS = [
     "-munsafe-fp-atomics",  # hardware fp32 atomic add for the split-M weight-gradient reduction
     "-Wno-unused-result",
 ]
+# per-file extras.  attention: keep the MFMA accumulators in the (unified) VGPR file -- the online-softmax rescale and the
+# dS products read/modify them with VALU every tile, and the accumulator-file round trip (v_accvgpr_read/write) was 25-35 %
+# of the loop's instructions in a VALU-bound kernel.
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -46,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, src + ".o")
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -45,7 +45,7 @@ struct NtTile {
     static constexpr int RPI = 1024 / (BK * 2);          // rows per 1-KiB wave instruction (direct-to-LDS)
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, bool PIN = false>
 FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
                           int m0, int M, const bf16_t* __restrict__ W, long ldw, int n0, int nk, int tid) {
     using T = NtTile<BM, BN, BK, WM, WN>;
@@ -153,10 +153,14 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
             if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
+            // pin the order "reads of slice kk+1, then MFMAs of slice kk": the MFMAs then wait with a COUNTED lgkmcnt (only
+            // for the older reads) instead of the lgkmcnt(0) the scheduler produces when it sinks the reads below the MFMAs
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!GLDS) {
             if (kt + 1 < nk) swrite(cur ^ 1);
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         else if constexpr (NSTAGE == 3)
             nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
         else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
+            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
     }
 
     if constexpr (EXT) {
@@ -457,17 +461,21 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         else if constexpr (NSTAGE == 3)
             nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
         else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
+            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
     }
 
     // ---------------- epilogue ----------------
+    // A lane owns output row m and, per accumulator quad rq, 4 consecutive columns; lanes l and l+32 own the two halves of
+    // the same 8-column group.  Two quads are exchanged across the half-waves (v_permlane32_swap) so that every lane stores
+    // 16 contiguous bytes: half as many store instructions for the same bytes (the store tail is issue-bound).
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm) {
         const int m = m0 + (wm * T::TM + tm) * 32 + li;
-        if (m >= p.M) continue;
+        if (m >= p.M) continue;  // lanes l and l+32 share m, so swap partners are active together
         const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
 #pragma unroll
-        for (int tn = 0; tn < T::TN; ++tn)
+        for (int tn = 0; tn < T::TN; ++tn) {
+            u32x2 pk[4], pkz[4];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const int n = n0 + (wn * T::TN + tn) * 32 + rq * 8 + 4 * g;
@@ -496,12 +504,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
                         z[j] = rbf(v[j]);
                         o[j] = gelu_tanh_f(z[j]);
                     }
-                    if (p.out2) {  // pre-activation stash
-                        u32x2 pk;
-                        pk[0] = pack2bf(z[0], z[1]);
-                        pk[1] = pack2bf(z[2], z[3]);
-                        *reinterpret_cast<u32x2*>(p.out2 + (long)m * p.ldo2 + n) = pk;
-                    }
+                    pkz[rq][0] = pack2bf(z[0], z[1]);  // pre-activation stash
+                    pkz[rq][1] = pack2bf(z[2], z[3]);
                 } else if constexpr (EPI == EPI_RESID) {
                     u32x2 rr = *reinterpret_cast<const u32x2*>(p.resid + (long)m * p.ldr + n);
                     float rv[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)), bf2f((bf16_t)(rr[1] & 0xffff)),
@@ -525,11 +529,31 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = rbf(v[j]) * gelu_tanh_grad_f(zv[j]);
                 }
-                u32x2 pk;
-                pk[0] = pack2bf(o[0], o[1]);
-                pk[1] = pack2bf(o[2], o[3]);
-                *reinterpret_cast<u32x2*>(p.out + (long)m * p.ldo + n) = pk;
+                pk[rq][0] = pack2bf(o[0], o[1]);
+                pk[rq][1] = pack2bf(o[2], o[3]);
             }
+            // quads (0,1) and (2,3): after the swap lanes 0-31 hold columns [8k, 8k+8) of quad k, lanes 32-63 those of quad k+1
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int nq = n0 + (wn * T::TN + tn) * 32 + (2 * q2 + g) * 8;
+                {
+                    u32x4 w;
+                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * q2][0], pk[2 * q2 + 1][0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * q2][1], pk[2 * q2 + 1][1], false, false);
+                    w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
+                    *reinterpret_cast<u32x4*>(p.out + (long)m * p.ldo + nq) = w;
+                }
+                if constexpr (EPI == EPI_GELU) {
+                    if (p.out2) {
+                        u32x4 w;
+                        auto s0 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][0], pkz[2 * q2 + 1][0], false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][1], pkz[2 * q2 + 1][1], false, false);
+                        w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
+                        *reinterpret_cast<u32x4*>(p.out2 + (long)m * p.ldo2 + nq) = w;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -564,7 +588,7 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
             a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
         }
     }
-    const size_t smem = NSTAGE * T::STAGE;
+    const size_t smem = (NSTAGE == 5 ? 2 : NSTAGE) * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
         if (smem > 65536) {
         static bool attr_set = false;  // per instantiation
@@ -682,7 +706,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K % 64 != 0 || a.K2 % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: K and K2 must be multiples of 64");
     if (a.N % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: N must be a multiple of 64");
-    if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 4) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
+    if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 8) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
     if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && a.w_grp_n == 0 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
         ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)a.K, st);
@@ -705,6 +729,8 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 5: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 6: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 4, 2, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 7: return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
+            case 13: return launch_nt<192, 128, 64, 2, 2, true, 1, 5>(a, st);  // 7 + pinned read/MFMA order
+            case 14: if (a.N % 256 == 0) return launch_nt<256, 256, 32, 2, 4, true, 1, 4>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
             case 12: if (a.N % 256 == 0) return launch_nt<192, 256, 32, 2, 4, true, 1, 4>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
             case 9: return launch_nt<192, 128, 32, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, BK 32: 60 KB -> 2 WG / CU
             case 10: return launch_nt<128, 128, 64, 2, 2, true, 1, 3>(a, st);  // 3-stage ring, BK 64: 96 KB -> 1 WG / CU
