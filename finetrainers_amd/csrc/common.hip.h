@@ -80,11 +80,19 @@ FTMI_DEVICE s16x8 lds_tr_frag(const char* tile, int cbase, int rowa, int rowb, i
     return f;
 }
 
+// tanh via the hardware exp2 / rcp units: 1 - 2 / (1 + e^{2x}).  ~1e-6 absolute error (the results are rounded to bf16
+// right after); libm tanhf costs ~25 VALU instructions per element and made the GELU / GELU' GEMM epilogues 25-40 % of
+// their kernels.  Saturates correctly: e^{2x} -> inf gives 1, -> 0 gives -1.
+FTMI_DEVICE float fast_tanh(float x) {
+    const float e2x = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);  // 2 * log2(e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e2x);
+}
+
 FTMI_DEVICE float gelu_tanh_f(float x) {
     const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
     const float kKappa = 0.044715f;
     float inner = kBeta * (x + kKappa * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(inner));
+    return 0.5f * x * (1.0f + fast_tanh(inner));
 }
 
 // torch's gelu_backward(approximate="tanh") in fp32
@@ -94,7 +102,7 @@ FTMI_DEVICE float gelu_tanh_grad_f(float x) {
     float x_sq = x * x;
     float x_cube = x_sq * x;
     float inner = kBeta * (x + kKappa * x_cube);
-    float tanh_inner = tanhf(inner);
+    float tanh_inner = fast_tanh(inner);
     float left = 0.5f * x;
     float right = 1.0f + tanh_inner;
     float left_derivative = 0.5f * right;
