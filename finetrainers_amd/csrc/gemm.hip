@@ -45,7 +45,9 @@ struct NtTile {
     static constexpr int RPI = 1024 / (BK * 2);          // rows per 1-KiB wave instruction (direct-to-LDS)
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, bool PIN = false>
+// DBG (timing experiments only, results are wrong by construction): 1 = no global loads inside the K loop (LDS + MFMA time),
+// 2 = no MFMAs (global -> LDS pipeline time).
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, bool PIN = false, int DBG = 0>
 FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
                           int m0, int M, const bf16_t* __restrict__ W, long ldw, int n0, int nk, int tid) {
     using T = NtTile<BM, BN, BK, WM, WN>;
@@ -126,7 +128,7 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
+        if (DBG != 1 && kt + 1 < nk) {
             if constexpr (GLDS)
                 gl2lds(kt + 1, cur ^ 1);
             else
@@ -134,8 +136,102 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
         }
         const char* xs = smem + cur * T::STAGE;
         const char* ws = xs + BM * BK * 2;
-        constexpr int NKK = BK / 16;
+        constexpr int NKK = (DBG == 2) ? 0 : BK / 16;
         // fragments of k-slice kk+1 are fetched from LDS while the MFMAs of slice kk issue (register double buffer)
+        s16x8 wf[2][T::TN], xf[2][T::TM];
+        auto lfrag = [&](int buf, int kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) {
+                int row = (wn * T::TN + tn) * 32 + li;
+                wf[buf][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>(row, kk * 2 + g));
+            }
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) {
+                int row = (wm * T::TM + tm) * 32 + li;
+                xf[buf][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>(row, kk * 2 + g));
+            }
+        };
+        if constexpr (DBG != 2) lfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
+            // pin the order "reads of slice kk+1, then MFMAs of slice kk": the MFMAs then wait with a COUNTED lgkmcnt (only
+            // for the older reads) instead of the lgkmcnt(0) the scheduler produces when it sinks the reads below the MFMAs
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!GLDS) {
+            if (kt + 1 < nk) swrite(cur ^ 1);
+        }
+        __syncthreads();
+    }
+}
+
+// 2-stage direct-to-LDS K loop, second generation: the per-lane source offsets are computed once (32-bit, so the loads
+// use the SGPR-base + VGPR-offset form and the K advance is scalar), and the loads of tile kt+1 are issued in NKK
+// portions between the MFMA groups of tile kt instead of one burst (a burst fills the CU's vector-memory queue and
+// blocks every wave's instruction stream behind its own loads).
+template <int BM, int BN, int BK, int WM, int WN, int SPREAD = 4, bool PIN = false>
+FTMI_DEVICE void nt_run_k2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                           int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;  // 1 KiB wave-instructions per wave
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;
+    constexpr int LPT = XI + WI;
+    constexpr int NKK = BK / 16;
+    constexpr int LPS = (LPT + SPREAD - 1) / SPREAD;  // loads issued per k-slice (over the first SPREAD slices)
+
+    uint32_t off[LPT];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        int blk = wave * XI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        int gr = min(m0 + row, M - 1);
+        off[i] = (uint32_t)(((long)gr * ldx + c * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int blk = wave * WI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        off[XI + i] = (uint32_t)(((long)row * ldw + c * 8) * 2);
+    }
+    auto issue = [&](int i, const char* xb, const char* wb, char* stage) {
+        if (i < XI)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
+                                             (__attribute__((address_space(3))) void*)(stage + (wave * XI + i) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + off[i]),
+                                             (__attribute__((address_space(3))) void*)(stage + BM * BK * 2 + (wave * WI + (i - XI)) * 1024), 16, 0, 0);
+    };
+    {
+        const char* xb = (const char*)X;
+        const char* wb = (const char*)W;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) issue(i, xb, wb, smem);
+    }
+    __syncthreads();
+
+    // fragment read offsets inside a stage (loop invariant)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // the last iteration re-stages its own tile into the idle buffer: branch-free loop body, one wasted tile load
+        const int ktn = min(kt + 1, nk - 1);
+        const char* xb = (const char*)X + (long)ktn * BK * 2;
+        const char* wb = (const char*)W + (long)ktn * BK * 2;
+        char* nstage = smem + (cur ^ 1) * T::STAGE;
+        const char* xs = smem + cur * T::STAGE;
+        const char* ws = xs + BM * BK * 2;
         s16x8 wf[2][T::TN], xf[2][T::TM];
         auto lfrag = [&](int buf, int kk) {
 #pragma unroll
@@ -152,18 +248,15 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
         lfrag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+            for (int i = kk * LPS; i < (kk + 1) * LPS && i < LPT; ++i) issue(i, xb, wb, nstage);
             if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
-            // pin the order "reads of slice kk+1, then MFMAs of slice kk": the MFMAs then wait with a COUNTED lgkmcnt (only
-            // for the older reads) instead of the lgkmcnt(0) the scheduler produces when it sinks the reads below the MFMAs
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (!GLDS) {
-            if (kt + 1 < nk) swrite(cur ^ 1);
         }
         __syncthreads();
     }
@@ -384,6 +477,148 @@ FTMI_DEVICE void nt_run_k_pp(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* sm
     if (wm == 0) pp_barrier();  // re-align the two wave rows
 }
 
+// ------------------------------------------------------------------------------------------------
+// 8-phase K loop: 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 per wave), 128 KiB LDS = 2 buffers x 4
+// half-tiles of 16 KiB.  A K-tile is staged as four half-tiles in the order its readers need them:
+//   j = 0: X rows of the waves' first 64-row sub-tile, 1: W rows of their first 32-column sub-tile, 2: W second, 3: X second
+// and consumed in four phases, one output quadrant (64 x 32 per wave, 8 MFMAs) each:
+//   P0 reads X0,W0 -> acc(X0,W0) | P1 reads W1 -> acc(X0,W1) | P2 reads X1 -> acc(X1,W1) | P3 reads nothing -> acc(X1,W0)
+// Every phase also stages ONE half-tile, five half-tiles ahead of the phase index, and retires loads with a COUNTED
+// vmcnt (three half-tiles stay in flight across the barriers; vmcnt never drains inside the loop).  The two wave rows
+// run one barrier apart, so on each SIMD one wave is in its MFMA cluster while the other issues reads and loads.
+// Hazards (q = global phase index, h = global half-tile index, phase q stages h = q + 5):
+//   RAW  half-tiles read in phase q are retired by every wave's vmcnt in the load segment of phase q-1, which precedes a
+//        barrier that both wave rows pass before either reads (one barrier of stagger included);
+//   WAR  h = q + 5 overwrites h - 8 = q - 3, whose last reader ran in phase <= q - 3 (W0 is kept in registers for P3,
+//        never re-read), i.e. at least four barriers earlier.
+// ------------------------------------------------------------------------------------------------
+FTMI_DEVICE void wait_vm_halves(int halves) {
+    // outstanding loads of this wave allowed to remain: 2 per half-tile
+    if (halves >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (halves == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (halves == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int DBG = 0>
+FTMI_DEVICE void nt_run_k_8ph(f32x16 (&acc)[2][4], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M,
+                              const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+    constexpr int BK = 64, HALF = 16384, TILE = 4 * HALF;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int li = lane & 31, g = lane >> 5;
+
+    // staging: this wave owns 1-KiB blocks 2*wave, 2*wave+1 (8 rows x 128 B) of every half-tile
+    uint32_t soff[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);  // local row 0..127
+        const int cs = lane & 7;
+        const int c = cs ^ ((r >> 1) & 7);
+        const int xr = (r >> 6) * 128 + (r & 63);
+        const int wrow = (r >> 5) * 64 + (r & 31);
+        soff[0][i] = (uint32_t)(((long)min(m0 + xr, M - 1) * ldx + c * 8) * 2);
+        soff[3][i] = (uint32_t)(((long)min(m0 + xr + 64, M - 1) * ldx + c * 8) * 2);
+        soff[1][i] = (uint32_t)(((long)wrow * ldw + c * 8) * 2);
+        soff[2][i] = (uint32_t)(((long)(wrow + 32) * ldw + c * 8) * 2);
+    }
+    const int nh_total = 4 * nk;
+    auto stage = [&](int j, int t) {  // j compile-time after unrolling
+        const char* base = (j == 0 || j == 3) ? (const char*)X : (const char*)W;
+        base += (long)t * BK * 2;
+        char* dst = smem + (t & 1) * TILE + j * HALF + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[j][i]),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+    // fragment read offsets inside a half-tile
+    int xo[2][4], wo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        wo[k] = nt_lds_off<64>(wc * 32 + li, k * 2 + g);
+#pragma unroll
+        for (int tmi = 0; tmi < 2; ++tmi) xo[tmi][k] = nt_lds_off<64>(wr * 64 + tmi * 32 + li, k * 2 + g);
+    }
+
+    // prologue: half-tiles 0..4 in flight, 0 and 1 landed
+    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+    if (nk > 1) stage(0, 1);
+    wait_vm_halves(min(4, nh_total - 1) - 1);
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");
+
+    s16x8 x0[2][4], x1[2][4], w0[4], w1[4];
+    for (int t = 0; t < nk; ++t) {
+        const char* tb = smem + (t & 1) * TILE;
+        const int q = 4 * t;
+        // ---------------- P0 ----------------
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w0[k] = *reinterpret_cast<const s16x8*>(tb + HALF + wo[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int tmi = 0; tmi < 2; ++tmi) x0[tmi][k] = *reinterpret_cast<const s16x8*>(tb + xo[tmi][k]);
+        if (DBG != 1 && q + 5 < nh_total) stage(1, t + 1);
+        wait_vm_halves(min(q + 5, nh_total - 1) - (q + 2));
+        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < (DBG == 2 ? 0 : 4); ++k)
+#pragma unroll
+            for (int tmi = 0; tmi < 2; ++tmi) acc[0][tmi] = mfma32(w0[k], x0[tmi][k], acc[0][tmi]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        // ---------------- P1 ----------------
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w1[k] = *reinterpret_cast<const s16x8*>(tb + 2 * HALF + wo[k]);
+        if (DBG != 1 && q + 6 < nh_total) stage(2, t + 1);
+        wait_vm_halves(min(q + 6, nh_total - 1) - (q + 3));
+        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < (DBG == 2 ? 0 : 4); ++k)
+#pragma unroll
+            for (int tmi = 0; tmi < 2; ++tmi) acc[1][tmi] = mfma32(w1[k], x0[tmi][k], acc[1][tmi]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        // ---------------- P2 ----------------
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int tmi = 0; tmi < 2; ++tmi) x1[tmi][k] = *reinterpret_cast<const s16x8*>(tb + 3 * HALF + xo[tmi][k]);
+        if (DBG != 1 && q + 7 < nh_total) stage(3, t + 1);
+        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < (DBG == 2 ? 0 : 4); ++k)
+#pragma unroll
+            for (int tmi = 0; tmi < 2; ++tmi) acc[1][2 + tmi] = mfma32(w1[k], x1[tmi][k], acc[1][2 + tmi]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        // ---------------- P3 ----------------
+        if (DBG != 1 && q + 8 < nh_total) stage(0, t + 2);
+        wait_vm_halves(min(q + 8, nh_total - 1) - (q + 5));
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k = 0; k < (DBG == 2 ? 0 : 4); ++k)
+#pragma unroll
+            for (int tmi = 0; tmi < 2; ++tmi) acc[0][2 + tmi] = mfma32(w0[k], x1[tmi][k], acc[0][2 + tmi]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+    }
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");  // re-align the two wave rows
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs p) {
     using T = NtTile<BM, BN, BK, WM, WN>;
@@ -424,12 +659,16 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        if constexpr (NSTAGE == 4)
+        if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
+            nt_run_k_8ph<NSTAGE - 9>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14))
+            nt_run_k2<BM, BN, BK, WM, WN, (NSTAGE == 12 ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        else if constexpr (NSTAGE == 4)
             nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
         else if constexpr (NSTAGE == 3)
             nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
         else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
+            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5, (NSTAGE == 6 ? 1 : NSTAGE == 7 ? 2 : 0)>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
     }
 
     if constexpr (EXT) {
@@ -456,7 +695,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
         const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
                                            : p.W2 + (long)n0 * p.ldw2;
-        if constexpr (NSTAGE == 4)
+        if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
+            nt_run_k_8ph<NSTAGE - 9>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14))
+            nt_run_k2<BM, BN, BK, WM, WN, (NSTAGE == 12 ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        else if constexpr (NSTAGE == 4)
             nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 3)
             nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
@@ -588,7 +831,7 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
             a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
         }
     }
-    const size_t smem = (NSTAGE == 5 ? 2 : NSTAGE) * T::STAGE;
+    const size_t smem = (NSTAGE >= 5 ? 2 : NSTAGE) * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
         if (smem > 65536) {
         static bool attr_set = false;  // per instantiation
@@ -720,7 +963,27 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
     if (wide) {
         int variant = a.variant;
-        if (variant == 8) variant = (a.M >= 1024) ? 7 : 1;  // auto: 192x128 tiles fill 256 CUs x 2 WG best at M = 5376 (measured)
+        if (variant == 8) {
+            // auto: 192 x 128 tiles (2 workgroups / CU -> 512 slots) unless 256 x 256 tiles (1 / CU -> 256 slots) quantise
+            // clearly better onto the chip (e.g. M 5376, N 6144: 1344 tiles = 2.6 rounds vs 504 tiles = 1.97 rounds)
+            static int nt192 = -1, nt256 = -1;
+            if (nt192 < 0) {
+                const char* e = getenv("FTMI_NT192");
+                nt192 = e ? atoi(e) : 36;
+                e = getenv("FTMI_NT256");
+                nt256 = e ? atoi(e) : 0;  // 256 x 256 tiles measured no faster inside the step (tools/ab_variants.sh)
+            }
+            if (a.M < 1024) {
+                variant = 1;
+            } else {
+                auto g256 = [](int g) { return g <= 0 || g % 256 == 0; };
+                const bool ok256 = a.N % 256 == 0 && g256(a.w_grp_n) && g256(a.w2_grp_n) && g256(a.xk_grp_n) && g256(a.x2_grp_n);
+                const long t192 = (long)((a.M + 191) / 192) * (a.N / 128), t256 = (long)((a.M + 255) / 256) * (a.N / 256);
+                const double e192 = (double)t192 / (double)(((t192 + 511) / 512) * 512);
+                const double e256 = ok256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
+                variant = (nt256 > 0 && e256 > e192 + 0.05) ? nt256 : nt192;
+            }
+        }
         switch (variant) {
             case 0: return launch_nt<128, 128, 64, 2, 2, false, 1>(a, st);
             case 2: return launch_nt<128, 128, 32, 2, 2, true, 1>(a, st);
@@ -730,6 +993,20 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 6: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 4, 2, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 7: return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
             case 13: return launch_nt<192, 128, 64, 2, 2, true, 1, 5>(a, st);  // 7 + pinned read/MFMA order
+            case 20: return launch_nt<192, 128, 64, 2, 2, true, 1, 6>(a, st);  // timing experiment: no global loads in the K loop
+            case 21: return launch_nt<192, 128, 64, 2, 2, true, 1, 7>(a, st);  // timing experiment: no MFMAs
+            case 22: return launch_nt<256, 256, 64, 2, 4, true, 1, 6>(a, st);
+            case 30: return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // second-generation 2-stage loop
+            case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, 12>(a, st);  // 30 with the loads spread over 2 slices
+            case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, 13>(a, st);  // 30 with the loads in one burst
+            case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, 14>(a, st);  // 30 + pinned read / MFMA order
+            case 39: return launch_nt<192, 128, 64, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, 120 KB -> 1 WG / CU
+            case 31: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);
+            case 33: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 9>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // 8-phase loop
+            case 34: return launch_nt<256, 256, 64, 2, 4, true, 1, 10>(a, st);  // timing experiment: no staging in the loop
+            case 35: return launch_nt<256, 256, 64, 2, 4, true, 1, 11>(a, st);  // timing experiment: no MFMAs
+            case 32: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 2, true, 1, 8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // 4 waves, 128 x 128 per wave
+            case 23: return launch_nt<256, 256, 64, 2, 4, true, 1, 7>(a, st);
             case 14: if (a.N % 256 == 0) return launch_nt<256, 256, 32, 2, 4, true, 1, 4>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
             case 12: if (a.N % 256 == 0) return launch_nt<192, 256, 32, 2, 4, true, 1, 4>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
             case 9: return launch_nt<192, 128, 32, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, BK 32: 60 KB -> 2 WG / CU

@@ -16,13 +16,25 @@ for (M, N, K) in shapes:
         if ref is None:
             ref = out
         ok = torch.equal(out, ref)
-        for _ in range(3):
-            ops.gemm_nt(x, w, b, variant=v)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        n = 20
-        for _ in range(n):
-            ops.gemm_nt(x, w, b, variant=v)
-        e.record(); torch.cuda.synchronize()
-        ms = s.elapsed_time(e) / n
+        ms = 1e9
+        for rep in range(3):  # clocks ramp under load: long warm-up, best of 3 passes
+            for _ in range(30):
+                ops.gemm_nt(x, w, b, variant=v)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            n = 50
+            for _ in range(n):
+                ops.gemm_nt(x, w, b, variant=v)
+            e.record(); torch.cuda.synchronize()
+            ms = min(ms, s.elapsed_time(e) / n)
         print(f"M{M} N{N} K{K} variant {v}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF/s  same_as_v{variants[0]}={ok}", flush=True)
+    # calibration only: the vendor library GEMM (hipBLASLt through torch) on the same shape -- not used by the product path
+    for _ in range(50):
+        torch.nn.functional.linear(x, w, b)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        torch.nn.functional.linear(x, w, b)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 20
+    print(f"M{M} N{N} K{K} hipBLASLt  : {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:7.1f} TF/s", flush=True)
