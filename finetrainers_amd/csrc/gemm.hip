@@ -864,15 +864,16 @@ static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
 // 128-wide tiles and the K loop is latency-bound, so one workgroup owns a 32 x 64 output tile and its 4 waves split K
 // four ways (operands straight from global/L2 into MFMA fragments, no LDS staging), then reduce through LDS.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmNtArgs p) {
-    __shared__ float red[4][2][16][64];  // [wave][n-subtile][acc register][lane]
+template <int KS>
+__global__ __launch_bounds__(KS * 64) void gemm_nt_skinny_kernel(GemmNtArgs p) {
+    __shared__ float red[KS][2][16][64];  // [wave][n-subtile][acc register][lane]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, g = lane >> 5;
     const int ntm = (p.M + 31) / 32;
     const int m0 = (blockIdx.x % ntm) * 32, n0 = (blockIdx.x / ntm) * 64;
     const bf16_t* X = p.X;
     if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-    const int kq = p.K / 4, k0 = wave * kq;
+    const int kq = p.K / KS, k0 = wave * kq;
     const int row = min(m0 + li, p.M - 1);
     const bf16_t* xp = X + (long)row * p.ldx + k0 + g * 8;
     const bf16_t* wp0 = p.W + (long)(n0 + li) * p.ldw + k0 + g * 8;
@@ -916,14 +917,142 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmNtArgs p) {
     __syncthreads();
     const int m = m0 + li;
     if (m >= p.M) return;
-    // wave w finalises accumulator registers 4w..4w+3 (= 4 consecutive n) of both n-subtiles
+    // each wave finalises 4 accumulator registers (= 4 consecutive n) of one or both n-subtiles, partials summed in a fixed order
+    constexpr int TNW = (KS == 4) ? 2 : 1;  // n-subtiles per wave
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) {
+        const int tn = (KS == 4) ? t : (wave >> 2);
+        const int wq = wave & 3;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wq * 4 + j;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < KS; w += 4)
+                s += (red[w][tn][r][lane] + red[w + 1][tn][r][lane]) + (red[w + 2][tn][r][lane] + red[w + 3][tn][r][lane]);
+            v[j] = s;
+        }
+        const int n = n0 + tn * 32 + wq * 8 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+        if (p.bias) {
+            u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
+            v[0] += bf2f((bf16_t)(raw[0] & 0xffff));
+            v[1] += bf2f((bf16_t)(raw[0] >> 16));
+            v[2] += bf2f((bf16_t)(raw[1] & 0xffff));
+            v[3] += bf2f((bf16_t)(raw[1] >> 16));
+        }
+        u32x2 pk;
+        pk[0] = pack2bf(v[0], v[1]);
+        pk[1] = pack2bf(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(p.out + (long)m * p.ldo + n) = pk;
+    }
+}
+
+// Skinny NT GEMM, second generation.  The first one gathers MFMA fragments straight from global memory: every lane reads
+// 16 bytes of a different row, so a wave instruction touches 32 half-used cache lines and the kernel is bound by the
+// CU's line rate (measured 15 us for 64 MB of L2 traffic).  Here every wave still owns a quarter of K, but streams its
+// operands through a PRIVATE 3-stage LDS ring with direct-to-LDS loads of whole 128-byte row segments (16 full lines per
+// instruction), retired by counted vmcnt -- no workgroup barrier inside the K loop.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = 12288, NST = 3;  // bytes per chunk (32 x 64 X + 64 x 64 W), stages per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const int ntm = (p.M + 31) / 32;
+    const int m0 = (blockIdx.x % ntm) * 32, n0 = (blockIdx.x / ntm) * 64;
+    const bf16_t* X = p.X;
+    if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
+    const int kq = p.K / 4, k0 = wave * kq, nch = kq / 64;
+    char* ring = smem + wave * (NST * CH);
+
+    uint32_t off[12];
+    {
+        const int r8 = lane >> 3, cs = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 8 + r8;
+            const int c = cs ^ ((row >> 1) & 7);
+            off[i] = (uint32_t)(((long)min(m0 + row, p.M - 1) * p.ldx + k0 + c * 8) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + r8;
+            const int c = cs ^ ((row >> 1) & 7);
+            off[4 + i] = (uint32_t)(((long)(n0 + row) * p.ldw + k0 + c * 8) * 2);
+        }
+    }
+    auto issue = [&](int ck) {
+        char* st = ring + (ck % NST) * CH;
+        const char* xb = (const char*)X + (long)ck * 128;
+        const char* wb = (const char*)p.W + (long)ck * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
+                                             (__attribute__((address_space(3))) void*)(st + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + off[4 + i]),
+                                             (__attribute__((address_space(3))) void*)(st + 4096 + i * 1024), 16, 0, 0);
+    };
+    int xo[4], wo0[4], wo1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        xo[kk] = nt_lds_off<64>(li, kk * 2 + g);
+        wo0[kk] = 4096 + nt_lds_off<64>(li, kk * 2 + g);
+        wo1[kk] = 4096 + nt_lds_off<64>(32 + li, kk * 2 + g);
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+    }
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 2) issue(2);
+    for (int ck = 0; ck < nch; ++ck) {
+        const int ahead = min(NST - 1, nch - 1 - ck);  // chunks that may stay in flight
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* st = ring + (ck % NST) * CH;
+        s16x8 xf[4], w0[4], w1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            xf[kk] = *reinterpret_cast<const s16x8*>(st + xo[kk]);
+            w0[kk] = *reinterpret_cast<const s16x8*>(st + wo0[kk]);
+            w1[kk] = *reinterpret_cast<const s16x8*>(st + wo1[kk]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (ck + NST < nch) issue(ck + NST);  // the stage just read is free again
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            acc0 = mfma32(w0[kk], xf[kk], acc0);
+            acc1 = mfma32(w1[kk], xf[kk], acc1);
+        }
+    }
+    __syncthreads();  // every wave is done with its ring: reuse the memory for the cross-wave reduction
+    float* red = reinterpret_cast<float*>(smem);  // [wave][n-subtile][acc register][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[((wave * 2 + 0) * 16 + r) * 64 + lane] = acc0[r];
+        red[((wave * 2 + 1) * 16 + r) * 64 + lane] = acc1[r];
+    }
+    __syncthreads();
+    const int m = m0 + li;
+    if (m >= p.M) return;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = wave * 4 + j;
-            v[j] = (red[0][tn][r][lane] + red[1][tn][r][lane]) + (red[2][tn][r][lane] + red[3][tn][r][lane]);
+            auto R = [&](int w) { return red[((w * 2 + tn) * 16 + r) * 64 + lane]; };
+            v[j] = (R(0) + R(1)) + (R(2) + R(3));
         }
         const int n = n0 + tn * 32 + wave * 8 + 4 * g;
 #pragma unroll
@@ -953,7 +1082,24 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
     if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && a.w_grp_n == 0 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
         ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)a.K, st);
-        hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(256), 0, st, a);
+        static int ks = -1;
+        if (ks < 0) {
+            const char* e = getenv("FTMI_SKINNY_KS");
+            ks = e ? atoi(e) : 2;  // 2 = LDS-ring kernel, 4 / 8 = direct-gather kernel with a 4- / 8-way K split
+        }
+        // 8-way K split when it divides into whole load batches: halves the dependent load->MFMA chain of every wave
+        if (ks == 2 && a.K % 256 == 0) {
+            constexpr int kSmem = 4 * 3 * 12288;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(gemm_nt_skinny2_kernel<0>, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(256), kSmem, st, a);
+        } else if (ks == 8 && a.K % 1024 == 0)
+            hipLaunchKernelGGL(gemm_nt_skinny_kernel<8>, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL(gemm_nt_skinny_kernel<4>, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(256), 0, st, a);
         return check_launch("gemm_nt_skinny");
     }
     if ((a.w_grp_n > 0 && a.w_grp_n % 64) || (a.w2_grp_n > 0 && a.w2_grp_n % 64))
