@@ -16,6 +16,8 @@
 // Three kernels: forward (O, LSE), backward dK/dV (one workgroup per 128 keys, loops over queries),
 // backward dQ (one workgroup per 128 queries, loops over keys).  Scores are recomputed in both
 // backward kernels, so no atomics are needed and results are deterministic.
+#include <type_traits>
+
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -49,35 +51,43 @@ FTMI_DEVICE AttnBlock attn_block(int bid, int ntile, int H, int B) {
     return r;
 }
 
-// 256 threads load one [64 tok][64 d] bf16 tile as 2 x 16-byte chunks per thread.  A wave instruction
-// covers 16 rows x 64 contiguous bytes.  slot = wave + 4*it : rows (slot&3)*16.., chunks (slot>>2)*4..
-struct TileCoord {
-    int row, chunk;
+// A [64 tok][64 d] bf16 tile (8 KiB) is staged by eight direct-to-LDS wave loads of 1 KiB (8 rows x 128 B each, two per
+// wave).  The LDS destination of such a load is wave-linear, so the lds_rt_off chunk swizzle is applied to the per-lane
+// SOURCE address (slot s of row r receives source chunk s ^ f(r); the read side applies the same involution).  Source
+// offsets are computed once per kernel (32-bit, relative to the tile's first row); rows past the end of the sequence
+// are clamped (their scores are neutralised by +-inf statistics), which only the last tile needs.
+struct TileDma {
+    uint32_t off[2], offl[2];
 };
-FTMI_DEVICE TileCoord tile_coord(int tid, int it) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int slot = wave + 4 * it;
-    TileCoord c;
-    c.row = (slot & 3) * 16 + (lane & 15);
-    c.chunk = (slot >> 2) * 4 + (lane >> 4);
-    return c;
-}
-
-FTMI_DEVICE void load_tile(s16x8 (&r)[2], const bf16_t* base, long row_stride, int row0, int nrows, int tid) {
+FTMI_DEVICE TileDma tile_dma_setup(long stride, int nrows, int wave, int lane) {
+    TileDma d;
+    const int last0 = ((nrows + 63) / 64 - 1) * 64;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        TileCoord c = tile_coord(tid, it);
-        int gr = min(row0 + c.row, nrows - 1);
-        r[it] = *reinterpret_cast<const s16x8*>(base + (long)gr * row_stride + c.chunk * 8);
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3), slot = lane & 7;
+        const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+        const int chunk = slot ^ f;
+        d.off[i] = (uint32_t)(((long)row * stride + chunk * 8) * 2);
+        d.offl[i] = (uint32_t)(((long)min(row, nrows - 1 - last0) * stride + chunk * 8) * 2);
+    }
+    return d;
+}
+// The load is issued through inline asm on purpose: hipcc does not know the alias set of the transposing LDS reads
+// (ds_read_b64_tr_b16 is an intrinsic without a memory operand), so with the builtin form of the DMA it parks an
+// s_waitcnt vmcnt(0) in front of the first such read of every tile -- i.e. it waits for the NEXT tile's loads in the
+// middle of the current tile.  The asm form is invisible to that analysis; tile_dma_wait() before the tile barrier is the
+// (only) wait that retires it.
+FTMI_DEVICE void tile_dma_issue(const TileDma& d, const bf16_t* base, long stride, int t, bool last, char* lds, int wave) {
+    const char* b = (const char*)base + (long)t * 64 * stride * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t o = last ? d.offl[i] : d.off[i];
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + (wave * 2 + i) * 1024));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(o), "s"(b) : "memory", "m0");
     }
 }
-FTMI_DEVICE void store_tile_rm(const s16x8 (&r)[2], char* lds, int tid) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        TileCoord c = tile_coord(tid, it);
-        *reinterpret_cast<s16x8*>(lds + lds_rt_off(c.row, c.chunk)) = r[it];
-    }
-}
+FTMI_DEVICE void tile_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // row fragment (non-reduction index = token row) of a [64 tok][64 d] image: lane (row, g) reads d = 16 c + 8 g .. +7
 FTMI_DEVICE s16x8 read_row_frag(const char* lds, int row, int c, int g) {
     return *reinterpret_cast<const s16x8*>(lds + lds_rt_off(row, c * 2 + g));
@@ -98,16 +108,12 @@ FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-static constexpr int kFwdLds = 2 * 8192 + 256;
+static constexpr int kFwdLds = 2 * 16384 + 2 * 256;  // two (K, V) tile buffers + two key-bias rows
 
 template <bool HAS_KB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ks = smem;
-    char* vs = smem + 8192;
-    float* kb = reinterpret_cast<float*>(smem + 2 * 8192);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
     const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 127) / 128, a.H, a.B);
     const int h = blk.h, b = blk.b;
@@ -125,6 +131,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const float* kbias = a.kbias ? a.kbias + (long)b * a.Sk : nullptr;
 
     float m_run = -INFINITY, l_run = 0.f;
+    s16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
     f32x16 oacc[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -132,27 +141,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
 
     const int nt = (a.Sk + 63) / 64;
-    s16x8 kr[2], vr[2];
+    const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
     float kbr = 0.f;
-    auto gload = [&](int t) {
-        load_tile(kr, kbase, a.k_ss, t * 64, a.Sk, tid);
-        load_tile(vr, vbase, a.v_ss, t * 64, a.Sk, tid);
-        if (tid < 64) {
-            int j = t * 64 + tid;
-            kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;
+    // stage tile t into buffer `buf`: K and V by DMA; the key-bias row (log2 domain, -inf for padded keys) through a register
+    auto stage = [&](int t, int buf) {
+        char* tb = smem + buf * 16384;
+        tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
+        tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+        if constexpr (HAS_KB) {
+            if (tid < 64) {
+                int j = t * 64 + tid;
+                kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;
+            }
         }
     };
-    auto lwrite = [&]() {
-        store_tile_rm(kr, ks, tid);
-        store_tile_rm(vr, vs, tid);
-        if (tid < 64) kb[tid] = kbr;
+    auto stage_commit = [&](int buf) {
+        if constexpr (HAS_KB) {
+            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384)[buf * 64 + tid] = kbr;
+        }
     };
 
-    gload(0);
-    lwrite();
+    stage(0, 0);
+    stage_commit(0);
+    tile_dma_wait();
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) gload(t + 1);
+    auto body = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        const char* ks = smem + cur * 16384;
+        const char* vs = ks + 8192;
+        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
 
         f32x16 st[2];
 #pragma unroll
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 st[js] = mfma32(kf, qf[c], st[js]);
             }
         }
-        // scores in the log2 domain: x = s * (scale * log2 e) + bias;  row max / exp2 / row sum per lane (= per query row)
+        // scores in the log2 domain: x = s * (scale * log2 e) + bias;  row max / exp2 per lane (= per query row)
         float mx = -INFINITY;
         if constexpr (HAS_KB) {
 #pragma unroll
@@ -190,23 +208,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = fast_exp2(m_run - m_new);
-        float rs = 0.f;
 #pragma unroll
         for (int js = 0; js < 2; ++js)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = HAS_KB ? fast_exp2(st[js][r] - m_new) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_new));
-                st[js][r] = p;
-                rs += p;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
+            for (int r = 0; r < 16; ++r)
+                st[js][r] = HAS_KB ? fast_exp2(st[js][r] - m_new) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_new));
         m_run = m_new;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
 
+        // The row sum of P rides on the matrix pipe: an all-ones A-slot fragment makes every row of the product the column
+        // sums of P^T (= per-query sums over this tile's keys, both half-waves included), so the 32 adds + cross-half
+        // shuffle per lane become 4 MFMAs in a kernel whose bound is VALU issue.  The sum is taken over the bf16-rounded
+        // probabilities that also feed P.V, so numerator and denominator of the softmax use the same numbers.
+        f32x16 lsum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
 #pragma unroll
         for (int js = 0; js < 2; ++js)
 #pragma unroll
@@ -217,10 +236,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
                     oacc[dt] = mfma32(vf, pf, oacc[dt]);
                 }
+                lsum = mfma32(ones, pf, lsum);
             }
-        __syncthreads();
-        if (t + 1 < nt) lwrite();
-        __syncthreads();
+        l_run = l_run * alpha + lsum[0];
+        if (t + 1 < nt) stage_commit(cur ^ 1);
+        tile_dma_wait();
+        __syncthreads();  // tile t+1 landed (the barrier drains this wave's DMA first) and tile t's buffer is free again
+    };
+    for (int t = 0; t < nt; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nt) body(t + 1, std::integral_constant<int, 1>{});
     }
 
     if (i < a.Sq) {
@@ -280,16 +305,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward: dK, dV
 // ------------------------------------------------------------------------------------------------
-static constexpr int kDkvLds = 2 * 8192 + 512;
+static constexpr int kDkvLds = 2 * 16384 + 2 * 512;  // two (Q, dO) tile buffers + two (lse, delta) rows
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* qs = smem;
-    char* dos = smem + 8192;
-    float* lses = reinterpret_cast<float*>(smem + 2 * 8192);
-    float* dels = lses + 64;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
     const AttnBlock blk = attn_block(blockIdx.x, (a.Sk + 127) / 128, a.H, a.B);
     const int h = blk.h, b = blk.b;
@@ -322,31 +342,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         }
 
     const int ni = (a.Sq + 63) / 64;
-    s16x8 qr[2], dor[2];
+    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane);
     float lser = 0.f, delr = 0.f;
-    auto gload = [&](int t) {
-        load_tile(qr, qbase, a.q_ss, t * 64, a.Sq, tid);
-        load_tile(dor, dobase, a.do_ss, t * 64, a.Sq, tid);
+    auto stage = [&](int t, int buf) {
+        char* tb = smem + buf * 16384;
+        tile_dma_issue(qd, qbase, a.q_ss, t, t == ni - 1, tb, wave);
+        tile_dma_issue(dod, dobase, a.do_ss, t, t == ni - 1, tb + 8192, wave);
         if (tid < 64) {
             int i = t * 64 + tid;
             lser = (i < a.Sq) ? lsebase[i] : INFINITY;  // +inf => p = 0 for padded query rows
             delr = (i < a.Sq) ? delbase[i] : 0.f;
         }
     };
-    auto lwrite = [&]() {
-        store_tile_rm(qr, qs, tid);
-        store_tile_rm(dor, dos, tid);
+    auto stage_commit = [&](int buf) {
         if (tid < 64) {
-            lses[tid] = lser;
-            dels[tid] = delr;
+            float* st = reinterpret_cast<float*>(smem + 2 * 16384) + buf * 128;
+            st[tid] = lser;
+            st[64 + tid] = delr;
         }
     };
 
-    gload(0);
-    lwrite();
+    stage(0, 0);
+    stage_commit(0);
+    tile_dma_wait();
     __syncthreads();
-    for (int t = 0; t < ni; ++t) {
-        if (t + 1 < ni) gload(t + 1);
+    auto body = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        const char* qs = smem + cur * 16384;
+        const char* dos = qs + 8192;
+        const float* lses = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 128;
+        const float* dels = lses + 64;
+        if (t + 1 < ni) stage(t + 1, cur ^ 1);
 #pragma unroll
         for (int is = 0; is < 2; ++is) {
             f32x16 s, dp;
@@ -388,9 +414,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 }
             }
         }
+        if (t + 1 < ni) stage_commit(cur ^ 1);
+        tile_dma_wait();
         __syncthreads();
-        if (t + 1 < ni) lwrite();
-        __syncthreads();
+    };
+    for (int t = 0; t < ni; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ni) body(t + 1, std::integral_constant<int, 1>{});
     }
 
     if (j < a.Sk) {
@@ -414,15 +444,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // backward: dQ
 // ------------------------------------------------------------------------------------------------
-static constexpr int kDqLds = 2 * 8192 + 256;
+static constexpr int kDqLds = 2 * 16384 + 2 * 256;
 
+template <bool HAS_KB>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ks = smem;
-    char* vs = smem + 8192;
-    float* kb = reinterpret_cast<float*>(smem + 2 * 8192);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
     const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 127) / 128, a.H, a.B);
     const int h = blk.h, b = blk.b;
@@ -452,27 +479,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) dqt[dt][r] = 0.f;
 
     const int nt = (a.Sk + 63) / 64;
-    s16x8 kr[2], vr[2];
+    const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
     float kbr = 0.f;
-    auto gload = [&](int t) {
-        load_tile(kr, kbase, a.k_ss, t * 64, a.Sk, tid);
-        load_tile(vr, vbase, a.v_ss, t * 64, a.Sk, tid);
-        if (tid < 64) {
-            int j = t * 64 + tid;
-            kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;  // -inf => p = 0 for padded keys
+    auto stage = [&](int t, int buf) {
+        char* tb = smem + buf * 16384;
+        tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
+        tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+        if constexpr (HAS_KB) {
+            if (tid < 64) {
+                int j = t * 64 + tid;
+                kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;  // -inf => p = 0 for padded keys
+            }
         }
     };
-    auto lwrite = [&]() {
-        store_tile_rm(kr, ks, tid);
-        store_tile_rm(vr, vs, tid);
-        if (tid < 64) kb[tid] = kbr;
+    auto stage_commit = [&](int buf) {
+        if constexpr (HAS_KB) {
+            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384)[buf * 64 + tid] = kbr;
+        }
     };
 
-    gload(0);
-    lwrite();
+    stage(0, 0);
+    stage_commit(0);
+    tile_dma_wait();
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) gload(t + 1);
+    auto body = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        const char* ks = smem + cur * 16384;
+        const char* vs = ks + 8192;
+        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
 #pragma unroll
         for (int js = 0; js < 2; ++js) {
             f32x16 s, dp;
@@ -490,11 +525,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (HAS_KB) b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = rq * 4 + j;
-                    float p = fast_exp2(__builtin_fmaf(s[r], sl, b4[j] - lse_i));
+                    float p = HAS_KB ? fast_exp2(__builtin_fmaf(s[r], sl, b4[j] - lse_i)) : fast_exp2(__builtin_fmaf(s[r], sl, -lse_i));
                     dp[r] = p * (dp[r] - del_i);
                 }
             }
@@ -508,9 +544,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
             }
         }
+        if (t + 1 < nt) stage_commit(cur ^ 1);
+        tile_dma_wait();
         __syncthreads();
-        if (t + 1 < nt) lwrite();
-        __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nt) body(t + 1, std::integral_constant<int, 1>{});
     }
 
     if (i < a.Sq) {
@@ -540,7 +580,10 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
     rc = check_launch("attn_bwd_dkdv");
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
+    if (a.kbias || (a.Sk % 64) != 0)
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
+    else
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
     return check_launch("attn_bwd_dq");
 }
 

@@ -161,7 +161,13 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+                for (int tm = 0; tm < T::TM; ++tm) {
+                    if constexpr (DBG == 3) {
+                        asm volatile("" ::"v"(wf[kk & 1][tn]), "v"(xf[kk & 1][tm]));  // keep the LDS reads, drop the MFMA
+                    } else {
+                        acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+                    }
+                }
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!GLDS) {
@@ -357,6 +363,90 @@ FTMI_DEVICE void nt_run_k_ring(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* 
         cur = (cur == 2) ? 0 : cur + 1;
         nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
     }
+}
+
+// NS-stage LDS ring, second generation: hoisted 32-bit source offsets, the loads of tile kt+NS-1 issued in two portions
+// inside iteration kt, retired with a constant counted vmcnt ((NS-2) tiles stay in flight across the barrier).  The loop is
+// branch-free: past the end of K it re-stages the last tile into buffers nobody reads again (NS-1 wasted tile loads per
+// call) and drains them before returning.  192x128x32 with NS = 4 is 80 KB: two workgroups per CU, 60 KB in flight each.
+template <int BM, int BN, int BK, int WM, int WN, int NS>
+FTMI_DEVICE void nt_run_k_ring2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                                int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;
+    constexpr int LPT = XI + WI;
+    constexpr int NKK = BK / 16;
+    static_assert((BM * BK * 2 / 1024) % T::NW == 0 && (BN * BK * 2 / 1024) % T::NW == 0, "tile does not split into whole wave loads");
+
+    uint32_t off[LPT];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        int blk = wave * XI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        off[i] = (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int blk = wave * WI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        off[XI + i] = (uint32_t)(((long)row * ldw + c * 8) * 2);
+    }
+    auto issue = [&](int i, const char* xb, const char* wb, char* stage) {
+        if (i < XI)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
+                                             (__attribute__((address_space(3))) void*)(stage + (wave * XI + i) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + off[i]),
+                                             (__attribute__((address_space(3))) void*)(stage + BM * BK * 2 + (wave * WI + (i - XI)) * 1024), 16, 0, 0);
+    };
+    // prologue: tiles 0 .. NS-2 in flight (clamped), tile 0 landed
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) {
+        const int tc = min(t, nk - 1);
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) issue(i, (const char*)X + (long)tc * BK * 2, (const char*)W + (long)tc * BK * 2, smem + t * T::STAGE);
+    }
+    wait_vmcnt_barrier<(NS - 2) * LPT>();
+
+    int cur = 0, nxt = NS - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ktn = min(kt + NS - 1, nk - 1);
+        const char* xb = (const char*)X + (long)ktn * BK * 2;
+        const char* wb = (const char*)W + (long)ktn * BK * 2;
+        char* nstage = smem + nxt * T::STAGE;
+        const char* xs = smem + cur * T::STAGE;
+        const char* ws = xs + BM * BK * 2;
+        s16x8 wf[NKK][T::TN], xf[NKK][T::TM];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) wf[kk][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>((wn * T::TN + tn) * 32 + li, kk * 2 + g));
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) xf[kk][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>((wm * T::TM + tm) * 32 + li, kk * 2 + g));
+        }
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+            for (int i = kk * ((LPT + NKK - 1) / NKK); i < (kk + 1) * ((LPT + NKK - 1) / NKK) && i < LPT; ++i) issue(i, xb, wb, nstage);
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk][tn], xf[kk][tm], acc[tn][tm]);
+        }
+        // tile kt+1 must have landed; tiles kt+2 .. kt+NS-1 may stay in flight
+        wait_vmcnt_barrier<(NS - 2) * LPT>();
+        cur = (cur == NS - 1) ? 0 : cur + 1;
+        nxt = (nxt == NS - 1) ? 0 : nxt + 1;
+    }
+    wait_vmcnt_barrier<0>();  // drain the clamped re-loads before the buffers are reused
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,7 +749,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
+        if constexpr (NSTAGE == 16)
+            nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
             nt_run_k_8ph<NSTAGE - 9>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
         else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14))
             nt_run_k2<BM, BN, BK, WM, WN, (NSTAGE == 12 ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
@@ -668,7 +760,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         else if constexpr (NSTAGE == 3)
             nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
         else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5, (NSTAGE == 6 ? 1 : NSTAGE == 7 ? 2 : 0)>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
+            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5, (NSTAGE == 6 ? 1 : NSTAGE == 7 ? 2 : NSTAGE == 15 ? 3 : 0)>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
     }
 
     if constexpr (EXT) {
@@ -695,7 +787,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
         const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
                                            : p.W2 + (long)n0 * p.ldw2;
-        if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
+        if constexpr (NSTAGE == 16)
+            nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
             nt_run_k_8ph<NSTAGE - 9>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14))
             nt_run_k2<BM, BN, BK, WM, WN, (NSTAGE == 12 ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
@@ -831,7 +925,7 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
             a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
         }
     }
-    const size_t smem = (NSTAGE >= 5 ? 2 : NSTAGE) * T::STAGE;
+    const size_t smem = (NSTAGE == 16 ? 4 : NSTAGE >= 5 ? 2 : NSTAGE) * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
         if (smem > 65536) {
         static bool attr_set = false;  // per instantiation
@@ -1113,9 +1207,13 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             // auto: 192 x 128 tiles (2 workgroups / CU -> 512 slots) unless 256 x 256 tiles (1 / CU -> 256 slots) quantise
             // clearly better onto the chip (e.g. M 5376, N 6144: 1344 tiles = 2.6 rounds vs 504 tiles = 1.97 rounds)
             static int nt192 = -1, nt256 = -1;
+            static double thr256 = 0.05;
             if (nt192 < 0) {
                 const char* e = getenv("FTMI_NT192");
                 nt192 = e ? atoi(e) : 36;
+                e = getenv("FTMI_NT256");
+                e = getenv("FTMI_NT256_THR");
+                if (e) thr256 = atof(e);
                 e = getenv("FTMI_NT256");
                 nt256 = e ? atoi(e) : 0;  // 256 x 256 tiles measured no faster inside the step (tools/ab_variants.sh)
             }
@@ -1127,7 +1225,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
                 const long t192 = (long)((a.M + 191) / 192) * (a.N / 128), t256 = (long)((a.M + 255) / 256) * (a.N / 256);
                 const double e192 = (double)t192 / (double)(((t192 + 511) / 512) * 512);
                 const double e256 = ok256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
-                variant = (nt256 > 0 && e256 > e192 + 0.05) ? nt256 : nt192;
+                variant = (nt256 > 0 && e256 > e192 + thr256) ? nt256 : nt192;
             }
         }
         switch (variant) {
@@ -1141,12 +1239,14 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 13: return launch_nt<192, 128, 64, 2, 2, true, 1, 5>(a, st);  // 7 + pinned read/MFMA order
             case 20: return launch_nt<192, 128, 64, 2, 2, true, 1, 6>(a, st);  // timing experiment: no global loads in the K loop
             case 21: return launch_nt<192, 128, 64, 2, 2, true, 1, 7>(a, st);  // timing experiment: no MFMAs
+            case 24: return launch_nt<192, 128, 64, 2, 2, true, 1, 15>(a, st);  // timing experiment: loads + LDS reads, no MFMAs
             case 22: return launch_nt<256, 256, 64, 2, 4, true, 1, 6>(a, st);
             case 30: return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // second-generation 2-stage loop
             case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, 12>(a, st);  // 30 with the loads spread over 2 slices
             case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, 13>(a, st);  // 30 with the loads in one burst
             case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, 14>(a, st);  // 30 + pinned read / MFMA order
             case 39: return launch_nt<192, 128, 64, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, 120 KB -> 1 WG / CU
+            case 40: return launch_nt<192, 128, 32, 2, 2, true, 1, 16>(a, st);  // 4-stage ring, BK 32, 80 KB -> 2 WG / CU, 60 KB in flight each
             case 31: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);
             case 33: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 9>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // 8-phase loop
             case 34: return launch_nt<256, 256, 64, 2, 4, true, 1, 10>(a, st);  // timing experiment: no staging in the loop

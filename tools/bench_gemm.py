@@ -3,7 +3,7 @@ import sys, os, math, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finetrainers_amd import ops, _lib
 dev = torch.device("cuda", 0)
-shapes = [(5376, 2048, 2048), (5376, 6144, 2048), (5376, 8192, 2048), (5376, 2048, 8192), (5376, 2048, 6144)]
+shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")] if os.environ.get("SHAPES") else [(5376, 2048, 2048), (5376, 6144, 2048), (5376, 8192, 2048), (5376, 2048, 8192), (5376, 2048, 6144)]
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3".split(","))]
 g = torch.Generator(device=dev).manual_seed(0)
 for (M, N, K) in shapes:
