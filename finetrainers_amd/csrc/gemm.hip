@@ -13,6 +13,8 @@
 // launched by the reference step (SURVEY 2c K6,K7,K10,K14,K15,K17,K18,K19,K21).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -449,6 +451,107 @@ FTMI_DEVICE void nt_run_k_ring2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char*
     wait_vmcnt_barrier<0>();  // drain the clamped re-loads before the buffers are reused
 }
 
+// NS-stage LDS ring with the fragment reads software-pipelined ACROSS the tile barrier: the fragments of tile kt+1 are read
+// (into the other half of a register double buffer) while the MFMAs of tile kt issue, so no LDS latency is exposed after the
+// barrier; a tile's buffer is free as soon as its fragments are in registers, so NS-1 tiles stay in flight.  Written for
+// 256 x 256 x 32 tiles, 8 waves (128 KB): 96 KB in flight, one barrier per 16 MFMAs of a wave.
+template <int BM, int BN, int BK, int WM, int WN, int NS>
+FTMI_DEVICE void nt_run_k_ring3(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                                int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;
+    constexpr int LPT = XI + WI;
+    constexpr int NKK = BK / 16;
+    static_assert((BM * BK * 2 / 1024) % T::NW == 0 && (BN * BK * 2 / 1024) % T::NW == 0, "tile does not split into whole wave loads");
+
+    uint32_t off[LPT];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        int blk = wave * XI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        off[i] = (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int blk = wave * WI + i;
+        int row = blk * T::RPI + lane / T::CPR;
+        int cs = lane % T::CPR;
+        int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        off[XI + i] = (uint32_t)(((long)row * ldw + c * 8) * 2);
+    }
+    auto issue_tile = [&](int t, int buf) {
+        const int tc = min(t, nk - 1);
+        const char* xb = (const char*)X + (long)tc * BK * 2;
+        const char* wb = (const char*)W + (long)tc * BK * 2;
+        char* stage = smem + buf * T::STAGE;
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
+                                             (__attribute__((address_space(3))) void*)(stage + (wave * XI + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + off[XI + i]),
+                                             (__attribute__((address_space(3))) void*)(stage + BM * BK * 2 + (wave * WI + i) * 1024), 16, 0, 0);
+    };
+    int xo[NKK][T::TM], wo[NKK][T::TN];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+        for (int tn = 0; tn < T::TN; ++tn) wo[kk][tn] = BM * BK * 2 + nt_lds_off<BK>((wn * T::TN + tn) * 32 + li, kk * 2 + g);
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm) xo[kk][tm] = nt_lds_off<BK>((wm * T::TM + tm) * 32 + li, kk * 2 + g);
+    }
+    s16x8 wf[2][NKK][T::TN], xf[2][NKK][T::TM];
+    auto read_frags = [&](auto P, int buf) {
+        constexpr int par = decltype(P)::value;
+        const char* st = smem + buf * T::STAGE;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) wf[par][kk][tn] = *reinterpret_cast<const s16x8*>(st + wo[kk][tn]);
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) xf[par][kk][tm] = *reinterpret_cast<const s16x8*>(st + xo[kk][tm]);
+        }
+    };
+
+    // prologue: NS tiles in flight, tiles 0 and 1 landed, fragments of tile 0 in registers, buffer 0 free again
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t) issue_tile(t, t);
+    wait_vmcnt_barrier<(NS - 3) * LPT>();
+    read_frags(std::integral_constant<int, 0>{}, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue_tile(NS - 1, NS - 1);
+
+    int bnext = 1;   // buffer of tile kt+1
+    int bfree = 0;   // buffer of tile kt (free: its fragments are in registers)
+    auto body = [&](int kt, auto P) {
+        constexpr int par = decltype(P)::value;
+        issue_tile(kt + NS, bfree);
+        read_frags(std::integral_constant<int, par ^ 1>{}, bnext);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[par][kk][tn], xf[par][kk][tm], acc[tn][tm]);
+        // tile kt+2 must have landed before the next iteration reads it; NS-2 younger tiles may stay in flight
+        wait_vmcnt_barrier<(NS - 2) * LPT>();
+        bfree = bnext;
+        bnext = (bnext == NS - 1) ? 0 : bnext + 1;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        body(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < nk) body(kt + 1, std::integral_constant<int, 1>{});
+    }
+    wait_vmcnt_barrier<0>();  // drain the clamped re-loads before the buffers are reused
+}
+
 // ------------------------------------------------------------------------------------------------
 // "Ping-pong" K loop for one 8-wave workgroup per CU (192 x 256 tile, BK = 32, 4-stage LDS ring, direct-to-LDS loads).
 // The two wave rows (wm = 0 / 1; waves i and i+4 share a SIMD) run ONE BARRIER apart: every K-tile is a load segment
@@ -749,7 +852,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        if constexpr (NSTAGE == 16)
+        if constexpr (NSTAGE == 17)
+            nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        else if constexpr (NSTAGE == 16)
             nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
         else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
             nt_run_k_8ph<NSTAGE - 9>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
@@ -787,7 +892,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
         const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
                                            : p.W2 + (long)n0 * p.ldw2;
-        if constexpr (NSTAGE == 16)
+        if constexpr (NSTAGE == 17)
+            nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        else if constexpr (NSTAGE == 16)
             nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
             nt_run_k_8ph<NSTAGE - 9>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
@@ -925,7 +1032,7 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
             a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
         }
     }
-    const size_t smem = (NSTAGE == 16 ? 4 : NSTAGE >= 5 ? 2 : NSTAGE) * T::STAGE;
+    const size_t smem = ((NSTAGE == 16 || NSTAGE == 17) ? 4 : NSTAGE >= 5 ? 2 : NSTAGE) * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
         if (smem > 65536) {
         static bool attr_set = false;  // per instantiation
@@ -1246,6 +1353,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, 13>(a, st);  // 30 with the loads in one burst
             case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, 14>(a, st);  // 30 + pinned read / MFMA order
             case 39: return launch_nt<192, 128, 64, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, 120 KB -> 1 WG / CU
+            case 41: if (a.N % 256 == 0) return launch_nt<256, 256, 32, 2, 4, true, 1, 17>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 12>(a, st);  // pipelined 4-stage ring
             case 40: return launch_nt<192, 128, 32, 2, 2, true, 1, 16>(a, st);  // 4-stage ring, BK 32, 80 KB -> 2 WG / CU, 60 KB in flight each
             case 31: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);
             case 33: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 9>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // 8-phase loop
