@@ -442,6 +442,167 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// backward: dK, dV for FEW keys (LTX cross-attention: 128 text tokens against 2688 queries).  The kernel above gives such a
+// problem ceil(Sk/128) * H * B = 64 workgroups that each walk all the queries.  Here a workgroup owns 32 keys and its four
+// waves split every 128-query block four ways (wave w takes queries 32w .. 32w+31 of the block), so there are 4x more
+// workgroups with 4x shorter loops; the four partial dK / dV are summed through LDS in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+static constexpr int kDkvSqLds = 2 * 32768 + 2 * 1024;  // two (Q, dO) 128-row buffers + two (lse, delta) 128-entry rows
+
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sk + 31) / 32, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int j = blk.tile * 32 + li;
+    const int jc = min(j, a.Sk - 1);
+    const float sl = a.scale * kLog2e;
+
+    const bf16_t* kp = a.k + (long)b * a.k_sb + (long)h * a.k_sh + (long)jc * a.k_ss;
+    const bf16_t* vp = a.v + (long)b * a.v_sb + (long)h * a.v_sh + (long)jc * a.v_ss;
+    s16x8 kf[4], vf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        kf[c] = *reinterpret_cast<const s16x8*>(kp + c * 16 + g * 8);
+        vf[c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
+    }
+    const float bias_j = a.kbias ? a.kbias[(long)b * a.Sk + jc] * kLog2e : 0.f;
+
+    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
+    const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
+    const float* lsebase = a.lse2 + ((long)b * a.H + h) * a.Sq;
+    const float* delbase = a.delta + ((long)b * a.H + h) * a.Sq;
+
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dkt[dt][r] = 0.f;
+            dvt[dt][r] = 0.f;
+        }
+
+    const int n64 = (a.Sq + 63) / 64, nb = (a.Sq + 127) / 128;
+    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane);
+    float lser = 0.f, delr = 0.f;
+    // buffer layout: [Q rows 0-63][Q rows 64-127][dO rows 0-63][dO rows 64-127]; a 64-row tile wholly past the end re-reads
+    // the last real tile (finite data, neutralised by lse = +inf)
+    auto stage = [&](int t, int buf) {
+        char* tb = smem + buf * 32768;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int t64 = min(2 * t + half, n64 - 1);
+            tile_dma_issue(qd, qbase, a.q_ss, t64, t64 == n64 - 1, tb + half * 8192, wave);
+            tile_dma_issue(dod, dobase, a.do_ss, t64, t64 == n64 - 1, tb + 16384 + half * 8192, wave);
+        }
+        if (tid < 128) {
+            int i = t * 128 + tid;
+            lser = (i < a.Sq) ? lsebase[i] : INFINITY;  // +inf => p = 0 for padded query rows
+            delr = (i < a.Sq) ? delbase[i] : 0.f;
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if (tid < 128) {
+            float* st = reinterpret_cast<float*>(smem + 2 * 32768) + buf * 256;
+            st[tid] = lser;
+            st[128 + tid] = delr;
+        }
+    };
+
+    stage(0, 0);
+    stage_commit(0);
+    tile_dma_wait();
+    __syncthreads();
+    auto body = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        const char* qs = smem + cur * 32768 + (wave >> 1) * 8192;        // this wave's 64-row tile ...
+        const char* dos = smem + cur * 32768 + 16384 + (wave >> 1) * 8192;
+        const int is = wave & 1;                                          // ... and 32-row half of it
+        const float* lses = reinterpret_cast<const float*>(smem + 2 * 32768) + cur * 256 + wave * 32;
+        const float* dels = lses + 128;
+        if (t + 1 < nb) stage(t + 1, cur ^ 1);
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = 0.f;
+            dp[r] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s16x8 qf = read_row_frag(qs, is * 32 + li, c, g);
+            s = mfma32(qf, kf[c], s);
+            s16x8 dof = read_row_frag(dos, is * 32 + li, c, g);
+            dp = mfma32(dof, vf[c], dp);
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + rq * 8 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + rq * 8 + 4 * g);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int r = rq * 4 + jj;
+                float p = fast_exp2(__builtin_fmaf(s[r], sl, bias_j - l4[jj]));
+                float ds = p * (dp[r] - d4[jj]);
+                s[r] = p;
+                dp[r] = ds;
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            s16x8 pf = pack_frag(s, hh);
+            s16x8 dsf = pack_frag(dp, hh);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                s16x8 dotf = read_tr_frag(dos, dt * 32, is * 32 + hh * 16, lane);
+                dvt[dt] = mfma32(dotf, pf, dvt[dt]);
+                s16x8 qtf = read_tr_frag(qs, dt * 32, is * 32 + hh * 16, lane);
+                dkt[dt] = mfma32(qtf, dsf, dkt[dt]);
+            }
+        }
+        if (t + 1 < nb) stage_commit(cur ^ 1);
+        tile_dma_wait();
+        __syncthreads();
+    };
+    for (int t = 0; t < nb; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nb) body(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    // cross-wave reduction: red[wave][array: dk0, dk1, dv0, dv1][register][lane]; wave w then finalises array w
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[((wave * 4 + 0) * 16 + r) * 64 + lane] = dkt[0][r];
+        red[((wave * 4 + 1) * 16 + r) * 64 + lane] = dkt[1][r];
+        red[((wave * 4 + 2) * 16 + r) * 64 + lane] = dvt[0][r];
+        red[((wave * 4 + 3) * 16 + r) * 64 + lane] = dvt[1][r];
+    }
+    __syncthreads();
+    if (j < a.Sk) {
+        const int arr = wave, dt = arr & 1;
+        const bool is_dk = arr < 2;
+        bf16_t* op = is_dk ? a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh + (long)j * a.dk_ss
+                           : a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh + (long)j * a.dv_ss;
+        const float mul = is_dk ? a.scale : 1.0f;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int r = rq * 4 + jj;
+                auto R = [&](int w) { return red[((w * 4 + arr) * 16 + r) * 64 + lane]; };
+                v[jj] = ((R(0) + R(1)) + (R(2) + R(3))) * mul;
+            }
+            u32x2 pk;
+            pk[0] = pack2bf(v[0], v[1]);
+            pk[1] = pack2bf(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(op + dt * 32 + rq * 8 + 4 * g) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: dQ
 // ------------------------------------------------------------------------------------------------
 static constexpr int kDqLds = 2 * 16384 + 2 * 256;
@@ -577,7 +738,17 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
     int rc = check_launch("attn_delta");
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
+    const long wg128 = (long)((a.Sk + 127) / 128) * a.H * a.B;
+    if (wg128 < 256 && a.Sq >= 512) {  // few keys: split the queries across the waves instead (see the kernel's header)
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_sq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSqLds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_dkdv_sq_kernel, dim3(((a.Sk + 31) / 32) * a.H * a.B), dim3(256), kDkvSqLds, st, a);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
+    }
     rc = check_launch("attn_bwd_dkdv");
     if (rc) return rc;
     if (a.kbias || (a.Sk % 64) != 0)

@@ -135,7 +135,9 @@ ATTN_CASES = [
     (1, 2, 32, 32, False),     # cfg 1 self-attention (one partial tile)
     (2, 3, 100, 77, True),     # ragged both ways
     (1, 4, 2688, 2688, False), # cfg 2 self-attention length
-    (2, 4, 2688, 128, True),   # cfg 2 cross-attention with text mask
+    (2, 4, 2688, 128, True),   # cfg 2 cross-attention with text mask (few keys: split-query dK/dV kernel)
+    (1, 2, 600, 77, True),     # split-query dK/dV kernel, ragged queries (last 128-block holds 88) and keys
+    (1, 1, 520, 33, False),    # split-query dK/dV kernel, second 64-row tile of the last block wholly past the end
 ]
 
 
