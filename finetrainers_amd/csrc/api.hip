@@ -223,6 +223,42 @@ int ftmi_linear_lora_fwd(int M, int K, int N, int r, float lora_scale, const voi
     return gemm_nt(a, st);
 }
 
+int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* dy, const void* xa, const void* w_t,
+                         const void* a_t, const void* b_t, void* dxa_ws, void* dx, float* grad_a, float* grad_b, int variant,
+                         ftmi_stream stream) {
+    if (!dy || (dx && !w_t)) return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_bwd: null tensor");
+    if (r < 0 || (r % 64)) return set_error(FTMI_ERR_UNSUPPORTED, "ftmi_linear_lora_bwd: rank must be 0 or a multiple of 64");
+    if (r > 0 && (!x || !xa || !a_t || !b_t || !dxa_ws || !grad_a || !grad_b))
+        return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_bwd: LoRA tensors missing");
+    hipStream_t st = (hipStream_t)stream;
+    if (r > 0) {
+        GemmNtArgs d;  // dxa = s * dy B  (B^T is the K-contiguous operand)
+        d.X = (const bf16_t*)dy; d.ldx = N; d.W = (const bf16_t*)b_t; d.ldw = N; d.M = M; d.N = r; d.K = N; d.alpha = lora_scale;
+        d.out = (bf16_t*)dxa_ws; d.ldo = r; d.variant = variant;
+        int rc = gemm_nt(d, st);
+        if (rc) return rc;
+    }
+    if (dx) {
+        GemmNtArgs a;  // dx = dy W (+ dxa A as a K-extension)
+        a.X = (const bf16_t*)dy; a.ldx = N; a.W = (const bf16_t*)w_t; a.ldw = N; a.M = M; a.N = K; a.K = N;
+        a.out = (bf16_t*)dx; a.ldo = K; a.variant = variant;
+        if (r > 0) { a.X2 = (const bf16_t*)dxa_ws; a.ldx2 = r; a.W2 = (const bf16_t*)a_t; a.ldw2 = r; a.K2 = r; }
+        int rc = gemm_nt(a, st);
+        if (rc) return rc;
+    }
+    if (r > 0) {
+        GemmTnArgs t;  // dB += dy^T xa
+        t.U = (const bf16_t*)dy; t.ldu = N; t.V = (const bf16_t*)xa; t.ldv = r; t.C = grad_b; t.ldc = r; t.M = M; t.P = N; t.Q = r;
+        int rc = gemm_tn(t, st);
+        if (rc) return rc;
+        GemmTnArgs u;  // dA += dxa^T x
+        u.U = (const bf16_t*)dxa_ws; u.ldu = r; u.V = (const bf16_t*)x; u.ldv = K; u.C = grad_a; u.ldc = K; u.M = M; u.P = r; u.Q = K;
+        rc = gemm_tn(u, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 size_t ftmi_ltx_workspace_bytes(const ftmi_ltx_config* cfg) { return cfg ? ltx_workspace_bytes(*cfg) : 0; }
 
 int ftmi_ltx_workspace_offset(const ftmi_ltx_config* cfg, const char* name, int layer, size_t* offset) {

@@ -117,6 +117,22 @@ def linear_lora_fwd(x, w, bias, a_bf, b_bf, lora_scale: float, variant: int = 0)
     return y, xa
 
 
+def linear_lora_bwd(x, dy, xa, w_t, a_t, b_t, lora_scale: float, grad_a=None, grad_b=None, need_dx: bool = True, variant: int = 0):
+    """Backward of ``linear_lora_fwd``: returns (dx [M,K] bf16 or None, grad_a [r,K] fp32, grad_b [N,r] fp32); the gradient
+    buffers are accumulated into when given (``.grad`` semantics).  ``w_t = W^T``, ``a_t = A^T``, ``b_t = B^T`` in bf16."""
+    M, N = dy.shape
+    K = w_t.shape[0] if w_t is not None else x.shape[1]
+    r = 0 if a_t is None else a_t.shape[1]
+    dx = torch.empty((M, K), dtype=bf16, device=dy.device) if need_dx else None
+    dxa = torch.empty((M, r), dtype=bf16, device=dy.device) if r else None
+    if r:
+        grad_a = torch.zeros((r, K), dtype=torch.float32, device=dy.device) if grad_a is None else grad_a
+        grad_b = torch.zeros((N, r), dtype=torch.float32, device=dy.device) if grad_b is None else grad_b
+    check(_lib.load().ftmi_linear_lora_bwd(M, K, N, r, float(lora_scale), ptr(x), ptr(dy), ptr(xa), ptr(w_t), ptr(a_t), ptr(b_t), ptr(dxa), ptr(dx),
+                                            ptr(grad_a), ptr(grad_b), variant, stream_ptr()), "ftmi_linear_lora_bwd")
+    return dx, grad_a, grad_b
+
+
 def noise_pack(latents, noise, mean, std, sigma, sigma_first=None, first_frame_tokens: int = 0):
     """latents/noise [B,C,F,H,W] bf16 -> (x_t, target) [B, F*H*W, C] bf16."""
     B, C = latents.shape[:2]

@@ -22,8 +22,10 @@
  *   ftmi_clip_adamw_step ............... utils/torch.py:99-161,299-374 (clip_grad_norm_) +
  *                                        optimizer.py:117-125 (torch.optim.AdamW step) over the flat LoRA buffer
  *   ftmi_lora_refresh .................. (new) bf16 working copies of the fp32 LoRA matrices after a step
- *   ftmi_linear_lora_fwd ............... peft lora.Linear.forward over a frozen nn.Linear
- *                                        (trainer/sft_trainer/trainer.py:121-136 injects them)
+ *   ftmi_linear_lora_fwd / _bwd ........ peft lora.Linear.forward over a frozen nn.Linear
+ *                                        (trainer/sft_trainer/trainer.py:121-136 injects them) and the autograd
+ *                                        backward the reference gets from loss.backward() (trainer.py:481): dgrad to
+ *                                        the input, weight gradients of A and B only (the base weight is frozen)
  */
 #ifndef FTMI355_H
 #define FTMI355_H
@@ -83,6 +85,16 @@ int ftmi_attn_bwd(const ftmi_attn_desc* desc, const void* q, const void* k, cons
  * ------------------------------------------------------------------------------------------------------------ */
 int ftmi_linear_lora_fwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* w, const void* bias,
                          const void* a_bf, const void* b_bf, void* y, void* xa_out, int variant, ftmi_stream stream);
+
+/* Backward of the above.  dy [M,N] bf16; xa [M,r] = the forward's xa_out; w_t [K,N] = W^T (bf16, made once with
+ * ftmi_transpose_bf16), a_t [K,r] = A^T, b_t [r,N] = B^T (bf16 working copies, see ftmi_lora_refresh).
+ *   dxa_ws [M,r] bf16 scratch <- bf16(lora_scale * dy B)
+ *   dx [M,K] bf16            <- bf16(bf16(dy W) + dxa A)            (may be NULL: input needs no gradient)
+ *   grad_a [r,K] fp32        += dxa^T x       grad_b [N,r] fp32 += dy^T xa      (accumulated, like .grad)
+ * r == 0 => dx only. */
+int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* dy, const void* xa,
+                         const void* w_t, const void* a_t, const void* b_t, void* dxa_ws, void* dx, float* grad_a,
+                         float* grad_b, int variant, ftmi_stream stream);
 
 /* Generic building blocks (exposed for tests / incremental adoption) */
 /* out[M,N] = bf16(alpha * x[M,K] w[N,K]^T + bias) ; epilogue: 0 store, 1 gelu-tanh (out2 <- pre-activation),

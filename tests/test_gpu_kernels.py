@@ -101,6 +101,34 @@ def test_linear_lora_fwd(M, variant):
     report(f"lora xa M={M}", xa, (x.float() @ A.t() * s).to(bf16), 6e-3)
 
 
+@pytest.mark.parametrize("M", [96, 700])
+def test_linear_lora_bwd(M):
+    """Autograd of peft lora.Linear over a frozen Linear (fp32 reference on the bf16 operands): dx, dA, dB."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    K, N, r, s = 2048, 2048, 64, 0.5
+    x, w, b = rnd((M, K), g), rnd((N, K), g, 1 / math.sqrt(K)), rnd((N,), g)
+    A = (torch.randn(r, K, generator=g) / math.sqrt(K)).to(bf16)
+    Bm = (torch.randn(N, r, generator=g) * 0.05).to(bf16)
+    dy = rnd((M, N), g)
+    xr = x.float().requires_grad_(True)
+    Ar, Br = A.float().requires_grad_(True), Bm.float().requires_grad_(True)
+    y = xr @ w.float().t() + b.float() + (xr @ Ar.t()) @ Br.t() * s
+    y.backward(dy.float())
+    _, xa = ops.linear_lora_fwd(x.to(dev), w.to(dev), b.to(dev), A.to(dev), Bm.to(dev), s, variant=8)
+    w_t = ops.transpose_bf16(w.to(dev))
+    ga0 = torch.ones((r, K), dtype=torch.float32, device=dev)  # pre-existing .grad content must be accumulated into
+    dx, ga, gb = ops.linear_lora_bwd(x.to(dev), dy.to(dev), xa, w_t, A.t().contiguous().to(dev), Bm.t().contiguous().to(dev), s, grad_a=ga0, variant=8)
+    torch.cuda.synchronize()
+    report(f"lora bwd dx M={M}", dx, xr.grad.to(bf16), 4e-3)
+    report(f"lora bwd dA M={M}", ga - 1.0, Ar.grad, 1e-2)
+    report(f"lora bwd dB M={M}", gb, Br.grad, 1e-2)
+    dx2, _, _ = ops.linear_lora_bwd(None, dy.to(dev), None, w_t, None, None, s, variant=8)  # r = 0: plain dgrad
+    report("plain dgrad", dx2, (dy.float() @ w.float()).to(bf16), 3e-3)
+
+
 @pytest.mark.parametrize("M,P,Q", [(64, 64, 64), (300, 128, 64), (1000, 64, 2048), (5376, 2048, 64), (333, 192, 2048), (256, 4096, 64)])
 def test_gemm_tn(M, P, Q):
     from finetrainers_amd import ops
