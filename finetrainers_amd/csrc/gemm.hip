@@ -183,7 +183,7 @@ FTMI_DEVICE void nt_run_k(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem,
 // use the SGPR-base + VGPR-offset form and the K advance is scalar), and the loads of tile kt+1 are issued in NKK
 // portions between the MFMA groups of tile kt instead of one burst (a burst fills the CU's vector-memory queue and
 // blocks every wave's instruction stream behind its own loads).
-template <int BM, int BN, int BK, int WM, int WN, int SPREAD = 4, bool PIN = false>
+template <int BM, int BN, int BK, int WM, int WN, int SPREAD = 4, bool PIN = false, bool BUF = false>
 FTMI_DEVICE void nt_run_k2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
                            int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
     using T = NtTile<BM, BN, BK, WM, WN>;
@@ -214,13 +214,27 @@ FTMI_DEVICE void nt_run_k2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem
         int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
         off[XI + i] = (uint32_t)(((long)row * ldw + c * 8) * 2);
     }
+    // BUF: the same loads through buffer descriptors (SGPR base + 32-bit VGPR offset + SGPR K advance): half the address payload
+    // per lane and no 64-bit VALU add per load
     auto issue = [&](int i, const char* xb, const char* wb, char* stage) {
-        if (i < XI)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
-                                             (__attribute__((address_space(3))) void*)(stage + (wave * XI + i) * 1024), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + off[i]),
-                                             (__attribute__((address_space(3))) void*)(stage + BM * BK * 2 + (wave * WI + (i - XI)) * 1024), 16, 0, 0);
+        if constexpr (BUF) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins do not type-check in hipcc's host pass over device templates
+            const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+            const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+            const int soff = (int)(xb - (const char*)X);  // = K advance in bytes, identical for X and W
+            if (i < XI)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(stage + (wave * XI + i) * 1024), 16, off[i], soff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(stage + BM * BK * 2 + (wave * WI + (i - XI)) * 1024), 16, off[i], soff, 0, 0);
+#endif
+        } else {
+            if (i < XI)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
+                                                 (__attribute__((address_space(3))) void*)(stage + (wave * XI + i) * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + off[i]),
+                                                 (__attribute__((address_space(3))) void*)(stage + BM * BK * 2 + (wave * WI + (i - XI)) * 1024), 16, 0, 0);
+        }
     };
     {
         const char* xb = (const char*)X;
@@ -858,8 +872,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
         else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
             nt_run_k_8ph<NSTAGE - 9>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
-        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14))
-            nt_run_k2<BM, BN, BK, WM, WN, (NSTAGE == 12 ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14) || NSTAGE == 18)
+            nt_run_k2<BM, BN, BK, WM, WN, ((NSTAGE == 12 || NSTAGE == 18) ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14, NSTAGE == 18>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
         else if constexpr (NSTAGE == 4)
             nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
         else if constexpr (NSTAGE == 3)
@@ -898,8 +912,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
             nt_run_k_8ph<NSTAGE - 9>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
-        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14))
-            nt_run_k2<BM, BN, BK, WM, WN, (NSTAGE == 12 ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14) || NSTAGE == 18)
+            nt_run_k2<BM, BN, BK, WM, WN, ((NSTAGE == 12 || NSTAGE == 18) ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14, NSTAGE == 18>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 4)
             nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 3)
@@ -1317,7 +1331,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             static double thr256 = 0.05;
             if (nt192 < 0) {
                 const char* e = getenv("FTMI_NT192");
-                nt192 = e ? atoi(e) : 36;
+                nt192 = e ? atoi(e) : 42;
                 e = getenv("FTMI_NT256");
                 e = getenv("FTMI_NT256_THR");
                 if (e) thr256 = atof(e);
@@ -1350,6 +1364,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 22: return launch_nt<256, 256, 64, 2, 4, true, 1, 6>(a, st);
             case 30: return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // second-generation 2-stage loop
             case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, 12>(a, st);  // 30 with the loads spread over 2 slices
+            case 42: return launch_nt<192, 128, 64, 2, 2, true, 1, 18>(a, st);  // 36 with buffer-descriptor loads
             case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, 13>(a, st);  // 30 with the loads in one burst
             case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, 14>(a, st);  // 30 + pinned read / MFMA order
             case 39: return launch_nt<192, 128, 64, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, 120 KB -> 1 WG / CU
