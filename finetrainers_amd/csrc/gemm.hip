@@ -284,6 +284,77 @@ FTMI_DEVICE void nt_run_k2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem
     }
 }
 
+// Register-staged twin of nt_run_k2 (timing comparison of the two staging paths under identical scheduling): tile kt+1 is
+// fetched with buffer_load_dwordx4 into VGPRs during the first two k-slices of tile kt and written to the other LDS stage
+// with ds_write_b128 (swizzled destination) after the last MFMA group, one barrier per tile.
+template <int BM, int BN, int BK, int WM, int WN>
+FTMI_DEVICE void nt_run_k2_reg(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                               int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;
+    constexpr int LPT = XI + WI;
+    constexpr int NKK = BK / 16;
+    constexpr int LPS = (LPT + 1) / 2;
+
+    uint32_t off[LPT];
+    int ldst[LPT];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        int row = (wave * XI + i) * T::RPI + lane / T::CPR, c = lane % T::CPR;
+        off[i] = (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2);
+        ldst[i] = nt_lds_off<BK>(row, c);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int row = (wave * WI + i) * T::RPI + lane / T::CPR, c = lane % T::CPR;
+        off[XI + i] = (uint32_t)(((long)row * ldw + c * 8) * 2);
+        ldst[XI + i] = BM * BK * 2 + nt_lds_off<BK>(row, c);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    u32x4 stg[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(i < XI ? xrs : wrs, off[i], 0, 0);
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) *reinterpret_cast<u32x4*>(smem + ldst[i]) = stg[i];
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int soff = min(kt + 1, nk - 1) * BK * 2;
+        char* nstage = smem + (cur ^ 1) * T::STAGE;
+        const char* xs = smem + cur * T::STAGE;
+        const char* ws = xs + BM * BK * 2;
+        s16x8 wf[2][T::TN], xf[2][T::TM];
+        auto lfrag = [&](int buf, int kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) wf[buf][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>((wn * T::TN + tn) * 32 + li, kk * 2 + g));
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) xf[buf][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>((wm * T::TM + tm) * 32 + li, kk * 2 + g));
+        };
+        lfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+            for (int i = kk * LPS; i < (kk + 1) * LPS && i < LPT; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(i < XI ? xrs : wrs, off[i], soff, 0);
+            if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+        }
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) *reinterpret_cast<u32x4*>(nstage + ldst[i]) = stg[i];
+        __syncthreads();
+    }
+#endif
+}
+
 template <int N>
 FTMI_DEVICE void wait_vmcnt_barrier() {
     // counted wait + raw barrier: a __syncthreads() here would drain every direct-to-LDS load in flight (vmcnt(0))
@@ -866,7 +937,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        if constexpr (NSTAGE == 17)
+        if constexpr (NSTAGE == 19)
+            nt_run_k2_reg<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        else if constexpr (NSTAGE == 17)
             nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
         else if constexpr (NSTAGE == 16)
             nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
@@ -906,7 +979,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
         const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
                                            : p.W2 + (long)n0 * p.ldw2;
-        if constexpr (NSTAGE == 17)
+        if constexpr (NSTAGE == 19)
+            nt_run_k2_reg<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        else if constexpr (NSTAGE == 17)
             nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
         else if constexpr (NSTAGE == 16)
             nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
@@ -1365,6 +1440,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 30: return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // second-generation 2-stage loop
             case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, 12>(a, st);  // 30 with the loads spread over 2 slices
             case 42: return launch_nt<192, 128, 64, 2, 2, true, 1, 18>(a, st);  // 36 with buffer-descriptor loads
+            case 43: return launch_nt<192, 128, 64, 2, 2, true, 1, 19>(a, st);  // register-staged twin of 42
             case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, 13>(a, st);  // 30 with the loads in one burst
             case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, 14>(a, st);  // 30 + pinned read / MFMA order
             case 39: return launch_nt<192, 128, 64, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, 120 KB -> 1 WG / CU
