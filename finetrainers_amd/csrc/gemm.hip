@@ -340,16 +340,20 @@ FTMI_DEVICE void nt_run_k2_reg(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* 
         lfrag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
+            // loads of tile kt+1 in slices 0 and 1, their LDS writes between the MFMAs of slices 2 and 3 (the other stage is free)
+            if (kk < 2) {
 #pragma unroll
-            for (int i = kk * LPS; i < (kk + 1) * LPS && i < LPT; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(i < XI ? xrs : wrs, off[i], soff, 0);
+                for (int i = kk * LPS; i < (kk + 1) * LPS && i < LPT; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(i < XI ? xrs : wrs, off[i], soff, 0);
+            } else {
+#pragma unroll
+                for (int i = (kk - 2) * LPS; i < (kk - 1) * LPS && i < LPT; ++i) *reinterpret_cast<u32x4*>(nstage + ldst[i]) = stg[i];
+            }
             if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
 #pragma unroll
             for (int tn = 0; tn < T::TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
         }
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) *reinterpret_cast<u32x4*>(nstage + ldst[i]) = stg[i];
         __syncthreads();
     }
 #endif
