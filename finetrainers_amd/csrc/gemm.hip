@@ -344,6 +344,7 @@ FTMI_DEVICE void nt_run_k2_reg(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* 
             if (kk < 2) {
 #pragma unroll
                 for (int i = kk * LPS; i < (kk + 1) * LPS && i < LPT; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(i < XI ? xrs : wrs, off[i], soff, 0);
+                __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the loads down to their ds_write (exposing the full latency)
             } else {
 #pragma unroll
                 for (int i = (kk - 2) * LPS; i < (kk - 1) * LPS && i < LPT; ++i) *reinterpret_cast<u32x4*>(nstage + ldst[i]) = stg[i];
