@@ -902,7 +902,56 @@ FTMI_DEVICE void nt_run_k_8ph(f32x16 (&acc)[2][4], char* smem, const bf16_t* __r
     if (wr == 0) asm volatile("s_barrier" ::: "memory");  // re-align the two wave rows
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int NSTAGE = 2>
+// ------------------------------------------------------------------------------------------------
+// K-loop selector of gemm_nt_kernel (template parameter LOOP).  KL_GEN2_BUF is the production loop; the others are kept as
+// bit-identical A/B partners (tools/bench_gemm.py, tools/ab_variants.sh) and as the timing experiments quoted in DESIGN.md.
+// ------------------------------------------------------------------------------------------------
+enum : int {
+    KL_2STAGE = 2,            // nt_run_k: first-generation 2-stage loop (register-staged when !GLDS)
+    KL_RING3 = 3,             // nt_run_k_ring: 3-stage ring, counted vmcnt
+    KL_PINGPONG = 4,          // nt_run_k_pp: 8-wave ping-pong, BK 32, 4 stages
+    KL_2STAGE_PIN = 5,        // KL_2STAGE + pinned read / MFMA order
+    KL_DBG_NOLOAD = 6,        // timing experiment: no global loads inside the K loop
+    KL_DBG_NOMFMA = 7,        // timing experiment: no LDS reads, no MFMAs
+    KL_GEN2 = 8,              // nt_run_k2: hoisted offsets, loads spread over 4 k-slices
+    KL_8PHASE = 9,            // nt_run_k_8ph (256 x 256 x 64 only)
+    KL_8PHASE_DBG_NOLOAD = 10,
+    KL_8PHASE_DBG_NOMFMA = 11,
+    KL_GEN2_SPREAD2 = 12,     // nt_run_k2, loads spread over 2 k-slices
+    KL_GEN2_BURST = 13,       // nt_run_k2, loads in one burst
+    KL_GEN2_PIN = 14,         // nt_run_k2 + pinned read / MFMA order
+    KL_DBG_LDSONLY = 15,      // timing experiment: loads + LDS reads, no MFMAs
+    KL_RING4 = 16,            // nt_run_k_ring2: 4-stage ring
+    KL_RING4_PIPE = 17,       // nt_run_k_ring3: 4-stage ring, fragment reads pipelined across the barrier
+    KL_GEN2_BUF = 18,         // nt_run_k2, spread 2, buffer-descriptor loads  (production)
+    KL_GEN2_REG = 19,         // nt_run_k2_reg: register-staged twin of KL_GEN2_BUF
+};
+constexpr int kl_lds_stages(int loop) { return (loop == KL_RING4 || loop == KL_RING4_PIPE) ? 4 : (loop == KL_RING3) ? 3 : (loop == KL_PINGPONG) ? 4 : 2; }
+
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int LOOP>
+FTMI_DEVICE void nt_k_loop(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M,
+                           const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+    if constexpr (LOOP == KL_GEN2_REG)
+        nt_run_k2_reg<BM, BN, BK, WM, WN>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
+    else if constexpr (LOOP == KL_RING4_PIPE)
+        nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
+    else if constexpr (LOOP == KL_RING4)
+        nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
+    else if constexpr (LOOP == KL_8PHASE || LOOP == KL_8PHASE_DBG_NOLOAD || LOOP == KL_8PHASE_DBG_NOMFMA)
+        nt_run_k_8ph<LOOP - KL_8PHASE>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
+    else if constexpr (LOOP == KL_GEN2 || LOOP == KL_GEN2_SPREAD2 || LOOP == KL_GEN2_BURST || LOOP == KL_GEN2_PIN || LOOP == KL_GEN2_BUF)
+        nt_run_k2<BM, BN, BK, WM, WN, ((LOOP == KL_GEN2_SPREAD2 || LOOP == KL_GEN2_BUF) ? 2 : LOOP == KL_GEN2_BURST ? 1 : 4), LOOP == KL_GEN2_PIN,
+                  LOOP == KL_GEN2_BUF>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
+    else if constexpr (LOOP == KL_PINGPONG)
+        nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X, ldx, m0, M, W, ldw, 0, nk, tid);
+    else if constexpr (LOOP == KL_RING3)
+        nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, ldx, m0, M, W, ldw, 0, nk, tid);
+    else
+        nt_run_k<BM, BN, BK, WM, WN, GLDS, LOOP == KL_2STAGE_PIN,
+                 (LOOP == KL_DBG_NOLOAD ? 1 : LOOP == KL_DBG_NOMFMA ? 2 : LOOP == KL_DBG_LDSONLY ? 3 : 0)>(acc, smem, X, ldx, m0, M, W, ldw, 0, nk, tid);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int LOOP = KL_2STAGE>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs p) {
     using T = NtTile<BM, BN, BK, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -942,22 +991,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        if constexpr (NSTAGE == 19)
-            nt_run_k2_reg<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
-        else if constexpr (NSTAGE == 17)
-            nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
-        else if constexpr (NSTAGE == 16)
-            nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
-        else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
-            nt_run_k_8ph<NSTAGE - 9>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
-        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14) || NSTAGE == 18)
-            nt_run_k2<BM, BN, BK, WM, WN, ((NSTAGE == 12 || NSTAGE == 18) ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14, NSTAGE == 18>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
-        else if constexpr (NSTAGE == 4)
-            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
-        else if constexpr (NSTAGE == 3)
-            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
-        else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5, (NSTAGE == 6 ? 1 : NSTAGE == 7 ? 2 : NSTAGE == 15 ? 3 : 0)>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, 0, p.K / BK, tid);
+        nt_k_loop<BM, BN, BK, WM, WN, GLDS, LOOP>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
     }
 
     if constexpr (EXT) {
@@ -984,22 +1018,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
         const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
                                            : p.W2 + (long)n0 * p.ldw2;
-        if constexpr (NSTAGE == 19)
-            nt_run_k2_reg<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
-        else if constexpr (NSTAGE == 17)
-            nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
-        else if constexpr (NSTAGE == 16)
-            nt_run_k_ring2<BM, BN, BK, WM, WN, 4>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
-        else if constexpr (NSTAGE == 9 || NSTAGE == 10 || NSTAGE == 11)
-            nt_run_k_8ph<NSTAGE - 9>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
-        else if constexpr (NSTAGE == 8 || (NSTAGE >= 12 && NSTAGE <= 14) || NSTAGE == 18)
-            nt_run_k2<BM, BN, BK, WM, WN, ((NSTAGE == 12 || NSTAGE == 18) ? 2 : NSTAGE == 13 ? 1 : 4), NSTAGE == 14, NSTAGE == 18>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
-        else if constexpr (NSTAGE == 4)
-            nt_run_k_pp<BM, BN, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
-        else if constexpr (NSTAGE == 3)
-            nt_run_k_ring<BM, BN, BK, WM, WN>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
-        else
-            nt_run_k<BM, BN, BK, WM, WN, GLDS, NSTAGE == 5>(acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, 0, p.K2 / BK, tid);
+        nt_k_loop<BM, BN, BK, WM, WN, GLDS, (LOOP == KL_DBG_NOLOAD || LOOP == KL_DBG_NOMFMA || LOOP == KL_DBG_LDSONLY) ? KL_2STAGE : LOOP>(
+            acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
     }
 
     // ---------------- epilogue ----------------
@@ -1095,7 +1115,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int NSTAGE>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int LOOP>
 static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
     using T = NtTile<BM, BN, BK, WM, WN>;
     const int ntm = (a0.M + BM - 1) / BM, ntn = a0.N / BN;
@@ -1126,31 +1146,31 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
             a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
         }
     }
-    const size_t smem = ((NSTAGE == 16 || NSTAGE == 17) ? 4 : NSTAGE >= 5 ? 2 : NSTAGE) * T::STAGE;
+    const size_t smem = (size_t)kl_lds_stages(LOOP) * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
         if (smem > 65536) {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, NSTAGE>),
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, LOOP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, NSTAGE>), dim3(8 * a.map_rm * a.map_rn), dim3(T::NT), smem, st, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, LOOP>), dim3(8 * a.map_rm * a.map_rn), dim3(T::NT), smem, st, a);
     return check_launch("gemm_nt");
 }
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, int NSTAGE>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, int LOOP>
 static int launch_nt2(const GemmNtArgs& a, hipStream_t st) {
-    return a.K2 > 0 ? launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, true, NSTAGE>(a, st)
-                    : launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, false, NSTAGE>(a, st);
+    return a.K2 > 0 ? launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, true, LOOP>(a, st)
+                    : launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, false, LOOP>(a, st);
 }
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int NSTAGE = 2>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int LOOP = KL_2STAGE>
 static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     switch (a.epi) {
-        case EPI_STORE: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE, NSTAGE>(a, st);
-        case EPI_GELU: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_GELU, NSTAGE>(a, st);
-        case EPI_RESID: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_RESID, NSTAGE>(a, st);
-        default: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_DGELU, NSTAGE>(a, st);
+        case EPI_STORE: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE, LOOP>(a, st);
+        case EPI_GELU: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_GELU, LOOP>(a, st);
+        case EPI_RESID: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_RESID, LOOP>(a, st);
+        default: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_DGELU, LOOP>(a, st);
     }
 }
 
@@ -1412,14 +1432,13 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             if (nt192 < 0) {
                 const char* e = getenv("FTMI_NT192");
                 nt192 = e ? atoi(e) : 42;
-                e = getenv("FTMI_NT256");
                 e = getenv("FTMI_NT256_THR");
                 if (e) thr256 = atof(e);
                 e = getenv("FTMI_NT256");
                 nt256 = e ? atoi(e) : 0;  // 256 x 256 tiles measured no faster inside the step (tools/ab_variants.sh)
             }
             if (a.M < 1024) {
-                variant = 1;
+                variant = 44;  // few rows (the text side): 128 x 128 tiles
             } else {
                 auto g256 = [](int g) { return g <= 0 || g % 256 == 0; };
                 const bool ok256 = a.N % 256 == 0 && g256(a.w_grp_n) && g256(a.w2_grp_n) && g256(a.xk_grp_n) && g256(a.x2_grp_n);
@@ -1437,31 +1456,32 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 5: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 6: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 4, 2, true, 1>(a, st); else return launch_nt<256, 128, 64, 4, 2, true, 1>(a, st);
             case 7: return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
-            case 13: return launch_nt<192, 128, 64, 2, 2, true, 1, 5>(a, st);  // 7 + pinned read/MFMA order
-            case 20: return launch_nt<192, 128, 64, 2, 2, true, 1, 6>(a, st);  // timing experiment: no global loads in the K loop
-            case 21: return launch_nt<192, 128, 64, 2, 2, true, 1, 7>(a, st);  // timing experiment: no MFMAs
-            case 24: return launch_nt<192, 128, 64, 2, 2, true, 1, 15>(a, st);  // timing experiment: loads + LDS reads, no MFMAs
-            case 22: return launch_nt<256, 256, 64, 2, 4, true, 1, 6>(a, st);
-            case 30: return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // second-generation 2-stage loop
-            case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, 12>(a, st);  // 30 with the loads spread over 2 slices
-            case 42: return launch_nt<192, 128, 64, 2, 2, true, 1, 18>(a, st);  // 36 with buffer-descriptor loads
-            case 43: return launch_nt<192, 128, 64, 2, 2, true, 1, 19>(a, st);  // register-staged twin of 42
-            case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, 13>(a, st);  // 30 with the loads in one burst
-            case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, 14>(a, st);  // 30 + pinned read / MFMA order
-            case 39: return launch_nt<192, 128, 64, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, 120 KB -> 1 WG / CU
-            case 41: if (a.N % 256 == 0) return launch_nt<256, 256, 32, 2, 4, true, 1, 17>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 12>(a, st);  // pipelined 4-stage ring
-            case 40: return launch_nt<192, 128, 32, 2, 2, true, 1, 16>(a, st);  // 4-stage ring, BK 32, 80 KB -> 2 WG / CU, 60 KB in flight each
-            case 31: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);
-            case 33: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, 9>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // 8-phase loop
-            case 34: return launch_nt<256, 256, 64, 2, 4, true, 1, 10>(a, st);  // timing experiment: no staging in the loop
-            case 35: return launch_nt<256, 256, 64, 2, 4, true, 1, 11>(a, st);  // timing experiment: no MFMAs
-            case 32: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 2, true, 1, 8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, 8>(a, st);  // 4 waves, 128 x 128 per wave
-            case 23: return launch_nt<256, 256, 64, 2, 4, true, 1, 7>(a, st);
-            case 14: if (a.N % 256 == 0) return launch_nt<256, 256, 32, 2, 4, true, 1, 4>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
-            case 12: if (a.N % 256 == 0) return launch_nt<192, 256, 32, 2, 4, true, 1, 4>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
-            case 9: return launch_nt<192, 128, 32, 2, 2, true, 1, 3>(a, st);   // 3-stage ring, BK 32: 60 KB -> 2 WG / CU
-            case 10: return launch_nt<128, 128, 64, 2, 2, true, 1, 3>(a, st);  // 3-stage ring, BK 64: 96 KB -> 1 WG / CU
-            case 11: return launch_nt<128, 128, 32, 2, 2, true, 1, 3>(a, st);  // 3-stage ring, BK 32: 48 KB -> 3 WG / CU
+            case 13: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_2STAGE_PIN>(a, st);  // 7 + pinned read/MFMA order
+            case 20: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_DBG_NOLOAD>(a, st);  // timing experiment: no global loads in the K loop
+            case 21: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_DBG_NOMFMA>(a, st);  // timing experiment: no MFMAs
+            case 24: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_DBG_LDSONLY>(a, st);  // timing experiment: loads + LDS reads, no MFMAs
+            case 22: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_DBG_NOLOAD>(a, st);
+            case 30: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2>(a, st);  // second-generation 2-stage loop
+            case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_SPREAD2>(a, st);  // 30 with the loads spread over 2 slices
+            case 42: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 36 with buffer-descriptor loads
+            case 43: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_REG>(a, st);  // register-staged twin of 42
+            case 44: return launch_nt<128, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // production loop on 128 x 128 tiles
+            case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BURST>(a, st);  // 30 with the loads in one burst
+            case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_PIN>(a, st);  // 30 + pinned read / MFMA order
+            case 39: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_RING3>(a, st);   // 3-stage ring, 120 KB -> 1 WG / CU
+            case 41: if (a.N % 256 == 0) return launch_nt<256, 256, 32, 2, 4, true, 1, KL_RING4_PIPE>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_SPREAD2>(a, st);  // pipelined 4-stage ring
+            case 40: return launch_nt<192, 128, 32, 2, 2, true, 1, KL_RING4>(a, st);  // 4-stage ring, BK 32, 80 KB -> 2 WG / CU, 60 KB in flight each
+            case 31: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_GEN2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2>(a, st);
+            case 33: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_8PHASE>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2>(a, st);  // 8-phase loop
+            case 34: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_8PHASE_DBG_NOLOAD>(a, st);  // timing experiment: no staging in the loop
+            case 35: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_8PHASE_DBG_NOMFMA>(a, st);  // timing experiment: no MFMAs
+            case 32: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_GEN2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2>(a, st);  // 4 waves, 128 x 128 per wave
+            case 23: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_DBG_NOMFMA>(a, st);
+            case 14: if (a.N % 256 == 0) return launch_nt<256, 256, 32, 2, 4, true, 1, KL_PINGPONG>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
+            case 12: if (a.N % 256 == 0) return launch_nt<192, 256, 32, 2, 4, true, 1, KL_PINGPONG>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1>(a, st);
+            case 9: return launch_nt<192, 128, 32, 2, 2, true, 1, KL_RING3>(a, st);   // 3-stage ring, BK 32: 60 KB -> 2 WG / CU
+            case 10: return launch_nt<128, 128, 64, 2, 2, true, 1, KL_RING3>(a, st);  // 3-stage ring, BK 64: 96 KB -> 1 WG / CU
+            case 11: return launch_nt<128, 128, 32, 2, 2, true, 1, KL_RING3>(a, st);  // 3-stage ring, BK 32: 48 KB -> 3 WG / CU
             default: return launch_nt<128, 128, 64, 2, 2, true, 1>(a, st);
         }
     }
