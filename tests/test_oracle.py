@@ -137,3 +137,85 @@ def test_sft_step_runs_and_updates():
     loss, gn, grads = ltx.sft_step(m, opt, inp)
     assert torch.isfinite(loss) and gn > 0
     assert any((before[n] != p).any() for n, p in ltx.lora_parameters(m))
+
+
+def test_gradient_noise_floor_of_bf16_rounding_points():
+    """Why the LoRA-gradient tolerance of the GPU parity tests is 1e-2 and not the north star's 1e-3.
+
+    Moving ONE family of bf16 rounding points of the reference graph -- (i) LoRA operands (A, B, x A^T) rounded to bf16, as
+    any MFMA path must, or (ii) the softmax probabilities rounded to bf16 before P.V, as every fused (flash) attention kernel
+    the reference itself dispatches to on a GPU does -- already moves the LoRA gradients by 3.5e-3 ... 5e-3 (relative L2,
+    whole gradient), while the loss moves by < 1e-4.  A fused bf16 implementation cannot agree with the eager bf16 graph to
+    1e-3 on gradients; it can (and the GPU tests require it to) stay inside this noise floor."""
+    import math
+
+    from oracle import ltx
+
+    cfg = ltx.LTXConfig.production(num_layers=1)
+    model = ltx.build_model(cfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
+    inp = ltx.synth_inputs(cfg, 1, 2, 4, 4, seed=3, mask_lens=[32], sigmas=[0.25])
+
+    def grads():
+        for p in model.parameters():
+            p.grad = None
+        loss = ltx.forward_loss(model, inp, contiguous_hidden_states=True)[0]
+        loss.backward()
+        return {n: p.grad.detach().clone() for n, p in ltx.lora_parameters(model)}, loss.item()
+
+    def rel(a, b):
+        num = sum((a[k] - b[k]).float().pow(2).sum().item() for k in a)
+        den = sum(b[k].float().pow(2).sum().item() for k in a)
+        return math.sqrt(num / den)
+
+    class RoundBoth(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.to(torch.bfloat16).float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.to(torch.bfloat16).float()
+
+    class RoundFwd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.to(torch.bfloat16).float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    g_ref, l_ref = grads()
+
+    orig_fwd = ltx.LoraLinear.forward
+
+    def lora_bf16(self, x):
+        result = self.base_layer(x)
+        a, b = self.lora_A["default"], self.lora_B["default"]
+        xa = RoundBoth.apply(torch.nn.functional.linear(x.float(), RoundBoth.apply(a.weight)) * self.scaling)
+        return (result.float() + torch.nn.functional.linear(xa, RoundBoth.apply(b.weight))).to(result.dtype)
+
+    ltx.LoraLinear.forward = lora_bf16
+    try:
+        g_i, l_i = grads()
+    finally:
+        ltx.LoraLinear.forward = orig_fwd
+
+    orig_sdpa = ltx.sdpa_math
+
+    def sdpa_bf16_p(q, k, v, attn_mask):
+        s = torch.matmul(q.float(), k.float().transpose(-1, -2)) / math.sqrt(q.shape[-1])
+        if attn_mask is not None:
+            s = s + attn_mask.float()
+        return torch.matmul(RoundFwd.apply(torch.softmax(s, dim=-1)), v.float()).to(q.dtype)
+
+    ltx.sdpa_math = sdpa_bf16_p
+    try:
+        g_ii, l_ii = grads()
+    finally:
+        ltx.sdpa_math = orig_sdpa
+
+    r_i, r_ii = rel(g_i, g_ref), rel(g_ii, g_ref)
+    print(f"[noise floor] bf16 LoRA operands: grad {r_i:.3e}, loss {abs(l_i - l_ref) / l_ref:.1e};  bf16 P: grad {r_ii:.3e}, loss {abs(l_ii - l_ref) / l_ref:.1e}")
+    assert abs(l_i - l_ref) / l_ref < 1e-3 and abs(l_ii - l_ref) / l_ref < 1e-3
+    assert 1.5e-3 < r_i < 2e-2 and 1.5e-3 < r_ii < 2e-2
