@@ -360,6 +360,87 @@ FTMI_DEVICE void nt_run_k2_reg(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* 
 #endif
 }
 
+// Register-staged loop with a TWO-tile global prefetch: at iteration kt the registers hold tile kt+1 (loaded during
+// iteration kt-1); they are written to the idle LDS stage first (the data landed long ago, no vmcnt stall), then re-used
+// for the loads of tile kt+2, which get a whole iteration to arrive.  Two LDS stages, one barrier per tile.
+template <int BM, int BN, int BK, int WM, int WN>
+FTMI_DEVICE void nt_run_k2_reg2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                                int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;
+    constexpr int LPT = XI + WI;
+    constexpr int NKK = BK / 16;
+
+    uint32_t off[LPT];
+    int ldst[LPT];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        int row = (wave * XI + i) * T::RPI + lane / T::CPR, c = lane % T::CPR;
+        off[i] = (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2);
+        ldst[i] = nt_lds_off<BK>(row, c);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        int row = (wave * WI + i) * T::RPI + lane / T::CPR, c = lane % T::CPR;
+        off[XI + i] = (uint32_t)(((long)row * ldw + c * 8) * 2);
+        ldst[XI + i] = BM * BK * 2 + nt_lds_off<BK>(row, c);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    u32x4 stg[LPT];
+    auto gload = [&](int t) {
+        const int soff = min(t, nk - 1) * BK * 2;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(i < XI ? xrs : wrs, off[i], soff, 0);
+    };
+    auto swrite = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) *reinterpret_cast<u32x4*>(stage + ldst[i]) = stg[i];
+    };
+    gload(0);
+    swrite(smem);
+    gload(1);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        char* nstage = smem + (cur ^ 1) * T::STAGE;
+        const char* xs = smem + cur * T::STAGE;
+        const char* ws = xs + BM * BK * 2;
+        s16x8 wf[2][T::TN], xf[2][T::TM];
+        auto lfrag = [&](int buf, int kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) wf[buf][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>((wn * T::TN + tn) * 32 + li, kk * 2 + g));
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) xf[buf][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>((wm * T::TM + tm) * 32 + li, kk * 2 + g));
+        };
+        lfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            if (kk == 0) {
+                swrite(nstage);  // tile kt+1: in registers since the previous iteration
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk == 1) {
+                gload(kt + 2);   // a whole iteration to land
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+        }
+        __syncthreads();
+    }
+#endif
+}
+
 template <int N>
 FTMI_DEVICE void wait_vmcnt_barrier() {
     // counted wait + raw barrier: a __syncthreads() here would drain every direct-to-LDS load in flight (vmcnt(0))
@@ -925,13 +1006,16 @@ enum : int {
     KL_RING4_PIPE = 17,       // nt_run_k_ring3: 4-stage ring, fragment reads pipelined across the barrier
     KL_GEN2_BUF = 18,         // nt_run_k2, spread 2, buffer-descriptor loads  (production)
     KL_GEN2_REG = 19,         // nt_run_k2_reg: register-staged twin of KL_GEN2_BUF
+    KL_GEN2_REG2 = 20,        // nt_run_k2_reg2: register-staged, two-tile global prefetch
 };
 constexpr int kl_lds_stages(int loop) { return (loop == KL_RING4 || loop == KL_RING4_PIPE) ? 4 : (loop == KL_RING3) ? 3 : (loop == KL_PINGPONG) ? 4 : 2; }
 
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int LOOP>
 FTMI_DEVICE void nt_k_loop(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M,
                            const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
-    if constexpr (LOOP == KL_GEN2_REG)
+    if constexpr (LOOP == KL_GEN2_REG2)
+        nt_run_k2_reg2<BM, BN, BK, WM, WN>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
+    else if constexpr (LOOP == KL_GEN2_REG)
         nt_run_k2_reg<BM, BN, BK, WM, WN>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
     else if constexpr (LOOP == KL_RING4_PIPE)
         nt_run_k_ring3<BM, BN, BK, WM, WN, 4>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
@@ -1435,7 +1519,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
                 e = getenv("FTMI_NT256_THR");
                 if (e) thr256 = atof(e);
                 e = getenv("FTMI_NT256");
-                nt256 = e ? atoi(e) : 0;  // 256 x 256 tiles measured no faster inside the step (tools/ab_variants.sh)
+                nt256 = e ? atoi(e) : 47;  // only where 256 x 256 tiles quantise clearly better (N = 6144): -0.5 ms/step (tools/ab_nt256.sh)
             }
             if (a.M < 1024) {
                 variant = 44;  // few rows (the text side): 128 x 128 tiles
@@ -1465,6 +1549,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_SPREAD2>(a, st);  // 30 with the loads spread over 2 slices
             case 42: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 36 with buffer-descriptor loads
             case 43: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_REG>(a, st);  // register-staged twin of 42
+            case 45: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_REG2>(a, st);  // register-staged, two-tile global prefetch
+            case 46: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128)
+            case 47: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 8 waves x (128 x 64)
             case 44: return launch_nt<128, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // production loop on 128 x 128 tiles
             case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BURST>(a, st);  // 30 with the loads in one burst
             case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_PIN>(a, st);  // 30 + pinned read / MFMA order
