@@ -1509,27 +1509,52 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (wide) {
         int variant = a.variant;
         if (variant == 8) {
-            // auto: 192 x 128 tiles (2 workgroups / CU -> 512 slots) unless 256 x 256 tiles (1 / CU -> 256 slots) quantise
-            // clearly better onto the chip (e.g. M 5376, N 6144: 1344 tiles = 2.6 rounds vs 504 tiles = 1.97 rounds)
-            static int nt192 = -1, nt256 = -1;
-            static double thr256 = 0.05;
-            if (nt192 < 0) {
+            // auto: pick the tile by the measured cost model of DESIGN.md section 6 -- a K-tile costs its SIMD 32 cycles per MFMA
+            // plus ~85 issue cycles per 1-KiB direct-to-LDS load, tiles run in rounds of (256 CUs x workgroups per CU):
+            //   192 x 128 (2 WG / CU), 192 x 256 and 256 x 256 (8 waves, 1 WG / CU; need 256-wide column groups)
+            static int force192 = -1, force256 = -1, use_model = 3;
+            if (force192 < 0) {
                 const char* e = getenv("FTMI_NT192");
-                nt192 = e ? atoi(e) : 42;
-                e = getenv("FTMI_NT256_THR");
-                if (e) thr256 = atof(e);
+                force192 = e ? atoi(e) : 0;
                 e = getenv("FTMI_NT256");
-                nt256 = e ? atoi(e) : 47;  // only where 256 x 256 tiles quantise clearly better (N = 6144): -0.5 ms/step (tools/ab_nt256.sh)
+                force256 = e ? atoi(e) : 0;
+                e = getenv("FTMI_NT_AUTO");
+                if (e) use_model = atoi(e);
             }
             if (a.M < 1024) {
                 variant = 44;  // few rows (the text side): 128 x 128 tiles
             } else {
                 auto g256 = [](int g) { return g <= 0 || g % 256 == 0; };
                 const bool ok256 = a.N % 256 == 0 && g256(a.w_grp_n) && g256(a.w2_grp_n) && g256(a.xk_grp_n) && g256(a.x2_grp_n);
-                const long t192 = (long)((a.M + 191) / 192) * (a.N / 128), t256 = (long)((a.M + 255) / 256) * (a.N / 256);
-                const double e192 = (double)t192 / (double)(((t192 + 511) / 512) * 512);
-                const double e256 = ok256 ? (double)t256 / (double)(((t256 + 255) / 256) * 256) : 0.0;
-                variant = (nt256 > 0 && e256 > e192 + thr256) ? nt256 : nt192;
+                struct Cand { int variant, bm, bn, per_cu; };
+                const Cand cands[3] = {{force192 ? force192 : 42, 192, 128, 2}, {49, 192, 256, 1}, {force256 ? force256 : 47, 256, 256, 1}};
+                double best = 0;
+                variant = cands[0].variant;
+                // FTMI_NT_AUTO: 1 = model on every launch, 2 = only launches without a LoRA K-extension (+ 256 x 256 where 192 x 128
+                // quantises >5 % worse), 3 (default) = like 2 but never the 192 x 256 tile, 0 = always 192 x 128.  Measured inside
+                // the step (tools/ab_env.sh FTMI_NT_AUTO "0 2 3 1"): 67.0 / 67.2 / 66.45 / 68.4 ms -- the one-workgroup-per-CU tiles
+                // win the L2-warm micro-benchmark on every shape but lose in the step wherever a second workgroup on the CU would
+                // have covered the K-extension restart, the epilogue and the HBM latency of cold weights.
+                const bool ext = a.K2 > 0;
+                for (int ci = 0; ci < (ok256 && use_model ? 3 : 1); ++ci) {
+                    const Cand& cd = cands[ci];
+                    if (ci == 1 && (use_model == 3 || (use_model == 2 && ext))) continue;
+                    if (ci == 2 && use_model >= 2 && ext) {
+                        const long t192 = (long)((a.M + 191) / 192) * (a.N / 128), t256 = (long)((a.M + 255) / 256) * (a.N / 256);
+                        const double e192 = (double)t192 / (double)(((t192 + 511) / 512) * 512), e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+                        if (!(e256 > e192 + 0.05)) continue;
+                    }
+                    const long tiles = (long)((a.M + cd.bm - 1) / cd.bm) * (a.N / cd.bn);
+                    const double per_tile = (double)cd.bm * cd.bn / 1024.0 * 4 * 32 / 4 + 85.0 * (cd.bm + cd.bn) * 128.0 / 1024.0 / 4;  // per K = 64
+                    const long full = tiles / (256L * cd.per_cu), rem = tiles % (256L * cd.per_cu);
+                    // a partially filled last round of a 2-per-CU tile runs one workgroup per CU at full speed
+                    const double rounds = full * cd.per_cu + (rem == 0 ? 0 : (rem <= 256 ? 1 : cd.per_cu));
+                    const double cost = rounds * per_tile;
+                    if (ci == 0 || cost < best * 0.97) {  // prefer the default unless clearly better
+                        if (ci == 0 || cost < best) best = cost;
+                        variant = cd.variant;
+                    }
+                }
             }
         }
         switch (variant) {
@@ -1552,6 +1577,8 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 45: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_REG2>(a, st);  // register-staged, two-tile global prefetch
             case 46: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128)
             case 47: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 8 waves x (128 x 64)
+            case 48: return launch_nt<384, 128, 64, 4, 2, true, 1, KL_GEN2_BUF>(a, st);  // two stacked 192 x 128 tiles sharing one W tile (8 waves, 1 WG / CU)
+            case 49: if (a.N % 256 == 0) return launch_nt<192, 256, 64, 2, 4, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 192 x 256, 8 waves
             case 44: return launch_nt<128, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // production loop on 128 x 128 tiles
             case 37: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BURST>(a, st);  // 30 with the loads in one burst
             case 38: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_PIN>(a, st);  // 30 + pinned read / MFMA order
