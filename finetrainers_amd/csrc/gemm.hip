@@ -284,6 +284,87 @@ FTMI_DEVICE void nt_run_k2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem
     }
 }
 
+// Two-segment form of nt_run_k2 (buffer-descriptor loads, spread 2) for the fused LoRA K-extension: K-tiles of (X, W) followed by
+// K-tiles of (X2, W2) run through ONE software pipeline -- the first extension tile is staged while the last base tile computes
+// (instead of restarting the pipeline with an exposed load latency), and `mid` (the bf16 re-rounding of the base result) runs
+// between the two.
+template <int BM, int BN, int BK, int WM, int WN, class MID>
+FTMI_DEVICE void nt_run_k2_seg(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M,
+                               const bf16_t* __restrict__ W, long ldw, int nk1, const bf16_t* __restrict__ X2, long ldx2,
+                               const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;
+    constexpr int LPT = XI + WI;
+    constexpr int NKK = BK / 16;
+    constexpr int LPS = (LPT + 1) / 2;
+
+    // offsets of the base segment live in registers for the whole loop; those of the extension (one or two tiles per launch) are
+    // recomputed when used, so the pipeline costs no extra live registers (a 2-waves-per-SIMD budget of 256 is tight)
+    auto load_off = [&](int i, long ldx_, long ldw_) -> uint32_t {
+        const bool isx = i < XI;
+        const int blk = isx ? wave * XI + i : wave * WI + (i - XI);
+        const int row = blk * T::RPI + lane / T::CPR, cs = lane % T::CPR;
+        const int c = (BK == 64) ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+        return isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx_ + c * 8) * 2) : (uint32_t)(((long)row * ldw_ + c * 8) * 2);
+    };
+    uint32_t off[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) off[i] = load_off(i, ldx, ldw);
+    auto issue = [&](auto SEG, int i, int tile, char* stage) {
+        constexpr int seg = decltype(SEG)::value;
+        const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(seg ? X2 : X), (short)0, 0x7fffffff, 0x00020000);
+        const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(seg ? W2 : W), (short)0, 0x7fffffff, 0x00020000);
+        const int soff = tile * BK * 2;
+        const uint32_t o = seg ? load_off(i, ldx2, ldw2) : off[i];
+        if (i < XI)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(stage + (wave * XI + i) * 1024), 16, o, soff, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(stage + BM * BK * 2 + (wave * WI + (i - XI)) * 1024), 16, o, soff, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) issue(S0{}, i, 0, smem);
+    __syncthreads();
+
+    int cur = 0;
+    auto iter = [&](auto NEXT, int next_tile) {
+        char* nstage = smem + (cur ^ 1) * T::STAGE;
+        const char* xs = smem + cur * T::STAGE;
+        const char* ws = xs + BM * BK * 2;
+        s16x8 wf[2][T::TN], xf[2][T::TM];
+        auto lfrag = [&](int buf, int kk) {
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn) wf[buf][tn] = *reinterpret_cast<const s16x8*>(ws + nt_lds_off<BK>((wn * T::TN + tn) * 32 + li, kk * 2 + g));
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) xf[buf][tm] = *reinterpret_cast<const s16x8*>(xs + nt_lds_off<BK>((wm * T::TM + tm) * 32 + li, kk * 2 + g));
+        };
+        lfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+            for (int i = kk * LPS; i < (kk + 1) * LPS && i < LPT; ++i) issue(NEXT, i, next_tile, nstage);
+            if (kk + 1 < NKK) lfrag((kk + 1) & 1, kk + 1);
+#pragma unroll
+            for (int tn = 0; tn < T::TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < T::TM; ++tm) acc[tn][tm] = mfma32(wf[kk & 1][tn], xf[kk & 1][tm], acc[tn][tm]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    };
+    for (int kt = 0; kt + 1 < nk1; ++kt) iter(S0{}, kt + 1);
+    iter(S1{}, 0);  // last base tile; the first extension tile lands meanwhile
+    mid();
+    for (int kt = 0; kt < nk2; ++kt) iter(S1{}, min(kt + 1, nk2 - 1));  // (the very last iteration re-stages its own tile: branch-free body)
+#endif
+}
+
 // Register-staged twin of nt_run_k2 (timing comparison of the two staging paths under identical scheduling): tile kt+1 is
 // fetched with buffer_load_dwordx4 into VGPRs during the first two k-slices of tile kt and written to the other LDS stage
 // with ds_write_b128 (swizzled destination) after the last MFMA group, one barrier per tile.
@@ -1075,11 +1156,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     {
         const bf16_t* X = p.X;
         if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        nt_k_loop<BM, BN, BK, WM, WN, GLDS, LOOP>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        if constexpr (!(EXT && LOOP == KL_GEN2_BUF))
+            nt_k_loop<BM, BN, BK, WM, WN, GLDS, LOOP>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
     }
 
     if constexpr (EXT) {
         // reference: result = base(x) [rounded to bf16]; result = result + lora (fp32) -> rounded to bf16
+        auto mid_round = [&]() {
 #pragma unroll
         for (int tn = 0; tn < T::TN; ++tn)
 #pragma unroll
@@ -1098,12 +1181,20 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[tn][tm][rq * 4 + j] = rbf(acc[tn][tm][rq * 4 + j] * p.alpha + bv[j]);
             }
+        };
         const bf16_t* X2 = p.X2;
         if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
         const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
                                            : p.W2 + (long)n0 * p.ldw2;
-        nt_k_loop<BM, BN, BK, WM, WN, GLDS, (LOOP == KL_DBG_NOLOAD || LOOP == KL_DBG_NOMFMA || LOOP == KL_DBG_LDSONLY) ? KL_2STAGE : LOOP>(
-            acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        if constexpr (LOOP == KL_GEN2_BUF) {
+            const bf16_t* X1 = p.X;
+            if (p.xk_grp_n > 0) X1 += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
+            nt_run_k2_seg<BM, BN, BK, WM, WN>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, X2, p.ldx2, W2t, p.ldw2, p.K2 / BK, tid, mid_round);
+        } else {
+            mid_round();
+            nt_k_loop<BM, BN, BK, WM, WN, GLDS, (LOOP == KL_DBG_NOLOAD || LOOP == KL_DBG_NOMFMA || LOOP == KL_DBG_LDSONLY) ? KL_2STAGE : LOOP>(
+                acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        }
     }
 
     // ---------------- epilogue ----------------
@@ -1572,7 +1663,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 22: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_DBG_NOLOAD>(a, st);
             case 30: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2>(a, st);  // second-generation 2-stage loop
             case 36: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_SPREAD2>(a, st);  // 30 with the loads spread over 2 slices
-            case 42: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 36 with buffer-descriptor loads
+            case 42: return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 36 with buffer-descriptor loads
             case 43: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_REG>(a, st);  // register-staged twin of 42
             case 45: return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_REG2>(a, st);  // register-staged, two-tile global prefetch
             case 46: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128)
