@@ -139,7 +139,7 @@ def main():
 
     prof = not args.no_prof
     if prof:
-        for k in range(4):
+        for k in range(5):
             lib.ftmi_prof_summary(k, None, None, None, None, None, 1)
         lib.ftmi_prof_enable(args.prof_stride)
     t0 = time.perf_counter()
@@ -194,7 +194,7 @@ def main():
             "final_loss": loss,
         }
         if prof:
-            classes = {0: "gemm_nt", 1: "gemm_tn", 2: "attn_fwd", 3: "attn_bwd"}
+            classes = {0: "gemm_nt", 1: "gemm_tn", 2: "attn_fwd", 3: "attn_bwd", 4: "gemm_nt_skinny"}
             kern = {}
             for k, name in classes.items():
                 tms, n, fl, an, afl = ctypes.c_double(0), ctypes.c_long(0), ctypes.c_double(0), ctypes.c_long(0), ctypes.c_double(0)
@@ -221,7 +221,7 @@ def main():
                     "share_of_step": g_["ms_per_step"] / ms,
                     "note": f"achieved = sum of algorithmic FLOPs (2*M*N*(K+K2)) / sum of HIP-event durations over every {args.prof_stride}-th "
                             "launch of the kernel, events recorded on the launch stream inside the timed region (the stride, coprime "
-                            "to the 23 GEMMs of a block, cycles through every shape)",
+                            "to the per-block launch counts, cycles through every shape; compare with the gemm_nt_kernel<...> rows of profiles/r01_c_kernel_stats.csv)",
                 }
                 if "attn_fwd" in kern and "attn_bwd" in kern:
                     a_ms = kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["ms_per_step"]

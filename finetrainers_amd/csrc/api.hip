@@ -38,8 +38,8 @@ struct ProfRec {
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 int g_prof_stride = 1;
-long g_prof_count[PROF_NCLASS] = {0, 0, 0, 0};     // all launches seen while enabled
-double g_prof_flops[PROF_NCLASS] = {0, 0, 0, 0};   // their algorithmic FLOPs
+long g_prof_count[PROF_NCLASS] = {};        // all launches seen while enabled
+double g_prof_flops[PROF_NCLASS] = {};    // their algorithmic FLOPs
 std::vector<ProfRec> g_prof_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 hipEvent_t g_prof_open[PROF_NCLASS];

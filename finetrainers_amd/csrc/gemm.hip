@@ -742,7 +742,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 8) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
     if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && a.w_grp_n == 0 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
-        ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)a.K, st);
+        ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
         static int ks = -1;
         if (ks < 0) {
             const char* e = getenv("FTMI_SKINNY_KS");

@@ -17,7 +17,7 @@ int check_launch(const char* what);
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3 };
 
 // ---- in-stream HIP-event profiler (bench.py's live roofline numbers) ----
-enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_ATTN_FWD = 2, PROF_ATTN_BWD = 3, PROF_NCLASS = 4 };
+enum { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_ATTN_FWD = 2, PROF_ATTN_BWD = 3, PROF_GEMM_SKINNY = 4, PROF_NCLASS = 5 };
 bool prof_enabled();
 bool prof_begin(int kclass, double flops, hipStream_t st);  // true if this launch is sampled (events recorded)
 void prof_end(int kclass, hipStream_t st);
