@@ -1,5 +1,7 @@
 // extern "C" surface of libftmi355 (declared in include/ftmi355.h): argument checking, translation of the
 // plain-pointer C structs into the internal launch arguments, error reporting.
+#include <stdlib.h>
+
 #include <mutex>
 #include <string.h>
 #include <utility>
@@ -46,6 +48,11 @@ hipEvent_t g_prof_open[PROF_NCLASS];
 double g_prof_open_flops[PROF_NCLASS];
 hipEvent_t g_prof_open_b[PROF_NCLASS];
 }  // namespace
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 bool prof_enabled() { return g_prof_on; }
 

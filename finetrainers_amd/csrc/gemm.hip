@@ -471,11 +471,7 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
     // with rocprofv3 FETCH_SIZE on the step's shapes (profiles/r01_pmc_traffic.json, tools/gpu_map_exp.sh): splitting the
     // token dimension over all 8 XCDs (gm = 8) moves the fewest bytes whenever M >= N; the launch grid is padded to 8*rm*rn.
     long best = -1;
-    static int force_gm = -1;
-    if (force_gm < 0) {
-        const char* e = getenv("FTMI_MAP_GM");
-        force_gm = e ? atoi(e) : 0;
-    }
+    static const int force_gm = env_int("FTMI_MAP_GM", 0);
     for (int gm = 1; gm <= 8; gm *= 2) {
         if (force_gm > 0 && gm != force_gm) continue;
         const int gn = 8 / gm;
@@ -743,11 +739,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
     if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && a.w_grp_n == 0 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
         ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
-        static int ks = -1;
-        if (ks < 0) {
-            const char* e = getenv("FTMI_SKINNY_KS");
-            ks = e ? atoi(e) : 2;  // 2 = LDS-ring kernel, 4 / 8 = direct-gather kernel with a 4- / 8-way K split
-        }
+        static const int ks = env_int("FTMI_SKINNY_KS", 2);  // 2 = LDS-ring kernel, 4 / 8 = direct-gather kernel with a 4- / 8-way K split
         // 8-way K split when it divides into whole load batches: halves the dependent load->MFMA chain of every wave
         if (ks == 2 && a.K % 256 == 0) {
             constexpr int kSmem = 4 * 3 * 12288;
@@ -774,15 +766,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             // auto: pick the tile by the measured cost model of DESIGN.md section 6 -- a K-tile costs its SIMD 32 cycles per MFMA
             // plus ~85 issue cycles per 1-KiB direct-to-LDS load, tiles run in rounds of (256 CUs x workgroups per CU):
             //   192 x 128 (2 WG / CU), 192 x 256 and 256 x 256 (8 waves, 1 WG / CU; need 256-wide column groups)
-            static int force192 = -1, force256 = -1, use_model = 3;
-            if (force192 < 0) {
-                const char* e = getenv("FTMI_NT192");
-                force192 = e ? atoi(e) : 0;
-                e = getenv("FTMI_NT256");
-                force256 = e ? atoi(e) : 0;
-                e = getenv("FTMI_NT_AUTO");
-                if (e) use_model = atoi(e);
-            }
+            static const int force192 = env_int("FTMI_NT192", 0), force256 = env_int("FTMI_NT256", 0), use_model = env_int("FTMI_NT_AUTO", 3);
             if (a.M < 1024) {
                 variant = 44;  // few rows (the text side): 128 x 128 tiles
             } else {
@@ -998,12 +982,7 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     const int bp = wideP ? 128 : 64, bq = wideP ? 64 : (wideQ ? 128 : 64);
     if (a.v_grp_p > 0 && a.v_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: group width vs tile");
     const int tiles = (a.P / bp) * (a.Q / bq);
-    static int target_wgs = 0;
-    if (target_wgs == 0) {
-        const char* e = getenv("FTMI_TN_TARGET_WGS");
-        target_wgs = e ? atoi(e) : 256;
-        if (target_wgs < 1) target_wgs = 256;
-    }
+    static const int target_wgs = env_int("FTMI_TN_TARGET_WGS", 256) > 0 ? env_int("FTMI_TN_TARGET_WGS", 256) : 256;
     // the split-M partials meet in fp32 atomics: more splits = more parallelism but P*Q atomics per split
     const int nb = a.batch > 0 ? a.batch : 1;
     // batched launches already fill the GPU with tiles x batch workgroups: split the token loop only as far as needed

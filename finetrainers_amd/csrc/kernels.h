@@ -13,6 +13,8 @@ typedef uint16_t bf16_t;
 
 int set_error(int code, const char* msg);
 int check_launch(const char* what);
+// tuning switch from the environment (read once per call site: `static const int v = env_int(...)` is thread-safe)
+int env_int(const char* name, int dflt);
 
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3 };
 

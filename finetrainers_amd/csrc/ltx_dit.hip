@@ -376,18 +376,23 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     // concurrently with the blocks still in flight (measured: 70.2 vs 69.6 ms/step -- the HBM-bound TN kernels slow the
     // co-running GEMMs by more than their own 2.2 ms, so it is off; kept because per-group completion is what a bucketed
     // gradient all-reduce would hook into).
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    static int tn_group = -1;
-    if (tn_group < 0) {
-        const char* e = getenv("FTMI_TN_GROUP");
-        tn_group = e ? atoi(e) : 0;
-    }
+    static const int tn_group = env_int("FTMI_TN_GROUP", 0);
     const bool use_side = r > 0 && tn_group > 0;
-    if (use_side && !side) {
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess)
-            return set_error(FTMI_ERR_LAUNCH, "ltx_backward: cannot create the side stream");
+    struct Side {
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr;
+        bool ok = false;
+        Side() {
+            ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess;
+        }
+    };
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    if (use_side) {
+        static Side s_side;  // created once, thread-safe (function-local static)
+        if (!s_side.ok) return set_error(FTMI_ERR_LAUNCH, "ltx_backward: cannot create the side stream");
+        side = s_side.stream; ev_ready = s_side.ready; ev_done = s_side.done;
     }
     auto lora_wgrad = [&](int l0, int nb, hipStream_t s2) -> int {
         char* blk0 = reinterpret_cast<char*>(ws) + L.blk0 + L.blk_stride * l0;
