@@ -144,8 +144,11 @@ def main():
         lib.ftmi_prof_enable(args.prof_stride)
     t0 = time.perf_counter()
     out = None
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # per-step device time (diagnostics only)
+    marks[0].record()
+    for i in range(args.steps):
         out = one_step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     par.wait_for_everyone()
     torch.cuda.synchronize()
@@ -192,6 +195,7 @@ def main():
             "step_tflop_algorithmic": step_tflop,
             "mfma_utilisation_step": step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS,
             "final_loss": loss,
+            "step_ms_min_median_max": [round(v, 3) for v in (lambda t: (t[0], t[len(t) // 2], t[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)))],
         }
         if prof:
             classes = {0: "gemm_nt", 1: "gemm_tn", 2: "attn_fwd", 3: "attn_bwd", 4: "gemm_nt_skinny"}
