@@ -37,7 +37,7 @@ def rnd(shape, gen, scale=1.0, dtype=bf16):
 
 
 # ----------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 55, 56])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (32, 2048, 2048), (1000, 192, 2048), (257, 64, 2048), (515, 6144, 2048), (2048, 6144, 256)])
 def test_gemm_nt_store(M, N, K, variant):
     from finetrainers_amd import ops
@@ -52,7 +52,7 @@ def test_gemm_nt_store(M, N, K, variant):
     assert (out.cpu() != ref).float().mean() < 0.02
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 55, 56])
 def test_gemm_nt_epilogues(variant):
     from finetrainers_amd import _lib, ops
 
@@ -82,7 +82,7 @@ def test_gemm_nt_epilogues(variant):
     report("epi dgelu", out, zz.grad.to(bf16), 3e-3)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 55, 56])
 @pytest.mark.parametrize("M", [32, 300])
 def test_linear_lora_fwd(M, variant):
     """peft lora.Linear semantics: bf16(base) + scale * (x A^T) B^T in fp32, re-rounded."""
