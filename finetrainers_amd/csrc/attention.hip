@@ -105,6 +105,29 @@ FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
     return __builtin_bit_cast(s16x8, w);
 }
 
+// Output rows: a lane owns one token row and its C-layout registers hold 4-column groups, so a direct store writes 8 bytes per
+// lane and a wave instruction touches 32 rows x 16 bytes.  Instead the wave stages its 32 x 64 bf16 block (4 KiB) in its own
+// LDS scratch (16-byte chunks XOR-swizzled by the row) and stores 8 rows x 128 contiguous bytes per instruction: whole lines.
+// `row_base` = global row of scratch row 0; rows >= nrows are dropped.
+FTMI_DEVICE void store_rows_via_lds(char* scr, const f32x16 (&t)[2], float mul, bf16_t* base, long row_stride, int row_base, int nrows, int lane) {
+    const int li = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            u32x2 pk;
+            pk[0] = pack2bf(t[dt][rq * 4 + 0] * mul, t[dt][rq * 4 + 1] * mul);
+            pk[1] = pack2bf(t[dt][rq * 4 + 2] * mul, t[dt][rq * 4 + 3] * mul);
+            *reinterpret_cast<u32x2*>(scr + li * 128 + (((dt * 4 + rq) ^ (li & 7)) << 4) + 8 * g) = pk;
+        }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(scr + row * 128 + ((chunk ^ (row & 7)) << 4));
+        if (row_base + row < nrows) *reinterpret_cast<u32x4*>(base + (long)(row_base + row) * row_stride + chunk * 8) = w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -248,25 +271,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         if (t + 1 < nt) body(t + 1, std::integral_constant<int, 1>{});
     }
 
-    if (i < a.Sq) {
+    {
         const float inv = 1.0f / l_run;
-        bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)i * a.o_ss;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                u32x2 pk;
-                pk[0] = pack2bf(oacc[dt][rq * 4 + 0] * inv, oacc[dt][rq * 4 + 1] * inv);
-                pk[1] = pack2bf(oacc[dt][rq * 4 + 2] * inv, oacc[dt][rq * 4 + 3] * inv);
-                *reinterpret_cast<u32x2*>(op + dt * 32 + rq * 8 + 4 * g) = pk;
-            }
-        if (g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
+        bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
+        store_rows_via_lds(smem + wave * 4096, oacc, inv, ob, a.o_ss, blk.tile * 128 + wave * 32, a.Sq, lane);
+        if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
     }
 }
 
 int attn_fwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_fwd: empty problem");
-    if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 4))
+    if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8))
         return set_error(FTMI_ERR_INVALID, "attn_fwd: token strides must keep 16-byte alignment");
     dim3 grid(((a.Sq + 127) / 128) * a.H * a.B);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);
@@ -423,21 +438,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         if (t + 1 < ni) body(t + 1, std::integral_constant<int, 1>{});
     }
 
-    if (j < a.Sk) {
-        bf16_t* dkp = a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh + (long)j * a.dk_ss;
-        bf16_t* dvp = a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh + (long)j * a.dv_ss;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                u32x2 pk;
-                pk[0] = pack2bf(dkt[dt][rq * 4 + 0] * a.scale, dkt[dt][rq * 4 + 1] * a.scale);
-                pk[1] = pack2bf(dkt[dt][rq * 4 + 2] * a.scale, dkt[dt][rq * 4 + 3] * a.scale);
-                *reinterpret_cast<u32x2*>(dkp + dt * 32 + rq * 8 + 4 * g) = pk;
-                pk[0] = pack2bf(dvt[dt][rq * 4 + 0], dvt[dt][rq * 4 + 1]);
-                pk[1] = pack2bf(dvt[dt][rq * 4 + 2], dvt[dt][rq * 4 + 3]);
-                *reinterpret_cast<u32x2*>(dvp + dt * 32 + rq * 8 + 4 * g) = pk;
-            }
+    {
+        bf16_t* dkb = a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh;
+        bf16_t* dvb = a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh;
+        store_rows_via_lds(smem + wave * 4096, dkt, a.scale, dkb, a.dk_ss, blk.tile * 128 + wave * 32, a.Sk, lane);
+        store_rows_via_lds(smem + wave * 4096, dvt, 1.0f, dvb, a.dv_ss, blk.tile * 128 + wave * 32, a.Sk, lane);
     }
 }
 
@@ -714,24 +719,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         if (t + 1 < nt) body(t + 1, std::integral_constant<int, 1>{});
     }
 
-    if (i < a.Sq) {
-        bf16_t* dqp = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh + (long)i * a.dq_ss;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                u32x2 pk;
-                pk[0] = pack2bf(dqt[dt][rq * 4 + 0] * a.scale, dqt[dt][rq * 4 + 1] * a.scale);
-                pk[1] = pack2bf(dqt[dt][rq * 4 + 2] * a.scale, dqt[dt][rq * 4 + 3] * a.scale);
-                *reinterpret_cast<u32x2*>(dqp + dt * 32 + rq * 8 + 4 * g) = pk;
-            }
+    {
+        bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
+        store_rows_via_lds(smem + wave * 4096, dqt, a.scale, dqb, a.dq_ss, blk.tile * 128 + wave * 32, a.Sq, lane);
     }
 }
 
 int attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_bwd: empty problem");
     if (!a.lse2 || !a.delta || !a.dout || !a.o) return set_error(FTMI_ERR_INVALID, "attn_bwd: missing lse/delta/dout/out");
-    if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8) || (a.do_ss % 8) || (a.dq_ss % 4) || (a.dk_ss % 4) || (a.dv_ss % 4))
+    if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8) || (a.do_ss % 8) || (a.dq_ss % 8) || (a.dk_ss % 8) || (a.dv_ss % 8))
         return set_error(FTMI_ERR_INVALID, "attn_bwd: token strides must keep 16-byte alignment");
     const long nrows = (long)a.B * a.H * a.Sq;
     ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);  // algorithmic: 5 matmuls (2.5x forward)
