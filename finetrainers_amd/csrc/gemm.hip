@@ -568,6 +568,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     char* scr = smem + wave * (32 * CPW * 16);
     auto scr_off = [&](int row, int chunk) { return row * (CPW * 16) + ((chunk ^ (row & (CPW - 1))) << 4); };
     const int srow = lane / CPW, schunk = lane % CPW;
+    // the row-wise epilogue inputs (residual, GELU pre-activation) come in the same way: whole-line loads into a second scratch block,
+    // then every lane picks its 8-byte pieces out of LDS
+    char* scr_in = smem + T::NW * (32 * CPW * 16) + wave * (32 * CPW * 16);
+    auto fetch = [&](const bf16_t* src, long ld, int tm) {  // global -> scratch, whole lines
+#pragma unroll
+        for (int it = 0; it < NSI; ++it) {
+            const int row = it * RPS + srow;
+            const int mm = min(m0 + (wm * T::TM + tm) * 32 + row, p.M - 1);
+            *reinterpret_cast<u32x4*>(scr_in + scr_off(row, schunk)) = *reinterpret_cast<const u32x4*>(src + (long)mm * ld + n0 + wn * T::TN * 32 + schunk * 8);
+        }
+    };
     auto flush = [&](bf16_t* dst, long ld, int tm) {  // scratch -> global, whole lines
 #pragma unroll
         for (int it = 0; it < NSI; ++it) {
@@ -582,6 +593,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         const int m = min(m0 + (wm * T::TM + tm) * 32 + li, p.M - 1);  // rows past M compute on row M-1 and are dropped by flush()
         const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
         u32x4 zst[T::TN][2];  // GELU: pre-activation chunks, flushed after the activation block
+        if constexpr (EPI == EPI_RESID) fetch(p.resid, p.ldr, tm);
+        if constexpr (EPI == EPI_DGELU) fetch(p.aux, p.ldaux, tm);
 #pragma unroll
         for (int tn = 0; tn < T::TN; ++tn) {
             u32x2 pk[4], pkz[4];
@@ -616,7 +629,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
                     pkz[rq][0] = pack2bf(z[0], z[1]);  // pre-activation stash
                     pkz[rq][1] = pack2bf(z[2], z[3]);
                 } else if constexpr (EPI == EPI_RESID) {
-                    u32x2 rr = *reinterpret_cast<const u32x2*>(p.resid + (long)m * p.ldr + n);
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(scr_in + scr_off(li, tn * 4 + rq) + 8 * g);
                     float rv[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)), bf2f((bf16_t)(rr[1] & 0xffff)),
                                    bf2f((bf16_t)(rr[1] >> 16))};
                     float y[4];
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = rv[j] + y[j];
                 } else {  // EPI_DGELU: grad_in = grad_out * gelu'(z)
-                    u32x2 zz = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
+                    const u32x2 zz = *reinterpret_cast<const u32x2*>(scr_in + scr_off(li, tn * 4 + rq) + 8 * g);
                     float zv[4] = {bf2f((bf16_t)(zz[0] & 0xffff)), bf2f((bf16_t)(zz[0] >> 16)), bf2f((bf16_t)(zz[1] & 0xffff)),
                                    bf2f((bf16_t)(zz[1] >> 16))};
 #pragma unroll
