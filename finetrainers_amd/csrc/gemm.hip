@@ -579,11 +579,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             *reinterpret_cast<u32x4*>(scr_in + scr_off(row, schunk)) = *reinterpret_cast<const u32x4*>(src + (long)mm * ld + n0 + wn * T::TN * 32 + schunk * 8);
         }
     };
-    auto flush = [&](bf16_t* dst, long ld, int tm) {  // scratch -> global, whole lines
+    auto flush = [&](const char* from, bf16_t* dst, long ld, int tm) {  // scratch -> global, whole lines
 #pragma unroll
         for (int it = 0; it < NSI; ++it) {
             const int row = it * RPS + srow;
-            const u32x4 w = *reinterpret_cast<const u32x4*>(scr + scr_off(row, schunk));
+            const u32x4 w = *reinterpret_cast<const u32x4*>(from + scr_off(row, schunk));
             const int mm = m0 + (wm * T::TM + tm) * 32 + row;
             if (mm < p.M) *reinterpret_cast<u32x4*>(dst + (long)mm * ld + n0 + wn * T::TN * 32 + schunk * 8) = w;
         }
@@ -592,7 +592,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     for (int tm = 0; tm < T::TM; ++tm) {
         const int m = min(m0 + (wm * T::TM + tm) * 32 + li, p.M - 1);  // rows past M compute on row M-1 and are dropped by flush()
         const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
-        u32x4 zst[T::TN][2];  // GELU: pre-activation chunks, flushed after the activation block
         if constexpr (EPI == EPI_RESID) fetch(p.resid, p.ldr, tm);
         if constexpr (EPI == EPI_DGELU) fetch(p.aux, p.ldaux, tm);
 #pragma unroll
@@ -668,19 +667,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
                 if constexpr (EPI == EPI_GELU) {
                     auto s0 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][0], pkz[2 * q2 + 1][0], false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][1], pkz[2 * q2 + 1][1], false, false);
-                    zst[tn][q2][0] = s0[0]; zst[tn][q2][1] = s1[0]; zst[tn][q2][2] = s0[1]; zst[tn][q2][3] = s1[1];
+                    u32x4 wz;
+                    wz[0] = s0[0]; wz[1] = s1[0]; wz[2] = s0[1]; wz[3] = s1[1];
+                    *reinterpret_cast<u32x4*>(scr_in + scr_off(li, chunk)) = wz;  // pre-activation stash: second scratch block
                 }
             }
         }
-        flush(p.out, p.ldo, tm);
+        flush(scr, p.out, p.ldo, tm);
         if constexpr (EPI == EPI_GELU) {
-            if (p.out2) {
-#pragma unroll
-                for (int tn = 0; tn < T::TN; ++tn)
-#pragma unroll
-                    for (int q2 = 0; q2 < 2; ++q2) *reinterpret_cast<u32x4*>(scr + scr_off(li, tn * 4 + 2 * q2 + g)) = zst[tn][q2];
-                flush(p.out2, p.ldo2, tm);
-            }
+            if (p.out2) flush(scr_in, p.out2, p.ldo2, tm);
         }
     }
 }
