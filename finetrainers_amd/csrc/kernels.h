@@ -143,9 +143,11 @@ int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, lon
 // affine RMSNorm over the full width (+ optional interleaved-pair RoPE), x row stride ldx
 // w_rows > 1: row i uses weight row (i % w_rows) of a [w_rows, D] table (rows interleaved over blocks)
 int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, bf16_t* y, long ldy,
-                    int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1);
+                    int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1, const bf16_t* x2 = nullptr, const bf16_t* w2 = nullptr,
+                    bf16_t* y2 = nullptr);  // x2 / w2 / y2: a second tensor set with the same strides processed by the same launch (q and k)
 int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy,
-                    long lddy, bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1);
+                    long lddy, bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1, const bf16_t* x2 = nullptr,
+                    const bf16_t* w2 = nullptr, const bf16_t* dy2 = nullptr, bf16_t* dx2 = nullptr);
 
 // out = bf(x * gate[b])
 int mul_gate(const bf16_t* x, const bf16_t* gate, long gate_bstride, bf16_t* out, int rows, int rows_per_batch, int D,

@@ -247,8 +247,8 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             FTMI_TRY(gemm_nt(a, st));
         }
         // 4. QK RMSNorm across heads + RoPE
-        FTMI_TRY(qknorm_rope_fwd(qkv, 3 * D, P(w.norm_q, (size_t)l * D), w.rope_cos, w.rope_sin, W(blk, L.qrot), D, M, c.S, D, c.eps_qk, st));
-        FTMI_TRY(qknorm_rope_fwd(qkv + D, 3 * D, P(w.norm_k, (size_t)l * D), w.rope_cos, w.rope_sin, W(blk, L.krot), D, M, c.S, D, c.eps_qk, st));
+        FTMI_TRY(qknorm_rope_fwd(qkv, 3 * D, P(w.norm_q, (size_t)l * D), w.rope_cos, w.rope_sin, W(blk, L.qrot), D, M, c.S, D, c.eps_qk, st, 1,
+                                 qkv + D, P(w.norm_k, (size_t)l * D), W(blk, L.krot)));  // q and k in one launch
         // 5. self-attention
         {
             AttnArgs a = attn_args(c, c.S, c.S);
@@ -504,8 +504,8 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             a.dv = dqkv + 2 * D;   set3(a.dv_sb, a.dv_sh, a.dv_ss, c.S, 3 * D);
             FTMI_TRY(attn_bwd(a, st));
         }
-        FTMI_TRY(qknorm_rope_bwd(qkv, 3 * D, P(w.norm_q, (size_t)l * D), w.rope_cos, w.rope_sin, W(ws, L.s_dqr), D, dqkv, 3 * D, M, c.S, D, c.eps_qk, st));
-        FTMI_TRY(qknorm_rope_bwd(qkv + D, 3 * D, P(w.norm_k, (size_t)l * D), w.rope_cos, w.rope_sin, W(ws, L.s_dkr), D, dqkv + D, 3 * D, M, c.S, D, c.eps_qk, st));
+        FTMI_TRY(qknorm_rope_bwd(qkv, 3 * D, P(w.norm_q, (size_t)l * D), w.rope_cos, w.rope_sin, W(ws, L.s_dqr), D, dqkv, 3 * D, M, c.S, D, c.eps_qk, st, 1,
+                                 qkv + D, P(w.norm_k, (size_t)l * D), W(ws, L.s_dkr), dqkv + D));  // q and k in one launch
         if (r > 0) FTMI_TRY(lora_dxa(dqkv, 3 * D, M, 3, 0, l, W(blk, L.dxa_qkv)));
         if (l > 0) {
             GemmNtArgs a;

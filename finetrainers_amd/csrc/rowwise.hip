@@ -220,8 +220,12 @@ int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, lon
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                              bf16_t* __restrict__ y, long ldy, int rows, int rows_per_batch, float eps, int w_rows) {
+                                                              bf16_t* __restrict__ y, long ldy, int rows, int rows_per_batch, float eps, int w_rows,
+                                                              const bf16_t* __restrict__ x2, const bf16_t* __restrict__ w2, bf16_t* __restrict__ y2) {
     constexpr int D = kNch * 512;
+    if (blockIdx.y == 1) {  // pair launch (q and k of one projection): same strides and RoPE rows, second tensor set
+        x = x2; w = w2; y = y2;
+    }
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -261,18 +265,23 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
     }
 }
 int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, bf16_t* y, long ldy,
-                    int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows) {
+                    int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows, const bf16_t* x2, const bf16_t* w2, bf16_t* y2) {
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
     if ((ldx % 8) || (ldy % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
-    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, y, ldy, rows, rows_per_batch, eps, w_rows);
+    hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((rows + 3) / 4, x2 ? 2 : 1), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, y, ldy, rows, rows_per_batch, eps, w_rows,
+                       x2, w2, y2);
     return check_launch("qknorm_rope_fwd");
 }
 
 __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                               const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
-                                                              int rows, int rows_per_batch, float eps, int w_rows) {
+                                                              int rows, int rows_per_batch, float eps, int w_rows, const bf16_t* __restrict__ x2,
+                                                              const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dy2, bf16_t* __restrict__ dx2) {
     constexpr int D = kNch * 512;
+    if (blockIdx.y == 1) {
+        x = x2; w = w2; dy = dy2; dx = dx2;
+    }
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -326,10 +335,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
     }
 }
 int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy, long lddy,
-                    bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows) {
+                    bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows, const bf16_t* x2, const bf16_t* w2,
+                    const bf16_t* dy2, bf16_t* dx2) {
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
     if ((ldx % 8) || (lddy % 8) || (lddx % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
-    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps, w_rows);
+    hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4, x2 ? 2 : 1), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps, w_rows,
+                       x2, w2, dy2, dx2);
     return check_launch("qknorm_rope_bwd");
 }
 
