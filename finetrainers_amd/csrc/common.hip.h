@@ -80,6 +80,44 @@ FTMI_DEVICE s16x8 lds_tr_frag(const char* tile, int cbase, int rowa, int rowb, i
     return f;
 }
 
+// A [64 tok][64 d] bf16 tile (8 KiB) is staged by eight direct-to-LDS wave loads of 1 KiB (8 rows x 128 B each, two per
+// wave).  The LDS destination of such a load is wave-linear, so the lds_rt_off chunk swizzle is applied to the per-lane
+// SOURCE address (slot s of row r receives source chunk s ^ f(r); the read side applies the same involution).  Source
+// offsets are computed once per kernel (32-bit, relative to the tile's first row); rows past the end of the sequence
+// are clamped (their scores are neutralised by +-inf statistics), which only the last tile needs.
+struct TileDma {
+    uint32_t off[2], offl[2];
+};
+FTMI_DEVICE TileDma tile_dma_setup(long stride, int nrows, int wave, int lane) {
+    TileDma d;
+    const int last0 = ((nrows + 63) / 64 - 1) * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3), slot = lane & 7;
+        const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+        const int chunk = slot ^ f;
+        d.off[i] = (uint32_t)(((long)row * stride + chunk * 8) * 2);
+        d.offl[i] = (uint32_t)(((long)min(row, nrows - 1 - last0) * stride + chunk * 8) * 2);
+    }
+    return d;
+}
+// The load is issued through inline asm on purpose: hipcc does not know the alias set of the transposing LDS reads
+// (ds_read_b64_tr_b16 is an intrinsic without a memory operand), so with the builtin form of the DMA it parks an
+// s_waitcnt vmcnt(0) in front of the first such read of every tile -- i.e. it waits for the NEXT tile's loads in the
+// middle of the current tile.  The asm form is invisible to that analysis; tile_dma_wait() before the tile barrier is the
+// (only) wait that retires it.
+FTMI_DEVICE void tile_dma_issue(const TileDma& d, const bf16_t* base, long stride, int t, bool last, char* lds, int wave) {
+    const char* b = (const char*)base + (long)t * 64 * stride * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t o = last ? d.offl[i] : d.off[i];
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + (wave * 2 + i) * 1024));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(o), "s"(b) : "memory", "m0");
+    }
+}
+FTMI_DEVICE void tile_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // tanh via the hardware exp2 / rcp units: 1 - 2 / (1 + e^{2x}).  ~1e-6 absolute error (the results are rounded to bf16
 // right after); libm tanhf costs ~25 VALU instructions per element and made the GELU / GELU' GEMM epilogues 25-40 % of
 // their kernels.  Saturates correctly: e^{2x} -> inf gives 1, -> 0 gives -1.

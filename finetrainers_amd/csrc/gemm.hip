@@ -1192,6 +1192,104 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
         }
 }
 
+// Second generation of the TN kernel for token counts that are a multiple of 64: the [64 tok][64 col] sub-tiles are staged by
+// direct-to-LDS loads of whole 128-byte row segments (common.hip.h: TileDma) into a 3-stage ring, two steps stay in flight while
+// one is multiplied, ONE barrier per step.  (The first generation issues the loads of 4 steps together and only then starts
+// consuming them -- nothing is in flight while it computes -- and ran at 2.8 TB/s of the 6.5 TB/s a copy reaches.)
+// The loads go through inline asm for the same reason as in attention.hip (transposing LDS reads have no alias information).
+template <int BP, int BQ>
+__global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
+    constexpr int WP = 2, WQ = 2, NS = 3;
+    constexpr int TP = BP / WP / 32, TQ = BQ / WQ / 32;
+    constexpr int NU = BP / 64, NV = BQ / 64;     // sub-tiles per step
+    constexpr int STAGE = (NU + NV) * 8192;
+    constexpr int LPW = 2 * (NU + NV);            // loads per wave and step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave / WQ, wq = wave % WQ;
+    const int li = lane & 31, g = lane >> 5;
+
+    const int ntp = a.P / BP, ntq = a.Q / BQ;
+    int bid = blockIdx.x;
+    const int split = bid / (ntp * ntq);
+    bid -= split * ntp * ntq;
+    const int p0 = (bid / ntq) * BP, q0 = (bid % ntq) * BQ;
+    const int nsteps_total = a.M / 64;
+    const int s_begin = split * a.msteps_per_split;
+    const int n = min(nsteps_total, s_begin + a.msteps_per_split) - s_begin;
+    if (n <= 0) return;
+
+    const bf16_t* U = a.U + (long)blockIdx.y * a.u_bstride + p0;
+    const bf16_t* V = a.V + (long)blockIdx.y * a.v_bstride + q0;
+    float* C = a.C + (long)blockIdx.y * a.c_bstride;
+    if (a.v_grp_p > 0) V += (long)(p0 / a.v_grp_p) * a.v_grp_stride;
+
+    f32x16 acc[TP][TQ];
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const TileDma ud = tile_dma_setup(a.ldu, a.M, wave, lane), vd = tile_dma_setup(a.ldv, a.M, wave, lane);
+    auto stage = [&](int k) {  // step k of this workgroup -> ring slot k % NS
+        char* st = smem + (k % NS) * STAGE;
+#pragma unroll
+        for (int t = 0; t < NU; ++t) tile_dma_issue(ud, U + t * 64, a.ldu, s_begin + k, false, st + t * 8192, wave);
+#pragma unroll
+        for (int t = 0; t < NV; ++t) tile_dma_issue(vd, V + t * 64, a.ldv, s_begin + k, false, st + (NU + t) * 8192, wave);
+    };
+    stage(0);
+    if (n > 1) stage(1);
+    for (int k = 0; k < n; ++k) {
+        if (k + 1 < n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // step k landed for every wave; everyone is done with step k-1, whose slot the next load reuses
+        if (k + 2 < n) stage(k + 2);
+        const char* ut = smem + (k % NS) * STAGE;
+        const char* vt = ut + NU * 8192;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int rowa = kk * 16 + 8 * g, rowb = rowa + 4;  // k-group g reduces over tokens kk*16 + 8g + {0..7}
+            s16x8 uf[TP], vf[TQ];
+#pragma unroll
+            for (int i = 0; i < TP; ++i) {
+                const int pc = (wp * TP + i) * 32;
+                uf[i] = lds_tr_frag(ut + (pc >> 6) * 8192, pc & 63, rowa, rowb, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+                const int qc = (wq * TQ + j) * 32;
+                vf[j] = lds_tr_frag(vt + (qc >> 6) * 8192, qc & 63, rowa, rowb, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TP; ++i)
+#pragma unroll
+                for (int j = 0; j < TQ; ++j) acc[i][j] = mfma32(uf[i], vf[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TP; ++i)
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+            const int q = q0 + (wq * TQ + j) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = p0 + (wp * TP + i) * 32 + crow(r, g);
+                atomicAdd(C + (long)pp * a.ldc + q, acc[i][j][r] * a.scale);
+            }
+        }
+}
+
+template <int BP, int BQ>
+static void launch_tn2(const GemmTnArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int kSmem = 3 * (BP / 64 + BQ / 64) * 8192;
+    static const bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel<BP, BQ>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess);
+    (void)attr;
+    hipLaunchKernelGGL((gemm_tn2_kernel<BP, BQ>), grid, dim3(256), kSmem, st, a);
+}
+
 int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     GemmTnArgs a = a0;
     if (a.M <= 0) return 0;
@@ -1215,6 +1313,13 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     const int nsplit = (nsteps + per - 1) / per;
     const dim3 grid(tiles * nsplit, nb);
     ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q * nb, st);
+    static const int tn_gen = env_int("FTMI_TN_GEN", 2);
+    if (tn_gen == 2 && a.M % 64 == 0) {  // DMA-ring kernel (whole 64-token steps only)
+        if (wideP) launch_tn2<128, 64>(a, grid, st);
+        else if (wideQ) launch_tn2<64, 128>(a, grid, st);
+        else launch_tn2<64, 64>(a, grid, st);
+        return check_launch("gemm_tn");
+    }
     if (wideP)
         hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), 3 * 8192, st, a);
     else if (wideQ)
