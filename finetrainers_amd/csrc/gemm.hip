@@ -1301,7 +1301,7 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     const int bp = wideP ? 128 : 64, bq = wideP ? 64 : (wideQ ? 128 : 64);
     if (a.v_grp_p > 0 && a.v_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: group width vs tile");
     const int tiles = (a.P / bp) * (a.Q / bq);
-    static const int target_wgs = env_int("FTMI_TN_TARGET_WGS", 256) > 0 ? env_int("FTMI_TN_TARGET_WGS", 256) : 256;
+    static const int target_wgs = env_int("FTMI_TN_TARGET_WGS", 128) > 0 ? env_int("FTMI_TN_TARGET_WGS", 128) : 128;
     // the split-M partials meet in fp32 atomics: more splits = more parallelism but P*Q atomics per split
     const int nb = a.batch > 0 ? a.batch : 1;
     // batched launches already fill the GPU with tiles x batch workgroups: split the token loop only as far as needed

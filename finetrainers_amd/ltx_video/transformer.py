@@ -101,13 +101,18 @@ class _LTXDiTFunction(torch.autograd.Function):
         weights = module._c_weights(cos, sin)
         lib = _lib.load()
         ws_bytes = lib.ftmi_ltx_workspace_bytes(ctypes.byref(cfg))
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x_t.device)
+        # the activation workspace (10.4 GB at cfg 2) is recycled across steps instead of going back to the caching allocator:
+        # a multi-GB block that is freed and re-requested every step occasionally costs a device-synchronising hipMalloc
+        ws = module._acquire_workspace(ws_bytes, x_t.device)
         pred = torch.empty((B, S, module.config.out_channels), dtype=bf16, device=x_t.device)
         check(lib.ftmi_ltx_forward(ctypes.byref(cfg), ctypes.byref(weights), ptr(x_t), ptr(text), ptr(key_bias), ptr(tvals), ptr(pred),
                                    ptr(ws), ws_bytes, stream_ptr()), "ftmi_ltx_forward")
         ctx.module, ctx.cfg, ctx.weights, ctx.ws, ctx.ws_bytes = module, cfg, weights, ws, ws_bytes
         ctx.keep = (x_t, text, key_bias, tvals, cos, sin)
         module._last_workspace = (cfg, ws)
+        if not any(ctx.needs_input_grad) or module.lora_A is None:
+            module._release_workspace(ws)  # no backward will come for this call (its content stays readable until the next forward)
+            ctx.ws = None
         return pred
 
     @staticmethod
@@ -118,13 +123,24 @@ class _LTXDiTFunction(torch.autograd.Function):
         dpred = dpred.contiguous()
         # one flat fp32 gradient buffer [A | B]: a single contiguous all-reduce and a single clip+AdamW launch downstream
         n_a = module.lora_A.numel()
-        gflat = torch.zeros(n_a + module.lora_B.numel(), dtype=torch.float32, device=dpred.device)
+        # recycled across steps while nothing accumulated is alive in .grad (the usual zero_grad(set_to_none=True) loop); with
+        # gradient accumulation the previous .grad tensors ARE this buffer, so a fresh one is used and autograd adds the two
+        gflat = module._grad_flat_buf
+        reuse = (gflat is not None and gflat.numel() == n_a + module.lora_B.numel() and gflat.device == dpred.device
+                 and module.lora_A.grad is None and module.lora_B.grad is None)
+        if reuse:
+            gflat.zero_()
+        else:
+            gflat = torch.zeros(n_a + module.lora_B.numel(), dtype=torch.float32, device=dpred.device)
+            if module.lora_A.grad is None and module.lora_B.grad is None:
+                module._grad_flat_buf = gflat
         ga = gflat[:n_a].view_as(module.lora_A)
         gb = gflat[n_a:].view_as(module.lora_B)
         module._grad_flat = gflat
         _, text, key_bias, _, _, _ = ctx.keep
         check(_lib.load().ftmi_ltx_backward(ctypes.byref(ctx.cfg), ctypes.byref(ctx.weights), ptr(text), ptr(key_bias), ptr(dpred),
                                              ptr(ga), ptr(gb), ptr(ctx.ws), ctx.ws_bytes, stream_ptr()), "ftmi_ltx_backward")
+        module._release_workspace(ctx.ws)
         ctx.ws = None
         return None, None, None, None, None, None, None, ga, gb
 
@@ -172,6 +188,8 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         self._rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._last_workspace = None
         self._grad_flat = None
+        self._grad_flat_buf = None
+        self._ws_pool = []  # idle activation workspaces (uint8 tensors), see _acquire_workspace
         self.lora_flat = None
 
     # ------------------------------------------------------------------ weights
@@ -398,6 +416,18 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         if not return_dict:
             return (out,)
         return {"sample": out}
+
+    # ------------------------------------------------------------------ workspace pool
+    def _acquire_workspace(self, nbytes: int, device: torch.device) -> torch.Tensor:
+        for i, t in enumerate(self._ws_pool):
+            if t.numel() == nbytes and t.device == device:
+                return self._ws_pool.pop(i)
+        self._ws_pool.clear()  # a different problem size: do not hold on to the old blocks
+        return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+
+    def _release_workspace(self, ws: Optional[torch.Tensor]) -> None:
+        if ws is not None and len(self._ws_pool) < 2:
+            self._ws_pool.append(ws)
 
     # ------------------------------------------------------------------ debugging / tests
     def workspace_tensor(self, name: str, layer: int, shape, dtype=bf16) -> torch.Tensor:
