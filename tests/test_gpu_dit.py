@@ -260,3 +260,33 @@ def test_full_step_matches_oracle_step():
     print(f"[step] parameter-update rel_l2 = {upd:.3e}")
     # AdamW's first step is sign-like (m/sqrt(v) = +-1): only gradient entries that are ~0 can flip
     assert upd < 0.15
+
+
+def test_gradient_accumulation_and_buffer_recycling():
+    """`.grad` semantics of the flat LoRA-gradient buffer: a second backward without zero_grad ADDS (the reference's
+    gradient_accumulation_steps > 1), and after `grad = None` the recycled buffer holds exactly one step's gradient again."""
+    cfg, omodel, inp, spec, gmodel = _build(1, 1, 2, 4, 4, False, seed=21)
+
+    def one_backward():
+        pred, target, _ = _gpu_forward(spec, gmodel, inp)
+        ((pred.float() - target.float()) ** 2).mean().backward()
+        torch.cuda.synchronize()
+
+    gmodel.lora_A.grad = None
+    gmodel.lora_B.grad = None
+    one_backward()
+    ga1, gb1 = gmodel.lora_A.grad.detach().clone(), gmodel.lora_B.grad.detach().clone()
+    assert ga1.abs().max() > 0 and gb1.abs().max() > 0
+    one_backward()  # accumulates into the live .grad
+    rel_a = ((gmodel.lora_A.grad - 2 * ga1).norm() / (2 * ga1).norm()).item()
+    rel_b = ((gmodel.lora_B.grad - 2 * gb1).norm() / (2 * gb1).norm()).item()
+    print(f"[accumulate] dA rel {rel_a:.2e}  dB rel {rel_b:.2e}")
+    assert rel_a < 1e-5 and rel_b < 1e-5
+    gmodel.lora_A.grad = None
+    gmodel.lora_B.grad = None
+    one_backward()  # recycled buffer
+    rel_a = ((gmodel.lora_A.grad - ga1).norm() / ga1.norm()).item()
+    rel_b = ((gmodel.lora_B.grad - gb1).norm() / gb1.norm()).item()
+    assert rel_a < 1e-5 and rel_b < 1e-5
+    gmodel.lora_A.grad = None
+    gmodel.lora_B.grad = None
