@@ -13,8 +13,8 @@
 // tile as the row fragments, through gfx950's transposing LDS read (ds_read_b64_tr_b16): one swizzled
 // image per operand serves both orientations (common.hip.h: lds_rt_off / lds_tr_frag).
 //
-// Three kernels: forward (O, LSE), backward dK/dV (one workgroup per 128 keys, loops over queries),
-// backward dQ (one workgroup per 128 queries, loops over keys).  Scores are recomputed in both
+// Three kernels: forward (O, LSE), backward dQ (one workgroup per 128 queries, loops over keys; also produces
+// delta = rowsum(dO * O)), backward dK/dV (one workgroup per 128 keys, loops over queries).  Scores are recomputed in both
 // backward kernels, so no atomics are needed and results are deterministic.
 #include <type_traits>
 
@@ -254,31 +254,6 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     else
         hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), kFwdLds, st, a);
     return check_launch("attn_fwd");
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward: delta = rowsum(dO * O)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
-    const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);  // 8 lanes per (b,h,i) row
-    const int sub = threadIdx.x & 7;
-    const long nrows = (long)a.B * a.H * a.Sq;
-    float s = 0.f;
-    if (row < nrows) {
-        const int i = (int)(row % a.Sq);
-        const long bh = row / a.Sq;
-        const int h = (int)(bh % a.H), b = (int)(bh / a.H);
-        const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)i * a.o_ss + sub * 8;
-        const bf16_t* dp = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)i * a.do_ss + sub * 8;
-        s16x8 ov = *reinterpret_cast<const s16x8*>(op);
-        s16x8 dv = *reinterpret_cast<const s16x8*>(dp);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += bf2f((bf16_t)ov[e]) * bf2f((bf16_t)dv[e]);
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    if (row < nrows && sub == 0) a.delta[row] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -596,7 +571,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         dof[c] = *reinterpret_cast<const s16x8*>(dop + c * 16 + g * 8);
     }
     const float lse_i = a.lse2[((long)b * a.H + h) * a.Sq + ic];
-    const float del_i = a.delta[((long)b * a.H + h) * a.Sq + ic];
+    // delta_i = rowsum(dO_i * O_i): this wave already holds half of dO's row per lane in MFMA-fragment order, so it loads O the
+    // same way, sums its 32 products and meets the other half-wave with one shuffle -- the separate delta kernel (one more pass
+    // over dO and O, one more launch per attention) is gone.  The value is published for the dK/dV kernel, which runs after this one.
+    float del_i = 0.f;
+    {
+        const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)ic * a.o_ss;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const s16x8 of = *reinterpret_cast<const s16x8*>(op + c * 16 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) del_i += bf2f((bf16_t)dof[c][e]) * bf2f((bf16_t)of[e]);
+        }
+        del_i += __shfl_xor(del_i, 32, 64);
+        if (g == 0 && i < a.Sq) a.delta[((long)b * a.H + h) * a.Sq + i] = del_i;
+    }
 
     const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
@@ -694,10 +683,13 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (!a.lse2 || !a.delta || !a.dout || !a.o) return set_error(FTMI_ERR_INVALID, "attn_bwd: missing lse/delta/dout/out");
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8) || (a.do_ss % 8) || (a.dq_ss % 8) || (a.dk_ss % 8) || (a.dv_ss % 8))
         return set_error(FTMI_ERR_INVALID, "attn_bwd: token strides must keep 16-byte alignment");
-    const long nrows = (long)a.B * a.H * a.Sq;
     ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);  // algorithmic: 5 matmuls (2.5x forward)
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
-    int rc = check_launch("attn_delta");
+    // dQ first: it also computes delta = rowsum(dO * O) for its rows and publishes it for the dK/dV kernel
+    if (a.kbias || (a.Sk % 64) != 0)
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
+    else
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
+    int rc = check_launch("attn_bwd_dq");
     if (rc) return rc;
     const long wg128 = (long)((a.Sk + 127) / 128) * a.H * a.B;
     if (wg128 < 256 && a.Sq >= 512) {  // few keys: split the queries across the waves instead (see the kernel's header)
@@ -710,13 +702,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     } else {
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
     }
-    rc = check_launch("attn_bwd_dkdv");
-    if (rc) return rc;
-    if (a.kbias || (a.Sk % 64) != 0)
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
-    else
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
-    return check_launch("attn_bwd_dq");
+    return check_launch("attn_bwd_dkdv");
 }
 
 }  // namespace ftmi
