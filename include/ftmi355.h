@@ -51,7 +51,7 @@ int ftmi_last_error(char* buf, size_t len);
 /* In-stream HIP-event profiler used by bench.py for its live roofline figures: while enabled, every stride-th launch of a
  * kernel class is bracketed by two events on the launch stream (stride 1 = every launch; bracketing all ~1500 launches
  * of a step costs ~8 % of the step, sampling keeps the measurement inside the timed region at <1 %).  Classes: 0 gemm_nt
- * (the tiled kernel), 1 gemm_tn, 2 attention forward, 3 attention backward (delta + dK/dV + dQ), 4 the skinny (N <= 256) LoRA
+ * (the tiled kernel), 1 gemm_tn, 2 attention forward, 3 attention backward (dQ [+ delta] + dK/dV), 4 the skinny (N <= 256) LoRA
  * down-projection GEMM.  ftmi_prof_summary waits for the recorded
  * events and returns, for one class, the summed device time / count / algorithmic FLOPs of the SAMPLED launches and the
  * count / FLOPs of ALL launches seen (reset != 0 clears the class). */
@@ -74,7 +74,7 @@ typedef struct {
 
 int ftmi_attn_fwd(const ftmi_attn_desc* desc, const void* q, const void* k, const void* v, void* out, float* lse,
                   const float* key_bias, ftmi_stream stream);
-/* delta_ws: fp32 [B,H,Sq] scratch */
+/* delta_ws: fp32 [B,H,Sq] scratch (rowsum(dO * O), written by the dQ kernel, read by the dK/dV kernel) */
 int ftmi_attn_bwd(const ftmi_attn_desc* desc, const void* q, const void* k, const void* v, const void* out,
                   const float* lse, const void* dout, void* dq, void* dk, void* dv, float* delta_ws,
                   const float* key_bias, ftmi_stream stream);
