@@ -643,6 +643,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = rv[j] + y[j];
+                    if (p.out2) {
+                        const u32x2 g2 = *reinterpret_cast<const u32x2*>(p.gate2 + (long)b * p.gate2_bstride + n);
+                        const float g2v[4] = {bf2f((bf16_t)(g2[0] & 0xffff)), bf2f((bf16_t)(g2[0] >> 16)), bf2f((bf16_t)(g2[1] & 0xffff)),
+                                              bf2f((bf16_t)(g2[1] >> 16))};
+                        pkz[rq][0] = pack2bf(rbf(o[0]) * g2v[0], rbf(o[1]) * g2v[1]);
+                        pkz[rq][1] = pack2bf(rbf(o[2]) * g2v[2], rbf(o[3]) * g2v[3]);
+                    }
                 } else {  // EPI_DGELU: grad_in = grad_out * gelu'(z)
                     const u32x2 zz = *reinterpret_cast<const u32x2*>(scr_in + scr_off(li, tn * 4 + rq) + 8 * g);
                     float zv[4] = {bf2f((bf16_t)(zz[0] & 0xffff)), bf2f((bf16_t)(zz[0] >> 16)), bf2f((bf16_t)(zz[1] & 0xffff)),
@@ -664,6 +671,15 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
                     w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
                     *reinterpret_cast<u32x4*>(scr + scr_off(li, chunk)) = w;
                 }
+                if constexpr (EPI == EPI_RESID) {
+                    if (p.out2) {  // second output: bf(out * gate2[b]), staged in the second scratch block (its residual chunks are consumed)
+                        auto s0 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][0], pkz[2 * q2 + 1][0], false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][1], pkz[2 * q2 + 1][1], false, false);
+                        u32x4 wz;
+                        wz[0] = s0[0]; wz[1] = s1[0]; wz[2] = s0[1]; wz[3] = s1[1];
+                        *reinterpret_cast<u32x4*>(scr_in + scr_off(li, chunk)) = wz;
+                    }
+                }
                 if constexpr (EPI == EPI_GELU) {
                     auto s0 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][0], pkz[2 * q2 + 1][0], false, false);
                     auto s1 = __builtin_amdgcn_permlane32_swap(pkz[2 * q2][1], pkz[2 * q2 + 1][1], false, false);
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             }
         }
         flush(scr, p.out, p.ldo, tm);
-        if constexpr (EPI == EPI_GELU) {
+        if constexpr (EPI == EPI_GELU || EPI == EPI_RESID) {
             if (p.out2) flush(scr_in, p.out2, p.ldo2, tm);
         }
     }

@@ -36,6 +36,8 @@ struct ProfScope {
 };
 
 struct GemmNtArgs {
+    const bf16_t* gate2 = nullptr;  // EPI_RESID with out2: out2 = bf(out * gate2[b])  (the consumer's gate multiply, fused)
+    long gate2_bstride = 0;
     const bf16_t* X = nullptr;  // [M, ldx]
     long ldx = 0;
     const bf16_t* W = nullptr;  // [N, ldw]   (K-contiguous rows)
@@ -138,7 +140,8 @@ int norm_modulate_fwd(const bf16_t* x, const bf16_t* shift, const bf16_t* onep, 
                       int rows_per_batch, int D, float eps, int layernorm, hipStream_t st);
 // dx_out = (dres ? dres : 0) + norm_bwd(x, bf(dy * onep[b]))
 int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, long mod_bstride, const bf16_t* dres,
-                      bf16_t* dx, int rows, int rows_per_batch, int D, float eps, int layernorm, hipStream_t st);
+                      bf16_t* dx, int rows, int rows_per_batch, int D, float eps, int layernorm, hipStream_t st,
+                      const bf16_t* gate2 = nullptr, long gate2_bstride = 0, bf16_t* dx2 = nullptr);  // dx2 = bf(dx * gate2[b]) (optional)
 
 // affine RMSNorm over the full width (+ optional interleaved-pair RoPE), x row stride ldx
 // w_rows > 1: row i uses weight row (i % w_rows) of a [w_rows, D] table (rows interleaved over blocks)
@@ -148,10 +151,6 @@ int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos
 int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy,
                     long lddy, bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1, const bf16_t* x2 = nullptr,
                     const bf16_t* w2 = nullptr, const bf16_t* dy2 = nullptr, bf16_t* dx2 = nullptr);
-
-// out = bf(x * gate[b])
-int mul_gate(const bf16_t* x, const bf16_t* gate, long gate_bstride, bf16_t* out, int rows, int rows_per_batch, int D,
-             hipStream_t st);
 
 // latents [B,C,F*H*W] bf16 -> x_t, target packed [B, S, C]
 int noise_pack(const bf16_t* latents, const bf16_t* noise, const float* mean, const float* std_, const float* sigma,

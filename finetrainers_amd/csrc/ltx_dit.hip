@@ -355,7 +355,9 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     {
         const bf16_t* hL = W(ws, L.hs) + (size_t)c.L * M * D;
         const bf16_t* ao = W(ws, L.ada_out);
-        FTMI_TRY(norm_modulate_bwd(hL, d1, ao + 2 * D, 3L * D, nullptr, dh[0], M, c.S, D, c.eps_norm, 1, st));
+        // the gated copy bf(dh * gate_mlp) that opens the last block's backward is written by the same kernel (into dO, idle here)
+        const bf16_t* ada_last = W(ws, L.ada) + (size_t)(c.L - 1) * c.B * 8 * D;
+        FTMI_TRY(norm_modulate_bwd(hL, d1, ao + 2 * D, 3L * D, nullptr, dh[0], M, c.S, D, c.eps_norm, 1, st, ada_last + 5 * D, 8L * D, dO));
     }
     int cur = 0;
 
@@ -434,10 +436,10 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         const bf16_t* dhin = dh[cur];
 
         // ---- feed-forward ----
-        FTMI_TRY(mul_gate(dhin, ada + 5 * D, ab, d1, M, c.S, D, st));
+        // (dO holds bf(dhin * gate_mlp): written by the kernel that produced dhin)
         {
             GemmNtArgs a;
-            a.X = d1; a.ldx = D; a.W = P(w.w_ff2_t, (size_t)l * c.D_ff * D); a.ldw = D; a.M = M; a.N = c.D_ff; a.K = D;
+            a.X = dO; a.ldx = D; a.W = P(w.w_ff2_t, (size_t)l * c.D_ff * D); a.ldw = D; a.M = M; a.N = c.D_ff; a.K = D;
             a.out = W(ws, L.s_dbig); a.ldo = c.D_ff; a.epi = EPI_DGELU; a.aux = W(blk, L.z); a.ldaux = c.D_ff; a.variant = V;
             FTMI_TRY(gemm_nt(a, st));
         }
@@ -474,13 +476,13 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             GemmNtArgs a;
             a.X = gq2; a.ldx = D; a.W = P(w.w_q2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d2; a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = d3; a.ldr = D;
+            a.out2 = W(blk, L.g_o); a.ldo2 = D; a.gate2 = ada + 2 * D; a.gate2_bstride = ab; a.rows_per_batch = c.S;  // go = bf(dh1 * gate_msa), fused
             if (r > 0) { a.X2 = W(blk, L.dxa_q2); a.ldx2 = r; a.W2 = lat + 4L * D * r; a.ldw2 = r; a.K2 = r; }
             FTMI_TRY(gemm_nt(a, st));  // d2 = dh1
         }
 
         // ---- self-attention ----
         bf16_t* go = W(blk, L.g_o);  // d(attn1.to_out output)
-        FTMI_TRY(mul_gate(d2, ada + 2 * D, ab, go, M, c.S, D, st));
         if (r > 0) FTMI_TRY(lora_dxa(go, D, M, 1, 3, l, W(blk, L.dxa_o)));
         {
             GemmNtArgs a;
@@ -512,7 +514,8 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             a.X = dqkv; a.ldx = 3 * D; a.W = P(w.w_qkv_t, (size_t)l * 3 * D2); a.ldw = 3 * D; a.M = M; a.N = D; a.K = 3 * D; a.out = d1; a.ldo = D; a.variant = V;
             if (r > 0) { a.X2 = W(blk, L.dxa_qkv); a.ldx2 = 3 * r; a.W2 = P(w.lora_at_qkv, (size_t)l * D * 3 * r); a.ldw2 = 3 * r; a.K2 = 3 * r; }
             FTMI_TRY(gemm_nt(a, st));  // d1 = dn1
-            FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st));
+            const bf16_t* ada_prev = W(ws, L.ada) + (size_t)(l - 1) * c.B * 8 * D;  // the next block processed is l - 1
+            FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st, ada_prev + 5 * D, ab, dO));
             cur ^= 1;
         }
         if (use_side && (wgrad_pending_hi - l >= tn_group || l == 0)) {

@@ -140,7 +140,8 @@ template <bool LN>
 __global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                 const bf16_t* __restrict__ onep, long mod_bstride,
                                                                 const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int rows,
-                                                                int rows_per_batch, float eps) {
+                                                                int rows_per_batch, float eps, const bf16_t* __restrict__ gate2, long gate2_bstride,
+                                                                bf16_t* __restrict__ dx2) {
     constexpr int D = kNch * 512;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -204,16 +205,24 @@ __global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __
             o[e] = dres ? rv[e] + rbf(d) : d;
         }
         *reinterpret_cast<s16x8*>(dxp + off) = pack8(o);
+        if (dx2) {  // the consumer's first op, bf(dx * gate[b]) (a gate multiply), done here while dx is in registers: one pass and one launch less
+            float g2[8], o2[8];
+            unpack8(*reinterpret_cast<const s16x8*>(gate2 + (long)b * gate2_bstride + off), g2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o2[e] = rbf(o[e]) * g2[e];
+            *reinterpret_cast<s16x8*>(dx2 + (long)row * D + off) = pack8(o2);
+        }
     }
 }
 int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, long mod_bstride, const bf16_t* dres, bf16_t* dx,
-                      int rows, int rows_per_batch, int D, float eps, int layernorm, hipStream_t st) {
+                      int rows, int rows_per_batch, int D, float eps, int layernorm, hipStream_t st, const bf16_t* gate2, long gate2_bstride,
+                      bf16_t* dx2) {
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "norm_modulate: row width must be 2048");
     dim3 grid((rows + 3) / 4);
     if (layernorm)
-        hipLaunchKernelGGL(norm_modulate_bwd_kernel<true>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps);
+        hipLaunchKernelGGL(norm_modulate_bwd_kernel<true>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps, gate2, gate2_bstride, dx2);
     else
-        hipLaunchKernelGGL(norm_modulate_bwd_kernel<false>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps);
+        hipLaunchKernelGGL(norm_modulate_bwd_kernel<false>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps, gate2, gate2_bstride, dx2);
     return check_launch("norm_modulate_bwd");
 }
 
@@ -342,30 +351,6 @@ int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos
     hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4, x2 ? 2 : 1), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps, w_rows,
                        x2, w2, dy2, dx2);
     return check_launch("qknorm_rope_bwd");
-}
-
-// ---------------------------------------------------------------------------------------------------
-__global__ void mul_gate_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ gate, long gate_bstride, bf16_t* __restrict__ out,
-                                long nchunks, int chunks_per_row, int rows_per_batch) {
-    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (long)gridDim.x * blockDim.x) {
-        const long row = c / chunks_per_row;
-        const int ch = (int)(c % chunks_per_row);
-        const int b = (int)(row / rows_per_batch);
-        float xv[8], gv[8], o[8];
-        unpack8(*reinterpret_cast<const s16x8*>(x + c * 8), xv);
-        unpack8(*reinterpret_cast<const s16x8*>(gate + (long)b * gate_bstride + ch * 8), gv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = xv[e] * gv[e];
-        *reinterpret_cast<s16x8*>(out + c * 8) = pack8(o);
-    }
-}
-int mul_gate(const bf16_t* x, const bf16_t* gate, long gate_bstride, bf16_t* out, int rows, int rows_per_batch, int D, hipStream_t st) {
-    if (D % 8) return set_error(FTMI_ERR_UNSUPPORTED, "mul_gate: D % 8");
-    const long nchunks = (long)rows * (D / 8);
-    long blocks = (nchunks + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(mul_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, gate, gate_bstride, out, nchunks, D / 8, rows_per_batch);
-    return check_launch("mul_gate");
 }
 
 // ---------------------------------------------------------------------------------------------------
