@@ -75,7 +75,7 @@ def attn_bwd(q, k, v, out, lse, dout, key_bias=None, scale=None):
 
 def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0, epilogue: int = 0,
             resid: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
-            aux: Optional[torch.Tensor] = None, want_out2: bool = False, variant: int = 0):
+            aux: Optional[torch.Tensor] = None, want_out2: bool = False, variant: int = 8):
     """out[M,N] = epilogue(alpha * x[M,K] @ w[N,K]^T + bias)."""
     require_gpu_tensor(x, "x", bf16)
     require_gpu_tensor(w, "w", bf16)
@@ -106,7 +106,7 @@ def transpose_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def linear_lora_fwd(x, w, bias, a_bf, b_bf, lora_scale: float, variant: int = 0):
+def linear_lora_fwd(x, w, bias, a_bf, b_bf, lora_scale: float, variant: int = 8):
     M, K = x.shape
     N = w.shape[0]
     r = 0 if a_bf is None else a_bf.shape[0]
@@ -117,7 +117,7 @@ def linear_lora_fwd(x, w, bias, a_bf, b_bf, lora_scale: float, variant: int = 0)
     return y, xa
 
 
-def linear_lora_bwd(x, dy, xa, w_t, a_t, b_t, lora_scale: float, grad_a=None, grad_b=None, need_dx: bool = True, variant: int = 0):
+def linear_lora_bwd(x, dy, xa, w_t, a_t, b_t, lora_scale: float, grad_a=None, grad_b=None, need_dx: bool = True, variant: int = 8):
     """Backward of ``linear_lora_fwd``: returns (dx [M,K] bf16 or None, grad_a [r,K] fp32, grad_b [N,r] fp32); the gradient
     buffers are accumulated into when given (``.grad`` semantics).  ``w_t = W^T``, ``a_t = A^T``, ``b_t = B^T`` in bf16."""
     M, N = dy.shape

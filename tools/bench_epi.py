@@ -24,10 +24,10 @@ for (N, K) in [(8192, 2048), (2048, 8192), (2048, 2048)]:
     z = torch.randn((M, N), device=dev, generator=g).to(torch.bfloat16)
     fl = 2.0 * M * N * K
     for name, fn in [
-        ("store", lambda: ops.gemm_nt(x, w, b)),
-        ("gelu+stash", lambda: ops.gemm_nt(x, w, b, epilogue=_lib.EPI_GELU, want_out2=True)),
-        ("resid+gate", lambda: ops.gemm_nt(x, w, b, epilogue=_lib.EPI_RESID, resid=resid, gate=gate, rows_per_batch=M // 2)),
-        ("dgelu", lambda: ops.gemm_nt(x, w, None, epilogue=_lib.EPI_DGELU, aux=z)),
+        ("store", lambda: ops.gemm_nt(x, w, b, variant=8)),
+        ("gelu+stash", lambda: ops.gemm_nt(x, w, b, epilogue=_lib.EPI_GELU, want_out2=True, variant=8)),
+        ("resid+gate", lambda: ops.gemm_nt(x, w, b, epilogue=_lib.EPI_RESID, resid=resid, gate=gate, rows_per_batch=M // 2, variant=8)),
+        ("dgelu", lambda: ops.gemm_nt(x, w, None, epilogue=_lib.EPI_DGELU, aux=z, variant=8)),
     ]:
         us = timeit(fn)
         print(f"M{M} N{N} K{K} {name:11s}: {us:7.1f} us  {fl/us/1e6:7.1f} TF/s", flush=True)
