@@ -99,7 +99,8 @@ int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const voi
 
 /* Generic building blocks (exposed for tests / incremental adoption) */
 /* out[M,N] = bf16(alpha * x[M,K] w[N,K]^T + bias) ; epilogue: 0 store, 1 gelu-tanh (out2 <- pre-activation),
- * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux) */
+ * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux).  variant: 8 = automatic tile / K-loop choice (use this);
+ * other ids pin one kernel (bit-identical A/B partners, see gemm.hip) */
 int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha,
                  void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
                  const void* aux, int variant, ftmi_stream stream);
@@ -121,7 +122,7 @@ typedef struct {
     float lora_scale; /* alpha / r */
     float eps_norm;   /* 1e-6 (norm1 / norm2 / norm_out) */
     float eps_qk;     /* 1e-5 (norm_q / norm_k) */
-    int gemm_variant; /* 0 register-staged tiles, 1 direct global->LDS */
+    int gemm_variant; /* 8 = automatic tile / K-loop choice (production); other ids select one fixed kernel (A/B partners, gemm.hip) */
 } ftmi_ltx_config;
 
 /* All weights bf16 unless noted.  Per-block tensors are stacked along a leading L dimension.  "*_t" are
