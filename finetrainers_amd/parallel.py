@@ -96,7 +96,10 @@ class DataParallelBackend:
 
     def wait_for_everyone(self) -> None:
         if self.world_size > 1:
-            dist.barrier()
+            if self.backend == "nccl":
+                dist.barrier(device_ids=[self.device.index])  # explicit device: no "guessing device" warning, no wrong-GPU barrier
+            else:
+                dist.barrier()
 
     def destroy(self) -> None:
         if self._owns_pg and dist.is_initialized():
