@@ -693,11 +693,9 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (rc) return rc;
     const long wg128 = (long)((a.Sk + 127) / 128) * a.H * a.B;
     if (wg128 < 256 && a.Sq >= 512) {  // few keys: split the queries across the waves instead (see the kernel's header)
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_sq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSqLds);
-            attr_set = true;
-        }
+        static const bool attr_ok =  // once, thread-safe (forward and backward run on different host threads)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_sq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSqLds) == hipSuccess;
+        if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
         hipLaunchKernelGGL(attn_bwd_dkdv_sq_kernel, dim3(((a.Sk + 31) / 32) * a.H * a.B), dim3(256), kDkvSqLds, st, a);
     } else {
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);

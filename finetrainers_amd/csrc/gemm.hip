@@ -725,13 +725,11 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
     }
     const size_t smem = (size_t)kl_lds_stages(LOOP) * T::STAGE;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
-        if (smem > 65536) {
-        static bool attr_set = false;  // per instantiation
-        if (!attr_set) {
+    if (smem > 65536) {
+        static const bool attr_ok =  // once per instantiation, thread-safe
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, LOOP>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr_set = true;
-        }
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kl_lds_stages(LOOP) * T::STAGE)) == hipSuccess;
+        if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
     }
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, LOOP>), dim3(8 * a.map_rm * a.map_rn), dim3(T::NT), smem, st, a);
     return check_launch("gemm_nt");
@@ -978,11 +976,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         // 8-way K split when it divides into whole load batches: halves the dependent load->MFMA chain of every wave
         if (ks == 2 && a.K % 256 == 0) {
             constexpr int kSmem = 4 * 3 * 12288;
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
-                attr_set = true;
-            }
+            static const bool attr_ok =
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
+            if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
             hipLaunchKernelGGL(gemm_nt_skinny2_kernel<0>, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(256), kSmem, st, a);
         } else if (ks == 8 && a.K % 1024 == 0)
             hipLaunchKernelGGL(gemm_nt_skinny_kernel<8>, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(512), 0, st, a);
