@@ -274,3 +274,20 @@ def test_bench_and_entry_points_exist():
     assert callable(ge.build) and callable(ge.smoke)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True)
     assert out.returncode != 0 and "MI355X" in (out.stderr + out.stdout)  # refuses to run without the GPU
+
+
+def test_loss_weighting_and_density_schemes_match_oracle():
+    """Host mirrors of utils/diffusion.py (density sampling for every --flow_weighting_scheme, SD3 loss weights) against the
+    oracle's restatement, same generator state: bit-identical."""
+    from finetrainers_amd.utils import diffusion as host
+    from oracle import ltx
+
+    sig = torch.tensor([0.05, 0.25, 0.5, 0.7, 0.999])
+    for scheme in ("none", "sigma_sqrt", "cosmap", "logit_normal", "mode"):
+        assert torch.equal(host.compute_loss_weighting_for_sd3(scheme, sig), ltx.compute_loss_weighting_for_sd3(scheme, sig)), scheme
+    for scheme in ("none", "logit_normal", "mode"):
+        g1, g2 = torch.Generator().manual_seed(7), torch.Generator().manual_seed(7)
+        a = host.compute_density_for_timestep_sampling(scheme, 16, logit_mean=0.0, logit_std=1.0, mode_scale=1.29, device=torch.device("cpu"), generator=g1)
+        b = ltx.compute_density_for_timestep_sampling(scheme, 16, logit_mean=0.0, logit_std=1.0, mode_scale=1.29, generator=g2)
+        assert torch.equal(a, b), scheme
+        assert (a >= 0).all() and (a <= 1).all()
