@@ -30,6 +30,7 @@ class AttnDesc(Structure):
         ("B", c_int), ("H", c_int), ("Sq", c_int), ("Sk", c_int), ("d", c_int),
         ("q_strides", c_long * 3), ("k_strides", c_long * 3), ("v_strides", c_long * 3), ("o_strides", c_long * 3),
         ("do_strides", c_long * 3), ("dq_strides", c_long * 3), ("dk_strides", c_long * 3), ("dv_strides", c_long * 3),
+        ("bias_strides", c_long * 2),
         ("scale", c_float),
     ]
 
@@ -51,7 +52,7 @@ LTX_WEIGHT_FIELDS = [
     "cap_l1_w", "cap_l1_b", "cap_l2_w", "cap_l2_b", "tables", "table_out", "proj_out_w", "proj_out_b", "proj_out_w_t",
     "w_qkv", "b_qkv", "w_qkv_t", "norm_q", "norm_k", "w_o", "b_o", "w_o_t", "w_q2", "b_q2", "w_q2_t", "w_kv2", "b_kv2",
     "norm_q2", "norm_k2", "w_o2", "b_o2", "w_o2_t", "w_ff1", "b_ff1", "w_ff1_t", "w_ff2", "b_ff2", "w_ff2_t",
-    "lora_a", "lora_at", "lora_b", "lora_bt", "lora_at_qkv", "rope_cos", "rope_sin",
+    "lora_a_sp", "lora_bt_sp", "lora_b_ext", "lora_at_ext", "lora_at_qkv_ext", "rope_cos", "rope_sin",
 ]
 
 
@@ -73,6 +74,11 @@ _SIGS = {
                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ftmi_gemm_tn": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_float, c_void_p]),
     "ftmi_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ftmi_norm_modulate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "ftmi_norm_modulate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "ftmi_qknorm_rope_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_float, c_void_p]),
+    "ftmi_qknorm_rope_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_float,
+                                     c_void_p]),
     "ftmi_ltx_workspace_bytes": (c_size_t, [POINTER(LtxConfig)]),
     "ftmi_ltx_workspace_offset": (c_int, [POINTER(LtxConfig), c_char_p, c_int, POINTER(c_size_t)]),
     "ftmi_ltx_forward": (c_int, [POINTER(LtxConfig), POINTER(LtxWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -83,6 +89,7 @@ _SIGS = {
     "ftmi_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p]),
     "ftmi_clip_adamw_step": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 6 + [c_int, c_void_p, c_void_p, c_void_p]),
     "ftmi_lora_refresh": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "ftmi_lora_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

@@ -124,21 +124,34 @@ def _check_no_dropout_causal_gqa(dropout_p=0.0, is_causal=False, enable_gqa=Fals
         raise ValueError("The mi355x provider supports non-causal attention without dropout or GQA.")
 
 
+# -inf (and bool masks, which mean -inf) travel as a large finite negative: exp2 of it is exactly 0 for every kept key, and a row whose
+# keys are ALL masked stays finite (uniform over the masked keys) instead of producing NaN in a training step
+_MASKED = -1.0e30
+
+
 def _key_bias_from_mask(attn_mask: Optional[torch.Tensor], B: int, H: int, Sk: int) -> Optional[torch.Tensor]:
-    """Additive mask broadcastable to [B, H, S_q, S_k] whose value depends on (batch, key) only -- LTX's text mask is
-    [B, H, 1, T] -- -> fp32 [B, S_k]."""
+    """``attn_mask`` in torch SDPA's convention -- bool (True = keep) or additive float, broadcastable to [B, H, S_q, S_k] with
+    right-aligned dimensions -- whose value does not depend on the query (LTX's text mask is [B, H, 1, T]) -> fp32 key
+    bias [B, S_k] (one row per sample) or [B, H, S_k] (the mask differs between heads).  Anything else raises ``ValueError``."""
     if attn_mask is None:
         return None
     m = attn_mask
-    if m.dtype == torch.bool:
-        m = torch.zeros_like(m, dtype=torch.float32).masked_fill(~m, float("-inf"))
-    while m.dim() < 4:
+    if m.dim() > 4:
+        raise ValueError("mi355x provider: attn_mask has more than 4 dimensions")
+    while m.dim() < 4:  # torch aligns mask dimensions to the right: [L, S] -> [1, 1, L, S], [X, L, S] -> [1, X, L, S] (X = heads)
         m = m.unsqueeze(0)
-    if m.shape[-1] != Sk or m.shape[2] != 1:
-        raise ValueError("mi355x provider: attn_mask must broadcast over queries (shape [B|1, H|1, 1, S_k])")
-    if m.shape[1] != 1:
-        m = m[:, :1]  # the reference repeats one mask over heads (prepare_attention_mask)
-    return m.reshape(m.shape[0], Sk).expand(B, Sk).float().contiguous()
+    if m.shape[-1] != Sk or m.shape[2] != 1 or m.shape[0] not in (1, B) or m.shape[1] not in (1, H):
+        raise ValueError(f"mi355x provider: attn_mask {tuple(attn_mask.shape)} must broadcast to [B={B}, H={H}, 1, S_k={Sk}] (no per-query masks)")
+    if m.shape[1] == 1 or m.stride(1) == 0:  # one mask for all heads (also an expanded view of one)
+        m = m[:, :1]
+    if m.dtype == torch.bool:
+        m = torch.zeros(m.shape, dtype=torch.float32, device=m.device).masked_fill(~m, _MASKED)
+    else:
+        m = m.float().clamp_min(_MASKED)
+    m = m[:, :, 0]  # [B|1, H|1, Sk]
+    if m.shape[1] == 1:
+        return m[:, 0].expand(B, Sk).contiguous()
+    return m.expand(B, H, Sk).contiguous()  # a mask materialised per head is honoured per head, not reduced to head 0
 
 
 class _MI355XAttention(torch.autograd.Function):

@@ -101,6 +101,7 @@ static int fill_attn(const ftmi_attn_desc* d, AttnArgs& a) {
     a.dq_sb = d->dq_strides[0]; a.dq_sh = d->dq_strides[1]; a.dq_ss = d->dq_strides[2];
     a.dk_sb = d->dk_strides[0]; a.dk_sh = d->dk_strides[1]; a.dk_ss = d->dk_strides[2];
     a.dv_sb = d->dv_strides[0]; a.dv_sh = d->dv_strides[1]; a.dv_ss = d->dv_strides[2];
+    a.kb_sb = d->bias_strides[0]; a.kb_sh = d->bias_strides[1];
     return 0;
 }
 
@@ -221,60 +222,88 @@ int ftmi_transpose_bf16(const void* in, void* out, int rows, int cols, ftmi_stre
     return transpose_bf16((const bf16_t*)in, (bf16_t*)out, rows, cols, (hipStream_t)stream);
 }
 
-int ftmi_linear_lora_fwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* w, const void* bias, const void* a_bf,
-                         const void* b_bf, void* y, void* xa_out, int variant, ftmi_stream stream) {
+static int lora_down_call(const bf16_t* X, long ldx, int M, const bf16_t* w_sp, int r, int K, float alpha, bf16_t* out, hipStream_t st) {
+    GemmNtArgs d;
+    d.X = X; d.ldx = ldx; d.W = w_sp; d.ldw = K; d.M = M; d.N = 2 * r; d.K = K; d.alpha = alpha; d.split_r = r;
+    d.out = out; d.ldo = 3L * r; d.variant = 8;
+    return gemm_nt(d, st);
+}
+
+int ftmi_linear_lora_fwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* w, const void* bias, const void* a_sp,
+                         const void* b_ext, void* y, void* xa_out, int variant, ftmi_stream stream) {
     if (!x || !w || !y) return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_fwd: null tensor");
-    if (r > 0 && (!a_bf || !b_bf || !xa_out)) return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_fwd: LoRA tensors missing");
+    if (r > 0 && (!a_sp || !b_ext || !xa_out)) return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_fwd: LoRA tensors missing");
     if (r < 0 || (r % 64)) return set_error(FTMI_ERR_UNSUPPORTED, "ftmi_linear_lora_fwd: rank must be 0 or a multiple of 64");
     hipStream_t st = (hipStream_t)stream;
     GemmNtArgs a;
     a.X = (const bf16_t*)x; a.ldx = K; a.W = (const bf16_t*)w; a.ldw = K; a.M = M; a.N = N; a.K = K;
     a.bias = (const bf16_t*)bias; a.out = (bf16_t*)y; a.ldo = N; a.variant = variant;
     if (r > 0) {
-        GemmNtArgs d;
-        d.X = (const bf16_t*)x; d.ldx = K; d.W = (const bf16_t*)a_bf; d.ldw = K; d.M = M; d.N = r; d.K = K; d.alpha = lora_scale;
-        d.out = (bf16_t*)xa_out; d.ldo = r; d.variant = variant;
-        int rc = gemm_nt(d, st);
+        int rc = lora_down_call((const bf16_t*)x, K, M, (const bf16_t*)a_sp, r, K, lora_scale, (bf16_t*)xa_out, st);
         if (rc) return rc;
-        a.X2 = (const bf16_t*)xa_out; a.ldx2 = r; a.W2 = (const bf16_t*)b_bf; a.ldw2 = r; a.K2 = r;
+        a.X2 = (const bf16_t*)xa_out; a.ldx2 = 3 * r; a.W2 = (const bf16_t*)b_ext; a.ldw2 = 3 * r; a.K2 = 3 * r;
     }
     return gemm_nt(a, st);
 }
 
 int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* dy, const void* xa, const void* w_t,
-                         const void* a_t, const void* b_t, void* dxa_ws, void* dx, float* grad_a, float* grad_b, int variant,
+                         const void* bt_sp, const void* at_ext, void* dxa_ws, void* dx, float* grad_a, float* grad_b, int variant,
                          ftmi_stream stream) {
     if (!dy || (dx && !w_t)) return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_bwd: null tensor");
     if (r < 0 || (r % 64)) return set_error(FTMI_ERR_UNSUPPORTED, "ftmi_linear_lora_bwd: rank must be 0 or a multiple of 64");
-    if (r > 0 && (!x || !xa || !a_t || !b_t || !dxa_ws || !grad_a || !grad_b))
+    if (r > 0 && (!x || !xa || !bt_sp || !at_ext || !dxa_ws || !grad_a || !grad_b))
         return set_error(FTMI_ERR_INVALID, "ftmi_linear_lora_bwd: LoRA tensors missing");
     hipStream_t st = (hipStream_t)stream;
-    if (r > 0) {
-        GemmNtArgs d;  // dxa = s * dy B  (B^T is the K-contiguous operand)
-        d.X = (const bf16_t*)dy; d.ldx = N; d.W = (const bf16_t*)b_t; d.ldw = N; d.M = M; d.N = r; d.K = N; d.alpha = lora_scale;
-        d.out = (bf16_t*)dxa_ws; d.ldo = r; d.variant = variant;
-        int rc = gemm_nt(d, st);
+    if (r > 0) {  // dxa = s * dy B  (B^T is the K-contiguous operand), fp32-equivalent
+        int rc = lora_down_call((const bf16_t*)dy, N, M, (const bf16_t*)bt_sp, r, N, lora_scale, (bf16_t*)dxa_ws, st);
         if (rc) return rc;
     }
     if (dx) {
         GemmNtArgs a;  // dx = dy W (+ dxa A as a K-extension)
         a.X = (const bf16_t*)dy; a.ldx = N; a.W = (const bf16_t*)w_t; a.ldw = N; a.M = M; a.N = K; a.K = N;
         a.out = (bf16_t*)dx; a.ldo = K; a.variant = variant;
-        if (r > 0) { a.X2 = (const bf16_t*)dxa_ws; a.ldx2 = r; a.W2 = (const bf16_t*)a_t; a.ldw2 = r; a.K2 = r; }
+        if (r > 0) { a.X2 = (const bf16_t*)dxa_ws; a.ldx2 = 3 * r; a.W2 = (const bf16_t*)at_ext; a.ldw2 = 3 * r; a.K2 = 3 * r; }
         int rc = gemm_nt(a, st);
         if (rc) return rc;
     }
     if (r > 0) {
-        GemmTnArgs t;  // dB += dy^T xa
-        t.U = (const bf16_t*)dy; t.ldu = N; t.V = (const bf16_t*)xa; t.ldv = r; t.C = grad_b; t.ldc = r; t.M = M; t.P = N; t.Q = r;
+        GemmTnArgs t;  // dB += dy^T xa   (xa = hi + lo planes)
+        t.U = (const bf16_t*)dy; t.ldu = N; t.V = (const bf16_t*)xa; t.ldv = 3 * r; t.v_fold = r; t.C = grad_b; t.ldc = r; t.M = M; t.P = N; t.Q = r;
         int rc = gemm_tn(t, st);
         if (rc) return rc;
         GemmTnArgs u;  // dA += dxa^T x
-        u.U = (const bf16_t*)dxa_ws; u.ldu = r; u.V = (const bf16_t*)x; u.ldv = K; u.C = grad_a; u.ldc = K; u.M = M; u.P = r; u.Q = K;
+        u.U = (const bf16_t*)dxa_ws; u.ldu = 3 * r; u.u_fold = r; u.V = (const bf16_t*)x; u.ldv = K; u.C = grad_a; u.ldc = K; u.M = M; u.P = r; u.Q = K;
         rc = gemm_tn(u, st);
         if (rc) return rc;
     }
     return 0;
+}
+
+int ftmi_norm_modulate_fwd(const void* x, const void* shift, const void* onep, long mod_bstride, void* y, int rows, int rows_per_batch, int D,
+                           float eps, int layernorm, ftmi_stream stream) {
+    if (!x || !shift || !onep || !y || rows <= 0 || rows_per_batch <= 0) return set_error(FTMI_ERR_INVALID, "ftmi_norm_modulate_fwd: bad argument");
+    return norm_modulate_fwd((const bf16_t*)x, (const bf16_t*)shift, (const bf16_t*)onep, mod_bstride, (bf16_t*)y, rows, rows_per_batch, D, eps, layernorm,
+                             (hipStream_t)stream);
+}
+
+int ftmi_norm_modulate_bwd(const void* x, const void* dy, const void* onep, long mod_bstride, const void* dres, void* dx, int rows,
+                           int rows_per_batch, int D, float eps, int layernorm, ftmi_stream stream) {
+    if (!x || !dy || !onep || !dx || rows <= 0 || rows_per_batch <= 0) return set_error(FTMI_ERR_INVALID, "ftmi_norm_modulate_bwd: bad argument");
+    return norm_modulate_bwd((const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)onep, mod_bstride, (const bf16_t*)dres, (bf16_t*)dx, rows, rows_per_batch, D,
+                             eps, layernorm, (hipStream_t)stream);
+}
+
+int ftmi_qknorm_rope_fwd(const void* x, long ldx, const void* w, const float* cos_t, const float* sin_t, void* y, long ldy, int rows,
+                         int rows_per_batch, int D, float eps, ftmi_stream stream) {
+    if (!x || !w || !y || rows <= 0 || rows_per_batch <= 0 || (!cos_t) != (!sin_t)) return set_error(FTMI_ERR_INVALID, "ftmi_qknorm_rope_fwd: bad argument");
+    return qknorm_rope_fwd((const bf16_t*)x, ldx, (const bf16_t*)w, cos_t, sin_t, (bf16_t*)y, ldy, rows, rows_per_batch, D, eps, (hipStream_t)stream);
+}
+
+int ftmi_qknorm_rope_bwd(const void* x, long ldx, const void* w, const float* cos_t, const float* sin_t, const void* dy, long lddy, void* dx,
+                         long lddx, int rows, int rows_per_batch, int D, float eps, ftmi_stream stream) {
+    if (!x || !w || !dy || !dx || rows <= 0 || rows_per_batch <= 0 || (!cos_t) != (!sin_t)) return set_error(FTMI_ERR_INVALID, "ftmi_qknorm_rope_bwd: bad argument");
+    return qknorm_rope_bwd((const bf16_t*)x, ldx, (const bf16_t*)w, cos_t, sin_t, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, rows, rows_per_batch, D, eps,
+                           (hipStream_t)stream);
 }
 
 size_t ftmi_ltx_workspace_bytes(const ftmi_ltx_config* cfg) { return cfg ? ltx_workspace_bytes(*cfg) : 0; }
@@ -287,14 +316,14 @@ int ftmi_ltx_workspace_offset(const ftmi_ltx_config* cfg, const char* name, int 
 int ftmi_ltx_forward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* x_t, const void* text, const float* key_bias,
                      const float* sigma, void* pred, void* ws, size_t ws_bytes, ftmi_stream stream) {
     if (!cfg || !w || !x_t || !text || !sigma || !pred || !ws) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_forward: null argument");
-    if (cfg->r > 0 && (!w->lora_a || !w->lora_b)) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_forward: LoRA working copies missing");
+    if (cfg->r > 0 && (!w->lora_a_sp || !w->lora_b_ext)) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_forward: LoRA working copies missing");
     return ltx_forward(*cfg, *w, (const bf16_t*)x_t, (const bf16_t*)text, key_bias, sigma, (bf16_t*)pred, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int ftmi_ltx_backward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias, const void* dpred,
                       float* grad_a, float* grad_b, void* ws, size_t ws_bytes, ftmi_stream stream) {
     if (!cfg || !w || !dpred || !ws) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_backward: null argument");
-    if (cfg->r > 0 && (!grad_a || !grad_b || !w->lora_at || !w->lora_bt || !w->lora_at_qkv))
+    if (cfg->r > 0 && (!grad_a || !grad_b || !w->lora_at_ext || !w->lora_bt_sp || !w->lora_at_qkv_ext))
         return set_error(FTMI_ERR_INVALID, "ftmi_ltx_backward: LoRA gradient buffers / working copies missing");
     return ltx_backward(*cfg, *w, (const bf16_t*)text, key_bias, (const bf16_t*)dpred, grad_a, grad_b, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -323,19 +352,36 @@ int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, floa
     return adamw_clip_step(params, grads, exp_avg, exp_avg_sq, n, scratch, max_norm, lr, beta1, beta2, eps, weight_decay, step, grad_norm_out, st);
 }
 
-int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a, void* lora_at, void* lora_b, void* lora_bt, void* lora_at_qkv,
-                      int L, int r, int D, ftmi_stream stream) {
-    if (!a_f32 || !b_f32 || !lora_a || !lora_at || !lora_b || !lora_bt || !lora_at_qkv) return set_error(FTMI_ERR_INVALID, "ftmi_lora_refresh: null argument");
+int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
+                      void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream) {
+    if (!a_f32 || !b_f32 || !lora_a_sp || !lora_bt_sp || !lora_b_ext || !lora_at_ext || !lora_at_qkv_ext)
+        return set_error(FTMI_ERR_INVALID, "ftmi_lora_refresh: null argument");
     hipStream_t st = (hipStream_t)stream;
     const long per = (long)r * D;
-    int rc = lora_refresh(a_f32, (bf16_t*)lora_a, (bf16_t*)lora_at, r, D, L * 8, per, per, per, st);
+    LoraSplitArgs a;  // A [r, D]: row planes of A, column planes of A^T
+    a.w = a_f32; a.rows = r; a.cols = D; a.nmat = L * 8; a.in_bstride = per;
+    a.sp = (bf16_t*)lora_a_sp; a.sp_bstride = 2 * per;
+    a.t_ext = (bf16_t*)lora_at_ext; a.t_ext_bstride = 3 * per; a.ld_t_ext = 3L * r;
+    int rc = lora_split(a, st);
     if (rc) return rc;
-    rc = lora_refresh(b_f32, (bf16_t*)lora_b, (bf16_t*)lora_bt, D, r, L * 8, per, per, per, st);
+    LoraSplitArgs b;  // B [D, r]: column planes of B, row planes of B^T
+    b.w = b_f32; b.rows = D; b.cols = r; b.nmat = L * 8; b.in_bstride = per;
+    b.ext = (bf16_t*)lora_b_ext; b.ext_bstride = 3 * per; b.ld_ext = 3L * r;
+    b.t_sp = (bf16_t*)lora_bt_sp; b.t_sp_bstride = 2 * per;
+    rc = lora_split(b, st);
     if (rc) return rc;
-    // [A_q;A_k;A_v] (3r x D, contiguous inside a block's 8 adapters) -> (D x 3r)
-    rc = lora_refresh(a_f32, nullptr, (bf16_t*)lora_at_qkv, 3 * r, D, L, 8 * per, 0, 3 * per, st);
-    if (rc) return rc;
-    return 0;
+    LoraSplitArgs q;  // adapters 0,1,2 of every block side by side: [D, 9r]
+    q.w = a_f32; q.rows = r; q.cols = D; q.nmat = L * 3; q.inner_n = 3; q.in_bstride = 8 * per; q.in_istride = per;
+    q.t_ext = (bf16_t*)lora_at_qkv_ext; q.t_ext_bstride = 9 * per; q.t_ext_istride = 3L * r; q.ld_t_ext = 9L * r;
+    return lora_split(q, st);
+}
+
+int ftmi_lora_split(const float* w, int rows, int cols, void* sp, void* ext, void* t_sp, void* t_ext, ftmi_stream stream) {
+    if (!w) return set_error(FTMI_ERR_INVALID, "ftmi_lora_split: null argument");
+    LoraSplitArgs a;
+    a.w = w; a.rows = rows; a.cols = cols; a.nmat = 1;
+    a.sp = (bf16_t*)sp; a.ext = (bf16_t*)ext; a.ld_ext = 3L * cols; a.t_sp = (bf16_t*)t_sp; a.t_ext = (bf16_t*)t_ext; a.ld_t_ext = 3L * rows;
+    return lora_split(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

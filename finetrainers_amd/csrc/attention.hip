@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
-    const float* kbias = a.kbias ? a.kbias + (long)b * a.Sk : nullptr;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
 
     float m_run = -INFINITY, l_run = 0.f;
     s16x8 ones;
@@ -193,13 +193,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             mx *= sl;  // sl > 0
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // m_new == -inf only while every key seen so far carries a -inf bias: subtracting -inf would give NaN, and those keys must
+        // contribute exp2(-inf) = 0, so the exponent is taken against 0 instead (alpha = exp2(-inf - 0) = 0 scales the empty state)
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = fast_exp2(m_run - m_new);
+        const float m_eff = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run - m_eff);
 #pragma unroll
         for (int js = 0; js < 2; ++js)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                st[js][r] = HAS_KB ? fast_exp2(st[js][r] - m_new) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_new));
+                st[js][r] = HAS_KB ? fast_exp2(st[js][r] - m_eff) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_eff));
         m_run = m_new;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         kf[c] = *reinterpret_cast<const s16x8*>(kp + c * 16 + g * 8);
         vf[c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
     }
-    const float bias_j = a.kbias ? a.kbias[(long)b * a.Sk + jc] * kLog2e : 0.f;
+    const float bias_j = a.kbias ? a.kbias[(long)b * a.kb_sb + (long)h * a.kb_sh + jc] * kLog2e : 0.f;
 
     const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
     const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
         kf[c] = *reinterpret_cast<const s16x8*>(kp + c * 16 + g * 8);
         vf[c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
     }
-    const float bias_j = a.kbias ? a.kbias[(long)b * a.Sk + jc] * kLog2e : 0.f;
+    const float bias_j = a.kbias ? a.kbias[(long)b * a.kb_sb + (long)h * a.kb_sh + jc] * kLog2e : 0.f;
 
     const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
     const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
     const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
-    const float* kbias = a.kbias ? a.kbias + (long)b * a.Sk : nullptr;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
 
     f32x16 dqt[2];
 #pragma unroll

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "ltx_dit.hip", "api.hip"]
-HEADERS = ["common.hip.h", "kernels.h", "gemm_experimental.hip.h", os.path.join("..", "..", "include", "ftmi355.h")]
+HEADERS = ["common.hip.h", "kernels.h", os.path.join("..", "..", "include", "ftmi355.h")]
 LIB = os.path.join(HERE, "..", "libftmi355.so")
 FLAGS = [
     "--offload-arch=gfx950",
@@ -24,6 +24,11 @@ FLAGS = [
 # dS products read/modify them with VALU every tile, and the accumulator-file round trip (v_accvgpr_read/write) was 25-35 %
 # of the loop's instructions in a VALU-bound kernel.
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# FTMI_EXPERIMENTAL=1: also compile the research K loops / timing experiments of tools/gemm_experimental.hip.h (tools/bench_gemm.py,
+# tools/ab_variants.sh).  Never set for the product library.
+if os.environ.get("FTMI_EXPERIMENTAL", "0") not in ("", "0"):
+    FLAGS.append("-DFTMI_EXPERIMENTAL")
+    HEADERS.append(os.path.join("..", "..", "tools", "gemm_experimental.hip.h"))
 
 
 def _hipcc() -> str:

@@ -233,117 +233,6 @@ FTMI_DEVICE void nt_run_k2_seg(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* 
 #endif
 }
 
-#include "gemm_experimental.hip.h"
-
-// ------------------------------------------------------------------------------------------------
-// Hand-placed K loop (inline asm, one statement per instruction so hipcc still allocates the registers but cannot
-// re-order the stream).  tools/probe_mfma_dma.hip shows what the hardware allows: with ONE memory instruction behind
-// every MFMA a 256 x 256 tile's mix (per wave and 64 of K: 32 MFMA, 24 ds_read_b128, 8 direct-to-LDS loads) runs at the
-// MFMA-only rate, whereas the compiler-scheduled loops above lose a third.  Structure = nt_run_k_ring3 (4-stage ring of
-// BK = 32 tiles, fragments of tile kt+1 read while tile kt's MFMAs issue, loads of tile kt+4 behind them, vmcnt(8) so
-// two tiles stay in flight across the single barrier); written for 256 x 256 x 32, 8 waves (2 x 4).
-//   per tile and wave: MFMA_0 R_0  MFMA_1 R_1 ... MFMA_11 R_11  MFMA_12 D_0 ... MFMA_15 D_3  lgkmcnt(0) vmcnt(8) barrier
-// The lgkmcnt(0) sits at the END of the body (the last read was issued four MFMAs earlier) so that any register copy the
-// compiler places on the loop back-edge sees landed data.  Consecutive MFMAs use different accumulators (8 in rotation),
-// so no MFMA -> MFMA hazard needs software wait states; the caller pads before its first ordinary read of the accumulators.
-// ------------------------------------------------------------------------------------------------
-FTMI_DEVICE void asm_ds_read_b128(s16x8& dst, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
-FTMI_DEVICE void asm_mfma(f32x16& c, const s16x8& a, const s16x8& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
-
-template <int BM, int BN, int BK, int WM, int WN>
-FTMI_DEVICE void nt_run_k_asm(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
-                              int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    using T = NtTile<BM, BN, BK, WM, WN>;
-    constexpr int NS = 4;
-    static_assert(BK == 32 && T::TM == 4 && T::TN == 2 && T::NW == 8, "written for 256 x 256 x 32 tiles, 8 waves (2 x 4)");
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, g = lane >> 5;
-    constexpr int XI = BM * BK * 2 / 1024 / T::NW;  // 2
-    constexpr int WI = BN * BK * 2 / 1024 / T::NW;  // 2
-    constexpr int LPT = XI + WI;                    // 4 loads per wave and tile
-    static_assert(LPT == 4, "load schedule below assumes 4 loads per wave and tile");
-
-    uint32_t off[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const bool isx = i < XI;
-        const int blk = isx ? wave * XI + i : wave * WI + (i - XI);
-        const int row = blk * T::RPI + lane / T::CPR, cs = lane % T::CPR;
-        const int c = cs ^ ((row >> 2) & 3);
-        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
-    }
-    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
-    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    // LDS destination of load i inside a stage, and per-lane fragment read addresses inside a stage
-    uint32_t ddst[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) ddst[i] = lds0 + (i < XI ? (wave * XI + i) * 1024 : BM * BK * 2 + (wave * WI + (i - XI)) * 1024);
-    uint32_t ra[12];  // read i: i < 4: W fragment (kk = i / 2, tn = i % 2); else X fragment (kk = (i-4) / 4, tm = (i-4) % 4)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = lds0 + BM * BK * 2 + nt_lds_off<BK>((wn * T::TN + (i & 1)) * 32 + li, (i >> 1) * 2 + g);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ra[4 + i] = lds0 + nt_lds_off<BK>((wm * T::TM + (i & 3)) * 32 + li, (i >> 2) * 2 + g);
-
-    auto dma = [&](int i, int tile, int buf) {
-        const int soff = min(tile, nk - 1) * BK * 2;
-        const uint32_t dst = ddst[i] + buf * T::STAGE;
-        if (i < XI)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(xrs), "s"(soff) : "memory", "m0");
-        else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(wrs), "s"(soff) : "memory", "m0");
-    };
-    s16x8 wf[2][2][2], xf[2][2][4];  // [parity][kk][tile]
-    auto rd = [&](auto P, int i, uint32_t stage_off) {
-        constexpr int par = decltype(P)::value;
-        const uint32_t a = ra[i] + stage_off;
-        if (i < 4)
-            asm_ds_read_b128(wf[par][i >> 1][i & 1], a);
-        else
-            asm_ds_read_b128(xf[par][(i - 4) >> 2][(i - 4) & 3], a);
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-
-    // prologue (as nt_run_k_ring3): tiles 0..2 in flight, 0 and 1 landed, fragments of tile 0 in registers, then tile 3
-#pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) dma(i, t, t);
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 12; ++i) rd(P0{}, i, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) dma(i, NS - 1, NS - 1);
-
-    int bnext = 1, bfree = 0;
-    auto body = [&](int kt, auto P) {
-        constexpr int par = decltype(P)::value;
-        using PN = std::integral_constant<int, par ^ 1>;
-        const uint32_t so = bnext * T::STAGE;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int kk = i >> 3, tn = (i >> 2) & 1, tm = i & 3;
-            asm_mfma(acc[tn][tm], wf[par][kk][tn], xf[par][kk][tm]);
-            if (i < 12) rd(PN{}, i, so);
-            else dma(i - 12, kt + NS, bfree);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        bfree = bnext;
-        bnext = (bnext == NS - 1) ? 0 : bnext + 1;
-    };
-    for (int kt = 0; kt < nk; kt += 2) {
-        body(kt, P0{});
-        if (kt + 1 < nk) body(kt + 1, P1{});
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // K-loop selector of gemm_nt_kernel (template parameter LOOP).  KL_GEN2_BUF is the production loop; the others are kept as
 // bit-identical A/B partners (tools/bench_gemm.py, tools/ab_variants.sh) and as the timing experiments quoted in DESIGN.md.
@@ -373,80 +262,17 @@ enum : int {
 };
 constexpr int kl_lds_stages(int loop) { return (loop == KL_RING4 || loop == KL_RING4_PIPE || loop == KL_ASM_RING4) ? 4 : (loop == KL_RING3) ? 3 : (loop == KL_PINGPONG) ? 4 : 2; }
 
-// Hand-placed twin of the production 2-stage loop on 256 x 256 x 64 tiles (8 waves): per K-tile and wave 32 MFMAs; the 8 loads of
-// tile kt+1 sit behind the first MFMAs of k-slices 0 and 1 (so they have two slices to land), the 6 fragment reads of slice
-// kk+1 behind the MFMAs of slice kk, one vmcnt(0) + barrier per tile.
-template <int BM, int BN, int BK, int WM, int WN>
-FTMI_DEVICE void nt_run_k_asm2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
-                               int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    using T = NtTile<BM, BN, BK, WM, WN>;
-    static_assert(BK == 64 && T::TM == 4 && T::TN == 2 && T::NW == 8, "written for 256 x 256 x 64 tiles, 8 waves (2 x 4)");
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, g = lane >> 5;
-    constexpr int XI = BM * BK * 2 / 1024 / T::NW, WI = BN * BK * 2 / 1024 / T::NW, LPT = XI + WI;  // 4 + 4
-    static_assert(LPT == 8, "load schedule below assumes 8 loads per wave and tile");
-    uint32_t off[LPT], ddst[LPT];
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const bool isx = i < XI;
-        const int blk = isx ? wave * XI + i : wave * WI + (i - XI);
-        const int row = blk * T::RPI + lane / T::CPR, cs = lane % T::CPR;
-        const int c = cs ^ ((row >> 1) & 7);
-        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
-        ddst[i] = lds0 + (isx ? blk * 1024 : BM * BK * 2 + blk * 1024);
-    }
-    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
-    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
-    auto dma = [&](int i, int tile, uint32_t stage_off) {
-        const int soff = min(tile, nk - 1) * BK * 2;
-        const uint32_t dst = ddst[i] + stage_off;
-        if (i < XI)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(xrs), "s"(soff) : "memory", "m0");
-        else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(wrs), "s"(soff) : "memory", "m0");
-    };
-    // fragment read addresses inside a stage: [kk][6] = W tn 0,1 then X tm 0..3
-    uint32_t ra[4][6];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) ra[kk][t] = lds0 + BM * BK * 2 + nt_lds_off<BK>((wn * T::TN + t) * 32 + li, kk * 2 + g);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) ra[kk][2 + t] = lds0 + nt_lds_off<BK>((wm * T::TM + t) * 32 + li, kk * 2 + g);
-    }
-    s16x8 fr[2][6];  // [slice parity][W0, W1, X0..X3]
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) dma(i, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const uint32_t so = (kt & 1) * T::STAGE, sn = ((kt & 1) ^ 1) * T::STAGE;
-#pragma unroll
-        for (int t = 0; t < 6; ++t) asm_ds_read_b128(fr[0][t], ra[0][t] + so);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int tn = i >> 2, tm = i & 3;
-                asm_mfma(acc[tn][tm], fr[kk & 1][tn], fr[kk & 1][2 + tm]);
-                if (kk < 3 && i < 6) asm_ds_read_b128(fr[(kk + 1) & 1][i], ra[kk + 1][i] + so);
-                if (kk < 2 && i >= 4) dma(kk * 4 + (i - 4), kt + 1, sn);          // behind MFMAs 4..7: loads 0-3 (kk 0), 4-7 (kk 1)
-            }
-            if (kk < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+// Research scaffolding (alternative K loops, hand-placed asm loops, timing experiments with deliberately wrong results) lives in
+// tools/gemm_experimental.hip.h and is compiled only with -DFTMI_EXPERIMENTAL (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build):
+// the product library ships the production loop only.
+#ifdef FTMI_EXPERIMENTAL
+#include "../../tools/gemm_experimental.hip.h"
 #endif
-}
 
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int LOOP>
 FTMI_DEVICE void nt_k_loop(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M,
                            const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+#ifdef FTMI_EXPERIMENTAL
     if constexpr (LOOP == KL_ASM_2STAGE)
         nt_run_k_asm2<BM, BN, BK, WM, WN>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
     else if constexpr (LOOP == KL_ASM_RING4)
@@ -471,9 +297,13 @@ FTMI_DEVICE void nt_k_loop(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem
     else
         nt_run_k<BM, BN, BK, WM, WN, GLDS, LOOP == KL_2STAGE_PIN,
                  (LOOP == KL_DBG_NOLOAD ? 1 : LOOP == KL_DBG_NOMFMA ? 2 : LOOP == KL_DBG_LDSONLY ? 3 : 0)>(acc, smem, X, ldx, m0, M, W, ldw, 0, nk, tid);
+#else
+    static_assert(LOOP == KL_GEN2_BUF, "the product build ships the production K loop only");
+    nt_run_k2<BM, BN, BK, WM, WN, 2, false, true>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
+#endif
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int LOOP = KL_2STAGE>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int LOOP = KL_GEN2_BUF>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs p) {
     using T = NtTile<BM, BN, BK, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -739,7 +569,7 @@ static int launch_nt2(const GemmNtArgs& a, hipStream_t st) {
     return a.K2 > 0 ? launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, true, LOOP>(a, st)
                     : launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI, false, LOOP>(a, st);
 }
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int LOOP = KL_2STAGE>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int LOOP = KL_GEN2_BUF>
 static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
     switch (a.epi) {
         case EPI_STORE: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE, LOOP>(a, st);
@@ -871,13 +701,15 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
         for (int i = 0; i < 8; ++i) {
             const int row = i * 8 + r8;
             const int c = cs ^ ((row >> 1) & 7);
-            off[4 + i] = (uint32_t)(((long)(n0 + row) * p.ldw + k0 + c * 8) * 2);
+            off[4 + i] = (uint32_t)(((long)row * p.ldw + k0 + c * 8) * 2);
         }
     }
+    // first row of this tile's 64 weight rows (rows may live in strided groups; a tile never straddles a group)
+    const bf16_t* Wt = p.w_grp_n > 0 ? p.W + (long)(n0 / p.w_grp_n) * p.w_grp_stride + (long)(n0 % p.w_grp_n) * p.ldw : p.W + (long)n0 * p.ldw;
     auto issue = [&](int ck) {
         char* st = ring + (ck % NST) * CH;
         const char* xb = (const char*)X + (long)ck * 128;
-        const char* wb = (const char*)p.W + (long)ck * 128;
+        const char* wb = (const char*)Wt + (long)ck * 128;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
@@ -935,6 +767,27 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
     __syncthreads();
     const int m = m0 + li;
     if (m >= p.M) return;
+    if (p.split_r > 0) {
+        // the tile's 64 weight rows are the hi plane (sub-tile 0) and the lo plane (sub-tile 1) of 32 fp32 rows: t = alpha * (x.hi + x.lo)
+        // in fp32, stored as the three bf16 planes (hi(t), lo(t), hi(t)) of the K-extension operand
+        u32x2 hi, lo;
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave * 4 + j;
+            auto R = [&](int w, int tn) { return red[((w * 2 + tn) * 16 + r) * 64 + lane]; };
+            t[j] = (((R(0, 0) + R(1, 0)) + (R(2, 0) + R(3, 0))) + ((R(0, 1) + R(1, 1)) + (R(2, 1) + R(3, 1)))) * p.alpha;
+        }
+        const float h0 = rbf(t[0]), h1 = rbf(t[1]), h2 = rbf(t[2]), h3 = rbf(t[3]);
+        hi[0] = pack2bf(h0, h1); hi[1] = pack2bf(h2, h3);
+        lo[0] = pack2bf(t[0] - h0, t[1] - h1); lo[1] = pack2bf(t[2] - h2, t[3] - h3);
+        const int o = n0 / 2 + wave * 8 + 4 * g;  // output index (32 per tile)
+        bf16_t* dst = p.out + (long)m * p.ldo + (long)(o / p.split_r) * 3 * p.split_r + o % p.split_r;
+        *reinterpret_cast<u32x2*>(dst) = hi;
+        *reinterpret_cast<u32x2*>(dst + p.split_r) = lo;
+        *reinterpret_cast<u32x2*>(dst + 2 * p.split_r) = hi;
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
         float v[4];
@@ -970,6 +823,18 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (a.N % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: N must be a multiple of 64");
     if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 8) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
+    if (a.split_r > 0) {  // fp32-equivalent LoRA down-projection: always the LDS-ring skinny kernel (any M, any N, grouped W allowed)
+        if (a.K2 != 0 || a.epi != EPI_STORE || a.bias || a.K % 256 != 0 || a.split_r % 64 != 0 || (a.N / 2) % a.split_r != 0)
+            return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: split (hi/lo) mode needs a plain store, K % 256 == 0 and whole groups of split_r outputs");
+        if ((a.w_grp_n > 0 && a.w_grp_n % 64) || (a.xk_grp_n > 0 && a.xk_grp_n % 64)) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
+        ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
+        constexpr int kSmem = 4 * 3 * 12288;
+        static const bool attr_ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
+        if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL(gemm_nt_skinny2_kernel<0>, dim3(((a.M + 31) / 32) * (a.N / 64)), dim3(256), kSmem, st, a);
+        return check_launch("gemm_nt_skinny");
+    }
     if (a.variant != 0 && a.N <= 256 && a.K2 == 0 && a.epi == EPI_STORE && a.M >= 512 && a.w_grp_n == 0 && (a.xk_grp_n == 0 || a.xk_grp_n % 64 == 0)) {
         ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
         static const int ks = env_int("FTMI_SKINNY_KS", 2);  // 2 = LDS-ring kernel, 4 / 8 = direct-gather kernel with a 4- / 8-way K split
@@ -1034,6 +899,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
                 }
             }
         }
+#ifdef FTMI_EXPERIMENTAL
         switch (variant) {
             case 0: return launch_nt<128, 128, 64, 2, 2, false, 1>(a, st);
             case 2: return launch_nt<128, 128, 32, 2, 2, true, 1>(a, st);
@@ -1078,8 +944,15 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             default: return launch_nt<128, 128, 64, 2, 2, true, 1>(a, st);
         }
     }
-    if (a.variant == 0) return launch_nt<128, 64, 64, 2, 2, false, 1>(a, st);
-    return launch_nt<128, 64, 64, 2, 2, true, 1>(a, st);
+#else
+        switch (variant) {
+            case 44: return launch_nt<128, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 128 x 128 tiles (few rows)
+            case 47: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 8 waves x (128 x 64)
+            default: return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 42: 192 x 128, 2 workgroups per CU
+        }
+    }
+#endif
+    return launch_nt<128, 64, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // N % 128 != 0
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1110,7 +983,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     const int s_end = min(nsteps_total, s_begin + a.msteps_per_split);
     if (s_begin >= s_end) return;
 
-    const bf16_t* U = a.U + (long)blockIdx.y * a.u_bstride + p0;
+    const bf16_t* U = a.U + (long)blockIdx.y * a.u_bstride + (a.u_grp_p > 0 ? (long)(p0 / a.u_grp_p) * a.u_grp_stride + p0 % a.u_grp_p : (long)p0);
     const bf16_t* V = a.V + (long)blockIdx.y * a.v_bstride + q0;
     float* C = a.C + (long)blockIdx.y * a.c_bstride;
     if (a.v_grp_p > 0) V += (long)(p0 / a.v_grp_p) * a.v_grp_stride;
@@ -1209,13 +1082,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 // one is multiplied, ONE barrier per step.  (The first generation issues the loads of 4 steps together and only then starts
 // consuming them -- nothing is in flight while it computes -- and ran at 2.8 TB/s of the 6.5 TB/s a copy reaches.)
 // The loads go through inline asm for the same reason as in attention.hip (transposing LDS reads have no alias information).
-template <int BP, int BQ>
+// FU / FV = 2: the U / V operand is given as two bf16 column planes (hi, lo) a.u_fold / a.v_fold elements apart (an fp32 matrix split in
+// two); both planes are staged next to the other operand's tile and multiplied into the same accumulators, so the large operand is
+// still read once.
+template <int BP, int BQ, int FU, int FV>
 __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
     constexpr int WP = 2, WQ = 2, NS = 3;
     constexpr int TP = BP / WP / 32, TQ = BQ / WQ / 32;
-    constexpr int NU = BP / 64, NV = BQ / 64;     // sub-tiles per step
-    constexpr int STAGE = (NU + NV) * 8192;
-    constexpr int LPW = 2 * (NU + NV);            // loads per wave and step
+    constexpr int NU = BP / 64, NV = BQ / 64;     // sub-tiles per step and plane
+    constexpr int STAGE = (NU * FU + NV * FV) * 8192;
+    constexpr int LPW = 2 * (NU * FU + NV * FV);  // loads per wave and step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave / WQ, wq = wave % WQ;
@@ -1231,7 +1107,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
     const int n = min(nsteps_total, s_begin + a.msteps_per_split) - s_begin;
     if (n <= 0) return;
 
-    const bf16_t* U = a.U + (long)blockIdx.y * a.u_bstride + p0;
+    const bf16_t* U = a.U + (long)blockIdx.y * a.u_bstride + (a.u_grp_p > 0 ? (long)(p0 / a.u_grp_p) * a.u_grp_stride + p0 % a.u_grp_p : (long)p0);
     const bf16_t* V = a.V + (long)blockIdx.y * a.v_bstride + q0;
     float* C = a.C + (long)blockIdx.y * a.c_bstride;
     if (a.v_grp_p > 0) V += (long)(p0 / a.v_grp_p) * a.v_grp_stride;
@@ -1248,9 +1124,13 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
     auto stage = [&](int k) {  // step k of this workgroup -> ring slot k % NS
         char* st = smem + (k % NS) * STAGE;
 #pragma unroll
-        for (int t = 0; t < NU; ++t) tile_dma_issue(ud, U + t * 64, a.ldu, s_begin + k, false, st + t * 8192, wave);
+        for (int f = 0; f < FU; ++f)
 #pragma unroll
-        for (int t = 0; t < NV; ++t) tile_dma_issue(vd, V + t * 64, a.ldv, s_begin + k, false, st + (NU + t) * 8192, wave);
+            for (int t = 0; t < NU; ++t) tile_dma_issue(ud, U + t * 64 + f * a.u_fold, a.ldu, s_begin + k, false, st + (f * NU + t) * 8192, wave);
+#pragma unroll
+        for (int f = 0; f < FV; ++f)
+#pragma unroll
+            for (int t = 0; t < NV; ++t) tile_dma_issue(vd, V + t * 64 + f * a.v_fold, a.ldv, s_begin + k, false, st + (FU * NU + f * NV + t) * 8192, wave);
     };
     stage(0);
     if (n > 1) stage(1);
@@ -1260,25 +1140,33 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
         __syncthreads();  // step k landed for every wave; everyone is done with step k-1, whose slot the next load reuses
         if (k + 2 < n) stage(k + 2);
         const char* ut = smem + (k % NS) * STAGE;
-        const char* vt = ut + NU * 8192;
+        const char* vt = ut + FU * NU * 8192;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int rowa = kk * 16 + 8 * g, rowb = rowa + 4;  // k-group g reduces over tokens kk*16 + 8g + {0..7}
-            s16x8 uf[TP], vf[TQ];
+            s16x8 uf[FU][TP], vf[FV][TQ];
 #pragma unroll
-            for (int i = 0; i < TP; ++i) {
-                const int pc = (wp * TP + i) * 32;
-                uf[i] = lds_tr_frag(ut + (pc >> 6) * 8192, pc & 63, rowa, rowb, lane);
-            }
+            for (int f = 0; f < FU; ++f)
 #pragma unroll
-            for (int j = 0; j < TQ; ++j) {
-                const int qc = (wq * TQ + j) * 32;
-                vf[j] = lds_tr_frag(vt + (qc >> 6) * 8192, qc & 63, rowa, rowb, lane);
-            }
+                for (int i = 0; i < TP; ++i) {
+                    const int pc = (wp * TP + i) * 32;
+                    uf[f][i] = lds_tr_frag(ut + (f * NU + (pc >> 6)) * 8192, pc & 63, rowa, rowb, lane);
+                }
 #pragma unroll
-            for (int i = 0; i < TP; ++i)
+            for (int f = 0; f < FV; ++f)
 #pragma unroll
-                for (int j = 0; j < TQ; ++j) acc[i][j] = mfma32(uf[i], vf[j], acc[i][j]);
+                for (int j = 0; j < TQ; ++j) {
+                    const int qc = (wq * TQ + j) * 32;
+                    vf[f][j] = lds_tr_frag(vt + (f * NV + (qc >> 6)) * 8192, qc & 63, rowa, rowb, lane);
+                }
+#pragma unroll
+            for (int fu = 0; fu < FU; ++fu)
+#pragma unroll
+                for (int fv = 0; fv < FV; ++fv)
+#pragma unroll
+                    for (int i = 0; i < TP; ++i)
+#pragma unroll
+                        for (int j = 0; j < TQ; ++j) acc[i][j] = mfma32(uf[fu][i], vf[fv][j], acc[i][j]);
         }
     }
 #pragma unroll
@@ -1294,12 +1182,19 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
         }
 }
 
+template <int BP, int BQ, int FU, int FV>
+static int launch_tn2f(const GemmTnArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int kSmem = 3 * ((BP / 64) * FU + (BQ / 64) * FV) * 8192;
+    static const bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel<BP, BQ, FU, FV>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess);
+    if (!attr) return set_error(FTMI_ERR_LAUNCH, "gemm_tn: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL((gemm_tn2_kernel<BP, BQ, FU, FV>), grid, dim3(256), kSmem, st, a);
+    return 0;
+}
 template <int BP, int BQ>
-static void launch_tn2(const GemmTnArgs& a, dim3 grid, hipStream_t st) {
-    constexpr int kSmem = 3 * (BP / 64 + BQ / 64) * 8192;
-    static const bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel<BP, BQ>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess);
-    (void)attr;
-    hipLaunchKernelGGL((gemm_tn2_kernel<BP, BQ>), grid, dim3(256), kSmem, st, a);
+static int launch_tn2(const GemmTnArgs& a, dim3 grid, hipStream_t st) {
+    if (a.u_fold) return launch_tn2f<BP, BQ, 2, 1>(a, grid, st);
+    if (a.v_fold) return launch_tn2f<BP, BQ, 1, 2>(a, grid, st);
+    return launch_tn2f<BP, BQ, 1, 1>(a, grid, st);
 }
 
 int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
@@ -1326,18 +1221,27 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     const dim3 grid(tiles * nsplit, nb);
     ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q * nb, st);
     static const int tn_gen = env_int("FTMI_TN_GEN", 2);
+    if (a.u_fold && a.v_fold) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: only one operand may be a (hi, lo) pair");
+    if (a.u_grp_p > 0 && a.u_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: U group width vs tile");
     if (tn_gen == 2 && a.M % 64 == 0) {  // DMA-ring kernel (whole 64-token steps only)
-        if (wideP) launch_tn2<128, 64>(a, grid, st);
-        else if (wideQ) launch_tn2<64, 128>(a, grid, st);
-        else launch_tn2<64, 64>(a, grid, st);
-        return check_launch("gemm_tn");
+        int rc;
+        if (wideP) rc = launch_tn2<128, 64>(a, grid, st);
+        else if (wideQ) rc = launch_tn2<64, 128>(a, grid, st);
+        else rc = launch_tn2<64, 64>(a, grid, st);
+        return rc ? rc : check_launch("gemm_tn");
     }
-    if (wideP)
-        hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), 3 * 8192, st, a);
-    else if (wideQ)
-        hipLaunchKernelGGL((gemm_tn_kernel<64, 128>), grid, dim3(256), 3 * 8192, st, a);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, dim3(256), 2 * 8192, st, a);
+    // ragged token counts (tests, tiny clips): the register-staged kernel, one launch per plane of a folded operand
+    for (int f = 0; f < ((a.u_fold || a.v_fold) ? 2 : 1); ++f) {
+        GemmTnArgs b = a;
+        b.U = a.U + f * a.u_fold;
+        b.V = a.V + f * a.v_fold;
+        if (wideP)
+            hipLaunchKernelGGL((gemm_tn_kernel<128, 64>), grid, dim3(256), 3 * 8192, st, b);
+        else if (wideQ)
+            hipLaunchKernelGGL((gemm_tn_kernel<64, 128>), grid, dim3(256), 3 * 8192, st, b);
+        else
+            hipLaunchKernelGGL((gemm_tn_kernel<64, 64>), grid, dim3(256), 2 * 8192, st, b);
+    }
     return check_launch("gemm_tn");
 }
 

@@ -75,6 +75,11 @@ struct GemmNtArgs {
     long ldaux = 0;
     int epi = EPI_STORE;
     int variant = 0;  // 0 = register-staged tiles, 1 = direct global->LDS (BK64), 2/3 = BK32 direct-to-LDS
+    // fp32-equivalent LoRA down-projection (skinny kernel only).  split_r > 0: W holds 2N rows -- the bf16 hi and lo planes of an
+    // fp32 matrix interleaved in groups of 32 rows ([hi 0-31 | lo 0-31 | hi 32-63 | ...], N counts BOTH planes) -- the two partial
+    // products are added in fp32 and the fp32 result t is written as three bf16 column planes per group of split_r outputs:
+    // out[:, 3 split_r g + {0, split_r, 2 split_r} + i] = (hi(t), lo(t), hi(t)), the X2 operand layout of the K-extension.
+    int split_r = 0;
     // tile -> XCD rasterisation (filled by the launcher): the 8 XCDs form a map_gm x map_gn grid, each owning a
     // map_rm x map_rn rectangle of output tiles, so the tiles resident on one XCD share few operand panels in its L2
     int map_gm = 1, map_gn = 8, map_rm = 0, map_rn = 0;
@@ -91,6 +96,11 @@ struct GemmTnArgs {
     int M = 0, P = 0, Q = 0;
     int v_grp_p = 0;  // V column offset = (p0 / v_grp_p) * v_grp_stride
     long v_grp_stride = 0;
+    int u_grp_p = 0;  // U columns live in groups: column of p = (p / u_grp_p) * u_grp_stride + p % u_grp_p  (0 = contiguous)
+    long u_grp_stride = 0;
+    // fp32-equivalent operands: an operand given as bf16 (hi, lo) column planes u_fold / v_fold elements apart contributes
+    // hi^T.other + lo^T.other to the same C (at most one of the two may be folded)
+    long u_fold = 0, v_fold = 0;
     int msteps_per_split = 0;  // filled by the launcher
     float scale = 1.f;
     // batched form (blockIdx.y = batch index): element strides between consecutive problems (0 = shared operand)
@@ -112,7 +122,8 @@ struct AttnArgs {
     bf16_t* o = nullptr;  // forward output / backward input
     long o_sb = 0, o_sh = 0, o_ss = 0;
     float* lse2 = nullptr;        // [B, H, Sq] log2-domain log-sum-exp of the scaled scores
-    const float* kbias = nullptr;  // [B, Sk] additive key bias (natural units), may be null
+    const float* kbias = nullptr;  // additive key bias (natural units), may be null: element (b, h, j) at kbias[b * kb_sb + h * kb_sh + j]
+    long kb_sb = 0, kb_sh = 0;     // (kb_sh = 0: one bias row per sample, shared by the heads -- LTX's text mask)
     float scale = 0.125f;
     // backward only
     const bf16_t* dout = nullptr;
@@ -171,9 +182,23 @@ int small_linear(const bf16_t* x, const bf16_t* W, const bf16_t* bias, bf16_t* y
 int sumsq(const float* g, long n, float* out /* zeroed scalar */, hipStream_t st);
 int adamw_clip_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq_in, float max_norm, float lr,
                     float beta1, float beta2, float eps, float wd, int step, float* grad_norm_out, hipStream_t st);
-// bf16 working copies of a LoRA matrix W [rows, cols] fp32: W_bf [rows, cols] and W^T_bf [cols, rows]
-int lora_refresh(const float* w, bf16_t* w_bf, bf16_t* wt_bf, int rows, int cols, int nmat, long in_bstride, long same_bstride,
-                 long t_bstride, hipStream_t st);
+// bf16 (hi, lo) working copies of nmat fp32 matrices W [rows, cols] (hi = bf16(w), lo = bf16(w - hi); hi + lo carries 16 mantissa bits):
+//   sp  [2 rows, cols]   hi / lo planes of W interleaved in groups of 32 rows (operand of the split skinny GEMM)      (may be null)
+//   ext [rows, ld_ext]   [hi | hi | lo] along the columns, written at column offset ext_col0 (K-extension operand)   (may be null)
+//   t_sp [2 cols, rows], t_ext [cols, ld_t_ext]: the same two layouts of W^T                                            (may be null)
+struct LoraSplitArgs {
+    const float* w = nullptr;
+    int rows = 0, cols = 0, nmat = 0;
+    long in_bstride = 0;
+    bf16_t* sp = nullptr;    long sp_bstride = 0;
+    bf16_t* ext = nullptr;   long ext_bstride = 0, ld_ext = 0;
+    bf16_t* t_sp = nullptr;  long t_sp_bstride = 0;
+    bf16_t* t_ext = nullptr; long t_ext_bstride = 0, ld_t_ext = 0;
+    // matrices are numbered m = outer * inner_n + inner (inner_n = 0: flat): *_bstride applies per outer, *_istride per inner
+    int inner_n = 0;
+    long in_istride = 0, t_ext_istride = 0;
+};
+int lora_split(const LoraSplitArgs& a, hipStream_t st);
 // plain bf16 transpose [rows, cols] -> [cols, rows]
 int transpose_bf16(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t st);
 

@@ -27,7 +27,7 @@ struct WsLayout {
     // per-block backward stash: the dY / dXA operands of the LoRA weight gradients, consumed by batched launches at the end
     size_t g_o2, g_q2, g_o, g_qkv, dxa_o2, dxa_q2, dxa_o, dxa_qkv;
     // scratch
-    size_t s_n2, s_g, s_ln, s_dh0, s_dh1, s_d1, s_d2, s_d3, s_dqr, s_dkr, s_dbig, s_dqkv, s_dxa, s_delta, s_dkv2, s_dk2n;
+    size_t s_n2, s_g, s_ln, s_dh0, s_dh1, s_d1, s_d2, s_d3, s_dqr, s_dkr, s_dbig, s_delta;
 };
 
 struct Bump {
@@ -55,10 +55,10 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.hs = g.take((size_t)(c.L + 1) * M * D * e2);
     w.kv2_all = g.take(Mt * (size_t)c.L * 2 * D * e2);      // [Mt][L*2D]  (k | v per block)
     w.k2n_all = g.take(Mt * (size_t)c.L * D * e2);          // [Mt][L][D]
-    w.xa_kv2_all = g.take(Mt * (size_t)c.L * 2 * r * e2);   // [Mt][L*2r]
+    w.xa_kv2_all = g.take(Mt * (size_t)c.L * 2 * 3 * r * e2);   // [Mt][L][k|v][hi|lo|hi][r]
     w.g_kv2_all = g.take(Mt * (size_t)c.L * 2 * D * e2);
     w.g_k2n_all = g.take(Mt * (size_t)c.L * D * e2);
-    w.dxa_kv2_all = g.take(Mt * (size_t)c.L * 2 * r * e2);
+    w.dxa_kv2_all = g.take(Mt * (size_t)c.L * 2 * 3 * r * e2);
     Bump b;
     w.n1 = b.take(M * D * e2);
     w.qkv = b.take(M * 3 * D * e2);
@@ -66,25 +66,25 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.krot = b.take(M * D * e2);
     w.o1 = b.take(M * D * e2);
     w.lse1 = b.take((size_t)c.B * c.H * c.S * 4);
-    w.xa_qkv = b.take(M * 3 * r * e2);
-    w.xa_o = b.take(M * r * e2);
+    w.xa_qkv = b.take(M * 9 * r * e2);  // [M][q|k|v][hi|lo|hi][r]: fp32-equivalent s * x A^T as bf16 planes
+    w.xa_o = b.take(M * 3 * r * e2);
     w.h1 = b.take(M * D * e2);
     w.q2raw = b.take(M * D * e2);
     w.q2n = b.take(M * D * e2);
     w.o2 = b.take(M * D * e2);
     w.lse2 = b.take((size_t)c.B * c.H * c.S * 4);
-    w.xa_q2 = b.take(M * r * e2);
-    w.xa_o2 = b.take(M * r * e2);
+    w.xa_q2 = b.take(M * 3 * r * e2);
+    w.xa_o2 = b.take(M * 3 * r * e2);
     w.h2 = b.take(M * D * e2);
     w.z = b.take(M * (size_t)c.D_ff * e2);
     w.g_o2 = b.take(M * D * e2);
     w.g_q2 = b.take(M * D * e2);
     w.g_o = b.take(M * D * e2);
     w.g_qkv = b.take(M * 3 * D * e2);
-    w.dxa_o2 = b.take(M * r * e2);
-    w.dxa_q2 = b.take(M * r * e2);
-    w.dxa_o = b.take(M * r * e2);
-    w.dxa_qkv = b.take(M * 3 * r * e2);
+    w.dxa_o2 = b.take(M * 3 * r * e2);
+    w.dxa_q2 = b.take(M * 3 * r * e2);
+    w.dxa_o = b.take(M * 3 * r * e2);
+    w.dxa_qkv = b.take(M * 9 * r * e2);
     w.blk_stride = b.off;
     w.blk0 = g.take(w.blk_stride * c.L);
     w.s_n2 = g.take(M * D * e2);
@@ -98,11 +98,7 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.s_dqr = g.take(M * D * e2);
     w.s_dkr = g.take(M * D * e2);
     w.s_dbig = g.take(M * (size_t)c.D_ff * e2);
-    w.s_dqkv = g.take(M * 3 * D * e2);
-    w.s_dxa = g.take((M > Mt ? M : Mt) * 3 * r * e2);
     w.s_delta = g.take((size_t)c.B * c.H * c.S * 4);
-    w.s_dkv2 = g.take(Mt * 2 * D * e2);
-    w.s_dk2n = g.take(Mt * D * e2);
     w.total = g.off;
     return w;
 }
@@ -133,6 +129,18 @@ int linear(const bf16_t* X, long ldx, int M, const bf16_t* Wt, long ldw, int N, 
     GemmNtArgs a;
     a.X = X; a.ldx = ldx; a.W = Wt; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
     a.bias = bias; a.alpha = alpha; a.out = out; a.ldo = ldo; a.variant = variant;
+    return gemm_nt(a, st);
+}
+
+// LoRA down-projection at fp32-equivalent precision: t = alpha * X . Wf^T for an fp32 matrix Wf given as interleaved bf16 (hi, lo) row
+// planes `w_sp` ([2 nout, K], kernels.h LoraSplitArgs), t kept as bf16 planes (hi | lo | hi) per group of r outputs: out [M, 3 nout].
+// The reference runs this product in fp32 (trainer/sft_trainer/trainer.py:132-136 casts the LoRA parameters to fp32).
+int lora_down(const bf16_t* X, long ldx, int M, const bf16_t* w_sp, int nout, int K, int r, float alpha, bf16_t* out, hipStream_t st,
+              int xk_grp_stride = 0) {
+    GemmNtArgs a;
+    a.X = X; a.ldx = ldx; a.W = w_sp; a.ldw = K; a.M = M; a.N = 2 * nout; a.K = K; a.alpha = alpha;
+    if (xk_grp_stride > 0) { a.xk_grp_n = 2 * r; a.xk_grp_stride = xk_grp_stride; }  // output group g (one adapter) reads X columns g * stride ...
+    a.split_r = r; a.out = out; a.ldo = 3L * nout; a.variant = 8;
     return gemm_nt(a, st);
 }
 
@@ -209,12 +217,12 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
         a.X = e; a.ldx = D; a.W = P(w.w_kv2, 0); a.ldw = D; a.M = Mt; a.N = c.L * 2 * D; a.K = D;
         a.bias = P(w.b_kv2, 0); a.out = W(ws, L.kv2_all); a.ldo = ldkv; a.variant = V;
         if (r > 0) {
-            GemmNtArgs x;  // XA[:, (l,k|v)] = s * e A_{l,k|v}^T : adapters 5,6 of block l are 2r consecutive rows, blocks 8rD apart
-            x.X = e; x.ldx = D; x.W = P(w.lora_a, 5L * r * D); x.ldw = D; x.w_grp_n = 2 * r; x.w_grp_stride = 8L * r * D;
-            x.M = Mt; x.N = c.L * 2 * r; x.K = D; x.alpha = s; x.out = W(ws, L.xa_kv2_all); x.ldo = (long)c.L * 2 * r; x.variant = V;
+            GemmNtArgs x;  // XA[:, (l,k|v)] = s * e A_{l,k|v}^T : adapters 5,6 of block l are 2 * 2r consecutive plane rows, blocks 8 * 2r * D apart
+            x.X = e; x.ldx = D; x.W = P(w.lora_a_sp, 5L * 2 * r * D); x.ldw = D; x.w_grp_n = 4 * r; x.w_grp_stride = 16L * r * D;
+            x.M = Mt; x.N = c.L * 4 * r; x.K = D; x.alpha = s; x.split_r = r; x.out = W(ws, L.xa_kv2_all); x.ldo = (long)c.L * 6 * r; x.variant = V;
             FTMI_TRY(gemm_nt(x, st));
-            a.X2 = W(ws, L.xa_kv2_all); a.ldx2 = (long)c.L * 2 * r; a.x2_grp_n = D; a.x2_grp_stride = r; a.K2 = r;
-            a.W2 = P(w.lora_b, 5L * D * r); a.ldw2 = r; a.w2_grp_n = 2 * D; a.w2_grp_stride = 8L * D * r;
+            a.X2 = W(ws, L.xa_kv2_all); a.ldx2 = (long)c.L * 6 * r; a.x2_grp_n = D; a.x2_grp_stride = 3 * r; a.K2 = 3 * r;
+            a.W2 = P(w.lora_b_ext, 5L * D * 3 * r); a.ldw2 = 3 * r; a.w2_grp_n = 2 * D; a.w2_grp_stride = 8L * D * 3 * r;
         }
         FTMI_TRY(gemm_nt(a, st));
         // k2 = norm_k(k2raw): rows ordered (token, block): row i = t * L + l reads kv2_all + i * 2D, weight row l
@@ -228,8 +236,8 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
         bf16_t* hout = W(ws, L.hs) + (size_t)(l + 1) * M * D;
         const bf16_t* ada = W(ws, L.ada) + (size_t)l * c.B * 8 * D;  // [B][8][D]
         const long ab = 8L * D;
-        const bf16_t* la = w.lora_a ? P(w.lora_a, (size_t)l * 8 * r * D) : nullptr;   // [8][r][D]
-        const bf16_t* lb = w.lora_b ? P(w.lora_b, (size_t)l * 8 * D * r) : nullptr;   // [8][D][r]
+        const bf16_t* la = w.lora_a_sp ? P(w.lora_a_sp, (size_t)l * 8 * 2 * r * D) : nullptr;   // [8][2r][D]  (hi, lo) planes of A
+        const bf16_t* lb = w.lora_b_ext ? P(w.lora_b_ext, (size_t)l * 8 * D * 3 * r) : nullptr;  // [8][D][3r]  [B_hi | B_hi | B_lo]
         bf16_t* n1 = W(blk, L.n1);
         bf16_t* qkv = W(blk, L.qkv);
 
@@ -241,8 +249,8 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             a.X = n1; a.ldx = D; a.W = P(w.w_qkv, (size_t)l * 3 * D2); a.ldw = D; a.M = M; a.N = 3 * D; a.K = D;
             a.bias = P(w.b_qkv, (size_t)l * 3 * D); a.out = qkv; a.ldo = 3 * D; a.variant = V;
             if (r > 0) {
-                FTMI_TRY(linear(n1, D, M, la, D, 3 * r, D, nullptr, W(blk, L.xa_qkv), 3 * r, V, st, s));
-                a.X2 = W(blk, L.xa_qkv); a.ldx2 = 3 * r; a.W2 = lb; a.ldw2 = r; a.K2 = r; a.x2_grp_n = D; a.x2_grp_stride = r;
+                FTMI_TRY(lora_down(n1, D, M, la, 3 * r, D, r, s, W(blk, L.xa_qkv), st));
+                a.X2 = W(blk, L.xa_qkv); a.ldx2 = 9 * r; a.W2 = lb; a.ldw2 = 3 * r; a.K2 = 3 * r; a.x2_grp_n = D; a.x2_grp_stride = 3 * r;
             }
             FTMI_TRY(gemm_nt(a, st));
         }
@@ -266,8 +274,8 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             a.bias = P(w.b_o, (size_t)l * D); a.out = W(blk, L.h1); a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = h0; a.ldr = D; a.gate = ada + 2 * D; a.gate_bstride = ab; a.rows_per_batch = c.S;
             if (r > 0) {
-                FTMI_TRY(linear(W(blk, L.o1), D, M, la + 3L * r * D, D, r, D, nullptr, W(blk, L.xa_o), r, V, st, s));
-                a.X2 = W(blk, L.xa_o); a.ldx2 = r; a.W2 = lb + 3L * D * r; a.ldw2 = r; a.K2 = r;
+                FTMI_TRY(lora_down(W(blk, L.o1), D, M, la + 3L * 2 * r * D, r, D, r, s, W(blk, L.xa_o), st));
+                a.X2 = W(blk, L.xa_o); a.ldx2 = 3 * r; a.W2 = lb + 3L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r;
             }
             FTMI_TRY(gemm_nt(a, st));
         }
@@ -278,8 +286,8 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             a.X = h1; a.ldx = D; a.W = P(w.w_q2, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D;
             a.bias = P(w.b_q2, (size_t)l * D); a.out = W(blk, L.q2raw); a.ldo = D; a.variant = V;
             if (r > 0) {
-                FTMI_TRY(linear(h1, D, M, la + 4L * r * D, D, r, D, nullptr, W(blk, L.xa_q2), r, V, st, s));
-                a.X2 = W(blk, L.xa_q2); a.ldx2 = r; a.W2 = lb + 4L * D * r; a.ldw2 = r; a.K2 = r;
+                FTMI_TRY(lora_down(h1, D, M, la + 4L * 2 * r * D, r, D, r, s, W(blk, L.xa_q2), st));
+                a.X2 = W(blk, L.xa_q2); a.ldx2 = 3 * r; a.W2 = lb + 4L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r;
             }
             FTMI_TRY(gemm_nt(a, st));
             FTMI_TRY(qknorm_rope_fwd(W(blk, L.q2raw), D, P(w.norm_q2, (size_t)l * D), nullptr, nullptr, W(blk, L.q2n), D, M, c.S, D, c.eps_qk, st));
@@ -292,7 +300,7 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             a.v = W(ws, L.kv2_all) + (size_t)l * 2 * D + D;      set3(a.v_sb, a.v_sh, a.v_ss, c.T, (long)c.L * 2 * D);
             a.o = W(blk, L.o2);           set3(a.o_sb, a.o_sh, a.o_ss, c.S, D);
             a.lse2 = WF(blk, L.lse2);
-            a.kbias = key_bias;
+            a.kbias = key_bias; a.kb_sb = c.T;
             FTMI_TRY(attn_fwd(a, st));
         }
         // 10. to_out (+ LoRA), residual (no gate)
@@ -302,8 +310,8 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             a.bias = P(w.b_o2, (size_t)l * D); a.out = W(blk, L.h2); a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = h1; a.ldr = D;
             if (r > 0) {
-                FTMI_TRY(linear(W(blk, L.o2), D, M, la + 7L * r * D, D, r, D, nullptr, W(blk, L.xa_o2), r, V, st, s));
-                a.X2 = W(blk, L.xa_o2); a.ldx2 = r; a.W2 = lb + 7L * D * r; a.ldw2 = r; a.K2 = r;
+                FTMI_TRY(lora_down(W(blk, L.o2), D, M, la + 7L * 2 * r * D, r, D, r, s, W(blk, L.xa_o2), st));
+                a.X2 = W(blk, L.xa_o2); a.ldx2 = 3 * r; a.W2 = lb + 7L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r;
             }
             FTMI_TRY(gemm_nt(a, st));
         }
@@ -365,12 +373,8 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     // gradients dB += dY^T XA and dA += dXA^T X only feed the gradient buffer, so dY / dXA are kept per block and all 28
     // blocks of one adapter are reduced by ONE batched launch after the loop (fills the GPU instead of 28 latency-bound ones).
     auto lora_dxa = [&](const bf16_t* dY, long lddy, int rows, int nadp, int adp, int l, bf16_t* dxa_out) -> int {
-        const bf16_t* lbt = P(w.lora_bt, ((size_t)l * 8 + adp) * r * D);  // [nadp*r][D]
-        GemmNtArgs a;
-        a.X = dY; a.ldx = lddy; a.W = lbt; a.ldw = D; a.M = rows; a.N = nadp * r; a.K = D; a.alpha = s;
-        if (nadp > 1) { a.xk_grp_n = r; a.xk_grp_stride = D; }
-        a.out = dxa_out; a.ldo = (long)nadp * r; a.variant = V;
-        return gemm_nt(a, st);
+        const bf16_t* lbt = P(w.lora_bt_sp, ((size_t)l * 8 + adp) * 2 * r * D);  // [nadp * 2r][D]: (hi, lo) planes of B^T
+        return lora_down(dY, lddy, rows, lbt, nadp * r, D, r, s, dxa_out, st, nadp > 1 ? D : 0);
     };
 
     // LoRA weight gradients dB += dY^T XA, dA += dXA^T X only feed the gradient buffer.  Default: ONE batched launch per adapter
@@ -410,13 +414,14 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         float* gb = grad_b + (size_t)l0 * 8 * D * r;
         for (const G& gr : groups) {
             GemmTnArgs t;  // dB[l] += dY[l]^T XA[l]
-            t.U = W(blk0, gr.dy); t.ldu = gr.lddy; t.V = W(blk0, gr.xa); t.ldv = (long)gr.nadp * r;
+            t.U = W(blk0, gr.dy); t.ldu = gr.lddy; t.V = W(blk0, gr.xa); t.ldv = (long)gr.nadp * 3 * r; t.v_fold = r;  // XA = hi + lo planes
             t.C = gb + (size_t)gr.adp * D * r; t.ldc = r; t.M = gr.rows; t.P = gr.nadp * D; t.Q = r;
-            if (gr.nadp > 1) { t.v_grp_p = D; t.v_grp_stride = r; }
+            if (gr.nadp > 1) { t.v_grp_p = D; t.v_grp_stride = 3 * r; }
             t.batch = nb; t.u_bstride = bs; t.v_bstride = bs; t.c_bstride = 8L * D * r;
             FTMI_TRY(gemm_tn(t, s2));
             GemmTnArgs u;  // dA[l] += dXA[l]^T X[l]
-            u.U = W(blk0, gr.dxa); u.ldu = (long)gr.nadp * r; u.V = gr.x; u.ldv = gr.ldx;
+            u.U = W(blk0, gr.dxa); u.ldu = (long)gr.nadp * 3 * r; u.u_fold = r; u.V = gr.x; u.ldv = gr.ldx;
+            if (gr.nadp > 1) { u.u_grp_p = r; u.u_grp_stride = 3 * r; }
             u.C = ga + (size_t)gr.adp * r * D; u.ldc = D; u.M = gr.rows; u.P = gr.nadp * r; u.Q = D;
             u.batch = nb; u.u_bstride = bs; u.v_bstride = gr.x_bs; u.c_bstride = 8L * r * D;
             FTMI_TRY(gemm_tn(u, s2));
@@ -430,7 +435,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         const bf16_t* h0 = W(ws, L.hs) + (size_t)l * M * D;
         const bf16_t* ada = W(ws, L.ada) + (size_t)l * c.B * 8 * D;
         const long ab = 8L * D;
-        const bf16_t* lat = w.lora_at ? P(w.lora_at, (size_t)l * 8 * D * r) : nullptr;  // [8][D][r]
+        const bf16_t* lat = w.lora_at_ext ? P(w.lora_at_ext, (size_t)l * 8 * D * 3 * r) : nullptr;  // [8][D][3r]  [A^T_hi | A^T_hi | A^T_lo]
         const bf16_t* h1 = W(blk, L.h1);
         const bf16_t* h2 = W(blk, L.h2);
         const bf16_t* dhin = dh[cur];
@@ -452,7 +457,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         {
             GemmNtArgs a;
             a.X = d3; a.ldx = D; a.W = P(w.w_o2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d1; a.ldo = D; a.variant = V;
-            if (r > 0) { a.X2 = W(blk, L.dxa_o2); a.ldx2 = r; a.W2 = lat + 7L * D * r; a.ldw2 = r; a.K2 = r; }
+            if (r > 0) { a.X2 = W(blk, L.dxa_o2); a.ldx2 = 3 * r; a.W2 = lat + 7L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r; }
             FTMI_TRY(gemm_nt(a, st));  // d1 = dO2
         }
         {
@@ -461,7 +466,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             a.k = W(ws, L.k2n_all) + (size_t)l * D;              set3(a.k_sb, a.k_sh, a.k_ss, c.T, (long)c.L * D);
             a.v = W(ws, L.kv2_all) + (size_t)l * 2 * D + D;      set3(a.v_sb, a.v_sh, a.v_ss, c.T, (long)c.L * 2 * D);
             a.o = W(blk, L.o2);           set3(a.o_sb, a.o_sh, a.o_ss, c.S, D);
-            a.lse2 = WF(blk, L.lse2); a.kbias = key_bias;
+            a.lse2 = WF(blk, L.lse2); a.kbias = key_bias; a.kb_sb = c.T;
             a.dout = d1;                  set3(a.do_sb, a.do_sh, a.do_ss, c.S, D);
             a.delta = WF(ws, L.s_delta);
             a.dq = d2;                    set3(a.dq_sb, a.dq_sh, a.dq_ss, c.S, D);
@@ -477,7 +482,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             a.X = gq2; a.ldx = D; a.W = P(w.w_q2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d2; a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = d3; a.ldr = D;
             a.out2 = W(blk, L.g_o); a.ldo2 = D; a.gate2 = ada + 2 * D; a.gate2_bstride = ab; a.rows_per_batch = c.S;  // go = bf(dh1 * gate_msa), fused
-            if (r > 0) { a.X2 = W(blk, L.dxa_q2); a.ldx2 = r; a.W2 = lat + 4L * D * r; a.ldw2 = r; a.K2 = r; }
+            if (r > 0) { a.X2 = W(blk, L.dxa_q2); a.ldx2 = 3 * r; a.W2 = lat + 4L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r; }
             FTMI_TRY(gemm_nt(a, st));  // d2 = dh1
         }
 
@@ -487,7 +492,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         {
             GemmNtArgs a;
             a.X = go; a.ldx = D; a.W = P(w.w_o_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = dO; a.ldo = D; a.variant = V;
-            if (r > 0) { a.X2 = W(blk, L.dxa_o); a.ldx2 = r; a.W2 = lat + 3L * D * r; a.ldw2 = r; a.K2 = r; }
+            if (r > 0) { a.X2 = W(blk, L.dxa_o); a.ldx2 = 3 * r; a.W2 = lat + 3L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r; }
             FTMI_TRY(gemm_nt(a, st));
         }
         bf16_t* dqkv = W(blk, L.g_qkv);
@@ -512,7 +517,7 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         if (l > 0) {
             GemmNtArgs a;
             a.X = dqkv; a.ldx = 3 * D; a.W = P(w.w_qkv_t, (size_t)l * 3 * D2); a.ldw = 3 * D; a.M = M; a.N = D; a.K = 3 * D; a.out = d1; a.ldo = D; a.variant = V;
-            if (r > 0) { a.X2 = W(blk, L.dxa_qkv); a.ldx2 = 3 * r; a.W2 = P(w.lora_at_qkv, (size_t)l * D * 3 * r); a.ldw2 = 3 * r; a.K2 = 3 * r; }
+            if (r > 0) { a.X2 = W(blk, L.dxa_qkv); a.ldx2 = 9 * r; a.W2 = P(w.lora_at_qkv_ext, (size_t)l * D * 9 * r); a.ldw2 = 9 * r; a.K2 = 9 * r; }
             FTMI_TRY(gemm_nt(a, st));  // d1 = dn1
             const bf16_t* ada_prev = W(ws, L.ada) + (size_t)(l - 1) * c.B * 8 * D;  // the next block processed is l - 1
             FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st, ada_prev + 5 * D, ab, dO));
@@ -533,9 +538,9 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         FTMI_TRY(qknorm_rope_bwd(W(ws, L.kv2_all), 2 * D, P(w.norm_k2, 0), nullptr, nullptr, W(ws, L.g_k2n_all), D, W(ws, L.g_kv2_all), 2 * D,
                                  Mt * c.L, Mt * c.L, D, c.eps_qk, st, c.L));
         GemmNtArgs a;  // dXA[:, (l,k|v)] = s * dY[:, (l,k|v) slice] B_{l,k|v}
-        a.X = W(ws, L.g_kv2_all); a.ldx = (long)c.L * 2 * D; a.xk_grp_n = r; a.xk_grp_stride = D;
-        a.W = P(w.lora_bt, 5L * r * D); a.ldw = D; a.w_grp_n = 2 * r; a.w_grp_stride = 8L * r * D;
-        a.M = Mt; a.N = c.L * 2 * r; a.K = D; a.alpha = s; a.out = W(ws, L.dxa_kv2_all); a.ldo = (long)c.L * 2 * r; a.variant = V;
+        a.X = W(ws, L.g_kv2_all); a.ldx = (long)c.L * 2 * D; a.xk_grp_n = 2 * r; a.xk_grp_stride = D;
+        a.W = P(w.lora_bt_sp, 5L * 2 * r * D); a.ldw = D; a.w_grp_n = 4 * r; a.w_grp_stride = 16L * r * D;
+        a.M = Mt; a.N = c.L * 4 * r; a.K = D; a.alpha = s; a.split_r = r; a.out = W(ws, L.dxa_kv2_all); a.ldo = (long)c.L * 6 * r; a.variant = V;
         FTMI_TRY(gemm_nt(a, st));
     }
 
@@ -543,14 +548,14 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     if (r > 0) {
         {   // attn2.to_k / to_v: operands are column slices of the all-block arrays (batch stride = one block's columns)
             GemmTnArgs t;
-            t.U = W(ws, L.g_kv2_all); t.ldu = (long)c.L * 2 * D; t.V = W(ws, L.xa_kv2_all); t.ldv = (long)c.L * 2 * r;
-            t.C = grad_b + 5L * D * r; t.ldc = r; t.M = Mt; t.P = 2 * D; t.Q = r; t.v_grp_p = D; t.v_grp_stride = r;
-            t.batch = c.L; t.u_bstride = 2L * D; t.v_bstride = 2L * r; t.c_bstride = 8L * D * r;
+            t.U = W(ws, L.g_kv2_all); t.ldu = (long)c.L * 2 * D; t.V = W(ws, L.xa_kv2_all); t.ldv = (long)c.L * 6 * r; t.v_fold = r;
+            t.C = grad_b + 5L * D * r; t.ldc = r; t.M = Mt; t.P = 2 * D; t.Q = r; t.v_grp_p = D; t.v_grp_stride = 3 * r;
+            t.batch = c.L; t.u_bstride = 2L * D; t.v_bstride = 6L * r; t.c_bstride = 8L * D * r;
             FTMI_TRY(gemm_tn(t, st));
             GemmTnArgs u;
-            u.U = W(ws, L.dxa_kv2_all); u.ldu = (long)c.L * 2 * r; u.V = e; u.ldv = D;
+            u.U = W(ws, L.dxa_kv2_all); u.ldu = (long)c.L * 6 * r; u.u_fold = r; u.u_grp_p = r; u.u_grp_stride = 3 * r; u.V = e; u.ldv = D;
             u.C = grad_a + 5L * r * D; u.ldc = D; u.M = Mt; u.P = 2 * r; u.Q = D;
-            u.batch = c.L; u.u_bstride = 2L * r; u.v_bstride = 0; u.c_bstride = 8L * r * D;
+            u.batch = c.L; u.u_bstride = 6L * r; u.v_bstride = 0; u.c_bstride = 8L * r * D;
             FTMI_TRY(gemm_tn(u, st));
         }
     }

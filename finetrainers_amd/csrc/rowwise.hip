@@ -592,12 +592,67 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const TIN* __restri
         if (r < rows && c < cols) out_t[(long)c * rows + r] = tile[tx][i];
     }
 }
-// nmat matrices [rows, cols] fp32 at stride in_bstride -> bf16 copies (same layout, may be null) and transposes
-int lora_refresh(const float* w, bf16_t* w_bf, bf16_t* wt_bf, int rows, int cols, int nmat, long in_bstride, long same_bstride,
-                 long t_bstride, hipStream_t st) {
-    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nmat);
-    hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, dim3(256), 0, st, w, w_bf, wt_bf, rows, cols, in_bstride, same_bstride, t_bstride);
-    return check_launch("lora_refresh");
+// fp32 LoRA matrices -> bf16 (hi, lo) working copies for the fp32-equivalent LoRA branch (LoraSplitArgs, kernels.h).
+// One 32 x 32 tile per workgroup; the transposed layouts go through LDS so that every store instruction writes 64-byte runs.
+__global__ __launch_bounds__(256) void lora_split_kernel(LoraSplitArgs a) {
+    __shared__ uint32_t tile[32][33];  // (hi | lo << 16) of element [i][j]
+    const int m = blockIdx.z;
+    const int outer = a.inner_n > 0 ? m / a.inner_n : m, inner = a.inner_n > 0 ? m % a.inner_n : 0;
+    const float* in = a.w + (long)outer * a.in_bstride + (long)inner * a.in_istride;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    bf16_t* sp = a.sp ? a.sp + (long)outer * a.sp_bstride : nullptr;
+    bf16_t* ext = a.ext ? a.ext + (long)outer * a.ext_bstride : nullptr;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        uint32_t pk = 0;
+        if (r < a.rows && c < a.cols) {
+            const float v = in[(long)r * a.cols + c];
+            const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+            pk = (uint32_t)hi | ((uint32_t)lo << 16);
+            if (sp) {  // rows interleaved in groups of 32: [hi rows 32g..32g+31 | lo rows 32g..32g+31]
+                const long row_hi = (long)(r >> 5) * 64 + (r & 31);
+                sp[row_hi * a.cols + c] = hi;
+                sp[(row_hi + 32) * a.cols + c] = lo;
+            }
+            if (ext) {
+                bf16_t* e = ext + (long)r * a.ld_ext + c;
+                e[0] = hi;
+                e[a.cols] = hi;
+                e[2 * a.cols] = lo;
+            }
+        }
+        tile[i][tx] = pk;
+    }
+    if (!a.t_sp && !a.t_ext) return;
+    __syncthreads();
+    bf16_t* t_sp = a.t_sp ? a.t_sp + (long)outer * a.t_sp_bstride : nullptr;
+    bf16_t* t_ext = a.t_ext ? a.t_ext + (long)outer * a.t_ext_bstride + (long)inner * a.t_ext_istride : nullptr;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;  // element [r][c] of W = element [c][r] of W^T
+        if (r < a.rows && c < a.cols) {
+            const uint32_t pk = tile[tx][i];
+            const bf16_t hi = (bf16_t)(pk & 0xffff), lo = (bf16_t)(pk >> 16);
+            if (t_sp) {
+                const long row_hi = (long)(c >> 5) * 64 + (c & 31);
+                t_sp[row_hi * a.rows + r] = hi;
+                t_sp[(row_hi + 32) * a.rows + r] = lo;
+            }
+            if (t_ext) {
+                bf16_t* e = t_ext + (long)c * a.ld_t_ext + r;
+                e[0] = hi;
+                e[a.rows] = hi;
+                e[2 * a.rows] = lo;
+            }
+        }
+    }
+}
+int lora_split(const LoraSplitArgs& a, hipStream_t st) {
+    if (a.rows <= 0 || a.cols <= 0 || a.nmat <= 0) return 0;
+    if ((a.sp && a.rows % 32) || (a.t_sp && a.cols % 32)) return set_error(FTMI_ERR_UNSUPPORTED, "lora_split: interleaved planes need multiples of 32 rows");
+    dim3 grid((a.cols + 31) / 32, (a.rows + 31) / 32, a.nmat);
+    hipLaunchKernelGGL(lora_split_kernel, grid, dim3(256), 0, st, a);
+    return check_launch("lora_split");
 }
 int transpose_bf16(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t st) {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, 1);

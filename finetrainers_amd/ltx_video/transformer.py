@@ -11,7 +11,8 @@ HBM layout (designed for 288 GB, not ported from the reference's per-module para
     K-contiguous GEMM kernel (costs 1x extra weight memory, 3.6 GB);
   * the 224 LoRA adapters live in two flat fp32 parameters ``lora_A`` [L,8,r,D] and ``lora_B`` [L,8,D,r]
     (adapter order q,k,v,out of attn1 then attn2) -> one fused clip+AdamW launch and one contiguous
-    all-reduce; bf16 working copies (A, A^T, B, B^T) are refreshed after each optimiser step;
+    all-reduce; the LoRA branch runs at fp32-equivalent precision like the reference's (fp32 adapters,
+    trainer.py:132-136): bf16 (hi, lo) working copies of A / B are refreshed after each optimiser step;
   * all activations of a step live in one caller-owned workspace (about 0.37 GB per block at B=2).
 peft/diffusers-compatible names are provided by ``state_dict()`` / ``lora_state_dict()`` views.
 """
@@ -307,8 +308,9 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         self.lora_A = nn.Parameter(self.lora_flat[:n].view(L, 8, r, D))
         self.lora_B = nn.Parameter(self.lora_flat[n:].view(L, 8, D, r))
         self.lora_rank, self.lora_alpha = int(r), float(lora_alpha if lora_alpha is not None else r)
-        for n, shp in (("lora_a_bf", (L, 8, r, D)), ("lora_at_bf", (L, 8, D, r)), ("lora_b_bf", (L, 8, D, r)), ("lora_bt_bf", (L, 8, r, D)),
-                       ("lora_at_qkv_bf", (L, D, 3 * r))):
+        # bf16 (hi, lo) working copies for the fp32-equivalent LoRA branch (include/ftmi355.h, ftmi_ltx_weights)
+        for n, shp in (("lora_a_sp", (L, 8, 2 * r, D)), ("lora_bt_sp", (L, 8, 2 * r, D)), ("lora_b_ext", (L, 8, D, 3 * r)),
+                       ("lora_at_ext", (L, 8, D, 3 * r)), ("lora_at_qkv_ext", (L, D, 9 * r))):
             self.register_buffer(n, torch.zeros(shp, dtype=bf16, device=self.device), persistent=False)
         self._lora_versions = None
 
@@ -353,8 +355,8 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         if not force and ver == self._lora_versions:
             return
         c = self.config
-        check(_lib.load().ftmi_lora_refresh(ptr(self.lora_A), ptr(self.lora_B), ptr(self.lora_a_bf), ptr(self.lora_at_bf), ptr(self.lora_b_bf),
-                                             ptr(self.lora_bt_bf), ptr(self.lora_at_qkv_bf), c.num_layers, self.lora_rank, c.inner_dim, stream_ptr()),
+        check(_lib.load().ftmi_lora_refresh(ptr(self.lora_A), ptr(self.lora_B), ptr(self.lora_a_sp), ptr(self.lora_bt_sp), ptr(self.lora_b_ext),
+                                             ptr(self.lora_at_ext), ptr(self.lora_at_qkv_ext), c.num_layers, self.lora_rank, c.inner_dim, stream_ptr()),
               "ftmi_lora_refresh")
         self._lora_versions = ver
 
@@ -371,9 +373,9 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         for n in self._frozen_names:
             setattr(w, n, getattr(self, n).data_ptr())
         if self.lora_A is not None:
-            w.lora_a, w.lora_at = self.lora_a_bf.data_ptr(), self.lora_at_bf.data_ptr()
-            w.lora_b, w.lora_bt = self.lora_b_bf.data_ptr(), self.lora_bt_bf.data_ptr()
-            w.lora_at_qkv = self.lora_at_qkv_bf.data_ptr()
+            w.lora_a_sp, w.lora_bt_sp = self.lora_a_sp.data_ptr(), self.lora_bt_sp.data_ptr()
+            w.lora_b_ext, w.lora_at_ext = self.lora_b_ext.data_ptr(), self.lora_at_ext.data_ptr()
+            w.lora_at_qkv_ext = self.lora_at_qkv_ext.data_ptr()
         w.rope_cos, w.rope_sin = cos.data_ptr(), sin.data_ptr()
         return w
 

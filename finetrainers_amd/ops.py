@@ -21,7 +21,7 @@ def _strides3(t: torch.Tensor) -> Tuple[int, int, int]:
     return (t.stride(0), t.stride(1), t.stride(2))
 
 
-def _desc(q, k, v, o, scale, dout=None, dq=None, dk=None, dv=None) -> AttnDesc:
+def _desc(q, k, v, o, scale, dout=None, dq=None, dk=None, dv=None, key_bias=None) -> AttnDesc:
     B, H, Sq, d = q.shape
     Sk = k.shape[2]
     if d != 64:
@@ -31,6 +31,11 @@ def _desc(q, k, v, o, scale, dout=None, dq=None, dk=None, dv=None) -> AttnDesc:
     desc = AttnDesc()
     desc.B, desc.H, desc.Sq, desc.Sk, desc.d = B, H, Sq, Sk, d
     desc.scale = float(scale)
+    if key_bias is not None:
+        if key_bias.shape not in ((B, Sk), (B, H, Sk)) or key_bias.stride(-1) != 1:
+            raise ValueError("key_bias must be fp32 [B, Sk] or [B, H, Sk] with contiguous keys")
+        desc.bias_strides[0] = key_bias.stride(0)
+        desc.bias_strides[1] = key_bias.stride(1) if key_bias.dim() == 3 else 0
     for name, t in (("q_strides", q), ("k_strides", k), ("v_strides", v), ("o_strides", o), ("do_strides", dout),
                     ("dq_strides", dq), ("dk_strides", dk), ("dv_strides", dv)):
         if t is not None:
@@ -51,8 +56,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_bias: Option
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     if key_bias is not None:
         require_gpu_tensor(key_bias, "key_bias", torch.float32)
-        key_bias = key_bias.contiguous()
-    desc = _desc(q, k, v, out, scale)
+    desc = _desc(q, k, v, out, scale, key_bias=key_bias)
     check(_lib.load().ftmi_attn_fwd(ctypes.byref(desc), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(key_bias), stream_ptr()), "ftmi_attn_fwd")
     return out, lse
 
@@ -67,7 +71,7 @@ def attn_bwd(q, k, v, out, lse, dout, key_bias=None, scale=None):
     dk = torch.empty((B, Sk, H, d), dtype=bf16, device=q.device).permute(0, 2, 1, 3)
     dv = torch.empty((B, Sk, H, d), dtype=bf16, device=q.device).permute(0, 2, 1, 3)
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-    desc = _desc(q, k, v, out, scale, dout, dq, dk, dv)
+    desc = _desc(q, k, v, out, scale, dout, dq, dk, dv, key_bias=key_bias)
     check(_lib.load().ftmi_attn_bwd(ctypes.byref(desc), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(dout), ptr(dq), ptr(dk), ptr(dv),
                                      ptr(delta), ptr(key_bias), stream_ptr()), "ftmi_attn_bwd")
     return dq, dk, dv
@@ -106,31 +110,86 @@ def transpose_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def linear_lora_fwd(x, w, bias, a_bf, b_bf, lora_scale: float, variant: int = 8):
+def lora_split(w: torch.Tensor, sp: bool = False, ext: bool = False, t_sp: bool = False, t_ext: bool = False):
+    """bf16 (hi, lo) working copies of an fp32 LoRA matrix w [rows, cols] (include/ftmi355.h: ftmi_lora_split).  Returns the requested
+    layouts in the order (sp [2 rows, cols], ext [rows, 3 cols], t_sp [2 cols, rows], t_ext [cols, 3 rows])."""
+    require_gpu_tensor(w, "w", torch.float32)
+    w = w.contiguous()
+    rows, cols = w.shape
+    mk = lambda want, shape: torch.empty(shape, dtype=bf16, device=w.device) if want else None
+    o = (mk(sp, (2 * rows, cols)), mk(ext, (rows, 3 * cols)), mk(t_sp, (2 * cols, rows)), mk(t_ext, (cols, 3 * rows)))
+    check(_lib.load().ftmi_lora_split(ptr(w), rows, cols, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), stream_ptr()), "ftmi_lora_split")
+    return tuple(t for t in o if t is not None)
+
+
+def linear_lora_fwd(x, w, bias, lora_a, lora_b, lora_scale: float, variant: int = 8):
+    """peft ``lora.Linear`` forward over a frozen bf16 Linear with fp32 adapters ``lora_a`` [r,K], ``lora_b`` [N,r] (None: plain
+    linear).  Returns (y [M,N] bf16, xa [M,3r]: lora_scale * x A^T as bf16 (hi | lo | hi) planes, kept for the backward)."""
     M, K = x.shape
     N = w.shape[0]
-    r = 0 if a_bf is None else a_bf.shape[0]
+    r = 0 if lora_a is None else lora_a.shape[0]
     y = torch.empty((M, N), dtype=bf16, device=x.device)
-    xa = torch.empty((M, r), dtype=bf16, device=x.device) if r else None
-    check(_lib.load().ftmi_linear_lora_fwd(M, K, N, r, float(lora_scale), ptr(x), ptr(w), ptr(bias), ptr(a_bf), ptr(b_bf), ptr(y), ptr(xa),
+    xa = torch.empty((M, 3 * r), dtype=bf16, device=x.device) if r else None
+    a_sp = b_ext = None
+    if r:
+        (a_sp,) = lora_split(lora_a, sp=True)
+        (b_ext,) = lora_split(lora_b, ext=True)
+    check(_lib.load().ftmi_linear_lora_fwd(M, K, N, r, float(lora_scale), ptr(x), ptr(w), ptr(bias), ptr(a_sp), ptr(b_ext), ptr(y), ptr(xa),
                                             variant, stream_ptr()), "ftmi_linear_lora_fwd")
     return y, xa
 
 
-def linear_lora_bwd(x, dy, xa, w_t, a_t, b_t, lora_scale: float, grad_a=None, grad_b=None, need_dx: bool = True, variant: int = 8):
+def linear_lora_bwd(x, dy, xa, w_t, lora_a, lora_b, lora_scale: float, grad_a=None, grad_b=None, need_dx: bool = True, variant: int = 8):
     """Backward of ``linear_lora_fwd``: returns (dx [M,K] bf16 or None, grad_a [r,K] fp32, grad_b [N,r] fp32); the gradient
-    buffers are accumulated into when given (``.grad`` semantics).  ``w_t = W^T``, ``a_t = A^T``, ``b_t = B^T`` in bf16."""
+    buffers are accumulated into when given (``.grad`` semantics).  ``w_t = W^T`` bf16; ``lora_a`` / ``lora_b`` fp32."""
     M, N = dy.shape
     K = w_t.shape[0] if w_t is not None else x.shape[1]
-    r = 0 if a_t is None else a_t.shape[1]
+    r = 0 if lora_a is None else lora_a.shape[0]
     dx = torch.empty((M, K), dtype=bf16, device=dy.device) if need_dx else None
-    dxa = torch.empty((M, r), dtype=bf16, device=dy.device) if r else None
+    dxa = torch.empty((M, 3 * r), dtype=bf16, device=dy.device) if r else None
+    bt_sp = at_ext = None
     if r:
+        (at_ext,) = lora_split(lora_a, t_ext=True)
+        (bt_sp,) = lora_split(lora_b, t_sp=True)
         grad_a = torch.zeros((r, K), dtype=torch.float32, device=dy.device) if grad_a is None else grad_a
         grad_b = torch.zeros((N, r), dtype=torch.float32, device=dy.device) if grad_b is None else grad_b
-    check(_lib.load().ftmi_linear_lora_bwd(M, K, N, r, float(lora_scale), ptr(x), ptr(dy), ptr(xa), ptr(w_t), ptr(a_t), ptr(b_t), ptr(dxa), ptr(dx),
-                                            ptr(grad_a), ptr(grad_b), variant, stream_ptr()), "ftmi_linear_lora_bwd")
+    check(_lib.load().ftmi_linear_lora_bwd(M, K, N, r, float(lora_scale), ptr(x), ptr(dy), ptr(xa), ptr(w_t), ptr(bt_sp), ptr(at_ext), ptr(dxa),
+                                            ptr(dx), ptr(grad_a), ptr(grad_b), variant, stream_ptr()), "ftmi_linear_lora_bwd")
     return dx, grad_a, grad_b
+
+
+def norm_modulate(x, shift, onep, rows_per_batch: int, eps: float = 1e-6, layernorm: bool = False):
+    """y = bf16(bf16(norm(x)) * onep[b]) + shift[b]; x [rows, 2048] bf16, shift / onep [B, 2048] bf16 (onep = 1 + scale)."""
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().ftmi_norm_modulate_fwd(ptr(x), ptr(shift), ptr(onep), shift.stride(0), ptr(y), rows, rows_per_batch, D, float(eps), int(layernorm),
+                                              stream_ptr()), "ftmi_norm_modulate_fwd")
+    return y
+
+
+def norm_modulate_bwd(x, dy, onep, rows_per_batch: int, eps: float = 1e-6, layernorm: bool = False, dres=None):
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().ftmi_norm_modulate_bwd(ptr(x), ptr(dy), ptr(onep), onep.stride(0), ptr(dres), ptr(dx), rows, rows_per_batch, D, float(eps),
+                                              int(layernorm), stream_ptr()), "ftmi_norm_modulate_bwd")
+    return dx
+
+
+def qknorm_rope(x, w, cos=None, sin=None, rows_per_batch: Optional[int] = None, eps: float = 1e-5):
+    """rope(bf16(rms_norm(x) * w)); x [rows, 2048] bf16 (row stride free), cos / sin fp32 [rows_per_batch, 1024] or None."""
+    rows, D = x.shape
+    y = torch.empty((rows, D), dtype=bf16, device=x.device)
+    check(_lib.load().ftmi_qknorm_rope_fwd(ptr(x), x.stride(0), ptr(w), ptr(cos), ptr(sin), ptr(y), D, rows, rows_per_batch or rows, D, float(eps),
+                                            stream_ptr()), "ftmi_qknorm_rope_fwd")
+    return y
+
+
+def qknorm_rope_bwd(x, w, dy, cos=None, sin=None, rows_per_batch: Optional[int] = None, eps: float = 1e-5):
+    rows, D = x.shape
+    dx = torch.empty((rows, D), dtype=bf16, device=x.device)
+    check(_lib.load().ftmi_qknorm_rope_bwd(ptr(x), x.stride(0), ptr(w), ptr(cos), ptr(sin), ptr(dy), dy.stride(0), ptr(dx), D, rows, rows_per_batch or rows, D,
+                                            float(eps), stream_ptr()), "ftmi_qknorm_rope_bwd")
+    return dx
 
 
 def noise_pack(latents, noise, mean, std, sigma, sigma_first=None, first_frame_tokens: int = 0):

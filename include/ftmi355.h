@@ -21,7 +21,7 @@
  *   ftmi_mse_loss ...................... trainer/sft_trainer/trainer.py:463-480 (+ d loss / d pred)
  *   ftmi_clip_adamw_step ............... utils/torch.py:99-161,299-374 (clip_grad_norm_) +
  *                                        optimizer.py:117-125 (torch.optim.AdamW step) over the flat LoRA buffer
- *   ftmi_lora_refresh .................. (new) bf16 working copies of the fp32 LoRA matrices after a step
+ *   ftmi_lora_refresh / ftmi_lora_split  (new) bf16 (hi, lo) working copies of the fp32 LoRA matrices after a step
  *   ftmi_linear_lora_fwd / _bwd ........ peft lora.Linear.forward over a frozen nn.Linear
  *                                        (trainer/sft_trainer/trainer.py:121-136 injects them) and the autograd
  *                                        backward the reference gets from loss.backward() (trainer.py:481): dgrad to
@@ -62,13 +62,15 @@ int ftmi_prof_summary(int kernel_class, double* sampled_ms, long* sampled_launch
 /* ------------------------------------------------------------------------------------------------------------
  * Attention provider level.  q,k,v,out,dout,dq,dk,dv: bf16, head_dim 64 contiguous; element (b,h,s,:) lives at
  * base + b*stride[0] + h*stride[1] + s*stride[2] (strides in elements).  lse: fp32 [B,H,Sq] (log2 domain,
- * written by fwd, read by bwd).  key_bias: optional fp32 [B,Sk] additive bias per key (attn_mask broadcast over
- * heads and queries), NULL for none.  Non-causal, no dropout.
+ * written by fwd, read by bwd).  key_bias: optional fp32 additive bias per (batch, head, key) (an attn_mask that broadcasts over
+ * queries; desc.bias_strides = {Sk, 0} for the usual [B,Sk] mask shared by the heads), NULL for none.  A bias of -inf removes the key
+ * (softmax weight exactly 0).  Non-causal, no dropout.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct {
     int B, H, Sq, Sk, d;
     long q_strides[3], k_strides[3], v_strides[3], o_strides[3];
     long do_strides[3], dq_strides[3], dk_strides[3], dv_strides[3]; /* backward only */
+    long bias_strides[2]; /* key_bias element (b,h,j) at key_bias[b*bias_strides[0] + h*bias_strides[1] + j]; {Sk, 0} = one row per sample */
     float scale;
 } ftmi_attn_desc;
 
@@ -80,21 +82,22 @@ int ftmi_attn_bwd(const ftmi_attn_desc* desc, const void* q, const void* k, cons
                   const float* key_bias, ftmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Linear (+ LoRA) building block:  y = bf16(x W^T + b) [+ lora_scale * (x A^T) B^T, re-rounded], bf16 operands.
- * a_bf [r,K], b_bf [N,r] are the bf16 working copies of the fp32 LoRA matrices; xa_out [M,r] receives
- * bf16(lora_scale * x A^T) (kept for the backward).  r == 0 => plain linear (a_bf, b_bf, xa_out may be NULL).
+ * Linear (+ LoRA) building block:  y = bf16( bf16(x W^T + b) + lora_scale * (x A^T) B^T ), the LoRA branch at fp32-equivalent
+ * precision (peft lora.Linear with fp32 adapter weights).  a_sp [2r,K] and b_ext [N,3r] are working copies of the fp32 A [r,K] and
+ * B [N,r] made by ftmi_lora_split (sp of A, ext of B); xa_out [M,3r] receives lora_scale * x A^T as bf16 planes (hi | lo | hi) and
+ * is kept for the backward.  r == 0 => plain linear (a_sp, b_ext, xa_out may be NULL).
  * ------------------------------------------------------------------------------------------------------------ */
 int ftmi_linear_lora_fwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* w, const void* bias,
-                         const void* a_bf, const void* b_bf, void* y, void* xa_out, int variant, ftmi_stream stream);
+                         const void* a_sp, const void* b_ext, void* y, void* xa_out, int variant, ftmi_stream stream);
 
-/* Backward of the above.  dy [M,N] bf16; xa [M,r] = the forward's xa_out; w_t [K,N] = W^T (bf16, made once with
- * ftmi_transpose_bf16), a_t [K,r] = A^T, b_t [r,N] = B^T (bf16 working copies, see ftmi_lora_refresh).
- *   dxa_ws [M,r] bf16 scratch <- bf16(lora_scale * dy B)
+/* Backward of the above.  dy [M,N] bf16; xa [M,3r] = the forward's xa_out; w_t [K,N] = W^T (bf16, made once with
+ * ftmi_transpose_bf16); bt_sp [2r,N] = t_sp of B, at_ext [K,3r] = t_ext of A (ftmi_lora_split).
+ *   dxa_ws [M,3r] bf16 scratch <- lora_scale * dy B as planes (hi | lo | hi)
  *   dx [M,K] bf16            <- bf16(bf16(dy W) + dxa A)            (may be NULL: input needs no gradient)
  *   grad_a [r,K] fp32        += dxa^T x       grad_b [N,r] fp32 += dy^T xa      (accumulated, like .grad)
  * r == 0 => dx only. */
 int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const void* x, const void* dy, const void* xa,
-                         const void* w_t, const void* a_t, const void* b_t, void* dxa_ws, void* dx, float* grad_a,
+                         const void* w_t, const void* bt_sp, const void* at_ext, void* dxa_ws, void* dx, float* grad_a,
                          float* grad_b, int variant, ftmi_stream stream);
 
 /* Generic building blocks (exposed for tests / incremental adoption) */
@@ -109,6 +112,24 @@ int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, lo
                  ftmi_stream stream);
 /* out[cols,rows] = in[rows,cols]^T (bf16); used once at load time for the dgrad copies of frozen weights */
 int ftmi_transpose_bf16(const void* in, void* out, int rows, int cols, ftmi_stream stream);
+
+/* Row-wise building blocks (width D = 2048; one wavefront per token row; every op of the eager chain fused in registers with a bf16
+ * round wherever the reference's eager bf16 graph materialises a tensor).
+ *  norm_modulate: y = bf16(bf16(norm(x)) * onep[b]) + shift[b], norm = RMSNorm (layernorm = 0) or LayerNorm (1), no affine -- the
+ *    reference's _patched_rms_norm_forward (finetrainers/patches/dependencies/diffusers/rms_norm.py:17-29) / nn.LayerNorm followed by
+ *    the AdaLN modulate `* (1 + scale) + shift` of the LTX block; b = row / rows_per_batch, shift / onep rows mod_bstride apart.
+ *    bwd: dx = (dres ? dres + : ) norm_bwd(x, bf16(dy * onep[b])).
+ *  qknorm_rope: y = rope(bf16(rms_norm(x) * w)) -- norm_q / norm_k (affine RMSNorm over the full width) followed by apply_rotary_emb
+ *    (finetrainers/patches/models/ltx_video/patch.py:23-33); cos / sin fp32 [rows_per_batch, D/2] (one value per rotated pair) or NULL
+ *    for no rotation (cross-attention).  bwd returns d x.  Row strides ldx / ldy / lddy / lddx in elements. */
+int ftmi_norm_modulate_fwd(const void* x, const void* shift, const void* onep, long mod_bstride, void* y, int rows, int rows_per_batch,
+                           int D, float eps, int layernorm, ftmi_stream stream);
+int ftmi_norm_modulate_bwd(const void* x, const void* dy, const void* onep, long mod_bstride, const void* dres, void* dx, int rows,
+                           int rows_per_batch, int D, float eps, int layernorm, ftmi_stream stream);
+int ftmi_qknorm_rope_fwd(const void* x, long ldx, const void* w, const float* cos_t, const float* sin_t, void* y, long ldy, int rows,
+                         int rows_per_batch, int D, float eps, ftmi_stream stream);
+int ftmi_qknorm_rope_bwd(const void* x, long ldx, const void* w, const float* cos_t, const float* sin_t, const void* dy, long lddy,
+                         void* dx, long lddx, int rows, int rows_per_batch, int D, float eps, ftmi_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LTX-Video DiT level
@@ -148,12 +169,15 @@ typedef struct {
     const void *w_o2, *b_o2, *w_o2_t;                    /* [L,D,D] [L,D] [L,D,D] */
     const void *w_ff1, *b_ff1, *w_ff1_t;                 /* [L,D_ff,D] [L,D_ff] [L,D,D_ff] */
     const void *w_ff2, *b_ff2, *w_ff2_t;                 /* [L,D,D_ff] [L,D] [L,D_ff,D] */
-    /* bf16 working copies of the LoRA matrices, refreshed by ftmi_lora_refresh */
-    const void* lora_a;      /* [L,8,r,D]  A          */
-    const void* lora_at;     /* [L,8,D,r]  A^T        */
-    const void* lora_b;      /* [L,8,D,r]  B          */
-    const void* lora_bt;     /* [L,8,r,D]  B^T        */
-    const void* lora_at_qkv; /* [L,D,3r]   [A_q;A_k;A_v]^T */
+    /* bf16 working copies of the fp32 LoRA matrices, refreshed by ftmi_lora_refresh.  The reference computes the LoRA branch in
+     * fp32 (trainer/sft_trainer/trainer.py:132-136); here every fp32 LoRA value v travels as two bf16 numbers hi = bf16(v),
+     * lo = bf16(v - hi) (16 mantissa bits) and every product is evaluated as hi*hi + lo*hi + hi*lo on the bf16 MFMA with fp32
+     * accumulation -- fp32-equivalent to ~2^-16 relative. */
+    const void* lora_a_sp;       /* [L,8,2r,D]  A   as (hi, lo) row planes interleaved per 32 rows: operand of x A^T      */
+    const void* lora_bt_sp;      /* [L,8,2r,D]  B^T the same way:                                  operand of dY B        */
+    const void* lora_b_ext;      /* [L,8,D,3r]  [B_hi | B_hi | B_lo]:   K-extension operand of the forward projections   */
+    const void* lora_at_ext;     /* [L,8,D,3r]  [A^T_hi | A^T_hi | A^T_lo]: K-extension operand of the dgrads            */
+    const void* lora_at_qkv_ext; /* [L,D,9r]    the same for the fused q|k|v dgrad (adapters 0,1,2 side by side)          */
     const float *rope_cos, *rope_sin; /* fp32 [S, D/2]: one (cos, sin) per rotated pair */
 } ftmi_ltx_weights;
 
@@ -190,9 +214,14 @@ int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, floa
                          float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, float* grad_norm_out,
                          ftmi_stream stream);
 
-/* fp32 flat LoRA params (A region [L,8,r,D] then B region [L,8,D,r]) -> the bf16 working copies of ftmi_ltx_weights */
-int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a, void* lora_at, void* lora_b, void* lora_bt,
-                      void* lora_at_qkv, int L, int r, int D, ftmi_stream stream);
+/* fp32 flat LoRA params (A region [L,8,r,D] then B region [L,8,D,r]) -> the bf16 (hi, lo) working copies of ftmi_ltx_weights */
+int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
+                      void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream);
+
+/* The same split for ONE fp32 matrix w [rows, cols] (building block of ftmi_linear_lora_fwd/_bwd callers): any of the four outputs
+ * may be NULL.  sp [2 rows, cols]: (hi, lo) row planes interleaved per 32 rows; ext [rows, 3 cols]: [hi | hi | lo];
+ * t_sp [2 cols, rows], t_ext [cols, 3 rows]: the same two layouts of w^T. */
+int ftmi_lora_split(const float* w, int rows, int cols, void* sp, void* ext, void* t_sp, void* t_ext, ftmi_stream stream);
 
 #ifdef __cplusplus
 }

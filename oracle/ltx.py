@@ -147,10 +147,20 @@ def apply_rotary_emb(x: torch.Tensor, freqs: Tuple[torch.Tensor, torch.Tensor]) 
     return out
 
 
+def native_sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """What the reference executes: its NATIVE provider (attention_dispatch.py:938-962) is a pass-through to
+    ``torch.nn.functional.scaled_dot_product_attention`` with dropout 0, non-causal, default scale.  On the CPU
+    torch dispatches bf16 inputs to ``aten::_scaled_dot_product_flash_attention_for_cpu`` (+ ``..._backward``;
+    recorded by tests/test_oracle.py::test_native_sdpa_dispatch): scores and softmax statistics in fp32, the
+    probabilities rounded to bf16 before P.V, dS rounded to bf16 before the dQ / dK products -- the same rounding
+    points as a fused GPU kernel.  Inputs [B, H, S, d]."""
+    return F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=0.0, is_causal=False)
+
+
 def sdpa_math(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_mask: Optional[torch.Tensor]) -> torch.Tensor:
-    """Attention semantics = torch native SDPA (attention_dispatch.py:938-962), evaluated as the
-    fp32-accumulate math form on the (bf16-rounded) inputs: softmax(q k^T / sqrt(d) + mask) v.
-    Inputs [B, H, S, d]; output cast to the input dtype."""
+    """NOT on the oracle's path: the fp32-probability "math" form softmax(q k^T / sqrt(d) + mask) v on the
+    bf16-rounded inputs, kept as a comparison point for the attention-kernel tests (the reference's own provider
+    tests compare against ``_NATIVE_MATH``, tests/models/attention_dispatch.py:48-78)."""
     scale = 1.0 / math.sqrt(q.shape[-1])
     s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
     if attn_mask is not None:
@@ -207,7 +217,7 @@ class Attention(nn.Module):
         key = key.unflatten(2, (self.heads, -1)).transpose(1, 2)
         value = value.unflatten(2, (self.heads, -1)).transpose(1, 2)
 
-        hidden_states = sdpa_math(query, key, value, attention_mask)
+        hidden_states = native_sdpa(query, key, value, attention_mask)
         hidden_states = hidden_states.transpose(1, 2).flatten(2, 3)
         hidden_states = hidden_states.to(query.dtype)
 
@@ -469,6 +479,87 @@ class LTXVideoTransformer3DModel(nn.Module):
         if not return_dict:
             return (output,)
         return {"sample": output}
+
+
+# --------------------------------------------------------------------------------------
+# accumulation-order variant (for the parity-tolerance "triangle": fp32 oracle <-> bf16 oracle <-> kernel)
+# --------------------------------------------------------------------------------------
+
+
+class _ChunkedLinear(torch.autograd.Function):
+    """``F.linear`` for a frozen bf16 weight with the SAME rounding points as torch's (fp32 accumulation, one round
+    to bf16 at the output, in forward and in the input gradient) but a different fp32 summation order: partial
+    products over chunks of the reduction axis are summed left to right.  Any two correct bf16 implementations of
+    the reference graph (CPU vs GPU, two BLAS libraries, two tile shapes) differ at least like this."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, chunk):
+        ctx.save_for_backward(w)
+        ctx.chunk = chunk
+        acc = None
+        for k0 in range(0, x.shape[-1], chunk):
+            t = x[..., k0:k0 + chunk].float() @ w[:, k0:k0 + chunk].float().t()
+            acc = t if acc is None else acc + t
+        if b is not None:
+            acc = acc + b.float()
+        return acc.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        acc = None
+        for n0 in range(0, w.shape[0], ctx.chunk):
+            t = g[..., n0:n0 + ctx.chunk].float() @ w[n0:n0 + ctx.chunk].float()
+            acc = t if acc is None else acc + t
+        return acc.to(g.dtype), None, None, None
+
+
+class accumulation_order_variant:
+    """Context manager: every frozen bf16 ``F.linear`` of the oracle sums its reduction in ``chunk``-wide partials.
+    ``rel_l2(grads(variant), grads(oracle))`` is the op-order noise floor of the LoRA gradients: the part of a
+    kernel-vs-oracle difference that no implementation can remove (tests/test_oracle.py pins its size)."""
+
+    def __init__(self, chunk: int = 512):
+        self.chunk = chunk
+
+    def __enter__(self):
+        self._orig = F.linear
+        orig, chunk = self._orig, self.chunk
+
+        def linear(x, w, b=None):
+            if x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and not w.requires_grad and x.shape[-1] > chunk:
+                return _ChunkedLinear.apply(x, w, b, chunk)
+            return orig(x, w, b)
+
+        F.linear = linear
+        torch.nn.functional.linear = linear
+        return self
+
+    def __exit__(self, *exc):
+        F.linear = self._orig
+        torch.nn.functional.linear = self._orig
+        return False
+
+
+def lora_grads(model: nn.Module, inp: "StepInputs", flow_weighting_scheme: str = "none") -> Tuple[Dict[str, torch.Tensor], float]:
+    """({peft name without the adapter infix: gradient}, loss) of one forward + backward of the oracle."""
+    for p in model.parameters():
+        p.grad = None
+    loss = forward_loss(model, inp, flow_weighting_scheme, contiguous_hidden_states=True)[0]
+    loss.backward()
+    return {n.replace(".default", ""): p.grad.detach().clone() for n, p in lora_parameters(model)}, loss.item()
+
+
+def grads_rel_l2(a: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor]) -> Tuple[float, float]:
+    """(all gradients as one vector, worst single adapter tensor) relative L2 error of ``a`` against ``b``."""
+    num = den = 0.0
+    worst = 0.0
+    for k, gb in b.items():
+        d = (a[k].float().cpu() - gb.float()).pow(2).sum().item()
+        n = gb.float().pow(2).sum().item()
+        num, den = num + d, den + n
+        worst = max(worst, math.sqrt(d / max(n, 1e-60)))
+    return math.sqrt(num / max(den, 1e-60)), worst
 
 
 # --------------------------------------------------------------------------------------

@@ -32,12 +32,17 @@ def report(name, got, ref, rel_tol, max_ulp_frac=None):
     return err
 
 
+# the tiled-GEMM kernels the product library ships: 8 = automatic choice (production), 42 / 44 / 47 pin 192x128 / 128x128 / 256x256 tiles
+# (the research variants of tools/gemm_experimental.hip.h are not in the product build)
+SHIPPED_VARIANTS = [8, 42, 44, 47]
+
+
 def rnd(shape, gen, scale=1.0, dtype=bf16):
     return (torch.randn(shape, generator=gen) * scale).to(dtype)
 
 
 # ----------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 55, 56])
+@pytest.mark.parametrize("variant", SHIPPED_VARIANTS)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (32, 2048, 2048), (1000, 192, 2048), (257, 64, 2048), (515, 6144, 2048), (2048, 6144, 256)])
 def test_gemm_nt_store(M, N, K, variant):
     from finetrainers_amd import ops
@@ -52,7 +57,7 @@ def test_gemm_nt_store(M, N, K, variant):
     assert (out.cpu() != ref).float().mean() < 0.02
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 55, 56])
+@pytest.mark.parametrize("variant", SHIPPED_VARIANTS)
 def test_gemm_nt_epilogues(variant):
     from finetrainers_amd import _lib, ops
 
@@ -82,49 +87,63 @@ def test_gemm_nt_epilogues(variant):
     report("epi dgelu", out, zz.grad.to(bf16), 3e-3)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 30, 31, 32, 33, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 55, 56])
-@pytest.mark.parametrize("M", [32, 300])
+def _split_ref(t):
+    """What the kernels carry for an fp32 LoRA value: hi = bf16(t), lo = bf16(t - hi)."""
+    hi = t.to(bf16)
+    lo = (t - hi.float()).to(bf16)
+    return hi, lo
+
+
+@pytest.mark.parametrize("variant", SHIPPED_VARIANTS)
+@pytest.mark.parametrize("M", [32, 300, 5376])
 def test_linear_lora_fwd(M, variant):
-    """peft lora.Linear semantics: bf16(base) + scale * (x A^T) B^T in fp32, re-rounded."""
+    """peft lora.Linear semantics with fp32 adapters (trainer.py:132-136): bf16(base) + scale * (x A^T) B^T evaluated in fp32,
+    re-rounded.  The LoRA branch must be fp32-equivalent: checked against an fp64 evaluation, far below bf16 resolution."""
     from finetrainers_amd import ops
 
     dev = _dev()
     g = torch.Generator().manual_seed(17)
     K, N, r, s = 2048, 2048, 64, 0.5
     x, w, b = rnd((M, K), g), rnd((N, K), g, 1 / math.sqrt(K)), rnd((N,), g)
-    A = torch.randn(r, K, generator=g) / math.sqrt(K)
+    A = torch.randn(r, K, generator=g) / math.sqrt(K)          # fp32 adapter weights, NOT bf16-representable
     Bm = torch.randn(N, r, generator=g) * 0.05
     base = (x.float() @ w.float().t() + b.float()).to(bf16)
-    ref = (base.float() + (x.float() @ A.t()) @ Bm.t() * s).to(bf16)
-    y, xa = ops.linear_lora_fwd(x.to(dev), w.to(dev), b.to(dev), A.to(bf16).to(dev), Bm.to(bf16).to(dev), s, variant=variant)
-    report(f"linear+lora M={M} v{variant}", y, ref, 4e-3)
-    report(f"lora xa M={M}", xa, (x.float() @ A.t() * s).to(bf16), 6e-3)
+    xa64 = x.double() @ A.double().t() * s
+    ref = (base.double() + xa64 @ Bm.double().t()).float().to(bf16)
+    y, xa = ops.linear_lora_fwd(x.to(dev), w.to(dev), b.to(dev), A.to(dev), Bm.to(dev), s, variant=variant)
+    report(f"linear+lora M={M} v{variant}", y, ref, 3e-3)
+    xa = xa.float().cpu()
+    hi, lo, hi2 = xa[:, :r], xa[:, r:2 * r], xa[:, 2 * r:]
+    assert torch.equal(hi, hi2)
+    err = ((hi.double() + lo.double()) - xa64).norm() / xa64.norm()
+    print(f"[parity] lora xa (hi+lo) vs fp64   M={M}: rel_l2={err:.3e}")
+    assert err < 2e-5, "x A^T must carry fp32-equivalent precision (bf16 operands would give ~3e-3)"
 
 
-@pytest.mark.parametrize("M", [96, 700])
+@pytest.mark.parametrize("M", [96, 700, 5376])
 def test_linear_lora_bwd(M):
-    """Autograd of peft lora.Linear over a frozen Linear (fp32 reference on the bf16 operands): dx, dA, dB."""
+    """Autograd of peft lora.Linear over a frozen Linear with fp32 adapters: dx (bf16), dA / dB (fp32-equivalent)."""
     from finetrainers_amd import ops
 
     dev = _dev()
     g = torch.Generator().manual_seed(23)
     K, N, r, s = 2048, 2048, 64, 0.5
     x, w, b = rnd((M, K), g), rnd((N, K), g, 1 / math.sqrt(K)), rnd((N,), g)
-    A = (torch.randn(r, K, generator=g) / math.sqrt(K)).to(bf16)
-    Bm = (torch.randn(N, r, generator=g) * 0.05).to(bf16)
+    A = torch.randn(r, K, generator=g) / math.sqrt(K)
+    Bm = torch.randn(N, r, generator=g) * 0.05
     dy = rnd((M, N), g)
-    xr = x.float().requires_grad_(True)
-    Ar, Br = A.float().requires_grad_(True), Bm.float().requires_grad_(True)
-    y = xr @ w.float().t() + b.float() + (xr @ Ar.t()) @ Br.t() * s
-    y.backward(dy.float())
+    xr = x.double().requires_grad_(True)
+    Ar, Br = A.double().requires_grad_(True), Bm.double().requires_grad_(True)
+    y = xr @ w.double().t() + b.double() + (xr @ Ar.t()) @ Br.t() * s
+    y.backward(dy.double())
     _, xa = ops.linear_lora_fwd(x.to(dev), w.to(dev), b.to(dev), A.to(dev), Bm.to(dev), s, variant=8)
     w_t = ops.transpose_bf16(w.to(dev))
     ga0 = torch.ones((r, K), dtype=torch.float32, device=dev)  # pre-existing .grad content must be accumulated into
-    dx, ga, gb = ops.linear_lora_bwd(x.to(dev), dy.to(dev), xa, w_t, A.t().contiguous().to(dev), Bm.t().contiguous().to(dev), s, grad_a=ga0, variant=8)
+    dx, ga, gb = ops.linear_lora_bwd(x.to(dev), dy.to(dev), xa, w_t, A.to(dev), Bm.to(dev), s, grad_a=ga0, variant=8)
     torch.cuda.synchronize()
-    report(f"lora bwd dx M={M}", dx, xr.grad.to(bf16), 4e-3)
-    report(f"lora bwd dA M={M}", ga - 1.0, Ar.grad, 1e-2)
-    report(f"lora bwd dB M={M}", gb, Br.grad, 1e-2)
+    report(f"lora bwd dx M={M}", dx, xr.grad.float().to(bf16), 4e-3)
+    report(f"lora bwd dA M={M}", ga - 1.0, Ar.grad.float(), 5e-5)   # fp32-equivalent (bf16 operands: ~4e-3)
+    report(f"lora bwd dB M={M}", gb, Br.grad.float(), 5e-5)
     dx2, _, _ = ops.linear_lora_bwd(None, dy.to(dev), None, w_t, None, None, s, variant=8)  # r = 0: plain dgrad
     report("plain dgrad", dx2, (dy.float() @ w.float()).to(bf16), 3e-3)
 
@@ -293,6 +312,7 @@ def test_clip_adamw_matches_torch():
 
 
 def test_lora_refresh_layouts():
+    """The bf16 (hi, lo) working copies of the flat fp32 LoRA buffer (include/ftmi355.h: ftmi_ltx_weights)."""
     from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoTransformer3DModel
 
     model = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=2), device=_dev())
@@ -301,11 +321,92 @@ def test_lora_refresh_layouts():
         model.lora_B.normal_(0, 0.02)
     model.refresh_lora_copies(force=True)
     torch.cuda.synchronize()
-    A, Bm = model.lora_A.detach(), model.lora_B.detach()
-    assert torch.equal(model.lora_a_bf, A.to(bf16))
-    assert torch.equal(model.lora_at_bf, A.to(bf16).transpose(-1, -2).contiguous())
-    assert torch.equal(model.lora_b_bf, Bm.to(bf16))
-    assert torch.equal(model.lora_bt_bf, Bm.to(bf16).transpose(-1, -2).contiguous())
+    A, Bm = model.lora_A.detach(), model.lora_B.detach()   # [L,8,r,D], [L,8,D,r]
+    r = 64
+
+    def planes(t):
+        hi = t.to(bf16)
+        return hi, (t - hi.float()).to(bf16)
+
+    def interleave(hi, lo):  # [..., rows, cols] -> [..., 2 rows, cols]: groups of 32 rows, hi then lo
+        sh = hi.shape
+        h = hi.reshape(*sh[:-2], sh[-2] // 32, 32, sh[-1])
+        l = lo.reshape(*sh[:-2], sh[-2] // 32, 32, sh[-1])
+        return torch.cat([h, l], dim=-2).reshape(*sh[:-2], 2 * sh[-2], sh[-1])
+
+    a_hi, a_lo = planes(A)
+    b_hi, b_lo = planes(Bm)
+    assert (a_lo.float().abs().max() > 0) and ((a_hi.float() + a_lo.float() - A).abs().max() < 2.0 ** -16 * A.abs().max())
+    assert torch.equal(model.lora_a_sp, interleave(a_hi, a_lo))
+    assert torch.equal(model.lora_bt_sp, interleave(b_hi.transpose(-1, -2).contiguous(), b_lo.transpose(-1, -2).contiguous()))
+    assert torch.equal(model.lora_b_ext, torch.cat([b_hi, b_hi, b_lo], dim=-1))
+    at_hi, at_lo = a_hi.transpose(-1, -2), a_lo.transpose(-1, -2)
+    at_ext = torch.cat([at_hi, at_hi, at_lo], dim=-1)
+    assert torch.equal(model.lora_at_ext, at_ext)
     for l in range(2):
-        stacked = A[l, :3].reshape(3 * 64, 2048).to(bf16)
-        assert torch.equal(model.lora_at_qkv_bf[l], stacked.t().contiguous())
+        assert torch.equal(model.lora_at_qkv_ext[l], torch.cat([at_ext[l, 0], at_ext[l, 1], at_ext[l, 2]], dim=-1))
+
+
+# ----------------------------------------------------------------------------------------------------
+# row-wise kernels, forward AND backward, against the eager bf16 torch graph of the oracle (same rounding points)
+@pytest.mark.parametrize("layernorm", [False, True])
+@pytest.mark.parametrize("rows,rpb", [(8, 4), (301, 301), (5376, 2688)])
+def test_norm_modulate_fwd_bwd(rows, rpb, layernorm):
+    from finetrainers_amd import ops
+    from oracle import ltx
+
+    dev = _dev()
+    D = 2048
+    g = torch.Generator().manual_seed(rows + layernorm)
+    nb = (rows + rpb - 1) // rpb
+    x, dy, dres = rnd((rows, D), g, 2.0), rnd((rows, D), g), rnd((rows, D), g)
+    scale, shift = rnd((nb, D), g, 0.3), rnd((nb, D), g, 0.3)
+    onep = (1 + scale.float()).to(bf16)   # the eager graph materialises (1 + scale) in bf16
+    xr = x.clone().requires_grad_(True)
+    bidx = torch.arange(rows) // rpb
+    if layernorm:
+        n = torch.nn.functional.layer_norm(xr, (D,), eps=1e-6)
+    else:
+        n = ltx.RMSNorm(D, eps=1e-6, elementwise_affine=False)(xr)
+    y_ref = n * onep[bidx] + shift[bidx]
+    y_ref.backward(dy)
+    y = ops.norm_modulate(x.to(dev), shift.to(dev), onep.to(dev), rpb, 1e-6, layernorm)
+    tag = f"norm_modulate {'LN' if layernorm else 'RMS'} {rows}"
+    report(tag + " fwd", y, y_ref.detach(), 2e-3)
+    dx = ops.norm_modulate_bwd(x.to(dev), dy.to(dev), onep.to(dev), rpb, 1e-6, layernorm)
+    report(tag + " bwd", dx, xr.grad, 4e-3)
+    dx2 = ops.norm_modulate_bwd(x.to(dev), dy.to(dev), onep.to(dev), rpb, 1e-6, layernorm, dres=dres.to(dev))
+    report(tag + " bwd+res", dx2, (dres.float() + xr.grad.float()).to(bf16), 4e-3)
+
+
+@pytest.mark.parametrize("rope", [True, False])
+@pytest.mark.parametrize("B,S", [(1, 32), (2, 150), (2, 2688)])
+def test_qknorm_rope_fwd_bwd(B, S, rope):
+    """norm_q / norm_k (rms_norm.py:17-29) + apply_rotary_emb (patch.py:23-33) and their autograd backward."""
+    from finetrainers_amd import ops
+    from finetrainers_amd.ltx_video.transformer import ltx_rope_tables
+    from oracle import ltx
+
+    dev = _dev()
+    D = 2048
+    g = torch.Generator().manual_seed(B * 1000 + S + rope)
+    x, dy = rnd((B, S, D), g, 1.5), rnd((B, S, D), g)
+    w = (1.0 + 0.1 * torch.randn(D, generator=g)).to(bf16)
+    norm = ltx.RMSNorm(D, eps=1e-5, elementwise_affine=True)
+    norm.weight.data = w.clone()
+    xr = x.clone().requires_grad_(True)
+    y_ref = norm(xr)
+    cos = sin = None
+    if rope:
+        F_, H_, W_ = {32: (2, 4, 4), 150: (3, 5, 10), 2688: (7, 16, 24)}[S]
+        scale = [1 / (25 / 8), 32, 32]
+        cos_full, sin_full = ltx.LTXVideoRotaryPosEmbed(D)(x, F_, H_, W_, scale)
+        y_ref = ltx.apply_rotary_emb(y_ref, (cos_full, sin_full))
+        cos, sin = (t.to(dev) for t in ltx_rope_tables(F_, H_, W_, scale, dim=D))
+    y_ref.backward(dy)
+    xd = x.reshape(B * S, D).to(dev)
+    y = ops.qknorm_rope(xd, w.to(dev), cos, sin, rows_per_batch=S, eps=1e-5)
+    tag = f"qknorm{'+rope' if rope else ''} B{B} S{S}"
+    report(tag + " fwd", y, y_ref.detach().reshape(B * S, D), 2e-3)
+    dx = ops.qknorm_rope_bwd(xd, w.to(dev), dy.reshape(B * S, D).to(dev), cos, sin, rows_per_batch=S, eps=1e-5)
+    report(tag + " bwd", dx, xr.grad.reshape(B * S, D), 5e-3)

@@ -200,8 +200,22 @@ def test_attention_provider_registry_semantics():
     # LTX's [B, H, 1, T] additive mask -> per-key bias
     m = ((1 - torch.tensor([[1.0, 1, 0, 0], [1, 0, 0, 0]]).to(torch.bfloat16)) * -10000.0).unsqueeze(1)
     m4 = m.repeat_interleave(3, dim=0).view(2, 3, 1, 4)
-    kb = ad._key_bias_from_mask(m4, 2, 3, 4)
-    assert kb.shape == (2, 4) and kb[0, 2] == -9984.0 and kb[0, 0] == 0
+    kb = ad._key_bias_from_mask(m4, 2, 3, 4)  # materialised per head (diffusers' prepare_attention_mask): honoured per head
+    assert kb.shape == (2, 3, 4) and kb[0, 1, 2] == -9984.0 and kb[0, 2, 0] == 0 and kb.dtype == torch.float32
+    kb = ad._key_bias_from_mask(m.unsqueeze(1).expand(2, 3, 1, 4), 2, 3, 4)  # an expanded view of one mask -> one row per sample
+    assert kb.shape == (2, 4) and kb[0, 2] == -9984.0 and kb[0, 0] == 0 and kb[1, 1] == -9984.0
+    # torch SDPA aligns mask dimensions to the RIGHT: a 3-D [X, 1, S_k] mask is per HEAD, not per sample
+    kb = ad._key_bias_from_mask(torch.zeros(3, 1, 4), 2, 3, 4)
+    assert kb.shape == (2, 3, 4)
+    with pytest.raises(ValueError):
+        ad._key_bias_from_mask(torch.zeros(2, 1, 4), 2, 3, 4)  # would silently treat the batch axis as heads
+    with pytest.raises(ValueError):
+        ad._key_bias_from_mask(torch.zeros(2, 3, 5, 4), 2, 3, 4)  # per-query masks are not supported
+    # bool masks / -inf: masked keys become a large FINITE negative (weight exactly 0, never NaN)
+    kb = ad._key_bias_from_mask(torch.tensor([[True, False, True, True]]), 2, 3, 4)
+    assert kb.shape == (2, 4) and kb[1, 1] < -1e29 and torch.isfinite(kb).all() and kb[0, 0] == 0
+    kb = ad._key_bias_from_mask(torch.tensor([[0.0, float("-inf"), 0.0, 0.0]]), 2, 3, 4)
+    assert torch.isfinite(kb).all() and kb[0, 1] < -1e29
     assert ad.register_into_finetrainers() is False  # the reference package is not importable in this image
 
 

@@ -139,83 +139,57 @@ def test_sft_step_runs_and_updates():
     assert any((before[n] != p).any() for n, p in ltx.lora_parameters(m))
 
 
-def test_gradient_noise_floor_of_bf16_rounding_points():
-    """Why the LoRA-gradient tolerance of the GPU parity tests is 1e-2 and not the north star's 1e-3.
+def test_native_sdpa_dispatch():
+    """The oracle's attention IS ``torch.nn.functional.scaled_dot_product_attention`` (what the reference's native provider
+    calls, attention_dispatch.py:938-962).  Record which CPU kernels that dispatches to for the oracle's bf16 tensors: the
+    fused CPU flash kernels, forward and backward -- bf16 probabilities, like a GPU flash kernel, not the fp32 math form."""
+    from torch.profiler import ProfilerActivity, profile
 
-    Moving ONE family of bf16 rounding points of the reference graph -- (i) LoRA operands (A, B, x A^T) rounded to bf16, as
-    any MFMA path must, or (ii) the softmax probabilities rounded to bf16 before P.V, as every fused (flash) attention kernel
-    the reference itself dispatches to on a GPU does -- already moves the LoRA gradients by 3.5e-3 ... 5e-3 (relative L2,
-    whole gradient), while the loss moves by < 1e-4.  A fused bf16 implementation cannot agree with the eager bf16 graph to
-    1e-3 on gradients; it can (and the GPU tests require it to) stay inside this noise floor."""
-    import math
+    q, k, v = (torch.randn(1, 4, 48, 64).to(torch.bfloat16).requires_grad_() for _ in range(3))
+    mask = torch.zeros(1, 4, 1, 48, dtype=torch.bfloat16)
+    mask[..., 40:] = -10000.0
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        ltx.native_sdpa(q, k, v, mask).float().sum().backward()
+    names = {e.key for e in prof.key_averages()}
+    print("[sdpa-dispatch]", sorted(n for n in names if "attention" in n))
+    assert "aten::scaled_dot_product_attention" in names
+    assert "aten::_scaled_dot_product_flash_attention_for_cpu" in names
+    assert "aten::_scaled_dot_product_flash_attention_for_cpu_backward" in names
+    # and it agrees with the fp32-probability math form to the reference's own provider tolerance (atol 5e-3)
+    # (the reference's own shape and seed: tests/models/attention_dispatch.py:113-120)
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(2, 8, 256, 64).to(torch.bfloat16) for _ in range(3))
+    assert (ltx.native_sdpa(q, k, v, None).float() - ltx.sdpa_math(q, k, v, None).float()).abs().max() < 5e-3
 
-    from oracle import ltx
 
+def test_lora_gradient_tolerance_triangle():
+    """Why the GPU parity tests bound the LoRA-gradient error by a measured figure and not by the north star's 1e-3.
+
+    Triangle on one case (production width, 1 block, 32 tokens; identical inputs, identical weights):
+      (a) bf16 oracle  vs  the same oracle with another fp32 SUMMATION ORDER in the frozen linears -- every rounding point
+          identical (``ltx.accumulation_order_variant``): the gradients move by ~4e-3 (relative L2, all adapters), the loss
+          by ~1e-5.  This is the floor for ANY two implementations of the reference's bf16 graph (CPU vs GPU included);
+      (b) bf16 oracle  vs  the fp32 model on the same (bf16-valued) weights and inputs: ~8e-3 -- the reference's own
+          distance from exact arithmetic;
+      (c) [GPU tests] kernel vs bf16 oracle must stay below 1.5 x (a) measured on the same case.
+    A 1e-3 bound on gradients is below (a): it cannot be met by any bf16 implementation, the reference on other
+    hardware included; the loss bound of 1e-3 is met with two orders of magnitude to spare."""
     cfg = ltx.LTXConfig.production(num_layers=1)
     model = ltx.build_model(cfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
     inp = ltx.synth_inputs(cfg, 1, 2, 4, 4, seed=3, mask_lens=[32], sigmas=[0.25])
-
-    def grads():
-        for p in model.parameters():
-            p.grad = None
-        loss = ltx.forward_loss(model, inp, contiguous_hidden_states=True)[0]
-        loss.backward()
-        return {n: p.grad.detach().clone() for n, p in ltx.lora_parameters(model)}, loss.item()
-
-    def rel(a, b):
-        num = sum((a[k] - b[k]).float().pow(2).sum().item() for k in a)
-        den = sum(b[k].float().pow(2).sum().item() for k in a)
-        return math.sqrt(num / den)
-
-    class RoundBoth(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, t):
-            return t.to(torch.bfloat16).float()
-
-        @staticmethod
-        def backward(ctx, g):
-            return g.to(torch.bfloat16).float()
-
-    class RoundFwd(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, t):
-            return t.to(torch.bfloat16).float()
-
-        @staticmethod
-        def backward(ctx, g):
-            return g
-
-    g_ref, l_ref = grads()
-
-    orig_fwd = ltx.LoraLinear.forward
-
-    def lora_bf16(self, x):
-        result = self.base_layer(x)
-        a, b = self.lora_A["default"], self.lora_B["default"]
-        xa = RoundBoth.apply(torch.nn.functional.linear(x.float(), RoundBoth.apply(a.weight)) * self.scaling)
-        return (result.float() + torch.nn.functional.linear(xa, RoundBoth.apply(b.weight))).to(result.dtype)
-
-    ltx.LoraLinear.forward = lora_bf16
-    try:
-        g_i, l_i = grads()
-    finally:
-        ltx.LoraLinear.forward = orig_fwd
-
-    orig_sdpa = ltx.sdpa_math
-
-    def sdpa_bf16_p(q, k, v, attn_mask):
-        s = torch.matmul(q.float(), k.float().transpose(-1, -2)) / math.sqrt(q.shape[-1])
-        if attn_mask is not None:
-            s = s + attn_mask.float()
-        return torch.matmul(RoundFwd.apply(torch.softmax(s, dim=-1)), v.float()).to(q.dtype)
-
-    ltx.sdpa_math = sdpa_bf16_p
-    try:
-        g_ii, l_ii = grads()
-    finally:
-        ltx.sdpa_math = orig_sdpa
-
-    r_i, r_ii = rel(g_i, g_ref), rel(g_ii, g_ref)
-    print(f"[noise floor] bf16 LoRA operands: grad {r_i:.3e}, loss {abs(l_i - l_ref) / l_ref:.1e};  bf16 P: grad {r_ii:.3e}, loss {abs(l_ii - l_ref) / l_ref:.1e}")
-    assert abs(l_i - l_ref) / l_ref < 1e-3 and abs(l_ii - l_ref) / l_ref < 1e-3
-    assert 1.5e-3 < r_i < 2e-2 and 1.5e-3 < r_ii < 2e-2
+    g_ref, l_ref = ltx.lora_grads(model, inp)
+    with ltx.accumulation_order_variant(512):
+        g_ord, l_ord = ltx.lora_grads(model, inp)
+    m32 = ltx.build_model(cfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02, dtype=torch.float32)
+    m32.load_state_dict({k: v.float() for k, v in model.state_dict().items()})
+    inp32 = ltx.synth_inputs(cfg, 1, 2, 4, 4, seed=3, mask_lens=[32], sigmas=[0.25], dtype=torch.float32)
+    for f in ("latents", "noise", "encoder_hidden_states", "encoder_attention_mask"):
+        setattr(inp32, f, getattr(inp, f).float())
+    g_32, l_32 = ltx.lora_grads(m32, inp32)
+    a_glob, a_worst = ltx.grads_rel_l2(g_ord, g_ref)
+    b_glob, b_worst = ltx.grads_rel_l2(g_ref, g_32)
+    print(f"[triangle] (a) summation order: grad {a_glob:.3e} / worst adapter {a_worst:.3e}, loss {abs(l_ord - l_ref) / l_ref:.1e};  "
+          f"(b) bf16 vs fp32: grad {b_glob:.3e} / {b_worst:.3e}, loss {abs(l_32 - l_ref) / l_ref:.1e}")
+    assert abs(l_ord - l_ref) / l_ref < 1e-4 and abs(l_32 - l_ref) / l_ref < 1e-3
+    assert 1.5e-3 < a_glob < 1e-2, "summation order alone moves the gradients by more than the north star's 1e-3"
+    assert a_glob < b_glob < 3e-2

@@ -837,3 +837,184 @@ FTMI_DEVICE void nt_run_k_8ph(f32x16 (&acc)[2][4], char* smem, const bf16_t* __r
     if (wr == 0) asm volatile("s_barrier" ::: "memory");  // re-align the two wave rows
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hand-placed K loop (inline asm, one statement per instruction so hipcc still allocates the registers but cannot
+// re-order the stream).  tools/probe_mfma_dma.hip shows what the hardware allows: with ONE memory instruction behind
+// every MFMA a 256 x 256 tile's mix (per wave and 64 of K: 32 MFMA, 24 ds_read_b128, 8 direct-to-LDS loads) runs at the
+// MFMA-only rate, whereas the compiler-scheduled loops above lose a third.  Structure = nt_run_k_ring3 (4-stage ring of
+// BK = 32 tiles, fragments of tile kt+1 read while tile kt's MFMAs issue, loads of tile kt+4 behind them, vmcnt(8) so
+// two tiles stay in flight across the single barrier); written for 256 x 256 x 32, 8 waves (2 x 4).
+//   per tile and wave: MFMA_0 R_0  MFMA_1 R_1 ... MFMA_11 R_11  MFMA_12 D_0 ... MFMA_15 D_3  lgkmcnt(0) vmcnt(8) barrier
+// The lgkmcnt(0) sits at the END of the body (the last read was issued four MFMAs earlier) so that any register copy the
+// compiler places on the loop back-edge sees landed data.  Consecutive MFMAs use different accumulators (8 in rotation),
+// so no MFMA -> MFMA hazard needs software wait states; the caller pads before its first ordinary read of the accumulators.
+// ------------------------------------------------------------------------------------------------
+FTMI_DEVICE void asm_ds_read_b128(s16x8& dst, uint32_t addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
+FTMI_DEVICE void asm_mfma(f32x16& c, const s16x8& a, const s16x8& b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+
+template <int BM, int BN, int BK, int WM, int WN>
+FTMI_DEVICE void nt_run_k_asm(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                              int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    constexpr int NS = 4;
+    static_assert(BK == 32 && T::TM == 4 && T::TN == 2 && T::NW == 8, "written for 256 x 256 x 32 tiles, 8 waves (2 x 4)");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW;  // 2
+    constexpr int WI = BN * BK * 2 / 1024 / T::NW;  // 2
+    constexpr int LPT = XI + WI;                    // 4 loads per wave and tile
+    static_assert(LPT == 4, "load schedule below assumes 4 loads per wave and tile");
+
+    uint32_t off[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const bool isx = i < XI;
+        const int blk = isx ? wave * XI + i : wave * WI + (i - XI);
+        const int row = blk * T::RPI + lane / T::CPR, cs = lane % T::CPR;
+        const int c = cs ^ ((row >> 2) & 3);
+        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    // LDS destination of load i inside a stage, and per-lane fragment read addresses inside a stage
+    uint32_t ddst[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) ddst[i] = lds0 + (i < XI ? (wave * XI + i) * 1024 : BM * BK * 2 + (wave * WI + (i - XI)) * 1024);
+    uint32_t ra[12];  // read i: i < 4: W fragment (kk = i / 2, tn = i % 2); else X fragment (kk = (i-4) / 4, tm = (i-4) % 4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = lds0 + BM * BK * 2 + nt_lds_off<BK>((wn * T::TN + (i & 1)) * 32 + li, (i >> 1) * 2 + g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ra[4 + i] = lds0 + nt_lds_off<BK>((wm * T::TM + (i & 3)) * 32 + li, (i >> 2) * 2 + g);
+
+    auto dma = [&](int i, int tile, int buf) {
+        const int soff = min(tile, nk - 1) * BK * 2;
+        const uint32_t dst = ddst[i] + buf * T::STAGE;
+        if (i < XI)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(xrs), "s"(soff) : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(wrs), "s"(soff) : "memory", "m0");
+    };
+    s16x8 wf[2][2][2], xf[2][2][4];  // [parity][kk][tile]
+    auto rd = [&](auto P, int i, uint32_t stage_off) {
+        constexpr int par = decltype(P)::value;
+        const uint32_t a = ra[i] + stage_off;
+        if (i < 4)
+            asm_ds_read_b128(wf[par][i >> 1][i & 1], a);
+        else
+            asm_ds_read_b128(xf[par][(i - 4) >> 2][(i - 4) & 3], a);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    // prologue (as nt_run_k_ring3): tiles 0..2 in flight, 0 and 1 landed, fragments of tile 0 in registers, then tile 3
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) dma(i, t, t);
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 12; ++i) rd(P0{}, i, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) dma(i, NS - 1, NS - 1);
+
+    int bnext = 1, bfree = 0;
+    auto body = [&](int kt, auto P) {
+        constexpr int par = decltype(P)::value;
+        using PN = std::integral_constant<int, par ^ 1>;
+        const uint32_t so = bnext * T::STAGE;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = i >> 3, tn = (i >> 2) & 1, tm = i & 3;
+            asm_mfma(acc[tn][tm], wf[par][kk][tn], xf[par][kk][tm]);
+            if (i < 12) rd(PN{}, i, so);
+            else dma(i - 12, kt + NS, bfree);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        bfree = bnext;
+        bnext = (bnext == NS - 1) ? 0 : bnext + 1;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        body(kt, P0{});
+        if (kt + 1 < nk) body(kt + 1, P1{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+
+
+
+// Hand-placed twin of the production 2-stage loop on 256 x 256 x 64 tiles (8 waves): per K-tile and wave 32 MFMAs; the 8 loads of
+// tile kt+1 sit behind the first MFMAs of k-slices 0 and 1 (so they have two slices to land), the 6 fragment reads of slice
+// kk+1 behind the MFMAs of slice kk, one vmcnt(0) + barrier per tile.
+template <int BM, int BN, int BK, int WM, int WN>
+FTMI_DEVICE void nt_run_k_asm2(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx,
+                               int m0, int M, const bf16_t* __restrict__ W, long ldw, int nk, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = NtTile<BM, BN, BK, WM, WN>;
+    static_assert(BK == 64 && T::TM == 4 && T::TN == 2 && T::NW == 8, "written for 256 x 256 x 64 tiles, 8 waves (2 x 4)");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    constexpr int XI = BM * BK * 2 / 1024 / T::NW, WI = BN * BK * 2 / 1024 / T::NW, LPT = XI + WI;  // 4 + 4
+    static_assert(LPT == 8, "load schedule below assumes 8 loads per wave and tile");
+    uint32_t off[LPT], ddst[LPT];
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const bool isx = i < XI;
+        const int blk = isx ? wave * XI + i : wave * WI + (i - XI);
+        const int row = blk * T::RPI + lane / T::CPR, cs = lane % T::CPR;
+        const int c = cs ^ ((row >> 1) & 7);
+        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
+        ddst[i] = lds0 + (isx ? blk * 1024 : BM * BK * 2 + blk * 1024);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    auto dma = [&](int i, int tile, uint32_t stage_off) {
+        const int soff = min(tile, nk - 1) * BK * 2;
+        const uint32_t dst = ddst[i] + stage_off;
+        if (i < XI)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(xrs), "s"(soff) : "memory", "m0");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(off[i]), "s"(wrs), "s"(soff) : "memory", "m0");
+    };
+    // fragment read addresses inside a stage: [kk][6] = W tn 0,1 then X tm 0..3
+    uint32_t ra[4][6];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ra[kk][t] = lds0 + BM * BK * 2 + nt_lds_off<BK>((wn * T::TN + t) * 32 + li, kk * 2 + g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ra[kk][2 + t] = lds0 + nt_lds_off<BK>((wm * T::TM + t) * 32 + li, kk * 2 + g);
+    }
+    s16x8 fr[2][6];  // [slice parity][W0, W1, X0..X3]
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) dma(i, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t so = (kt & 1) * T::STAGE, sn = ((kt & 1) ^ 1) * T::STAGE;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) asm_ds_read_b128(fr[0][t], ra[0][t] + so);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int tn = i >> 2, tm = i & 3;
+                asm_mfma(acc[tn][tm], fr[kk & 1][tn], fr[kk & 1][2 + tm]);
+                if (kk < 3 && i < 6) asm_ds_read_b128(fr[(kk + 1) & 1][i], ra[kk + 1][i] + so);
+                if (kk < 2 && i >= 4) dma(kk * 4 + (i - 4), kt + 1, sn);          // behind MFMAs 4..7: loads 0-3 (kk 0), 4-7 (kk 1)
+            }
+            if (kk < 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+
