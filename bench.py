@@ -3,11 +3,13 @@
 49x512x768 clip, batch 2 per GPU, rank-64 LoRA, bf16, at 1/2/4/8 GPUs).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3          (spawns its 8 ranks itself: one process per GPU, RCCL over xGMI)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one full optimisation step of the reference's SFTTrainer._train body on synthetic latents already
 resident in HBM: noise/flow-match mix/pack -> 28-block DiT forward -> weighted MSE -> backward (LoRA grads) ->
-[DP: all-reduce of the flat LoRA gradient over RCCL] -> global-norm clip -> AdamW -> refresh of the bf16 LoRA copies.
+[DP: bucketed all-reduce (AVG) of the LoRA gradients over RCCL, overlapped with the backward] -> global-norm clip -> AdamW -> refresh of
+the bf16 (hi, lo) LoRA working copies.
 Nothing is skipped or cached between steps; weights are random-init of the production architecture (no checkpoints
 are reachable offline).  Prints ONE JSON line on rank 0.
 """
@@ -45,49 +47,94 @@ def parse():
     ap.add_argument("--width", type=int, default=24, help="latent width  (768 / 32)")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("FTMI_GEMM_VARIANT", "8")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-layers", type=int, default=2)
+    ap.add_argument("--cpu-baseline", choices=["full", "quick"], default="full",
+                    help="full: SURVEY 8d protocol (1 warm-up + 3 timed steps; cfg 2 on --cpu-baseline-layers blocks in bf16 and fp32, cfg 1 at full depth); "
+                         "quick: one un-warmed cfg-2 step on 2 blocks")
+    ap.add_argument("--cpu-baseline-layers", type=int, default=4)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events inside the timed region")
     ap.add_argument("--prof-stride", type=int, default=29, help="bracket every N-th launch of a kernel class with HIP events (1 = all)")
     return ap.parse_args()
 
 
-def _pmc_traffic(kernel: str):
-    """PMC counters cannot be read from inside the process being measured: the per-launch HBM traffic of the dominant kernel is
-    taken from the committed rocprofv3 --pmc summary of this same command (tools/gpu_traffic.sh); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def _profile_json(name: str):
     try:
-        with open(path) as f:
-            return json.load(f)[kernel]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
     except Exception:
         return None
 
 
+def _pmc_traffic(kernel: str):
+    """PMC counters cannot be read from inside the process being measured: the per-launch HBM traffic of the dominant kernel is
+    taken from the committed rocprofv3 --pmc summary of this same command (tools/gpu_pmc.sh); None if absent."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        d = _profile_json(name)
+        if d and kernel in d:
+            return d[kernel].get("hbm_bytes_per_launch"), name
+    return None, None
+
+
+def _cpu_steps(ltx, cfg, rank, dtype, B, F_, H_, W_, warm, timed):
+    model = ltx.build_model(cfg, seed=0, rank=rank, alpha=float(rank), dtype=dtype)
+    opt = ltx.make_optimizer(model)
+    inp = ltx.synth_inputs(cfg, B, F_, H_, W_, seed=1, mask_lens=[32, 96][:B], sigmas=[0.7, 0.25][:B], dtype=dtype)
+    for _ in range(warm):
+        ltx.sft_step(model, opt, inp)
+    ts = []
+    for _ in range(timed):
+        t0 = time.time()
+        ltx.sft_step(model, opt, inp)
+        ts.append(time.time() - t0)
+    return sum(ts) / len(ts), ts
+
+
 def cpu_baseline(args):
-    """The reference path (its CPU restatement, oracle/ltx.py) timed on this box's host cores: one forward+backward+
-    clip+AdamW step at the SAME clip shape and width, batch 1, on a bounded number of DiT blocks, scaled linearly to 28
-    blocks (blocks are identical; embeddings/tail are <1 % of the work)."""
+    """The reference path (its CPU restatement, oracle/ltx.py -- the real SFTTrainer cannot be imported here: no diffusers / peft) timed on
+    this box's host cores, SURVEY 8d protocol: all cores, no activation checkpointing, 1 warm-up + 3 timed optimisation steps
+    (forward + backward + clip + AdamW).  A BOUNDED sample: cfg 2 (clip 49x512x768, 2688 tokens) runs batch 1 on a few of the 28
+    identical blocks and is scaled linearly in blocks (embeddings / tail are < 1 % of the work) -- in bf16 (the reference's dtype)
+    and in fp32; cfg 1 (9x128x128, 32 tokens, batch 1) is measured at full depth.  `value` is cfg 2 / bf16 in the metric's unit."""
     from oracle import ltx
 
     torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    if args.cpu_baseline == "quick":
+        nl = 2
+        dt, _ = _cpu_steps(ltx, ltx.LTXConfig.production(num_layers=nl), args.rank, torch.bfloat16, 1, args.frames, args.height, args.width, 0, 1)
+        return {"value": 1.0 / (dt * 28.0 / nl), "unit": "samples/s", "cores": cores, "kind": "port",
+                "sample": f"QUICK: oracle, 1 un-warmed step, batch 1, cfg-2 clip, {nl} of 28 blocks = {dt:.1f} s, scaled x{28 / nl:g}", "step_s_measured": dt}
     nl = args.cpu_baseline_layers
     cfg = ltx.LTXConfig.production(num_layers=nl)
-    model = ltx.build_model(cfg, seed=0, rank=args.rank, alpha=float(args.rank))
-    opt = ltx.make_optimizer(model)
-    inp = ltx.synth_inputs(cfg, 1, args.frames, args.height, args.width, seed=1, mask_lens=[32], sigmas=[0.7])
-    cores = torch.get_num_threads()
-    t0 = time.time()
-    ltx.sft_step(model, opt, inp)
-    dt = time.time() - t0
-    per_sample_full = dt * (28.0 / nl)
-    return {
-        "value": 1.0 / per_sample_full,
-        "unit": "samples/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"oracle (CPU restatement of the reference step, bf16 storage) 1 step, batch 1, clip 49x512x768 "
-                  f"(2688 tokens), {nl} of 28 blocks timed = {dt:.1f} s, scaled x{28 // nl if 28 % nl == 0 else 28 / nl:g} to 28 blocks",
-        "step_s_measured": dt,
-    }
+    out = {"unit": "samples/s", "cores": cores, "kind": "port"}
+    dt_bf, ts_bf = _cpu_steps(ltx, cfg, args.rank, torch.bfloat16, 1, args.frames, args.height, args.width, 1, 3)
+    dt_32, ts_32 = _cpu_steps(ltx, cfg, args.rank, torch.float32, 1, args.frames, args.height, args.width, 1, 3)
+    dt_c1, ts_c1 = _cpu_steps(ltx, ltx.LTXConfig.production(num_layers=28), args.rank, torch.bfloat16, 1, 2, 4, 4, 1, 3)
+    scale = 28.0 / nl
+    out["value"] = 1.0 / (dt_bf * scale)
+    out["sample"] = (f"oracle (CPU restatement of the reference step), {cores} threads, 1 warm-up + 3 timed optimisation steps each: cfg 2 clip 49x512x768 "
+                     f"(2688 tokens) batch 1 on {nl} of 28 blocks, scaled x{scale:g}: bf16 {dt_bf:.2f} s/step -> {dt_bf * scale:.1f} s per sample-step, "
+                     f"fp32 {dt_32:.2f} s/step -> {dt_32 * scale:.1f} s; cfg 1 (9x128x128, 32 tokens, batch 1) at full depth, bf16: {dt_c1 * 1e3:.0f} ms/step")
+    out["cfg2_bf16"] = {"step_s_measured": ts_bf, "blocks": nl, "samples_per_s_scaled": 1.0 / (dt_bf * scale), "step_ms_scaled": dt_bf * scale * 1e3}
+    out["cfg2_fp32"] = {"step_s_measured": ts_32, "blocks": nl, "samples_per_s_scaled": 1.0 / (dt_32 * scale), "step_ms_scaled": dt_32 * scale * 1e3}
+    out["cfg1_bf16_full_depth"] = {"step_s_measured": ts_c1, "blocks": 28, "samples_per_s": 1.0 / dt_c1, "step_ms": dt_c1 * 1e3}
+    return out
+
+
+def _self_spawn(args) -> int:
+    """`python bench.py --gpus N` with N > 1 outside a launcher: re-execute under torch.distributed.run, one rank per GPU (the contract's
+    own launch line), on a free local port.  RCCL needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool; NCCL_P2P_DISABLE is never inherited."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("NCCL_P2P_DISABLE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -100,6 +147,10 @@ def main():
     from finetrainers_amd.parallel import DataParallelBackend
     from finetrainers_amd.trainer import MI355XSFTStep
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} MI355X visible")
+        raise SystemExit(_self_spawn(args))
     par = DataParallelBackend()
     if par.world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={par.world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -107,8 +158,8 @@ def main():
     lib = _lib.load()
 
     tcfg = LTXTransformerConfig(num_layers=args.layers)
-    spec = MI355XLTXVideoModelSpecification(tcfg, gemm_variant=args.gemm_variant)
-    model = spec.load_diffusion_models(device=dev, seed=0)["transformer"]  # identical weights on every rank
+    spec = MI355XLTXVideoModelSpecification(transformer_config=tcfg, gemm_variant=args.gemm_variant)
+    model = spec.load_diffusion_models(device=dev, random_init_seed=0)["transformer"]  # identical weights on every rank
     model.add_adapter(r=args.rank, lora_alpha=float(args.rank))
     with torch.no_grad():  # same LoRA init on every rank; B != 0 so every gradient path carries real data
         g = torch.Generator(device=dev).manual_seed(1)
@@ -232,15 +283,19 @@ def main():
                     "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s",
                     "frac": g_["tflops"] / PEAK_BF16_TFLOPS,
-                    "traffic": _pmc_traffic("gemm_nt_kernel"),
-                    "traffic_unit": "HBM/fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/r01_pmc_traffic.json)",
+                    "traffic": _pmc_traffic("gemm_nt_kernel")[0],
+                    "traffic_unit": f"HBM/fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/{_pmc_traffic('gemm_nt_kernel')[1]})",
                     "avg_launch_us": g_["avg_us"],
                     "launches_per_step": g_["launches_per_step"],
                     "share_of_step": g_["ms_per_step"] / ms,
                     "note": f"achieved = sum of algorithmic FLOPs (2*M*N*(K+K2)) / sum of HIP-event durations over every {args.prof_stride}-th "
                             "launch of the kernel, events recorded on the launch stream inside the timed region (the stride, coprime "
-                            "to the per-block launch counts, cycles through every shape; compare with the gemm_nt_kernel<...> rows of profiles/r01_c_kernel_stats.csv)",
+                            "to the per-block launch counts, cycles through every shape; compare with the gemm_nt_kernel<...> rows of profiles/r02_*_kernel_stats.csv)",
                 }
+                mf = _profile_json("r02_pmc_mfma.json")
+                if mf:  # counter-derived MFMA utilisation of the same command (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ..., tools/gpu_pmc.sh)
+                    res["roofline"]["mfma_busy_counter"] = mf.get("gemm_nt_kernel")
+                    res["mfma_utilisation_counters"] = mf.get("step")
                 if "attn_fwd" in kern and "attn_bwd" in kern:
                     a_ms = kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["ms_per_step"]
                     a_fl = kern["attn_fwd"]["tflops"] * kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["tflops"] * kern["attn_bwd"]["ms_per_step"]

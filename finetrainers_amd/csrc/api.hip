@@ -86,8 +86,8 @@ size_t ltx_workspace_bytes(const ftmi_ltx_config& c);
 int ltx_workspace_offset(const ftmi_ltx_config& c, const char* name, int layer, size_t* off);
 int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* x_t, const bf16_t* text, const float* key_bias,
                 const float* sigma, bf16_t* pred, void* ws, size_t ws_bytes, hipStream_t st);
-int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* text, const float* key_bias, const bf16_t* dpred,
-                 float* grad_a, float* grad_b, void* ws, size_t ws_bytes, hipStream_t st);
+int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* text, const float* key_bias, const bf16_t* dpred,
+                       float* grad_a, float* grad_b, void* ws, size_t ws_bytes, int l_hi, int l_lo, int accumulate, hipStream_t st);
 
 static int fill_attn(const ftmi_attn_desc* d, AttnArgs& a) {
     if (!d) return set_error(FTMI_ERR_INVALID, "attention: null descriptor");
@@ -320,12 +320,19 @@ int ftmi_ltx_forward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, cons
     return ltx_forward(*cfg, *w, (const bf16_t*)x_t, (const bf16_t*)text, key_bias, sigma, (bf16_t*)pred, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int ftmi_ltx_backward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias, const void* dpred,
-                      float* grad_a, float* grad_b, void* ws, size_t ws_bytes, ftmi_stream stream) {
+int ftmi_ltx_backward_range(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias, const void* dpred,
+                            float* grad_a, float* grad_b, void* ws, size_t ws_bytes, int l_hi, int l_lo, int accumulate, ftmi_stream stream) {
     if (!cfg || !w || !dpred || !ws) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_backward: null argument");
     if (cfg->r > 0 && (!grad_a || !grad_b || !w->lora_at_ext || !w->lora_bt_sp || !w->lora_at_qkv_ext))
         return set_error(FTMI_ERR_INVALID, "ftmi_ltx_backward: LoRA gradient buffers / working copies missing");
-    return ltx_backward(*cfg, *w, (const bf16_t*)text, key_bias, (const bf16_t*)dpred, grad_a, grad_b, ws, ws_bytes, (hipStream_t)stream);
+    return ltx_backward_range(*cfg, *w, (const bf16_t*)text, key_bias, (const bf16_t*)dpred, grad_a, grad_b, ws, ws_bytes, l_hi, l_lo, accumulate,
+                              (hipStream_t)stream);
+}
+
+int ftmi_ltx_backward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias, const void* dpred,
+                      float* grad_a, float* grad_b, void* ws, size_t ws_bytes, ftmi_stream stream) {
+    if (!cfg) return set_error(FTMI_ERR_INVALID, "ftmi_ltx_backward: null argument");
+    return ftmi_ltx_backward_range(cfg, w, text, key_bias, dpred, grad_a, grad_b, ws, ws_bytes, cfg->L, 0, /*accumulate=*/1, stream);
 }
 
 int ftmi_ltx_noise_pack(const void* latents, const void* noise, const float* mean, const float* std_, const float* sigma,

@@ -161,7 +161,7 @@ int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos
                     bf16_t* y2 = nullptr);  // x2 / w2 / y2: a second tensor set with the same strides processed by the same launch (q and k)
 int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy,
                     long lddy, bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows = 1, const bf16_t* x2 = nullptr,
-                    const bf16_t* w2 = nullptr, const bf16_t* dy2 = nullptr, bf16_t* dx2 = nullptr);
+                    const bf16_t* w2 = nullptr, const bf16_t* dy2 = nullptr, bf16_t* dx2 = nullptr, int row_grp = 0, int row_grp_span = 0);
 
 // latents [B,C,F*H*W] bf16 -> x_t, target packed [B, S, C]
 int noise_pack(const bf16_t* latents, const bf16_t* noise, const float* mean, const float* std_, const float* sigma,

@@ -342,12 +342,22 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
     return 0;
 }
 
-int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* text, const float* key_bias, const bf16_t* dpred,
-                 float* grad_a, float* grad_b, void* ws, size_t ws_bytes, hipStream_t st) {
+// Backward of blocks [l_lo, l_hi) in descending order (the tail first when l_hi == L).  When the call returns (stream order) the LoRA
+// gradients of exactly those blocks are FINAL -- all 8 adapters, the text-side ones included -- so a data-parallel caller can start
+// the gradient exchange of that block range while the next call computes the blocks below it (DDP's bucketed overlap,
+// finetrainers/parallel/ptd.py:462-463, without a reducer).  State between calls lives in the workspace; l_hi..l_lo must tile L..0.
+int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* text, const float* key_bias, const bf16_t* dpred,
+                       float* grad_a, float* grad_b, void* ws, size_t ws_bytes, int l_hi, int l_lo, int accumulate, hipStream_t st) {
     (void)text;
     FTMI_TRY(check_cfg(c));
     const WsLayout L = make_layout(c);
     if (ws_bytes < L.total) return set_error(FTMI_ERR_INVALID, "ltx_backward: workspace too small");
+    if (l_lo < 0 || l_hi > c.L || l_lo >= l_hi) return set_error(FTMI_ERR_INVALID, "ltx_backward: bad block range");
+    if (c.r > 0 && !accumulate && l_hi == c.L) {  // .grad was None: the weight-gradient kernels accumulate (split-token atomics), so start from zero
+        const size_t nbytes = (size_t)c.L * 8 * c.r * c.D * sizeof(float);
+        if (hipMemsetAsync(grad_a, 0, nbytes, st) != hipSuccess || hipMemsetAsync(grad_b, 0, nbytes, st) != hipSuccess)
+            return set_error(FTMI_ERR_LAUNCH, "ltx_backward: memset of the gradient buffer failed");
+    }
     const int M = c.B * c.S, Mt = c.B * c.T, D = c.D, r = c.r, V = c.gemm_variant;
     const long D2 = (long)D * D;
     const float s = c.lora_scale;
@@ -359,15 +369,15 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     bf16_t* dO = W(ws, L.s_d3);
 
     // ---- tail ----
-    FTMI_TRY(linear(dpred, c.C_out, M, P(w.proj_out_w_t, 0), c.C_out, D, c.C_out, nullptr, d1, D, V, st));
-    {
+    if (l_hi == c.L) {
+        FTMI_TRY(linear(dpred, c.C_out, M, P(w.proj_out_w_t, 0), c.C_out, D, c.C_out, nullptr, d1, D, V, st));
         const bf16_t* hL = W(ws, L.hs) + (size_t)c.L * M * D;
         const bf16_t* ao = W(ws, L.ada_out);
         // the gated copy bf(dh * gate_mlp) that opens the last block's backward is written by the same kernel (into dO, idle here)
         const bf16_t* ada_last = W(ws, L.ada) + (size_t)(c.L - 1) * c.B * 8 * D;
         FTMI_TRY(norm_modulate_bwd(hL, d1, ao + 2 * D, 3L * D, nullptr, dh[0], M, c.S, D, c.eps_norm, 1, st, ada_last + 5 * D, 8L * D, dO));
     }
-    int cur = 0;
+    int cur = (c.L - l_hi) & 1;  // the gradient of the residual stream ping-pongs between two buffers, one flip per finished block
 
     // LoRA adapter backward, critical-path half: dXA = s * dY B (needed at once by the dgrad K-extension).  The weight
     // gradients dB += dY^T XA and dA += dXA^T X only feed the gradient buffer, so dY / dXA are kept per block and all 28
@@ -428,9 +438,9 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
         }
         return 0;
     };
-    int wgrad_pending_hi = c.L;  // blocks [l, wgrad_pending_hi) have finished backward but not their weight gradients
+    int wgrad_pending_hi = l_hi;  // blocks [l, wgrad_pending_hi) have finished backward but not their weight gradients
 
-    for (int l = c.L - 1; l >= 0; --l) {
+    for (int l = l_hi - 1; l >= l_lo; --l) {
         char* blk = reinterpret_cast<char*>(ws) + L.blk0 + L.blk_stride * l;
         const bf16_t* h0 = W(ws, L.hs) + (size_t)l * M * D;
         const bf16_t* ada = W(ws, L.ada) + (size_t)l * c.B * 8 * D;
@@ -523,24 +533,27 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
             FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st, ada_prev + 5 * D, ab, dO));
             cur ^= 1;
         }
-        if (use_side && (wgrad_pending_hi - l >= tn_group || l == 0)) {
+        if (use_side && (wgrad_pending_hi - l >= tn_group || l == l_lo)) {
             if (hipEventRecord(ev_ready, st) != hipSuccess || hipStreamWaitEvent(side, ev_ready, 0) != hipSuccess)
                 return set_error(FTMI_ERR_LAUNCH, "ltx_backward: side-stream hand-off failed");
             FTMI_TRY(lora_wgrad(l, wgrad_pending_hi - l, side));
             wgrad_pending_hi = l;
         }
     }
-    if (r > 0 && !use_side) FTMI_TRY(lora_wgrad(0, c.L, st));
+    if (r > 0 && !use_side) FTMI_TRY(lora_wgrad(l_lo, l_hi - l_lo, st));
+    const int nb = l_hi - l_lo;
 
     // ---- text side of the cross-attention, all blocks at once (nothing upstream of `e` needs a gradient) ----
     if (r > 0) {
         // d(k2raw) = RMSNorm backward of d(k2n); rows ordered (token, block) like the forward
-        FTMI_TRY(qknorm_rope_bwd(W(ws, L.kv2_all), 2 * D, P(w.norm_k2, 0), nullptr, nullptr, W(ws, L.g_k2n_all), D, W(ws, L.g_kv2_all), 2 * D,
-                                 Mt * c.L, Mt * c.L, D, c.eps_qk, st, c.L));
+        // (row i of this call = (token i / nb, block l_lo + i % nb): rows of one token are L apart in the all-block arrays)
+        FTMI_TRY(qknorm_rope_bwd(W(ws, L.kv2_all) + (size_t)l_lo * 2 * D, 2 * D, P(w.norm_k2, (size_t)l_lo * D), nullptr, nullptr,
+                                 W(ws, L.g_k2n_all) + (size_t)l_lo * D, D, W(ws, L.g_kv2_all) + (size_t)l_lo * 2 * D, 2 * D,
+                                 Mt * nb, Mt * nb, D, c.eps_qk, st, nb, nullptr, nullptr, nullptr, nullptr, nb, c.L));
         GemmNtArgs a;  // dXA[:, (l,k|v)] = s * dY[:, (l,k|v) slice] B_{l,k|v}
-        a.X = W(ws, L.g_kv2_all); a.ldx = (long)c.L * 2 * D; a.xk_grp_n = 2 * r; a.xk_grp_stride = D;
-        a.W = P(w.lora_bt_sp, 5L * 2 * r * D); a.ldw = D; a.w_grp_n = 4 * r; a.w_grp_stride = 16L * r * D;
-        a.M = Mt; a.N = c.L * 4 * r; a.K = D; a.alpha = s; a.split_r = r; a.out = W(ws, L.dxa_kv2_all); a.ldo = (long)c.L * 6 * r; a.variant = V;
+        a.X = W(ws, L.g_kv2_all) + (size_t)l_lo * 2 * D; a.ldx = (long)c.L * 2 * D; a.xk_grp_n = 2 * r; a.xk_grp_stride = D;
+        a.W = P(w.lora_bt_sp, ((size_t)l_lo * 8 + 5) * 2 * r * D); a.ldw = D; a.w_grp_n = 4 * r; a.w_grp_stride = 16L * r * D;
+        a.M = Mt; a.N = nb * 4 * r; a.K = D; a.alpha = s; a.split_r = r; a.out = W(ws, L.dxa_kv2_all) + (size_t)l_lo * 6 * r; a.ldo = (long)c.L * 6 * r; a.variant = V;
         FTMI_TRY(gemm_nt(a, st));
     }
 
@@ -548,14 +561,14 @@ int ltx_backward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16
     if (r > 0) {
         {   // attn2.to_k / to_v: operands are column slices of the all-block arrays (batch stride = one block's columns)
             GemmTnArgs t;
-            t.U = W(ws, L.g_kv2_all); t.ldu = (long)c.L * 2 * D; t.V = W(ws, L.xa_kv2_all); t.ldv = (long)c.L * 6 * r; t.v_fold = r;
-            t.C = grad_b + 5L * D * r; t.ldc = r; t.M = Mt; t.P = 2 * D; t.Q = r; t.v_grp_p = D; t.v_grp_stride = 3 * r;
-            t.batch = c.L; t.u_bstride = 2L * D; t.v_bstride = 6L * r; t.c_bstride = 8L * D * r;
+            t.U = W(ws, L.g_kv2_all) + (size_t)l_lo * 2 * D; t.ldu = (long)c.L * 2 * D; t.V = W(ws, L.xa_kv2_all) + (size_t)l_lo * 6 * r; t.ldv = (long)c.L * 6 * r; t.v_fold = r;
+            t.C = grad_b + ((size_t)l_lo * 8 + 5) * D * r; t.ldc = r; t.M = Mt; t.P = 2 * D; t.Q = r; t.v_grp_p = D; t.v_grp_stride = 3 * r;
+            t.batch = nb; t.u_bstride = 2L * D; t.v_bstride = 6L * r; t.c_bstride = 8L * D * r;
             FTMI_TRY(gemm_tn(t, st));
             GemmTnArgs u;
-            u.U = W(ws, L.dxa_kv2_all); u.ldu = (long)c.L * 6 * r; u.u_fold = r; u.u_grp_p = r; u.u_grp_stride = 3 * r; u.V = e; u.ldv = D;
-            u.C = grad_a + 5L * r * D; u.ldc = D; u.M = Mt; u.P = 2 * r; u.Q = D;
-            u.batch = c.L; u.u_bstride = 6L * r; u.v_bstride = 0; u.c_bstride = 8L * r * D;
+            u.U = W(ws, L.dxa_kv2_all) + (size_t)l_lo * 6 * r; u.ldu = (long)c.L * 6 * r; u.u_fold = r; u.u_grp_p = r; u.u_grp_stride = 3 * r; u.V = e; u.ldv = D;
+            u.C = grad_a + ((size_t)l_lo * 8 + 5) * r * D; u.ldc = D; u.M = Mt; u.P = 2 * r; u.Q = D;
+            u.batch = nb; u.u_bstride = 6L * r; u.v_bstride = 0; u.c_bstride = 8L * r * D;
             FTMI_TRY(gemm_tn(u, st));
         }
     }

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                               const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
                                                               int rows, int rows_per_batch, float eps, int w_rows, const bf16_t* __restrict__ x2,
-                                                              const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dy2, bf16_t* __restrict__ dx2) {
+                                                              const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dy2, bf16_t* __restrict__ dx2,
+                                                              int row_grp, int row_grp_span) {
     constexpr int D = kNch * 512;
     if (blockIdx.y == 1) {
         x = x2; w = w2; dy = dy2; dx = dx2;
@@ -296,8 +297,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
     if (row >= rows) return;
     const int s = row % rows_per_batch;
     if (w_rows > 1) w += (long)(row % w_rows) * D;
-    const bf16_t* xp = x + (long)row * ldx;
-    const bf16_t* dyp = dy + (long)row * lddy;
+    // rows may live in groups: row i sits at position (i / row_grp) * row_grp_span + i % row_grp (a block range of the (token, block) arrays)
+    const long mrow = row_grp > 0 ? (long)(row / row_grp) * row_grp_span + row % row_grp : (long)row;
+    const bf16_t* xp = x + mrow * ldx;
+    const bf16_t* dyp = dy + mrow * lddy;
     float xv[kNch][8], gv[kNch][8];
     float s2 = 0.f;
 #pragma unroll
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) c2 += gv[it][e] * (xv[it][e] * rstd);
     c2 = wave_sum(c2) * (1.0f / D);
-    bf16_t* dxp = dx + (long)row * lddx;
+    bf16_t* dxp = dx + mrow * lddx;
 #pragma unroll
     for (int it = 0; it < kNch; ++it) {
         float o[8];
@@ -345,11 +348,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
 }
 int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos_t, const float* sin_t, const bf16_t* dy, long lddy,
                     bf16_t* dx, long lddx, int rows, int rows_per_batch, int D, float eps, hipStream_t st, int w_rows, const bf16_t* x2, const bf16_t* w2,
-                    const bf16_t* dy2, bf16_t* dx2) {
+                    const bf16_t* dy2, bf16_t* dx2, int row_grp, int row_grp_span) {
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
     if ((ldx % 8) || (lddy % 8) || (lddx % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
     hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4, x2 ? 2 : 1), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps, w_rows,
-                       x2, w2, dy2, dx2);
+                       x2, w2, dy2, dx2, row_grp, row_grp_span);
     return check_launch("qknorm_rope_bwd");
 }
 

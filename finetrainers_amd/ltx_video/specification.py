@@ -44,12 +44,36 @@ class FlowMatchSigmas:
 
 
 class MI355XLTXVideoModelSpecification:
-    def __init__(self, transformer_config: Optional[LTXTransformerConfig] = None, transformer_dtype: torch.dtype = torch.bfloat16,
-                 gemm_variant: int = 8, **kwargs) -> None:
+    def __init__(
+        self,
+        pretrained_model_name_or_path: Optional[str] = "Lightricks/LTX-Video",
+        tokenizer_id: Optional[str] = None,
+        text_encoder_id: Optional[str] = None,
+        transformer_id: Optional[str] = None,
+        vae_id: Optional[str] = None,
+        text_encoder_dtype: torch.dtype = torch.bfloat16,
+        transformer_dtype: torch.dtype = torch.bfloat16,
+        vae_dtype: torch.dtype = torch.bfloat16,
+        revision: Optional[str] = None,
+        cache_dir: Optional[str] = None,
+        condition_model_processors: Optional[list] = None,
+        latent_model_processors: Optional[list] = None,
+        transformer_config: Optional[LTXTransformerConfig] = None,
+        gemm_variant: int = 8,
+        **kwargs,
+    ) -> None:
+        """Same keyword arguments as the reference constructor (modeling_utils.py:33-70, ltx_video/base_specification.py:94-122; built
+        by train.py:48-66); ``transformer_config`` / ``gemm_variant`` are the MI355X additions."""
         if transformer_dtype != torch.bfloat16:
             raise ValueError("the MI355X backend computes in bf16 (fp32 accumulation); transformer_dtype must be torch.bfloat16")
-        self.transformer_dtype = transformer_dtype
+        self.pretrained_model_name_or_path = pretrained_model_name_or_path
+        self.tokenizer_id, self.text_encoder_id, self.transformer_id, self.vae_id = tokenizer_id, text_encoder_id, transformer_id, vae_id
+        self.text_encoder_dtype, self.transformer_dtype, self.vae_dtype = text_encoder_dtype, transformer_dtype, vae_dtype
+        self.revision, self.cache_dir = revision, cache_dir
+        self.condition_model_processors = condition_model_processors or []
+        self.latent_model_processors = latent_model_processors or []
         self.transformer_config = transformer_config or LTXTransformerConfig()
+        self.vae_config = None
         self.gemm_variant = gemm_variant
         self.first_frame_conditioning_p = 0.1  # base_specification.py:282
         self.min_first_frame_sigma = 0.25      # base_specification.py:283
@@ -60,15 +84,48 @@ class MI355XLTXVideoModelSpecification:
         return {"latents": (2, 3, 4)}
 
     def load_diffusion_models(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, device: Optional[torch.device] = None,
-                              seed: int = 0) -> Dict[str, Any]:
-        """-> {"transformer": nn.Module, "scheduler": ...} (base_specification.py:173-190).  Weights come from a
-        diffusers-format state dict when given, else random init of the production architecture."""
-        transformer = MI355XLTXVideoTransformer3DModel(self.transformer_config, device=device, gemm_variant=self.gemm_variant)
+                              random_init_seed: Optional[int] = None) -> Dict[str, Any]:
+        """-> {"transformer": nn.Module, "scheduler": ...} (base_specification.py:173-190).
+
+        Called with no arguments, as the trainer does (trainer/sft_trainer/trainer.py:88), it loads the frozen base weights from
+        ``transformer_id`` or ``<pretrained_model_name_or_path>/transformer`` (a local diffusers directory, read with safetensors) and
+        RAISES when there is none -- it never silently trains on noise.  ``state_dict`` injects a diffusers-format state dict (parity
+        tests); ``random_init_seed`` explicitly requests random weights of the production architecture (synthetic benchmarks)."""
+        from .. import wire
+
+        cfg = self.transformer_config
+        if state_dict is None and random_init_seed is None:
+            directory = wire.resolve_transformer_dir(self.pretrained_model_name_or_path, self.transformer_id)
+            disk_cfg = wire.load_transformer_config(directory)
+            if disk_cfg:
+                cfg = LTXTransformerConfig(**{k: disk_cfg[k] for k in ("in_channels", "out_channels", "patch_size", "patch_size_t", "num_attention_heads",
+                                                                      "attention_head_dim", "cross_attention_dim", "num_layers", "caption_channels")
+                                              if k in disk_cfg})
+                self.transformer_config = cfg
+            state_dict = wire.load_transformer_state_dict(directory)
+        transformer = MI355XLTXVideoTransformer3DModel(cfg, device=device, gemm_variant=self.gemm_variant)
         if state_dict is not None:
             transformer.load_diffusers_state_dict(state_dict)
         else:
-            transformer.init_random_(seed)
+            transformer.init_random_(random_init_seed)
         return {"transformer": transformer, "scheduler": FlowMatchSigmas()}
+
+    def _save_lora_weights(self, directory: str, transformer_state_dict: Optional[Dict[str, torch.Tensor]] = None, scheduler=None,
+                           metadata: Optional[Dict[str, str]] = None, *args, **kwargs) -> None:
+        """base_specification.py:379-397: ``pytorch_lora_weights.safetensors`` with ``transformer.``-prefixed peft keys + metadata
+        (the trainer passes ``{"lora_config": json}``, trainer.py:283-298).  Loadable by the reference's ``load_lora_weights``."""
+        from .. import wire
+
+        if transformer_state_dict is not None:
+            wire.save_lora_weights(directory, transformer_state_dict, metadata)
+        if scheduler is not None:
+            import json
+            import os
+
+            sdir = os.path.join(directory, "scheduler")
+            os.makedirs(sdir, exist_ok=True)
+            with open(os.path.join(sdir, "scheduler_config.json"), "w") as f:  # FlowMatchEulerDiscreteScheduler().save_pretrained equivalent
+                json.dump({"_class_name": "FlowMatchEulerDiscreteScheduler", "num_train_timesteps": scheduler.config.num_train_timesteps, "shift": 1.0}, f, indent=2)
 
     def load_condition_models(self):
         raise NotImplementedError("text encoders are outside the MI355X hot path; use the reference specification")

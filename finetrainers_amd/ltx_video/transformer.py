@@ -14,7 +14,8 @@ HBM layout (designed for 288 GB, not ported from the reference's per-module para
     all-reduce; the LoRA branch runs at fp32-equivalent precision like the reference's (fp32 adapters,
     trainer.py:132-136): bf16 (hi, lo) working copies of A / B are refreshed after each optimiser step;
   * all activations of a step live in one caller-owned workspace (about 0.37 GB per block at B=2).
-peft/diffusers-compatible names are provided by ``state_dict()`` / ``lora_state_dict()`` views.
+``state_dict()`` / ``load_state_dict()`` speak the diffusers + peft key layout (views, no copies); ``lora_state_dict()`` is the
+``get_peft_model_state_dict`` form.
 """
 
 from __future__ import annotations
@@ -122,28 +123,47 @@ class _LTXDiTFunction(torch.autograd.Function):
         if module.lora_A is None:
             return (None,) * 9
         dpred = dpred.contiguous()
-        # one flat fp32 gradient buffer [A | B]: a single contiguous all-reduce and a single clip+AdamW launch downstream
-        n_a = module.lora_A.numel()
-        # recycled across steps while nothing accumulated is alive in .grad (the usual zero_grad(set_to_none=True) loop); with
-        # gradient accumulation the previous .grad tensors ARE this buffer, so a fresh one is used and autograd adds the two
+        # ONE flat fp32 gradient buffer [A | B] -- a contiguous all-reduce per block range and a single clip+AdamW launch downstream.
+        # The buffer IS lora_A.grad / lora_B.grad: the kernels write (or, under gradient accumulation, add) straight into it and
+        # autograd gets None for the two parameters, so nothing is copied or re-added on the way.
+        n_a, n_b = module.lora_A.numel(), module.lora_B.numel()
+        ga_live, gb_live = module.lora_A.grad, module.lora_B.grad
         gflat = module._grad_flat_buf
-        reuse = (gflat is not None and gflat.numel() == n_a + module.lora_B.numel() and gflat.device == dpred.device
-                 and module.lora_A.grad is None and module.lora_B.grad is None)
-        if reuse:
-            gflat.zero_()
-        else:
-            gflat = torch.zeros(n_a + module.lora_B.numel(), dtype=torch.float32, device=dpred.device)
-            if module.lora_A.grad is None and module.lora_B.grad is None:
-                module._grad_flat_buf = gflat
+        own = gflat is not None and gflat.numel() == n_a + n_b and gflat.device == dpred.device
+        foreign = None
+        if ga_live is None and gb_live is None:  # zero_grad(set_to_none=True) happened (trainer.py:503): start from zero
+            if not own:
+                gflat = module._grad_flat_buf = torch.empty(n_a + n_b, dtype=torch.float32, device=dpred.device)
+            accumulate = 0
+        elif (own and ga_live is not None and gb_live is not None and ga_live.data_ptr() == gflat.data_ptr()
+              and gb_live.data_ptr() == gflat.data_ptr() + 4 * n_a):
+            accumulate = 1  # gradient accumulation: add into the live buffer
+        else:  # somebody installed their own .grad tensors: compute into a scratch buffer and let autograd accumulate
+            foreign = gflat = torch.empty(n_a + n_b, dtype=torch.float32, device=dpred.device)
+            accumulate = 0
         ga = gflat[:n_a].view_as(module.lora_A)
         gb = gflat[n_a:].view_as(module.lora_B)
-        module._grad_flat = gflat
         _, text, key_bias, _, _, _ = ctx.keep
-        check(_lib.load().ftmi_ltx_backward(ctypes.byref(ctx.cfg), ctypes.byref(ctx.weights), ptr(text), ptr(key_bias), ptr(dpred),
-                                             ptr(ga), ptr(gb), ptr(ctx.ws), ctx.ws_bytes, stream_ptr()), "ftmi_ltx_backward")
+        lib = _lib.load()
+        hook = module._grad_bucket_hook if foreign is None else None
+        L = module.config.num_layers
+        step = module.grad_bucket_blocks if (hook is not None and module.grad_bucket_blocks > 0) else L
+        hi = L
+        while hi > 0:  # block ranges in backward order; each range's gradients are final when its call returns (stream order)
+            lo = max(0, hi - step)
+            check(lib.ftmi_ltx_backward_range(ctypes.byref(ctx.cfg), ctypes.byref(ctx.weights), ptr(text), ptr(key_bias), ptr(dpred), ptr(ga), ptr(gb),
+                                              ptr(ctx.ws), ctx.ws_bytes, hi, lo, accumulate, stream_ptr()), "ftmi_ltx_backward")
+            if hook is not None:
+                hook(lo, hi, ga[lo:hi], gb[lo:hi])
+            hi = lo
         module._release_workspace(ctx.ws)
         ctx.ws = None
-        return None, None, None, None, None, None, None, ga, gb
+        if foreign is not None:
+            return None, None, None, None, None, None, None, ga, gb
+        module._grad_flat = gflat
+        if ga_live is None:
+            module.lora_A.grad, module.lora_B.grad = ga, gb
+        return (None,) * 9
 
 
 class MI355XLTXVideoTransformer3DModel(nn.Module):
@@ -190,6 +210,10 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         self._last_workspace = None
         self._grad_flat = None
         self._grad_flat_buf = None
+        # data-parallel gradient exchange (finetrainers_amd.trainer.MI355XSFTStep installs these): when set, the backward runs in ranges
+        # of `grad_bucket_blocks` blocks and calls hook(l_lo, l_hi, grad_A[l_lo:l_hi], grad_B[l_lo:l_hi]) as soon as a range is final
+        self._grad_bucket_hook = None
+        self.grad_bucket_blocks = 7
         self._ws_pool = []  # idle activation workspaces (uint8 tensors), see _acquire_workspace
         self.lora_flat = None
 
@@ -336,6 +360,80 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
             a.copy_(sd[f"{path}.lora_A.weight"].to(a))
             b.copy_(sd[f"{path}.lora_B.weight"].to(b))
         self._lora_versions = None
+
+    # ---- diffusers / peft shaped state dict (what the reference's save and checkpoint paths read, trainer.py:279-306) ----
+    def _base_views(self) -> Dict[str, torch.Tensor]:
+        """name -> view of the frozen bf16 base weights under diffusers' ``LTXVideoTransformer3DModel`` parameter names (no copies)."""
+        D = self.config.inner_dim
+        peft = ".base_layer" if self.lora_A is not None else ""
+        o = {
+            "proj_in.weight": self.proj_in_w, "proj_in.bias": self.proj_in_b, "scale_shift_table": self.table_out,
+            "time_embed.emb.timestep_embedder.linear_1.weight": self.time_l1_w, "time_embed.emb.timestep_embedder.linear_1.bias": self.time_l1_b,
+            "time_embed.emb.timestep_embedder.linear_2.weight": self.time_l2_w, "time_embed.emb.timestep_embedder.linear_2.bias": self.time_l2_b,
+            "time_embed.linear.weight": self.time_lin_w, "time_embed.linear.bias": self.time_lin_b,
+            "caption_projection.linear_1.weight": self.cap_l1_w, "caption_projection.linear_1.bias": self.cap_l1_b,
+            "caption_projection.linear_2.weight": self.cap_l2_w, "caption_projection.linear_2.bias": self.cap_l2_b,
+            "proj_out.weight": self.proj_out_w, "proj_out.bias": self.proj_out_b,
+        }
+        for l in range(self.config.num_layers):
+            p = f"transformer_blocks.{l}."
+            o[p + "scale_shift_table"] = self.tables[l]
+            for i, t in enumerate(("to_q", "to_k", "to_v")):
+                o[p + f"attn1.{t}{peft}.weight"] = self.w_qkv[l, i * D:(i + 1) * D]
+                o[p + f"attn1.{t}{peft}.bias"] = self.b_qkv[l, i * D:(i + 1) * D]
+            o[p + "attn1.norm_q.weight"], o[p + "attn1.norm_k.weight"] = self.norm_q[l], self.norm_k[l]
+            o[p + f"attn1.to_out.0{peft}.weight"], o[p + f"attn1.to_out.0{peft}.bias"] = self.w_o[l], self.b_o[l]
+            o[p + f"attn2.to_q{peft}.weight"], o[p + f"attn2.to_q{peft}.bias"] = self.w_q2[l], self.b_q2[l]
+            for i, t in enumerate(("to_k", "to_v")):
+                o[p + f"attn2.{t}{peft}.weight"] = self.w_kv2[l, i * D:(i + 1) * D]
+                o[p + f"attn2.{t}{peft}.bias"] = self.b_kv2[l, i * D:(i + 1) * D]
+            o[p + "attn2.norm_q.weight"], o[p + "attn2.norm_k.weight"] = self.norm_q2[l], self.norm_k2[l]
+            o[p + f"attn2.to_out.0{peft}.weight"], o[p + f"attn2.to_out.0{peft}.bias"] = self.w_o2[l], self.b_o2[l]
+            o[p + "ff.net.0.proj.weight"], o[p + "ff.net.0.proj.bias"] = self.w_ff1[l], self.b_ff1[l]
+            o[p + "ff.net.2.weight"], o[p + "ff.net.2.bias"] = self.w_ff2[l], self.b_ff2[l]
+        return o
+
+    def state_dict(self, *args, destination=None, prefix: str = "", keep_vars: bool = False, **kwargs) -> Dict[str, torch.Tensor]:
+        """Keys as the reference's peft-wrapped diffusers transformer would emit them: base weights under their diffusers names
+        (``.base_layer.`` once an adapter is attached), LoRA tensors as ``...lora_A.default.weight`` -- so ``get_peft_model_state_dict``
+        (trainer.py:283) and the DCP ``ModelWrapper`` (parallel/ptd.py:313-321) see the layout they expect.  All values are views."""
+        out = destination if destination is not None else {}
+        for k, v in self._base_views().items():
+            out[prefix + k] = v if keep_vars else v.detach()
+        if self.lora_A is not None:
+            for k, v in self.lora_state_dict(adapter_name="default").items():
+                out[prefix + k] = v if keep_vars else v.detach()
+        return out
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True, assign: bool = False):
+        """Accepts what ``state_dict()`` emits (and plain diffusers / peft key variants).  Values are COPIED into the stacked buffers and
+        the flat LoRA buffer (``assign=True`` is refused: it would break the aliasing the fused optimiser step relies on)."""
+        if assign:
+            raise ValueError("MI355XLTXVideoTransformer3DModel.load_state_dict(assign=True) is not supported: parameters are views of one flat buffer")
+        sd = {k.replace(".base_layer.", "."): v for k, v in state_dict.items()}
+        base = {k: v for k, v in sd.items() if "lora_" not in k}
+        lora = {k: v for k, v in sd.items() if "lora_" in k}
+        missing = []
+        if base:
+            want = {k.replace(".base_layer.", ".") for k in self._base_views()}
+            missing = sorted(want - set(base))
+            if strict and (missing or set(base) - want):
+                raise RuntimeError(f"load_state_dict: missing {missing[:5]}{'...' if len(missing) > 5 else ''}, unexpected {sorted(set(base) - want)[:5]}")
+            if not missing:
+                self.load_diffusers_state_dict(base)
+        if lora:
+            if self.lora_A is None:
+                raise RuntimeError("load_state_dict: LoRA tensors given but no adapter attached (call add_adapter first)")
+            self.load_lora_state_dict(lora)
+        return nn.modules.module._IncompatibleKeys(missing, [])
+
+    def _assert_flat_aliasing(self) -> None:
+        """The fused clip+AdamW updates ``lora_flat`` in place; lora_A / lora_B must still be views of it (``model.to(...)`` or a foreign
+        ``load_state_dict(assign=True)`` would silently detach them)."""
+        n = self.lora_A.numel()
+        if self.lora_A.data_ptr() != self.lora_flat.data_ptr() or self.lora_B.data_ptr() != self.lora_flat.data_ptr() + 4 * n:
+            raise RuntimeError("lora_A / lora_B no longer alias transformer.lora_flat (the module was moved or re-assigned after add_adapter); "
+                               "re-attach the adapter on the target device")
 
     def lora_grad_views(self) -> Dict[str, torch.Tensor]:
         out = {}

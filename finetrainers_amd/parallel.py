@@ -26,7 +26,10 @@ import torch.distributed as dist
 
 
 class DataParallelBackend:
-    def __init__(self, backend: Optional[str] = None, timeout_s: int = 300, device: Optional[torch.device] = None):
+    def __init__(self, backend: Optional[str] = None, timeout_s: int = 300, device: Optional[torch.device] = None,
+                 exercise_collectives: bool = False):
+        """``exercise_collectives``: create the process group and run every collective even at world size 1 (a one-rank RCCL
+        communicator) -- lets a single-GPU box execute the exact code path of the multi-GPU step."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -38,7 +41,8 @@ class DataParallelBackend:
         if use_gpu:
             torch.cuda.set_device(self.device)
         self._owns_pg = False
-        if self.world_size > 1 and not dist.is_initialized():
+        self.exercise_collectives = bool(exercise_collectives)
+        if (self.world_size > 1 or self.exercise_collectives) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
@@ -48,6 +52,11 @@ class DataParallelBackend:
             self._owns_pg = True
 
     # ---- properties mirroring BaseParallelBackend -------------------------------------------------------------
+    @property
+    def active(self) -> bool:
+        """True when gradients have to be exchanged (more than one rank, or a one-rank group kept on purpose)."""
+        return self.world_size > 1 or self.exercise_collectives
+
     @property
     def is_main_process(self) -> bool:
         return self.rank == 0
@@ -64,7 +73,7 @@ class DataParallelBackend:
     @torch.no_grad()
     def all_reduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
         """In-place average of the flat gradient buffer over all ranks (DDP's gradient all-reduce)."""
-        if self.world_size == 1:
+        if not self.active:
             return flat
         if self.backend == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG)
@@ -72,6 +81,17 @@ class DataParallelBackend:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.div_(self.world_size)
         return flat
+
+    @torch.no_grad()
+    def all_reduce_mean_async(self, t: torch.Tensor):
+        """Start averaging ``t`` over all ranks and return a handle for ``GradBucketReducer.finish``.  On RCCL the collective runs on
+        the process group's own stream (ordered after the work already queued on the current stream), so it overlaps whatever the
+        caller launches next; nothing blocks the host."""
+        if not self.active:
+            return None
+        if self.backend == "nccl":
+            return (dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True), None)
+        return (dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t)
 
     @torch.no_grad()
     def reduce_step_metrics(self, loss: torch.Tensor, grad_norm: torch.Tensor) -> Dict[str, torch.Tensor]:
@@ -86,7 +106,7 @@ class DataParallelBackend:
 
     @torch.no_grad()
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
-        if self.world_size > 1:
+        if self.active:
             dist.broadcast(t, src=src)
         return t
 
@@ -105,3 +125,34 @@ class DataParallelBackend:
         if self._owns_pg and dist.is_initialized():
             dist.destroy_process_group()
             self._owns_pg = False
+
+
+class GradBucketReducer:
+    """Bucketed, overlapped gradient exchange of the DP step -- the role of DDP's reducer (``replicate(bucket_cap_mb=100)``,
+    finetrainers/parallel/ptd.py:462-463) without parameter hooks: the DiT backward runs in block ranges
+    (``ftmi_ltx_backward_range``) and reports each range as soon as its LoRA gradients are final; the slices of the flat fp32
+    gradient buffer are all-reduced (AVG) right away on RCCL's stream while the remaining blocks compute.  At r = 64 a bucket of 7
+    blocks is 2 x 29.4 MB, i.e. 4 buckets per step (DDP's 100 MB cap would give 3); per-link xGMI time of the whole 235 MB exchange is
+    ~3 ms against a ~60 ms step, and only the last bucket (the first blocks) is exposed.  Every rank issues the same collectives in
+    the same order by construction (the bucket schedule is a function of L alone)."""
+
+    def __init__(self, backend: DataParallelBackend):
+        self.backend = backend
+        self._pending = []
+        self.buckets_issued = 0
+
+    def bucket_ready(self, l_lo: int, l_hi: int, grad_a: torch.Tensor, grad_b: torch.Tensor) -> None:
+        """Hook signature of ``MI355XLTXVideoTransformer3DModel._grad_bucket_hook``."""
+        for t in (grad_a, grad_b):
+            h = self.backend.all_reduce_mean_async(t)
+            if h is not None:
+                self._pending.append(h)
+        self.buckets_issued += 1
+
+    def finish(self) -> None:
+        """Make the current stream wait for every outstanding bucket (device-side wait on RCCL; gloo: host wait + divide)."""
+        for work, div in self._pending:
+            work.wait()
+            if div is not None:
+                div.div_(self.backend.world_size)
+        self._pending.clear()

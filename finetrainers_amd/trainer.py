@@ -22,17 +22,20 @@ from .utils import diffusion as diffusion_utils
 
 
 class _MSELossFunction(torch.autograd.Function):
+    """loss = scale * mean_b mean w_b (pred - target)^2 with d loss / d pred from the same kernel.  ``scale`` (1 / accumulation
+    steps) is applied exactly ONCE: the kernel folds it into the saved gradient, the returned loss is multiplied here."""
+
     @staticmethod
-    def forward(ctx, pred, target, weight, grad_scale):
-        loss, dpred = ops.mse_loss(pred.contiguous(), target.contiguous(), weight, want_grad=True, grad_scale=grad_scale)
+    def forward(ctx, pred, target, weight, scale):
+        loss, dpred = ops.mse_loss(pred.contiguous(), target.contiguous(), weight, want_grad=True, grad_scale=scale)
         ctx.save_for_backward(dpred)
-        return loss.reshape(())
+        loss = loss.reshape(())
+        return loss * scale if scale != 1.0 else loss
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        # g is 1.0 for loss.backward(); keep generality without a host sync
-        return dpred * g.to(dpred.dtype), None, None, None
+        return dpred * g.to(dpred.dtype), None, None, None  # g = 1 for loss.backward(); no host sync either way
 
 
 def sft_loss(pred: torch.Tensor, target: torch.Tensor, sigmas: torch.Tensor, flow_weighting_scheme: str = "none",
@@ -41,20 +44,27 @@ def sft_loss(pred: torch.Tensor, target: torch.Tensor, sigmas: torch.Tensor, flo
     batch, divided by the accumulation steps.  ``sigmas`` as returned by the spec ([B,S,1], constant per sample)."""
     per_sample_sigma = sigmas.reshape(sigmas.shape[0], -1)[:, 0].float()
     weights = diffusion_utils.compute_loss_weighting_for_sd3(flow_weighting_scheme, per_sample_sigma).float().contiguous()
-    scale = 1.0 / gradient_accumulation_steps
-    loss = _MSELossFunction.apply(pred, target, weights, scale)
-    return loss * scale if gradient_accumulation_steps > 1 else loss
+    return _MSELossFunction.apply(pred, target, weights, 1.0 / gradient_accumulation_steps)
 
 
 class MI355XSFTStep:
     """One LoRA SFT optimisation step on one rank (one process per GPU).  ``parallel`` is a
-    ``finetrainers_amd.parallel.DataParallelBackend`` (or None for a single GPU)."""
+    ``finetrainers_amd.parallel.DataParallelBackend`` (or None for a single GPU).
+
+    Data parallelism (reference: ``apply_ddp`` -> ``replicate``, parallel/ptd.py:462-463): on construction the LoRA parameters are
+    broadcast from rank 0 (DDP broadcasts module state the same way), every step each rank runs its own samples, and the LoRA
+    gradients are averaged bucket by bucket WHILE the backward is still running (``GradBucketReducer``).  With
+    ``gradient_accumulation_steps`` > 1 only the last micro-step of a group exchanges gradients (DDP's ``no_sync`` for the others) and
+    applies clip + AdamW (trainer.py:479-503)."""
 
     def __init__(self, transformer, specification, lr: float = 5e-5, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
                  max_grad_norm: float = 1.0, flow_weighting_scheme: str = "none", flow_logit_mean: float = 0.0, flow_logit_std: float = 1.0,
-                 flow_mode_scale: float = 1.29, parallel=None, generator: Optional[torch.Generator] = None):
+                 flow_mode_scale: float = 1.29, parallel=None, generator: Optional[torch.Generator] = None,
+                 gradient_accumulation_steps: int = 1, grad_bucket_blocks: int = 7):
         if transformer.lora_A is None:
             raise ValueError("attach a LoRA adapter first (transformer.add_adapter)")
+        if gradient_accumulation_steps < 1:
+            raise ValueError("gradient_accumulation_steps must be >= 1")
         self.transformer = transformer
         self.spec = specification
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
@@ -63,13 +73,25 @@ class MI355XSFTStep:
         self.flow_logit_mean, self.flow_logit_std, self.flow_mode_scale = flow_logit_mean, flow_logit_std, flow_mode_scale
         self.parallel = parallel
         self.generator = generator
+        self.gradient_accumulation_steps = gradient_accumulation_steps
+        self._micro_step = 0
         dev = transformer.device
+        transformer._assert_flat_aliasing()
         # flat fp32 optimiser state matching transformer.lora_flat = [A | B]
         self.n_a, self.n_b = transformer.lora_A.numel(), transformer.lora_B.numel()
         self.exp_avg = torch.zeros(self.n_a + self.n_b, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self._scratch = torch.zeros(2, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.reducer = None
+        if parallel is not None and parallel.active:
+            from .parallel import GradBucketReducer
+
+            # replicas must start from the same adapter: add_adapter draws A from each process's own RNG
+            parallel.broadcast_(transformer.lora_flat, src=0)
+            transformer._lora_versions = None
+            transformer.grad_bucket_blocks = grad_bucket_blocks
+            self.reducer = GradBucketReducer(parallel)
         from .ltx_video.specification import FlowMatchSigmas
 
         self.scheduler = FlowMatchSigmas()
@@ -84,24 +106,39 @@ class MI355XSFTStep:
         )
 
     def step(self, condition_model_conditions: Dict[str, Any], latent_model_conditions: Dict[str, Any], sigmas: Optional[torch.Tensor] = None,
-             **spec_kwargs) -> Dict[str, torch.Tensor]:
+             **spec_kwargs) -> Dict[str, Optional[torch.Tensor]]:
+        """One micro-step.  Returns device scalars ``loss`` (already divided by the accumulation steps, as trainer.py:479 logs it) and
+        ``grad_norm`` (None on the non-final micro-steps of an accumulation group, where no optimiser step happens)."""
         tr = self.transformer
+        tr._assert_flat_aliasing()
         latents = latent_model_conditions["latents"]
         B = latents.shape[0]
         if sigmas is None:
             sigmas = self.sample_sigmas(B)
+        gas = self.gradient_accumulation_steps
+        self._micro_step += 1
+        sync = self._micro_step % gas == 0  # last micro-step of the group: exchange gradients, clip, step (trainer.py:498)
         # 3. forward (trainer.py:452-461)
         pred, target, sig = self.spec.forward(
             transformer=tr, condition_model_conditions=dict(condition_model_conditions), latent_model_conditions=dict(latent_model_conditions),
             sigmas=sigmas, generator=self.generator, compute_posterior=True, **spec_kwargs,
         )
-        # 4. loss + backward (trainer.py:463-481)
-        loss = sft_loss(pred, target, sig, self.scheme)
-        loss.backward()
+        # 4. loss + backward (trainer.py:463-481): loss and d loss / d pred come out of one kernel and the DiT backward is seeded with
+        # that gradient directly (what loss.backward() would hand it, without the unit-seed multiply)
+        per_sample_sigma = sig.reshape(B, -1)[:, 0].float()
+        weights = diffusion_utils.compute_loss_weighting_for_sd3(self.scheme, per_sample_sigma).float().contiguous()
+        loss, dpred = ops.mse_loss(pred.detach(), target, weights, want_grad=True, grad_scale=1.0 / gas)
+        loss = loss.reshape(()) / gas if gas > 1 else loss.reshape(())
+        tr._grad_bucket_hook = self.reducer.bucket_ready if (self.reducer is not None and sync) else None
+        try:
+            pred.backward(dpred)  # DP: buckets of finished blocks are all-reduced (AVG) on RCCL's stream while this still runs
+        finally:
+            tr._grad_bucket_hook = None
+        if not sync:
+            return {"loss": loss.detach(), "grad_norm": None}
         gflat = self._flat_grad(tr.lora_A.grad, tr.lora_B.grad)
-        # DP: average the LoRA gradients across ranks (the reference's DDP does this inside backward, ptd.py:462-463)
-        if self.parallel is not None and self.parallel.world_size > 1:
-            self.parallel.all_reduce_mean_(gflat)
+        if self.reducer is not None:
+            self.reducer.finish()
         # 5-6. clip (utils/torch.py:99-161) + AdamW (optimizer.py:117-125), fused over the flat buffer
         self.step_count += 1
         grad_norm = self._clip_adamw(gflat)
@@ -112,7 +149,10 @@ class MI355XSFTStep:
     def _flat_grad(self, ga: torch.Tensor, gb: torch.Tensor) -> torch.Tensor:
         gflat = self.transformer._grad_flat
         if gflat is not None and ga.data_ptr() == gflat.data_ptr() and gb.data_ptr() == gflat.data_ptr() + 4 * self.n_a:
-            return gflat  # autograd kept our buffer (the usual case: .grad was None)
+            return gflat  # .grad IS the flat buffer the kernels wrote (the usual case)
+        if self.reducer is not None:
+            raise RuntimeError("data-parallel step: lora_A.grad / lora_B.grad are not the backend's flat gradient buffer (foreign .grad tensors "
+                               "were installed); the bucketed exchange would have missed them")
         return torch.cat([ga.reshape(-1), gb.reshape(-1)])
 
     def _clip_adamw(self, gflat: torch.Tensor) -> torch.Tensor:

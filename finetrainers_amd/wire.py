@@ -1,0 +1,243 @@
+"""Wire formats on either side of the MI355X SFT step: what feeds the step and what it emits, byte-compatible
+with the reference so that artefacts move freely between the two.
+
+  * precomputed samples ....... ``<dir>/finetrainers-precomputed-data/{latent|condition}-{index}.pt`` -- one ``torch.save``d dict per
+                                sample, keys per processor ``output_names`` (finetrainers/data/precomputation.py:13,413-420;
+                                LTX keys: finetrainers/models/ltx_video/base_specification.py:123-128).  ``PrecomputedSampleFeeder`` is the
+                                MI355X-side reader: a background thread loads and collates the next batches into pinned host memory and
+                                copies them to HBM on a side stream, so the ~65 ms step never waits for the disk or the PCIe copy.
+  * LoRA checkpoint ........... ``pytorch_lora_weights.safetensors`` with ``transformer.``-prefixed peft keys and the ``lora_config`` JSON
+                                + ``format: pt`` metadata (finetrainers/trainer/sft_trainer/trainer.py:283-298,
+                                finetrainers/utils/serialization.py:6-10); the reader mirrors
+                                finetrainers/patches/dependencies/diffusers/peft.py:31-58.
+  * base weights .............. a diffusers model directory ``<root>/transformer/diffusion_pytorch_model*.safetensors`` (+ index json),
+                                read with ``safetensors`` alone (what ``LTXVideoTransformer3DModel.from_pretrained(root,
+                                subfolder="transformer")`` reads, finetrainers/models/ltx_video/base_specification.py:173-190).
+Host-side I/O only: nothing here computes.
+"""
+
+from __future__ import annotations
+
+import glob
+import json
+import os
+import queue
+import threading
+from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
+
+import torch
+
+PRECOMPUTED_DATA_DIR = "finetrainers-precomputed-data"  # finetrainers/data/precomputation.py:13
+LORA_WEIGHT_NAME = "pytorch_lora_weights.safetensors"   # diffusers' LORA_WEIGHT_NAME_SAFE (what save_lora_weights writes)
+TRANSFORMER_WEIGHT_NAME = "diffusion_pytorch_model.safetensors"
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# precomputed samples
+# --------------------------------------------------------------------------------------------------------------------------
+def save_precomputed_item(item: Dict[str, Any], index: int, directory: str, data_type: str) -> str:
+    """finetrainers/data/precomputation.py:413-415."""
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, f"{data_type}-{index}.pt")
+    torch.save(item, path)
+    return path
+
+
+def load_precomputed_item(index: int, directory: str, data_type: str, map_location=None) -> Dict[str, Any]:
+    """finetrainers/data/precomputation.py:418-420."""
+    return torch.load(os.path.join(directory, f"{data_type}-{index}.pt"), map_location=map_location, weights_only=True)
+
+
+class PrecomputedSampleFeeder:
+    """Endless iterator of ``(condition_batch, latent_batch)`` over a reference precomputation directory.
+
+    Index assignment follows ``PrecomputedOnceDataIterable`` (precomputation.py:350-384): rank r owns the contiguous range
+    ``[r * n_per_rank, (r+1) * n_per_rank)`` with ``n_per_rank = max(1, n_items // world_size)`` and cycles through it.  Samples are
+    grouped into batches of equal latent resolution (``ResolutionSampler`` semantics, data/sampler.py:6-58, keyed by the spec's
+    ``_resolution_dim_keys``) and collated with the spec's ``collate_conditions`` / ``collate_latents``.
+    MI355X-side design: the disk read, the collation and the host->device copy run ``prefetch`` batches ahead on a worker thread
+    (pinned staging buffers, its own HIP stream); ``__next__`` only waits on an event."""
+
+    def __init__(self, save_dir: str, rank: int, world_size: int, batch_size: int, collate_conditions: Callable, collate_latents: Callable,
+                 resolution_dim_keys: Optional[Dict[str, Tuple[int, ...]]] = None, device: Optional[torch.device] = None, prefetch: int = 2):
+        self.dir = save_dir if os.path.basename(os.path.normpath(save_dir)) == PRECOMPUTED_DATA_DIR else os.path.join(save_dir, PRECOMPUTED_DATA_DIR)
+        n_lat = len(glob.glob(os.path.join(self.dir, "latent-*.pt")))
+        n_cond = len(glob.glob(os.path.join(self.dir, "condition-*.pt")))
+        if n_lat == 0 or n_lat != n_cond:
+            raise ValueError(f"{self.dir}: expected matching latent-*.pt / condition-*.pt files, found {n_lat} / {n_cond}")
+        if n_lat <= rank:
+            raise ValueError(f"Precomputed data directory does not contain enough items (required {rank + 1}, found {n_lat}).")
+        self.rank, self.world_size, self.batch_size = rank, world_size, batch_size
+        self.n_per_rank = max(1, n_lat // world_size)
+        self.collate_conditions, self.collate_latents = collate_conditions, collate_latents
+        self.dim_keys = resolution_dim_keys or {"latents": (2, 3, 4)}
+        self.device = device
+        self._use_gpu = device is not None and device.type == "cuda"
+        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, prefetch))
+        self._stop = threading.Event()
+        self._err: Optional[BaseException] = None
+        self._thread = threading.Thread(target=self._worker, name="ftmi-feeder", daemon=True)
+        self._thread.start()
+
+    def __len__(self) -> int:
+        return self.n_per_rank
+
+    # ---- worker side ---------------------------------------------------------------------------------------------------
+    def _sample_stream(self) -> Iterator[Tuple[Dict[str, Any], Dict[str, Any]]]:
+        i = 0
+        while True:
+            index = self.rank * self.n_per_rank + i
+            yield load_precomputed_item(index, self.dir, "condition", "cpu"), load_precomputed_item(index, self.dir, "latent", "cpu")
+            i = (i + 1) % self.n_per_rank
+
+    def _to_device(self, d: Dict[str, Any], stream) -> Dict[str, Any]:
+        out = {}
+        for k, v in d.items():
+            if torch.is_tensor(v) and self._use_gpu:
+                with torch.cuda.stream(stream):
+                    out[k] = v.pin_memory().to(self.device, non_blocking=True)
+            else:
+                out[k] = v
+        return out
+
+    def _worker(self) -> None:
+        try:
+            stream = torch.cuda.Stream(device=self.device) if self._use_gpu else None
+            buckets: Dict[Tuple[int, ...], List[Tuple[Dict[str, Any], Dict[str, Any]]]] = {}
+            key_name = next(iter(self.dim_keys))
+            for cond, lat in self._sample_stream():
+                if self._stop.is_set():
+                    return
+                dims = tuple(lat[key_name].size(x) for x in self.dim_keys[key_name])
+                bucket = buckets.setdefault(dims, [])
+                bucket.append((cond, lat))
+                if len(bucket) < self.batch_size:
+                    continue
+                conds, lats = zip(*buckets.pop(dims))
+                cb, lb = self.collate_conditions(list(conds)), self.collate_latents(list(lats))
+                cb, lb = self._to_device(cb, stream), self._to_device(lb, stream)
+                ev = None
+                if self._use_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                while not self._stop.is_set():
+                    try:
+                        self._q.put((cb, lb, ev), timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+        except BaseException as e:  # surfaced to the consumer: the step must not hang on a dead feeder
+            self._err = e
+            self._q.put(None)
+
+    # ---- consumer side -------------------------------------------------------------------------------------------------
+    def __iter__(self) -> "PrecomputedSampleFeeder":
+        return self
+
+    def __next__(self) -> Tuple[Dict[str, Any], Dict[str, Any]]:
+        item = self._q.get()
+        if item is None:
+            raise RuntimeError("precomputed-sample feeder failed") from self._err
+        cb, lb, ev = item
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)  # device-side wait only: the copy was issued batches ago
+        return cb, lb
+
+    def close(self) -> None:
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5)
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# LoRA checkpoint
+# --------------------------------------------------------------------------------------------------------------------------
+def lora_config_metadata(rank: int, lora_alpha: float, target_modules) -> Dict[str, str]:
+    """The metadata block of finetrainers/trainer/sft_trainer/trainer.py:285-291."""
+    cfg = {"r": rank, "lora_alpha": lora_alpha, "init_lora_weights": True, "target_modules": target_modules}
+    return {"lora_config": json.dumps(cfg, indent=4)}
+
+
+def save_lora_weights(directory: str, transformer_state_dict: Dict[str, torch.Tensor], metadata: Optional[Dict[str, str]] = None) -> str:
+    """``LTXPipeline.save_lora_weights(directory, state_dict, save_function=partial(safetensors_torch_save_function, metadata=...),
+    safe_serialization=True)`` (ltx_video/base_specification.py:379-395): peft keys gain the ``transformer.`` prefix, metadata gains
+    ``format: pt`` (utils/serialization.py:6-10)."""
+    from safetensors.torch import save_file
+
+    os.makedirs(directory, exist_ok=True)
+    weights = {}
+    for k, v in transformer_state_dict.items():
+        if "lora_" not in k:
+            raise ValueError(f"{k}: not a LoRA tensor (pass get_peft_model_state_dict / lora_state_dict output)")
+        key = k.replace(".default.", ".")
+        weights[key if key.startswith("transformer.") else f"transformer.{key}"] = v.detach().to("cpu").contiguous()
+    md = dict(metadata or {})
+    md["format"] = "pt"
+    path = os.path.join(directory, LORA_WEIGHT_NAME)
+    save_file(weights, path, md)
+    return path
+
+
+def load_lora_weights(path: str) -> Tuple[Dict[str, torch.Tensor], Dict[str, Any]]:
+    """-> (peft-keyed state dict without the ``transformer.`` prefix, lora_config dict); mirror of
+    finetrainers/patches/dependencies/diffusers/peft.py:31-58 up to the point where peft injects the adapter."""
+    from safetensors import safe_open
+
+    if os.path.isdir(path):
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if len(files) == 0:
+            raise ValueError(f"No .safetensors files found in {path}.")
+        path = files[0]
+    sd = {}
+    with safe_open(path, framework="pt") as f:
+        md = f.metadata() or {}
+        for k in f.keys():
+            if k.startswith("transformer."):
+                sd[k[len("transformer."):]] = f.get_tensor(k)
+    if "lora_config" not in md:
+        raise ValueError(f"{path}: no lora_config metadata (not written by finetrainers)")
+    return sd, json.loads(md["lora_config"])
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# base weights
+# --------------------------------------------------------------------------------------------------------------------------
+def resolve_transformer_dir(pretrained_model_name_or_path: Optional[str], transformer_id: Optional[str] = None) -> str:
+    """Local directory holding the transformer's safetensors: ``transformer_id`` itself or ``<root>/transformer`` (the two
+    ``from_pretrained`` forms of base_specification.py:176-188).  Hub ids are not resolvable here (no network): raise."""
+    for cand in ([transformer_id] if transformer_id else []) + ([os.path.join(pretrained_model_name_or_path, "transformer"), pretrained_model_name_or_path]
+                                                                if pretrained_model_name_or_path else []):
+        if cand and os.path.isdir(cand) and (glob.glob(os.path.join(cand, "*.safetensors")) or glob.glob(os.path.join(cand, "*.safetensors.index.json"))):
+            return cand
+    raise FileNotFoundError(
+        f"no local diffusers transformer weights under {transformer_id or pretrained_model_name_or_path!r} "
+        "(expected <root>/transformer/diffusion_pytorch_model*.safetensors); the MI355X backend never trains on random weights implicitly -- "
+        "pass a local snapshot directory, or call load_diffusion_models(random_init_seed=...) explicitly for synthetic benchmarks")
+
+
+def load_transformer_state_dict(directory: str) -> Dict[str, torch.Tensor]:
+    """All tensors of a (possibly sharded) diffusers safetensors checkpoint directory."""
+    from safetensors.torch import load_file
+
+    index = glob.glob(os.path.join(directory, "*.safetensors.index.json"))
+    if index:
+        with open(index[0]) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+    else:
+        files = [os.path.basename(p) for p in sorted(glob.glob(os.path.join(directory, "*.safetensors")))]
+    sd: Dict[str, torch.Tensor] = {}
+    for fn in files:
+        sd.update(load_file(os.path.join(directory, fn)))
+    return sd
+
+
+def load_transformer_config(directory: str) -> Dict[str, Any]:
+    p = os.path.join(directory, "config.json")
+    if not os.path.exists(p):
+        return {}
+    with open(p) as f:
+        return json.load(f)

@@ -11,7 +11,7 @@
  *
  *   ftmi_attn_fwd / ftmi_attn_bwd ...... a provider function of finetrainers/models/attention_dispatch.py:405-447
  *                                        (contract :295-362; native provider :938-962) and its autograd backward
- *   ftmi_ltx_forward / ftmi_ltx_backward the transformer call inside LTXVideoModelSpecification.forward
+ *   ftmi_ltx_forward / ftmi_ltx_backward[_range] the transformer call inside LTXVideoModelSpecification.forward
  *                                        (finetrainers/models/ltx_video/base_specification.py:336-342), i.e.
  *                                        _patched_LTXVideoTransformer3D_forward (finetrainers/patches/models/
  *                                        ltx_video/patch.py:38-127) + loss.backward() through it
@@ -197,6 +197,17 @@ int ftmi_ltx_forward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, cons
 /* Backward: dpred [B,S,C_out] bf16 -> LoRA gradients ACCUMULATED (+=) into fp32 grad_a [L,8,r,D] and grad_b [L,8,D,r]. */
 int ftmi_ltx_backward(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias,
                       const void* dpred, float* grad_a, float* grad_b, void* ws, size_t ws_bytes, ftmi_stream stream);
+
+/* The same backward in pieces: blocks [l_lo, l_hi) in descending order (the tail first when l_hi == L).  Successive calls must tile
+ * L..0 (e.g. [21,28) [14,21) [7,14) [0,7)); the state between calls lives in ws.  When a call returns (stream order) the gradients of
+ * all 8 adapters of exactly those blocks are final, so a data-parallel caller starts the all-reduce of grad_a[l_lo:l_hi] /
+ * grad_b[l_lo:l_hi] on its communication stream while the next call computes -- the bucketed, overlapped gradient exchange of the
+ * reference's DDP (finetrainers/parallel/ptd.py:462-463: replicate(bucket_cap_mb=100)) without a reducer.
+ * accumulate = 0: the whole gradient buffer is zeroed first (by the call with l_hi == L), i.e. ".grad was None";
+ * accumulate = 1: gradients are added to the buffer's content (gradient accumulation). */
+int ftmi_ltx_backward_range(const ftmi_ltx_config* cfg, const ftmi_ltx_weights* w, const void* text, const float* key_bias,
+                            const void* dpred, float* grad_a, float* grad_b, void* ws, size_t ws_bytes, int l_hi, int l_lo,
+                            int accumulate, ftmi_stream stream);
 
 /* latents, noise [B,C,F*H*W] bf16; mean,std fp32 [C]; sigma fp32 [B]; sigma_first fp32 [B] or NULL (first-frame
  * conditioning branch: tokens < first_frame_tokens use it) -> x_t, target [B,S,C] bf16 */

@@ -115,7 +115,7 @@ def _build(num_layers, B, F_, H_, W_, first_frame, seed):
     inp.latents_std = 1.0 + 0.2 * torch.rand(cfg.in_channels, generator=torch.Generator().manual_seed(6))
     if first_frame:
         inp.first_frame_sigma = torch.tensor([0.1, 0.6][:B])
-    spec = MI355XLTXVideoModelSpecification(LTXTransformerConfig(num_layers=num_layers))
+    spec = MI355XLTXVideoModelSpecification(transformer_config=LTXTransformerConfig(num_layers=num_layers))
     gmodel = spec.load_diffusion_models(state_dict=omodel.state_dict(), device=_dev())["transformer"]
     gmodel.add_adapter(r=64, lora_alpha=64)
     gmodel.load_lora_state_dict({k: v for k, v in omodel.state_dict().items() if "lora_" in k})

@@ -1,0 +1,218 @@
+"""Data-parallel step on the GPU: the block-range backward behind the bucketed gradient exchange, the exchange itself on RCCL (a
+one-rank communicator on a single-GPU box; two real ranks when two MI355X are visible), gradient accumulation.  pytest -m gpu."""
+
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _model_and_batch(num_layers, B, F_, H_, W_, seed=3, dev=None, data_seed=None):
+    """Same weights for every caller (CPU generator, fixed seed); data from `data_seed`."""
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
+
+    dev = dev or _dev()
+    spec = MI355XLTXVideoModelSpecification(transformer_config=LTXTransformerConfig(num_layers=num_layers))
+    model = spec.load_diffusion_models(device=dev, random_init_seed=0)["transformer"]
+    model.add_adapter(r=64, lora_alpha=64)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(seed)
+        model.lora_flat.copy_((torch.randn(model.lora_flat.shape, generator=g) * 0.02).to(dev))
+    gd = torch.Generator().manual_seed(100 if data_seed is None else data_seed)
+    lat = torch.randn((B, 128, F_, H_, W_), generator=gd).to(bf16).to(dev)
+    text = torch.randn((B, 128, 4096), generator=gd).to(bf16).to(dev)
+    noise = torch.randn((B, 128, F_, H_, W_), generator=gd).to(bf16).to(dev)
+    mask = torch.zeros((B, 128), dtype=bf16, device=dev)
+    for i in range(B):
+        mask[i, : (32 if i % 2 == 0 else 96)] = 1
+    cond = {"encoder_hidden_states": text, "encoder_attention_mask": mask}
+    latd = {"latents": lat, "latents_mean": torch.zeros(128, device=dev), "latents_std": torch.ones(128, device=dev)}
+    sig = torch.tensor([0.25, 0.7, 0.4, 0.9][:B], device=dev)
+    return spec, model, cond, latd, sig, noise
+
+
+def _grads(spec, model, cond, latd, sig, noise, hook=None, bucket=0):
+    model.lora_A.grad = None
+    model.lora_B.grad = None
+    model._grad_bucket_hook, model.grad_bucket_blocks = hook, bucket
+    try:
+        pred, target, _ = spec.forward(transformer=model, condition_model_conditions=dict(cond), latent_model_conditions=dict(latd), sigmas=sig,
+                                       noise=noise, force_first_frame_branch=False)
+        ((pred.float() - target.float()) ** 2).mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        model._grad_bucket_hook = None
+    return model.lora_A.grad.detach().clone(), model.lora_B.grad.detach().clone()
+
+
+def test_block_range_backward_matches_single_call():
+    """ftmi_ltx_backward_range over [3,5) [1,3) [0,1) == one ftmi_ltx_backward over [0,5): same gradients (fp32 atomics order aside),
+    ranges reported in backward order, each exactly once."""
+    spec, model, cond, latd, sig, noise = _model_and_batch(5, 2, 2, 4, 6)
+    ga0, gb0 = _grads(spec, model, cond, latd, sig, noise)
+    seen = []
+
+    def hook(lo, hi, ga, gb):
+        assert ga.shape[0] == hi - lo and gb.shape[0] == hi - lo
+        seen.append((lo, hi))
+
+    ga1, gb1 = _grads(spec, model, cond, latd, sig, noise, hook=hook, bucket=2)
+    assert seen == [(3, 5), (1, 3), (0, 1)]
+    for a, b, n in ((ga1, ga0, "dA"), (gb1, gb0, "dB")):
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"[ranges] {n} rel {rel:.2e}")
+        assert rel < 1e-5 and torch.isfinite(a).all()
+    assert (ga0[:, 5:7].abs().amax(dim=(1, 2, 3)) > 0).all()  # the text-side adapters (attn2.to_k / to_v) of every block got gradients
+
+
+def test_dp_step_on_rccl_single_rank():
+    """The multi-GPU step's code path on one GPU: a one-rank RCCL communicator, LoRA broadcast, bucketed ReduceOp.AVG all-reduces issued
+    from the backward on RCCL's stream, clip + AdamW after the join.  Must reproduce the non-distributed step."""
+    from finetrainers_amd.parallel import DataParallelBackend
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 90))
+    par = DataParallelBackend(backend="nccl", exercise_collectives=True)
+    try:
+        assert par.active and par.world_size == 1
+        outs = []
+        for use_par in (False, True):
+            spec, model, cond, latd, sig, noise = _model_and_batch(4, 2, 2, 4, 4)
+            step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99), parallel=par if use_par else None, grad_bucket_blocks=1)
+            for _ in range(2):
+                o = step.step(cond, latd, sigmas=sig, noise=noise, force_first_frame_branch=False)
+            torch.cuda.synchronize()
+            outs.append((o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().clone(), step.reducer))
+        (l0, g0, p0, _), (l1, g1, p1, red) = outs
+        print(f"[dp-1rank] loss {l0:.6f} / {l1:.6f}  grad_norm {g0:.6e} / {g1:.6e}  buckets {red.buckets_issued}")
+        assert red is not None and red.buckets_issued == 8  # 4 buckets per step x 2 steps
+        assert abs(l0 - l1) <= 1e-6 * abs(l0) and abs(g0 - g1) <= 1e-4 * g0
+        assert ((p0 - p1).norm() / p0.norm()).item() < 1e-6
+        m = par.reduce_step_metrics(o["loss"], o["grad_norm"])
+        assert abs(m["global_avg_loss"].item() - l1) < 1e-7
+    finally:
+        par.destroy()
+
+
+def test_gradient_accumulation_matches_oracle():
+    """gradient_accumulation_steps = 2 (trainer.py:476-503): two micro-batches, each loss / 2, gradients summed, ONE clip + AdamW.  The
+    accumulated LoRA gradient is compared with the oracle's; the scale must be 1/gas, not 1/gas^2."""
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
+    from finetrainers_amd.trainer import MI355XSFTStep, sft_loss
+    from oracle import ltx
+
+    dev = _dev()
+    cfg = ltx.LTXConfig.production(num_layers=1)
+    omodel = ltx.build_model(cfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
+    micro = [ltx.synth_inputs(cfg, 1, 2, 4, 4, seed=31 + i, mask_lens=[32 + 64 * i], sigmas=[0.25 + 0.45 * i]) for i in range(2)]
+    for p in omodel.parameters():
+        p.grad = None
+    losses_ref = []
+    for inp in micro:
+        loss, _, _ = ltx.forward_loss(omodel, inp, contiguous_hidden_states=True)
+        (loss / 2).backward()
+        losses_ref.append(loss.item() / 2)
+    g_ref = {n.replace(".default", ""): p.grad.detach().clone() for n, p in ltx.lora_parameters(omodel)}
+    gn_ref = torch.linalg.vector_norm(torch.stack([g.norm() for g in g_ref.values()])).item()
+
+    spec = MI355XLTXVideoModelSpecification(transformer_config=LTXTransformerConfig(num_layers=1))
+    gmodel = spec.load_diffusion_models(state_dict=omodel.state_dict(), device=dev)["transformer"]
+    gmodel.add_adapter(r=64, lora_alpha=64)
+    gmodel.load_state_dict({k: v for k, v in omodel.state_dict().items() if "lora_" in k}, strict=False)
+
+    def fwd(inp):
+        return spec.forward(
+            transformer=gmodel,
+            condition_model_conditions={"encoder_hidden_states": inp.encoder_hidden_states.to(dev), "encoder_attention_mask": inp.encoder_attention_mask.to(dev)},
+            latent_model_conditions={"latents": inp.latents.to(dev), "latents_mean": inp.latents_mean, "latents_std": inp.latents_std},
+            sigmas=inp.sigmas.to(dev), noise=inp.noise.to(dev), force_first_frame_branch=False)
+
+    # (a) the reference loop's form: sft_loss(..., gradient_accumulation_steps=2).backward() twice
+    for i, inp in enumerate(micro):
+        pred, target, sig = fwd(inp)
+        loss = sft_loss(pred, target, sig, "none", gradient_accumulation_steps=2)
+        loss.backward()
+        assert abs(loss.item() - losses_ref[i]) <= 1e-3 * abs(losses_ref[i])
+    torch.cuda.synchronize()
+    glob, worst = ltx.grads_rel_l2({k: v.float().cpu() for k, v in gmodel.lora_grad_views().items()}, g_ref)
+    print(f"[accumulate] sft_loss x2: grad rel_l2 {glob:.3e} (worst adapter {worst:.3e}); |g| oracle {gn_ref:.4e}")
+    assert glob < 1.5e-2  # 1/gas^2 instead of 1/gas would be 0.5
+    gmodel.lora_A.grad = None
+    gmodel.lora_B.grad = None
+
+    # (b) the fused step: micro-step 1 accumulates only, micro-step 2 clips and steps
+    step = MI355XSFTStep(gmodel, spec, lr=5e-5, betas=(0.9, 0.99), max_grad_norm=1.0, gradient_accumulation_steps=2)
+    before = gmodel.lora_flat.detach().clone()
+    outs = []
+    for inp in micro:
+        outs.append(step.step({"encoder_hidden_states": inp.encoder_hidden_states.to(dev), "encoder_attention_mask": inp.encoder_attention_mask.to(dev)},
+                              {"latents": inp.latents.to(dev), "latents_mean": inp.latents_mean, "latents_std": inp.latents_std},
+                              sigmas=inp.sigmas.to(dev), noise=inp.noise.to(dev), force_first_frame_branch=False))
+        if len(outs) == 1:
+            assert outs[0]["grad_norm"] is None and torch.equal(gmodel.lora_flat, before) and step.step_count == 0
+    torch.cuda.synchronize()
+    gn = outs[1]["grad_norm"].item()
+    print(f"[accumulate] fused step: grad_norm {gn:.5e} vs oracle {gn_ref:.5e}; losses {[o['loss'].item() for o in outs]} vs {losses_ref}")
+    assert abs(gn - gn_ref) <= 5e-3 * gn_ref
+    assert step.step_count == 1 and not torch.equal(gmodel.lora_flat, before) and gmodel.lora_A.grad is None
+
+
+def _two_rank_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+
+    from finetrainers_amd.parallel import DataParallelBackend
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    par = DataParallelBackend(backend="nccl")
+    try:
+        spec, model, cond, latd, sig, noise = _model_and_batch(4, 1, 2, 4, 4, seed=3 + rank, dev=par.device, data_seed=200 + rank)  # different LoRA init per rank
+        step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99), parallel=par, grad_bucket_blocks=2)  # rank 0's adapter is broadcast
+        o = step.step(cond, latd, sigmas=sig, noise=noise, force_first_frame_branch=False)
+        torch.cuda.synchronize()
+        q.put((rank, o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().cpu()))
+    finally:
+        par.destroy()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the round-end driver's multi-GPU node); single-GPU boxes run the one-rank RCCL test above")
+def test_dp_step_two_ranks_equals_concatenated_batch():
+    """Two ranks, same weights, different data: after one step both hold the parameters a single rank gets from the concatenated batch."""
+    import torch.multiprocessing as mp
+
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, l0, g0, p0), (_, l1, g1, p1) = res
+    assert torch.equal(p0, p1) and g0 == g1  # replicas stay bit-identical
+    # single rank, both samples in one batch
+    spec, model, cond0, lat0, sig0, n0 = _model_and_batch(4, 1, 2, 4, 4, seed=3, data_seed=200)
+    _, _, cond1, lat1, sig1, n1 = _model_and_batch(4, 1, 2, 4, 4, seed=3, data_seed=201)
+    cond = {k: torch.cat([cond0[k], cond1[k]]) for k in cond0}
+    latd = dict(lat0, latents=torch.cat([lat0["latents"], lat1["latents"]]))
+    step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99))
+    o = step.step(cond, latd, sigmas=torch.cat([sig0, sig1]), noise=torch.cat([n0, n1]), force_first_frame_branch=False)
+    torch.cuda.synchronize()
+    assert abs(o["loss"].item() - (l0 + l1) / 2) < 1e-5 * abs(o["loss"].item())
+    assert abs(o["grad_norm"].item() - g0) < 1e-3 * g0
+    rel = ((model.lora_flat.cpu() - p0).norm() / p0.norm()).item()
+    print(f"[dp-2rank] parameter rel diff vs concatenated batch: {rel:.2e}")
+    assert rel < 1e-5

@@ -26,8 +26,8 @@ def full():
 
     dev = _dev()
     tcfg = LTXTransformerConfig(num_layers=28)
-    spec = MI355XLTXVideoModelSpecification(tcfg)
-    model = spec.load_diffusion_models(device=dev, seed=0)["transformer"]
+    spec = MI355XLTXVideoModelSpecification(transformer_config=tcfg)
+    model = spec.load_diffusion_models(device=dev, random_init_seed=0)["transformer"]
     model.add_adapter(r=64, lora_alpha=64.0)
     g = torch.Generator(device=dev).manual_seed(3)
     with torch.no_grad():

@@ -256,6 +256,139 @@ def test_data_parallel_backend_world_size_2_gloo():
         assert main == (rank == 0)
 
 
+def _bucket_worker(rank, world, port, q):
+    """Two ranks drive GradBucketReducer exactly as the DiT backward does: block ranges in descending order, the slices of ONE flat
+    [A | B] buffer reported as each range becomes final, later ranges still being 'computed' (written) after earlier ones were issued."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from finetrainers_amd.parallel import DataParallelBackend, GradBucketReducer
+
+    par = DataParallelBackend(backend="gloo")
+    try:
+        L, per = 10, 6  # 10 "blocks", 6 floats of A and of B per block
+        flat = torch.zeros(2 * L * per)
+        ga, gb = flat[: L * per].view(L, per), flat[L * per:].view(L, per)
+        red = GradBucketReducer(par)
+        order = []
+        hi, step = L, 4
+        while hi > 0:
+            lo = max(0, hi - step)
+            for l in range(lo, hi):  # this range's gradients become final only now
+                ga[l] = float(rank + 1) * (l + 1)
+                gb[l] = -float(rank + 1) * (l + 1)
+            red.bucket_ready(lo, hi, ga[lo:hi], gb[lo:hi])
+            order.append((lo, hi))
+            hi = lo
+        red.finish()
+        q.put((rank, flat.tolist(), order, red.buckets_issued))
+    finally:
+        par.destroy()
+
+
+def test_bucketed_gradient_exchange_world_size_2_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    L, per = 10, 6
+    want = [1.5 * (l + 1) for l in range(L) for _ in range(per)] + [-1.5 * (l + 1) for l in range(L) for _ in range(per)]
+    for rank, flat, order, n in res:
+        assert flat == want           # every rank ends with the mean over ranks, A and B slices of every bucket
+        assert order == [(6, 10), (2, 6), (0, 2)] and n == 3   # same schedule on every rank: a function of L alone
+
+
+def test_wire_formats_roundtrip(tmp_path):
+    """LoRA checkpoint (transformer.-prefixed peft keys + lora_config / format metadata), diffusers transformer directory
+    (sharded safetensors + index), precomputed-sample files and the prefetching feeder."""
+    import json
+
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+
+    from finetrainers_amd import wire
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification, MI355XLTXVideoTransformer3DModel
+    from finetrainers_amd.ltx_video.transformer import DEFAULT_TARGET_MODULES
+
+    # --- LoRA checkpoint through the spec's _save_lora_weights, exactly as trainer.py:283-298 calls it
+    model = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=1), device=torch.device("cpu"))
+    model.add_adapter(r=64, lora_alpha=64)
+    with torch.no_grad():
+        model.lora_B.normal_(0, 0.02)
+    peft_sd = {k.replace(".default.", "."): v for k, v in model.state_dict().items() if "lora_" in k}  # get_peft_model_state_dict
+    assert len(peft_sd) == 16
+    spec = MI355XLTXVideoModelSpecification(pretrained_model_name_or_path=str(tmp_path / "nowhere"))
+    out_dir = str(tmp_path / "lora_weights" / "000010")
+    from finetrainers_amd.ltx_video.specification import FlowMatchSigmas
+
+    spec._save_lora_weights(out_dir, peft_sd, FlowMatchSigmas(), wire.lora_config_metadata(64, 64, DEFAULT_TARGET_MODULES))
+    path = os.path.join(out_dir, "pytorch_lora_weights.safetensors")
+    with safe_open(path, framework="pt") as f:
+        md = f.metadata()
+        keys = list(f.keys())
+    assert md["format"] == "pt" and json.loads(md["lora_config"]) == {"r": 64, "lora_alpha": 64, "init_lora_weights": True, "target_modules": DEFAULT_TARGET_MODULES}
+    assert all(k.startswith("transformer.transformer_blocks.0.attn") and ".default." not in k for k in keys) and len(keys) == 16
+    assert os.path.exists(os.path.join(out_dir, "scheduler", "scheduler_config.json"))
+    sd2, cfg2 = wire.load_lora_weights(out_dir)
+    assert cfg2["r"] == 64
+    fresh = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=1), device=torch.device("cpu"))
+    fresh.add_adapter(r=cfg2["r"], lora_alpha=cfg2["lora_alpha"], target_modules=cfg2["target_modules"])
+    fresh.load_state_dict(sd2, strict=False)
+    assert torch.equal(fresh.lora_A, model.lora_A) and torch.equal(fresh.lora_B, model.lora_B)
+    with pytest.raises(ValueError):
+        fresh.load_state_dict(sd2, assign=True)
+
+    # --- base weights: load_diffusion_models() with NO arguments must load from disk or raise, never random-init
+    with pytest.raises(FileNotFoundError, match="never trains on random weights"):
+        spec.load_diffusion_models(device=torch.device("cpu"))
+    tdir = tmp_path / "snapshot" / "transformer"
+    tdir.mkdir(parents=True)
+    base = {k: torch.randn(v.shape).to(torch.bfloat16) for k, v in MI355XLTXVideoTransformer3DModel(
+        LTXTransformerConfig(num_layers=1), device=torch.device("cpu")).state_dict().items() if v.numel() < 1_000_000}
+    names = sorted(base)
+    shards = {"diffusion_pytorch_model-00001-of-00002.safetensors": names[: len(names) // 2], "diffusion_pytorch_model-00002-of-00002.safetensors": names[len(names) // 2:]}
+    for fn, ks in shards.items():
+        save_file({k: base[k] for k in ks}, str(tdir / fn))
+    with open(tdir / "diffusion_pytorch_model.safetensors.index.json", "w") as f:
+        json.dump({"metadata": {}, "weight_map": {k: fn for fn, ks in shards.items() for k in ks}}, f)
+    with open(tdir / "config.json", "w") as f:
+        json.dump({"_class_name": "LTXVideoTransformer3DModel", "num_layers": 1, "num_attention_heads": 32, "attention_head_dim": 64}, f)
+    assert wire.resolve_transformer_dir(str(tmp_path / "snapshot")) == str(tdir)
+    got = wire.load_transformer_state_dict(str(tdir))
+    assert set(got) == set(base) and all(torch.equal(got[k], base[k]) for k in base)
+    assert wire.load_transformer_config(str(tdir))["num_layers"] == 1
+
+    # --- precomputed samples + feeder (rank 1 of 2, batch 2, two resolutions interleaved)
+    pdir = str(tmp_path / "out" / wire.PRECOMPUTED_DATA_DIR)
+    for i in range(8):
+        hw = 4 if i % 2 == 0 else 6
+        wire.save_precomputed_item({"latents": torch.full((1, 128, 2, hw, hw), float(i)), "num_frames": 2, "height": hw, "width": hw,
+                                    "latents_mean": torch.zeros(128), "latents_std": torch.ones(128)}, i, pdir, "latent")
+        wire.save_precomputed_item({"encoder_hidden_states": torch.full((1, 128, 8), float(i)), "encoder_attention_mask": torch.ones(1, 128)}, i, pdir, "condition")
+    assert wire.load_precomputed_item(3, pdir, "latent")["latents"][0, 0, 0, 0, 0] == 3
+    feeder = wire.PrecomputedSampleFeeder(str(tmp_path / "out"), rank=1, world_size=2, batch_size=2, collate_conditions=spec.collate_conditions,
+                                          collate_latents=spec.collate_latents, resolution_dim_keys=spec._resolution_dim_keys)
+    try:
+        assert len(feeder) == 4
+        seen = []
+        for _ in range(4):
+            cb, lb = next(feeder)
+            assert lb["latents"].shape[0] == 2 and cb["encoder_hidden_states"].shape[0] == 2 and lb["latents_mean"].shape == (128,)
+            ids = lb["latents"][:, 0, 0, 0, 0].tolist()
+            assert cb["encoder_hidden_states"][:, 0, 0].tolist() == ids      # latents stay paired with their conditions
+            assert len({int(i) % 2 for i in ids}) == 1                        # one resolution per batch
+            seen += ids
+        assert set(seen) == {4.0, 5.0, 6.0, 7.0}                              # rank 1 owns indices [4, 8) and cycles through them
+    finally:
+        feeder.close()
+
+
 def test_dp_gradient_average_equals_large_batch_gradient():
     """The DP contract of the step: averaging per-rank LoRA gradients (each the mean over its own samples) equals the gradient
     of the global-batch loss -- checked on the oracle (tiny config), world 2 emulated in-process."""
