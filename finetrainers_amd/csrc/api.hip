@@ -2,7 +2,9 @@
 // plain-pointer C structs into the internal launch arguments, error reporting.
 #include <stdlib.h>
 
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string.h>
 #include <utility>
 #include <vector>
@@ -12,13 +14,31 @@
 
 namespace ftmi {
 
-static std::mutex g_err_mu;
-static char g_err[512] = "";
+// Error messages live in a small ring, each entry tagged with the id of the thread whose call failed: ftmi_last_error() returns the newest
+// entry of the CALLING thread (forward runs on the Python thread, backward on the autograd engine's thread -- neither can overwrite the
+// message the other is about to read), falling back to the newest entry overall.  No thread-local storage inside the library.
+namespace {
+constexpr int kErrRing = 32;
+struct ErrEntry {
+    unsigned long long seq = 0;
+    unsigned long long tid = 0;
+    int code = 0;
+    char msg[480] = "";
+};
+std::mutex g_err_mu;
+ErrEntry g_err[kErrRing];
+unsigned long long g_err_seq = 0;
+unsigned long long self_tid() { return (unsigned long long)std::hash<std::thread::id>{}(std::this_thread::get_id()); }
+}  // namespace
 
 int set_error(int code, const char* msg) {
     std::lock_guard<std::mutex> lk(g_err_mu);
-    strncpy(g_err, msg, sizeof(g_err) - 1);
-    g_err[sizeof(g_err) - 1] = 0;
+    ErrEntry& e = g_err[g_err_seq % kErrRing];
+    e.seq = ++g_err_seq;
+    e.tid = self_tid();
+    e.code = code;
+    strncpy(e.msg, msg, sizeof(e.msg) - 1);
+    e.msg[sizeof(e.msg) - 1] = 0;
     return code;
 }
 
@@ -168,7 +188,16 @@ int ftmi_prof_summary(int kclass, double* total_ms, long* launches, double* tota
 int ftmi_last_error(char* buf, size_t len) {
     if (!buf || len == 0) return FTMI_ERR_INVALID;
     std::lock_guard<std::mutex> lk(g_err_mu);
-    strncpy(buf, g_err, len - 1);
+    const unsigned long long me = self_tid();
+    const ErrEntry* mine = nullptr;
+    const ErrEntry* newest = nullptr;
+    for (const ErrEntry& e : g_err) {
+        if (!e.seq) continue;
+        if (!newest || e.seq > newest->seq) newest = &e;
+        if (e.tid == me && (!mine || e.seq > mine->seq)) mine = &e;
+    }
+    const ErrEntry* pick = mine ? mine : newest;
+    strncpy(buf, pick ? pick->msg : "", len - 1);
     buf[len - 1] = 0;
     return 0;
 }

@@ -97,8 +97,13 @@ FTMI_DEVICE void store_rows_via_lds(char* scr, const f32x16 (&t)[2], float mul, 
 // ------------------------------------------------------------------------------------------------
 static constexpr int kFwdLds = 2 * 16384 + 2 * 256;  // two (K, V) tile buffers + two key-bias rows
 
-template <bool HAS_KB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+// FL: experiment flags (product = 0).  1: row sums by VALU adds instead of 4 all-ones MFMAs; 2: lazy rescale (skip the O rescale pass
+// unless the running max of some lane's row grew by more than 2^8); 4 / 8 / 16: timing ablations (no exp / no P.V / no tile reload) whose
+// results are WRONG by construction -- compiled only with -DFTMI_EXPERIMENTAL.
+enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_ABL_NOLOAD = 16 };
+
+template <bool HAS_KB, int FL = 0, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
@@ -157,7 +162,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         const char* ks = smem + cur * 16384;
         const char* vs = ks + 8192;
         const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
-        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        if constexpr (!(FL & AF_ABL_NOLOAD)) {
+            if (t + 1 < nt) stage(t + 1, cur ^ 1);
+        }
 
         f32x16 st[2];
 #pragma unroll
@@ -195,19 +202,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // m_new == -inf only while every key seen so far carries a -inf bias: subtracting -inf would give NaN, and those keys must
         // contribute exp2(-inf) = 0, so the exponent is taken against 0 instead (alpha = exp2(-inf - 0) = 0 scales the empty state)
-        const float m_new = fmaxf(m_run, mx);
+        float m_new = fmaxf(m_run, mx);
+        float alpha;
+        if constexpr (FL & AF_LAZY) {
+            // keep the old reference max while no row of the wave outgrew it by more than 2^8: the probabilities are then at most 2^8
+            // (exact in bf16's exponent range, same relative precision) and the whole O / l rescale pass is skipped for the tile
+            const bool grow = (mx - m_run) > 8.0f;  // also true for the first tile (m_run = -inf)
+            if (__builtin_amdgcn_ballot_w64(grow) == 0) {
+                m_new = m_run;
+                alpha = 1.0f;
+            } else {
+                const float m_eff0 = (m_new == -INFINITY) ? 0.f : m_new;
+                alpha = fast_exp2(m_run - m_eff0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
+        } else {
+            const float m_eff0 = (m_new == -INFINITY) ? 0.f : m_new;
+            alpha = fast_exp2(m_run - m_eff0);
+        }
         const float m_eff = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = fast_exp2(m_run - m_eff);
 #pragma unroll
         for (int js = 0; js < 2; ++js)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                st[js][r] = HAS_KB ? fast_exp2(st[js][r] - m_eff) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_eff));
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (FL & AF_ABL_NOEXP)
+                    st[js][r] = __builtin_fmaf(st[js][r], sl * 1e-3f, 0.01f);
+                else
+                    st[js][r] = HAS_KB ? fast_exp2(st[js][r] - m_eff) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_eff));
+            }
         m_run = m_new;
+        if constexpr (!(FL & AF_LAZY)) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
 
         // The row sum of P rides on the matrix pipe: an all-ones A-slot fragment makes every row of the product the column
         // sums of P^T (= per-query sums over this tile's keys, both half-waves included), so the 32 adds + cross-half
@@ -216,22 +248,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         f32x16 lsum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
+        float lval = 0.f;
 #pragma unroll
         for (int js = 0; js < 2; ++js)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 s16x8 pf = pack_frag(st[js], hh);
+                if constexpr (FL & AF_ABL_NOPV) {
+                    asm volatile("" ::"v"(pf));
+                } else {
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
-                    oacc[dt] = mfma32(vf, pf, oacc[dt]);
+                    for (int dt = 0; dt < 2; ++dt) {
+                        s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
+                        oacc[dt] = mfma32(vf, pf, oacc[dt]);
+                    }
                 }
-                lsum = mfma32(ones, pf, lsum);
+                if constexpr (FL & AF_VALU_ROWSUM) {
+                    // sum of the bf16-rounded probabilities this lane holds (numerator and denominator use the same numbers)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) lval += bf2f((bf16_t)pf[e]);
+                } else {
+                    lsum = mfma32(ones, pf, lsum);
+                }
             }
-        l_run = l_run * alpha + lsum[0];
-        if (t + 1 < nt) stage_commit(cur ^ 1);
-        tile_dma_wait();
-        __syncthreads();  // tile t+1 landed (the barrier drains this wave's DMA first) and tile t's buffer is free again
+        if constexpr (FL & AF_VALU_ROWSUM) {
+            lval += __shfl_xor(lval, 32, 64);
+            l_run = l_run * alpha + lval;
+        } else {
+            l_run = l_run * alpha + lsum[0];
+        }
+        if constexpr (!(FL & AF_ABL_NOLOAD)) {
+            if (t + 1 < nt) stage_commit(cur ^ 1);
+            tile_dma_wait();
+            __syncthreads();  // tile t+1 landed (the barrier drains this wave's DMA first) and tile t's buffer is free again
+        }
     };
     for (int t = 0; t < nt; t += 2) {
         body(t, std::integral_constant<int, 0>{});
@@ -252,6 +302,30 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
         return set_error(FTMI_ERR_INVALID, "attn_fwd: token strides must keep 16-byte alignment");
     dim3 grid(((a.Sq + 127) / 128) * a.H * a.B);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);
+#ifdef FTMI_EXPERIMENTAL
+    const int fv = env_int("FTMI_ATTN_FWD", 0);  // re-read every call: tools/bench_attn.py switches variants inside one process
+    if (fv && !(a.kbias || (a.Sk % 64) != 0)) {
+        switch (fv) {
+#define FTMI_AF(id, FLAGS, MINW) case id: hipLaunchKernelGGL((attn_fwd_kernel<false, FLAGS, MINW>), grid, dim3(256), kFwdLds, st, a); return check_launch("attn_fwd");
+            FTMI_AF(1, AF_VALU_ROWSUM, 1)
+            FTMI_AF(2, AF_LAZY, 1)
+            FTMI_AF(3, AF_VALU_ROWSUM | AF_LAZY, 1)
+            FTMI_AF(4, AF_ABL_NOEXP, 1)
+            FTMI_AF(5, AF_ABL_NOPV, 1)
+            FTMI_AF(6, AF_ABL_NOLOAD, 1)
+            FTMI_AF(7, AF_ABL_NOEXP | AF_ABL_NOLOAD, 1)
+            FTMI_AF(8, AF_ABL_NOEXP | AF_ABL_NOPV | AF_ABL_NOLOAD, 1)
+            FTMI_AF(10, 0, 2)
+            FTMI_AF(11, 0, 4)
+            FTMI_AF(12, AF_VALU_ROWSUM | AF_LAZY, 2)
+            FTMI_AF(13, AF_VALU_ROWSUM | AF_LAZY, 4)
+            FTMI_AF(14, AF_LAZY, 2)
+            FTMI_AF(15, AF_LAZY, 4)
+#undef FTMI_AF
+            default: break;
+        }
+    }
+#endif
     if (a.kbias || (a.Sk % 64) != 0)
         hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), kFwdLds, st, a);
     else

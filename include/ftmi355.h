@@ -45,7 +45,9 @@ extern "C" {
 typedef void* ftmi_stream; /* hipStream_t */
 
 int ftmi_version(void);
-/* Copies the message of the most recent failing call (process-wide slot, not thread-local) */
+/* Copies the message of the most recent failing call MADE BY THE CALLING THREAD (messages live in a ring tagged with the failing thread's
+ * id -- the trainer's forward and the autograd engine's backward run on different threads and cannot overwrite each other's message);
+ * falls back to the newest message of any thread.  No thread-local state inside the library. */
 int ftmi_last_error(char* buf, size_t len);
 
 /* In-stream HIP-event profiler used by bench.py for its live roofline figures: while enabled, every stride-th launch of a

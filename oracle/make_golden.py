@@ -204,6 +204,54 @@ def main() -> None:
             flow_logit_mean=0.0, flow_logit_std=1.0, flow_mode_scale=1.29, device=torch.device("cpu"), generator=gen,
         )
 
+    # ---- CogVideoX: the reference's spec.forward / RoPE table / frame padding / DDIM loss weight and sigma sampling ----
+    from oracle import cogvideox as cvx
+
+    cvx_ns = dict(TYPING_NS, get_3d_rotary_pos_embed=cvx.get_3d_rotary_pos_embed, get_resize_crop_region_for_grid=cvx.get_resize_crop_region_for_grid,
+                  DiagonalGaussianDistribution=None, CogVideoXTransformer3DModel=object, CogVideoXDDIMScheduler=cvx.CogVideoXDDIMScheduler)
+    ref_cvx_rope = extract("finetrainers/models/cogvideox/utils.py", "prepare_rotary_positional_embeddings", cvx_ns)
+    cvx_ns["prepare_rotary_positional_embeddings"] = ref_cvx_rope
+    ref_cvx_fwd = extract("finetrainers/models/cogvideox/base_specification.py", "forward", cvx_ns, cls="CogVideoXModelSpecification")
+    ref_cvx_pad = extract("finetrainers/models/cogvideox/base_specification.py", "_pad_frames", cvx_ns, cls="CogVideoXModelSpecification")
+    for name, (h, w, f, pt) in {"v10": (48, 48, 3, None), "v15": (48, 64, 4, 2)}.items():
+        c_, s_ = ref_cvx_rope(height=h, width=w, num_frames=f, vae_scale_factor_spatial=8, patch_size=2, patch_size_t=pt, attention_head_dim=16,
+                              device=torch.device("cpu"), base_height=192, base_width=192)
+        tensors[f"cvx.rope_{name}.cos"], tensors[f"cvx.rope_{name}.sin"] = c_, s_
+    lat5 = torch.randn(1, 3, 4, 6, 6, generator=g).bfloat16()
+    tensors["cvx.pad.in"] = lat5
+    tensors["cvx.pad.out2"] = ref_cvx_pad(lat5, 2).contiguous()
+    tensors["cvx.pad.out3"] = ref_cvx_pad(lat5, 3).contiguous()
+
+    def run_cvx(tag: str, cfg, frames: int, hh: int, ww: int, seed: int, rank: int) -> None:
+        model = cvx.build_model(cfg, seed=0, rank=rank, alpha=float(max(rank, 1)), lora_b_std=0.02 if rank else None)
+        sched = cvx.CogVideoXDDIMScheduler()
+        gg = torch.Generator().manual_seed(seed)
+        lat = torch.randn(2, frames, cfg.in_channels, hh, ww, generator=gg).bfloat16()
+        text = torch.randn(2, cfg.max_text_seq_length, cfg.text_embed_dim, generator=gg).bfloat16()
+        sig = torch.tensor([0.25, 0.7])
+        self_ns = types.SimpleNamespace(transformer_config=types.SimpleNamespace(**{k: getattr(cfg, k) for k in (
+            "sample_height", "sample_width", "patch_size", "patch_size_t", "ofs_embed_dim", "attention_head_dim", "use_rotary_positional_embeddings")}),
+            vae_config=types.SimpleNamespace(scaling_factor=1.15258426, invert_scale_latents=False), _pad_frames=ref_cvx_pad)
+        with torch.no_grad():
+            pred, target, sg = ref_cvx_fwd(self_ns, transformer=model, scheduler=sched, condition_model_conditions={"encoder_hidden_states": text},
+                                           latent_model_conditions={"latents": lat.clone()}, sigmas=sig, generator=torch.Generator().manual_seed(seed + 100),
+                                           compute_posterior=True)
+        tensors[f"{tag}.pred"], tensors[f"{tag}.target"], tensors[f"{tag}.sigmas"] = pred.contiguous(), target.contiguous(), sg.contiguous()
+        tensors[f"{tag}.meta"] = torch.tensor([frames, hh, ww, seed, rank], dtype=torch.int64)
+
+    run_cvx("cvx.spec_dummy", cvx.CogVideoXConfig.dummy(), 3, 6, 6, 5, 0)  # the reference's own fixture config (rotary, 2 layers)
+    cfg_2b1 = cvx.CogVideoXConfig(num_layers=1, sample_height=8, sample_width=12, sample_frames=9)  # 2b width (30 x 64), sincos positions, 1 layer
+    run_cvx("cvx.spec_2b1", cfg_2b1, 3, 8, 12, 6, 64)
+    ref_plw = extract("finetrainers/utils/diffusion.py", "prepare_loss_weights", dict(diff_ns, CogVideoXDDIMScheduler=cvx.CogVideoXDDIMScheduler))
+    sch = cvx.CogVideoXDDIMScheduler()
+    ts = torch.tensor([0, 250, 700, 999])
+    tensors["cvx.loss_weights"] = ref_plw(scheduler=sch, alphas=sch.alphas_cumprod[ts], sigmas=None, flow_weighting_scheme="none")
+    ddim_ns = dict(diff_ns, CogVideoXDDIMScheduler=cvx.CogVideoXDDIMScheduler)
+    ddim_ns["compute_density_for_timestep_sampling"] = ref_density
+    ref_ps_ddim = extract("finetrainers/utils/diffusion.py", "prepare_sigmas", ddim_ns)
+    tensors["cvx.sigmas"] = ref_ps_ddim(scheduler=sch, sigmas=table, batch_size=16, num_train_timesteps=1000, device=torch.device("cpu"),
+                                        generator=torch.Generator().manual_seed(33))
+
     # ---- grad clipping ----------------------------------------------------------------------
     from torch.utils._foreach_utils import (
         _device_has_foreach_support,

@@ -58,6 +58,19 @@ def test_c_abi_error_reporting(lib):
     desc = _lib.AttnDesc(B=1, H=1, Sq=64, Sk=64, d=32, scale=0.1)
     rc = lib.ftmi_attn_fwd(ctypes.byref(desc), None, None, None, None, None, None, None)
     assert rc == _lib.FTMI_ERR_UNSUPPORTED and "head_dim" in _lib.last_error()
+    # messages are kept per failing thread: another thread's failure does not replace the one this thread is about to read
+    import threading
+
+    def other():
+        d2 = _lib.AttnDesc(B=0, H=1, Sq=64, Sk=64, d=64, scale=0.1)
+        q = ctypes.c_void_p(16)
+        assert lib.ftmi_attn_fwd(ctypes.byref(d2), q, q, q, q, None, None, None) == _lib.FTMI_ERR_INVALID
+        assert "empty problem" in _lib.last_error()
+
+    th = threading.Thread(target=other)
+    th.start()
+    th.join()
+    assert "head_dim" in _lib.last_error()
 
 
 def test_product_path_never_imports_the_oracle():
