@@ -16,7 +16,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libftmi355.so")
+# FTMI_LIB_PATH: tools-only override (A/B of two builds of the library in one gpurun call); the product always loads the in-tree .so
+LIB_PATH = os.environ.get("FTMI_LIB_PATH") or os.path.join(_HERE, "libftmi355.so")
 
 FTMI_ERR_INVALID = -1
 FTMI_ERR_UNSUPPORTED = -2

@@ -62,6 +62,14 @@ FTMI_DEVICE s16x8 read_tr_frag(const char* lds, int dbase, int tok0, int lane) {
     const int g = lane >> 5;
     return lds_tr_frag(lds, dbase, tok0 + 4 * g, tok0 + 8 + 4 * g, lane);
 }
+// Loop-invariant fragments are fetched with ordinary global loads before the tile loop.  hipcc places the s_waitcnt vmcnt(N) of such a
+// load at its first USE -- inside the loop -- where the hardware counter also holds the (inline-asm, invisible to hipcc) DMA loads of
+// the next tile: every other tile the wave then waited for its own prefetch before starting the current tile's MFMAs (seen as
+// s_waitcnt vmcnt(3..0) in front of the first Q.K^T MFMAs and as 27 % SQ_WAIT_ANY).  Consuming the registers in an empty asm statement
+// BEFORE the loop moves those waits out of it.
+FTMI_DEVICE void settle(const s16x8& f) { asm volatile("" ::"v"(f)); }
+FTMI_DEVICE void settle(float f) { asm volatile("" ::"v"(f)); }
+
 FTMI_DEVICE s16x8 pack_frag(const f32x16& v, int hh) {
     u32x4 w;
 #pragma unroll
@@ -92,15 +100,46 @@ FTMI_DEVICE void store_rows_via_lds(char* scr, const f32x16 (&t)[2], float mul, 
     }
 }
 
+// max of the 16 accumulator registers of one MFMA tile: eight v_max3_f32 in ONE asm statement (no per-statement padding, no
+// canonicalising v_max in front of every operand, which is what fmaxf() on MFMA results compiles to).  The leading s_nop covers the
+// MFMA-result -> VALU-read wait states (8-pass MFMA: 12 states), which hipcc does not insert for operands of an asm statement.
+FTMI_DEVICE float max16(const f32x16& v) {
+    float r;
+    asm volatile(
+        "s_nop 11\n\t"
+        "v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %0, %0, %14, %15\n\t"
+        "v_max_f32 %0, %0, %16"
+        : "=&v"(r)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]),
+          "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    return r;
+}
+// max over the two half-waves (lanes l and l ^ 32 hold the same query row)
+FTMI_DEVICE float xhalf_max(float v) {
+    float t;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0\n\tv_max_f32 %0, %0, %1" : "+v"(v), "=&v"(t));
+    return v;
+}
+FTMI_DEVICE float xhalf_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 static constexpr int kFwdLds = 2 * 16384 + 2 * 256;  // two (K, V) tile buffers + two key-bias rows
 
-// FL: experiment flags (product = 0).  1: row sums by VALU adds instead of 4 all-ones MFMAs; 2: lazy rescale (skip the O rescale pass
+// FL: AF_LAZY | AF_MAX16 is what ships; the other flags are experiments.  1: row sums by VALU adds instead of 4 all-ones MFMAs; 2: lazy rescale (skip the O rescale pass
 // unless the running max of some lane's row grew by more than 2^8); 4 / 8 / 16: timing ablations (no exp / no P.V / no tile reload) whose
 // results are WRONG by construction -- compiled only with -DFTMI_EXPERIMENTAL.
-enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_ABL_NOLOAD = 16 };
+enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_ABL_NOLOAD = 16, AF_MAX16 = 32 };
 
 template <bool HAS_KB, int FL = 0, int MINW = 1>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
@@ -153,6 +192,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
         }
     };
 
+#pragma unroll
+    for (int c = 0; c < 4; ++c) settle(qf[c]);
     stage(0, 0);
     stage_commit(0);
     tile_dma_wait();
@@ -192,6 +233,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
                         mx = fmaxf(mx, x);
                     }
                 }
+        } else if constexpr (FL & AF_MAX16) {
+            mx = fmaxf(max16(st[0]), max16(st[1])) * sl;
         } else {
 #pragma unroll
             for (int js = 0; js < 2; ++js)
@@ -199,7 +242,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[js][r]);
             mx *= sl;  // sl > 0
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if constexpr (FL & AF_MAX16) mx = xhalf_max(mx);
+        else mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // m_new == -inf only while every key seen so far carries a -inf bias: subtracting -inf would give NaN, and those keys must
         // contribute exp2(-inf) = 0, so the exponent is taken against 0 instead (alpha = exp2(-inf - 0) = 0 scales the empty state)
         float m_new = fmaxf(m_run, mx);
@@ -296,6 +340,187 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+#ifdef FTMI_EXPERIMENTAL
+// ------------------------------------------------------------------------------------------------
+// forward, 64 query rows per wave (EXPERIMENT, not shipped: measured 156.6 us against 148.2 us for the 32-row kernel with the same lazy
+// rescale on the cfg-2 shape -- what it saves in LDS instructions it loses to 704 workgroups on 512 slots; profiles/README.md).
+// Measured on the first generation (tools/bench_attn.py ablations, profiles/README.md): the loop is bound by the ISSUE of its non-matrix
+// instructions -- removing the exp2s, the P.V half or the tile reload each saves its own share, the shares add up to the whole (nothing
+// overlaps), and the matrix pipe sits idle half of the time.  So this version cuts instructions per MFMA instead of adding overlap:
+//   * a wave owns TWO 32-row query tiles: every K row fragment and every V^T fragment read from LDS feeds two MFMAs (half the LDS
+//     instructions per MFMA), the loop overhead / DMA issue / barrier is shared by twice the work;
+//   * LAZY rescale: the running reference max m_ref of a row is only moved when some row of the wave outgrows it by more than 2^8
+//     (probabilities stay <= 2^8, same relative precision in bf16 / fp32); otherwise the tile costs no alpha, no O rescale, no l rescale;
+//   * the row sums stay on the matrix pipe (all-ones A operand) and accumulate across ALL tiles in one MFMA accumulator per query tile
+//     (never zeroed, rescaled only on the rare max move): 2 issue slots per 32 keys instead of 32 adds;
+//   * 3-input max (v_max3_f32), one v_permlane32_swap for the cross-half combine, scores consumed 32 keys at a time (live S: 32 registers).
+// Same LDS images, DMA staging and store path as the first generation.
+// ------------------------------------------------------------------------------------------------
+static constexpr float kLazyThr = 8.0f;  // log2 domain
+
+template <bool HAS_KB>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 255) / 256, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int row0 = blk.tile * 256 + wave * 64;  // first query row of this wave
+    const float sl = a.scale * kLog2e;
+
+    s16x8 qf[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int ic = min(row0 + qt * 32 + li, a.Sq - 1);
+        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qf[qt][c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+    }
+    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
+    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
+
+    float m_ref[2] = {-INFINITY, -INFINITY};
+    s16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
+    f32x16 oacc[2][2], lsum[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oacc[qt][0][r] = 0.f;
+            oacc[qt][1][r] = 0.f;
+            lsum[qt][r] = 0.f;
+        }
+    }
+
+    const int nt = (a.Sk + 63) / 64;
+    const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
+    float kbr = 0.f;
+    auto stage = [&](int t, int buf) {
+        char* tb = smem + buf * 16384;
+        tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
+        tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+        if constexpr (HAS_KB) {
+            if (tid < 64) {
+                int j = t * 64 + tid;
+                kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;
+            }
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if constexpr (HAS_KB) {
+            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384)[buf * 64 + tid] = kbr;
+        }
+    };
+
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        settle(qf[0][c]);
+        settle(qf[1][c]);
+    }
+    stage(0, 0);
+    stage_commit(0);
+    tile_dma_wait();
+    __syncthreads();
+    auto body = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        const char* ks = smem + cur * 16384;
+        const char* vs = ks + 8192;
+        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+#pragma unroll
+        for (int js = 0; js < 2; ++js) {  // 32 keys at a time
+            f32x16 st[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[qt][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);  // one LDS read, two MFMAs
+                st[0] = mfma32(kf, qf[0][c], st[0]);
+                st[1] = mfma32(kf, qf[1][c], st[1]);
+            }
+            s16x8 pf[2][2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                // x = s * sl (+ bias) in the log2 domain; row max over this lane's 16 keys, then across the two half-waves
+                float mx;
+                if constexpr (HAS_KB) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) st[qt][rq * 4 + j] = __builtin_fmaf(st[qt][rq * 4 + j], sl, b4[j]);
+                    }
+                }
+                mx = max16(st[qt]);
+                if constexpr (!HAS_KB) mx *= sl;  // sl > 0
+                mx = xhalf_max(mx);
+                // lazy reference max: move it only when some row of the wave outgrew it by more than 2^kLazyThr (always on the first tile)
+                if (__builtin_amdgcn_ballot_w64((mx - m_ref[qt]) > kLazyThr) != 0) {
+                    const float m_new = fmaxf(m_ref[qt], mx);
+                    // (m_new == -inf only while every key so far carries a -inf bias: those contribute exp2(-inf) = 0 against 0)
+                    const float alpha = fast_exp2(m_ref[qt] - ((m_new == -INFINITY) ? 0.f : m_new));
+                    m_ref[qt] = m_new;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        oacc[qt][0][r] *= alpha;
+                        oacc[qt][1][r] *= alpha;
+                        lsum[qt][r] *= alpha;
+                    }
+                }
+                const float m_eff = (m_ref[qt] == -INFINITY) ? 0.f : m_ref[qt];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    st[qt][r] = HAS_KB ? fast_exp2(st[qt][r] - m_eff) : fast_exp2(__builtin_fmaf(st[qt][r], sl, -m_eff));
+                pf[qt][0] = pack_frag(st[qt], 0);
+                pf[qt][1] = pack_frag(st[qt], 1);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);  // one fragment, two MFMAs
+                    oacc[0][dt] = mfma32(vf, pf[0][hh], oacc[0][dt]);
+                    oacc[1][dt] = mfma32(vf, pf[1][hh], oacc[1][dt]);
+                }
+                // row sums of the bf16-rounded probabilities on the matrix pipe (numerator and denominator use the same numbers)
+                lsum[0] = mfma32(ones, pf[0][hh], lsum[0]);
+                lsum[1] = mfma32(ones, pf[1][hh], lsum[1]);
+            }
+        }
+        if (t + 1 < nt) stage_commit(cur ^ 1);
+        tile_dma_wait();
+        __syncthreads();  // tile t+1 landed (the barrier drains this wave's DMA first) and tile t's buffer is free again
+    };
+    for (int t = 0; t < nt; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nt) body(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float l = lsum[qt][0];
+        store_rows_via_lds(smem + wave * 4096, oacc[qt], 1.0f / l, ob, a.o_ss, row0 + qt * 32, a.Sq, lane);
+        const int i = row0 + qt * 32 + li;
+        if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_ref[qt] + __log2f(l);
+    }
+}
+#endif  // FTMI_EXPERIMENTAL
+
+// Shipped kernels: forward and dK/dV with 32 rows per wave, dQ with 64 rows per wave (each the faster of its two generations on the
+// cfg-2 shapes, tools/bench_attn.py).  The experimental build can switch per kernel (FTMI_ATTN_GEN / _DQ_GEN / _DKV_GEN = 1 | 2).
+#ifdef FTMI_EXPERIMENTAL
+static int attn_gen(const char* which, int dflt) {
+    const int g = env_int("FTMI_ATTN_GEN", 0);  // re-read every call: tools/bench_attn.py switches inside one process
+    return env_int(which, g ? g : dflt);
+}
+#endif
+
 int attn_fwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_fwd: empty problem");
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8))
@@ -321,15 +546,29 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
             FTMI_AF(13, AF_VALU_ROWSUM | AF_LAZY, 4)
             FTMI_AF(14, AF_LAZY, 2)
             FTMI_AF(15, AF_LAZY, 4)
+            FTMI_AF(16, AF_LAZY | AF_MAX16, 1)
+            FTMI_AF(17, AF_MAX16, 1)
+            FTMI_AF(18, AF_LAZY | AF_MAX16, 2)
 #undef FTMI_AF
             default: break;
         }
     }
 #endif
+#ifdef FTMI_EXPERIMENTAL
+    if (attn_gen("FTMI_ATTN_FWD_GEN", 1) == 2) {  // 64 query rows per wave
+        dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
+        if (a.kbias || (a.Sk % 64) != 0)
+            hipLaunchKernelGGL(attn_fwd2_kernel<true>, grid2, dim3(256), kFwdLds, st, a);
+        else
+            hipLaunchKernelGGL(attn_fwd2_kernel<false>, grid2, dim3(256), kFwdLds, st, a);
+        return check_launch("attn_fwd");
+    }
+#endif
+    // lazy rescale + single-statement row max: 148 us against 159 us for the exact running max (cfg-2 self-attention, profiles/README.md)
     if (a.kbias || (a.Sk % 64) != 0)
-        hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), kFwdLds, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<true, AF_LAZY | AF_MAX16>), grid, dim3(256), kFwdLds, st, a);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), kFwdLds, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<false, AF_LAZY | AF_MAX16>), grid, dim3(256), kFwdLds, st, a);
     return check_launch("attn_fwd");
 }
 
@@ -393,6 +632,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         }
     };
 
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        settle(kf[c]);
+        settle(vf[c]);
+    }
+    settle(bias_j);
     stage(0, 0);
     stage_commit(0);
     tile_dma_wait();
@@ -531,6 +776,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
         }
     };
 
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        settle(kf[c]);
+        settle(vf[c]);
+    }
+    settle(bias_j);
     stage(0, 0);
     stage_commit(0);
     tile_dma_wait();
@@ -694,6 +945,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     };
 
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        settle(qf[c]);
+        settle(dof[c]);
+    }
+    settle(lse_i);
+    settle(del_i);
     stage(0, 0);
     stage_commit(0);
     tile_dma_wait();
@@ -755,6 +1013,319 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward dQ, second generation: 64 query rows per wave (same reasoning as attn_fwd2_kernel: the loop is bound by the issue of its
+// non-matrix instructions, so every K / V row fragment and every K^T fragment read from LDS now feeds two MFMAs).  Per 32 keys and
+// wave: 24 MFMAs, 16 LDS reads (first generation: 12 MFMAs per 16 reads).  delta = rowsum(dO * O) is still produced here.
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_KB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 255) / 256, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int row0 = blk.tile * 256 + wave * 64;
+    const float sl = a.scale * kLog2e;
+
+    s16x8 qf[2][4], dof[2][4];
+    float lse_i[2], del_i[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int i = row0 + qt * 32 + li;
+        const int ic = min(i, a.Sq - 1);
+        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
+        const bf16_t* dop = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)ic * a.do_ss;
+        const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)ic * a.o_ss;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qf[qt][c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+            dof[qt][c] = *reinterpret_cast<const s16x8*>(dop + c * 16 + g * 8);
+            const s16x8 of = *reinterpret_cast<const s16x8*>(op + c * 16 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += bf2f((bf16_t)dof[qt][c][e]) * bf2f((bf16_t)of[e]);
+        }
+        d = xhalf_sum(d);
+        del_i[qt] = d;
+        lse_i[qt] = a.lse2[((long)b * a.H + h) * a.Sq + ic];
+        if (g == 0 && i < a.Sq) a.delta[((long)b * a.H + h) * a.Sq + i] = d;  // published for the dK/dV kernel, which runs after this one
+    }
+
+    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
+    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
+
+    f32x16 dqt[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dqt[qt][0][r] = 0.f;
+            dqt[qt][1][r] = 0.f;
+        }
+
+    const int nt = (a.Sk + 63) / 64;
+    const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
+    float kbr = 0.f;
+    auto stage = [&](int t, int buf) {
+        char* tb = smem + buf * 16384;
+        tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
+        tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+        if constexpr (HAS_KB) {
+            if (tid < 64) {
+                int j = t * 64 + tid;
+                kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;  // -inf => p = 0 for padded keys
+            }
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if constexpr (HAS_KB) {
+            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384)[buf * 64 + tid] = kbr;
+        }
+    };
+
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        settle(qf[0][c]);
+        settle(qf[1][c]);
+        settle(dof[0][c]);
+        settle(dof[1][c]);
+    }
+    settle(lse_i[0]);
+    settle(lse_i[1]);
+    settle(del_i[0]);
+    settle(del_i[1]);
+    stage(0, 0);
+    stage_commit(0);
+    tile_dma_wait();
+    __syncthreads();
+    auto body = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        const char* ks = smem + cur * 16384;
+        const char* vs = ks + 8192;
+        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
+        if (t + 1 < nt) stage(t + 1, cur ^ 1);
+#pragma unroll
+        for (int js = 0; js < 2; ++js) {
+            f32x16 s[2], dp[2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[qt][r] = 0.f;
+                    dp[qt][r] = 0.f;
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
+                s[0] = mfma32(kf, qf[0][c], s[0]);
+                s[1] = mfma32(kf, qf[1][c], s[1]);
+                const s16x8 vf = read_row_frag(vs, js * 32 + li, c, g);
+                dp[0] = mfma32(vf, dof[0][c], dp[0]);
+                dp[1] = mfma32(vf, dof[1][c], dp[1]);
+            }
+            s16x8 dsf[2][2];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HAS_KB) b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = rq * 4 + j;
+                        const float p = HAS_KB ? fast_exp2(__builtin_fmaf(s[qt][r], sl, b4[j] - lse_i[qt])) : fast_exp2(__builtin_fmaf(s[qt][r], sl, -lse_i[qt]));
+                        dp[qt][r] = p * (dp[qt][r] - del_i[qt]);
+                    }
+                }
+                dsf[qt][0] = pack_frag(dp[qt], 0);
+                dsf[qt][1] = pack_frag(dp[qt], 1);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const s16x8 ktf = read_tr_frag(ks, dt * 32, js * 32 + hh * 16, lane);
+                    dqt[0][dt] = mfma32(ktf, dsf[0][hh], dqt[0][dt]);
+                    dqt[1][dt] = mfma32(ktf, dsf[1][hh], dqt[1][dt]);
+                }
+        }
+        if (t + 1 < nt) stage_commit(cur ^ 1);
+        tile_dma_wait();
+        __syncthreads();
+    };
+    for (int t = 0; t < nt; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nt) body(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) store_rows_via_lds(smem + wave * 4096, dqt[qt], a.scale, dqb, a.dq_ss, row0 + qt * 32, a.Sq, lane);
+}
+
+#ifdef FTMI_EXPERIMENTAL
+// ------------------------------------------------------------------------------------------------
+// backward dK / dV, 64 keys per wave (EXPERIMENT, not shipped: 508 us against 445 us for the whole backward with the 32-key kernel -- one
+// wave per SIMD leaves the LDS / MFMA latencies of its single in-order stream exposed).  64 keys per wave (two 32-key tiles share every Q / dO row fragment and every Q^T / dO^T
+// fragment read from LDS: 24 LDS reads per 32 MFMAs instead of 48).  The four accumulator sets (dK, dV for two key tiles = 128
+// registers) plus the K / V fragments (64) take the wave past 256 registers, so this kernel runs ONE wave per SIMD with the whole
+// 512-entry register file (one 256-thread workgroup per CU; 704 workgroups at the cfg-2 shape = 2.75 per CU).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv2_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sk + 255) / 256, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int key0 = blk.tile * 256 + wave * 64;
+    const float sl = a.scale * kLog2e;
+
+    s16x8 kf[2][4], vf[2][4];
+    float bias_j[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int jc = min(key0 + kt * 32 + li, a.Sk - 1);
+        const bf16_t* kp = a.k + (long)b * a.k_sb + (long)h * a.k_sh + (long)jc * a.k_ss;
+        const bf16_t* vp = a.v + (long)b * a.v_sb + (long)h * a.v_sh + (long)jc * a.v_ss;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            kf[kt][c] = *reinterpret_cast<const s16x8*>(kp + c * 16 + g * 8);
+            vf[kt][c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
+        }
+        bias_j[kt] = a.kbias ? a.kbias[(long)b * a.kb_sb + (long)h * a.kb_sh + jc] * kLog2e : 0.f;
+    }
+
+    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
+    const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
+    const float* lsebase = a.lse2 + ((long)b * a.H + h) * a.Sq;
+    const float* delbase = a.delta + ((long)b * a.H + h) * a.Sq;
+
+    f32x16 dkt[2][2], dvt[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkt[kt][dt][r] = 0.f;
+                dvt[kt][dt][r] = 0.f;
+            }
+
+    const int ni = (a.Sq + 63) / 64;
+    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane);
+    float lser = 0.f, delr = 0.f;
+    auto stage = [&](int t, int buf) {
+        char* tb = smem + buf * 16384;
+        tile_dma_issue(qd, qbase, a.q_ss, t, t == ni - 1, tb, wave);
+        tile_dma_issue(dod, dobase, a.do_ss, t, t == ni - 1, tb + 8192, wave);
+        if (tid < 64) {
+            int i = t * 64 + tid;
+            lser = (i < a.Sq) ? lsebase[i] : INFINITY;  // +inf => p = 0 for padded query rows
+            delr = (i < a.Sq) ? delbase[i] : 0.f;
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if (tid < 64) {
+            float* st = reinterpret_cast<float*>(smem + 2 * 16384) + buf * 128;
+            st[tid] = lser;
+            st[64 + tid] = delr;
+        }
+    };
+
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        settle(kf[0][c]);
+        settle(kf[1][c]);
+        settle(vf[0][c]);
+        settle(vf[1][c]);
+    }
+    settle(bias_j[0]);
+    settle(bias_j[1]);
+    stage(0, 0);
+    stage_commit(0);
+    tile_dma_wait();
+    __syncthreads();
+    auto body = [&](int t, auto CUR) {
+        constexpr int cur = decltype(CUR)::value;
+        const char* qs = smem + cur * 16384;
+        const char* dos = qs + 8192;
+        const float* lses = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 128;
+        const float* dels = lses + 64;
+        if (t + 1 < ni) stage(t + 1, cur ^ 1);
+#pragma unroll
+        for (int is = 0; is < 2; ++is) {  // 32 query rows at a time
+            f32x16 s[2], dp[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[kt][r] = 0.f;
+                    dp[kt][r] = 0.f;
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const s16x8 qf = read_row_frag(qs, is * 32 + li, c, g);
+                s[0] = mfma32(qf, kf[0][c], s[0]);
+                s[1] = mfma32(qf, kf[1][c], s[1]);
+                const s16x8 dof = read_row_frag(dos, is * 32 + li, c, g);
+                dp[0] = mfma32(dof, vf[0][c], dp[0]);
+                dp[1] = mfma32(dof, vf[1][c], dp[1]);
+            }
+            s16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + is * 32 + rq * 8 + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + is * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = rq * 4 + j;
+                        const float p = fast_exp2(__builtin_fmaf(s[kt][r], sl, bias_j[kt] - l4[j]));
+                        s[kt][r] = p;
+                        dp[kt][r] = p * (dp[kt][r] - d4[j]);
+                    }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    pf[kt][hh] = pack_frag(s[kt], hh);
+                    dsf[kt][hh] = pack_frag(dp[kt], hh);
+                }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const s16x8 dotf = read_tr_frag(dos, dt * 32, is * 32 + hh * 16, lane);
+                    dvt[0][dt] = mfma32(dotf, pf[0][hh], dvt[0][dt]);
+                    dvt[1][dt] = mfma32(dotf, pf[1][hh], dvt[1][dt]);
+                    const s16x8 qtf = read_tr_frag(qs, dt * 32, is * 32 + hh * 16, lane);
+                    dkt[0][dt] = mfma32(qtf, dsf[0][hh], dkt[0][dt]);
+                    dkt[1][dt] = mfma32(qtf, dsf[1][hh], dkt[1][dt]);
+                }
+        }
+        if (t + 1 < ni) stage_commit(cur ^ 1);
+        tile_dma_wait();
+        __syncthreads();
+    };
+    for (int t = 0; t < ni; t += 2) {
+        body(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ni) body(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    bf16_t* dkb = a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh;
+    bf16_t* dvb = a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        store_rows_via_lds(smem + wave * 4096, dkt[kt], a.scale, dkb, a.dk_ss, key0 + kt * 32, a.Sk, lane);
+        store_rows_via_lds(smem + wave * 4096, dvt[kt], 1.0f, dvb, a.dv_ss, key0 + kt * 32, a.Sk, lane);
+    }
+}
+#endif  // FTMI_EXPERIMENTAL
+
 int attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_bwd: empty problem");
     if (!a.lse2 || !a.delta || !a.dout || !a.o) return set_error(FTMI_ERR_INVALID, "attn_bwd: missing lse/delta/dout/out");
@@ -762,7 +1333,18 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         return set_error(FTMI_ERR_INVALID, "attn_bwd: token strides must keep 16-byte alignment");
     ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);  // algorithmic: 5 matmuls (2.5x forward)
     // dQ first: it also computes delta = rowsum(dO * O) for its rows and publishes it for the dK/dV kernel
-    if (a.kbias || (a.Sk % 64) != 0)
+#ifdef FTMI_EXPERIMENTAL
+    const int dq_gen = attn_gen("FTMI_ATTN_DQ_GEN", 2);
+#else
+    const int dq_gen = 2;
+#endif
+    if (dq_gen == 2) {
+        const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
+        if (a.kbias || (a.Sk % 64) != 0)
+            hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, grid2, dim3(256), kDqLds, st, a);
+        else
+            hipLaunchKernelGGL(attn_bwd_dq2_kernel<false>, grid2, dim3(256), kDqLds, st, a);
+    } else if (a.kbias || (a.Sk % 64) != 0)
         hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
     else
         hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
@@ -775,7 +1357,12 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
         hipLaunchKernelGGL(attn_bwd_dkdv_sq_kernel, dim3(((a.Sk + 31) / 32) * a.H * a.B), dim3(256), kDkvSqLds, st, a);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
+#ifdef FTMI_EXPERIMENTAL
+        if (attn_gen("FTMI_ATTN_DKV_GEN", 1) == 2)
+            hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, dim3(((a.Sk + 255) / 256) * a.H * a.B), dim3(256), kDkvLds, st, a);
+        else
+#endif
+            hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
     }
     return check_launch("attn_bwd_dkdv");
 }

@@ -61,8 +61,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.run(cmd, check=True)
         return o
 
+    # a change of flags (e.g. FTMI_EXPERIMENTAL on / off) invalidates every object
+    sig = " ".join(FLAGS) + " | " + repr(sorted(EXTRA_FLAGS.items()))
+    sig_path = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(sig_path) or open(sig_path).read() != sig:
+        force = True
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    with open(sig_path, "w") as f:
+        f.write(sig)
     lib = os.path.abspath(LIB)
     if force or _stale(lib, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
