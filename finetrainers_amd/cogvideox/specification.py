@@ -1,0 +1,85 @@
+"""CogVideoX on MI355X -- the first layer of the next model family (BASELINE config 3: CogVideoX-2b LoRA, 49x480x720,
+DP = 8).  What exists: the spec-level arithmetic of ``CogVideoXModelSpecification.forward``
+(finetrainers/models/cogvideox/base_specification.py:258-333) around the transformer call -- latent scaling, DDIM ``add_noise``,
+``get_velocity`` (velocity -> x0), the ``1 / (1 - alphas_cumprod[t])`` loss weight (finetrainers/utils/diffusion.py:117-130) -- as gfx950
+kernels behind the C ABI (``ftmi_ddim_add_noise`` / ``ftmi_ddim_get_velocity`` / ``ftmi_mse_loss``), and the joint text + video attention
+of every CogVideoX block through the ``mi355x`` attention provider (``ftmi_attn_fwd`` / ``_bwd``; 226 + 17 550 tokens, 30 heads of 64).
+What does NOT exist yet: the CogVideoX DiT block orchestrator (LayerNorm-zero modulation at width 1920, patch embed, fused LoRA
+projections) -- ``MI355XCogVideoXSpecOps.forward`` therefore takes the transformer as a callable (the reference's diffusers model with the
+``mi355x`` attention provider today, the native DiT later).  The oracle for all of it is ``oracle/cogvideox.py``.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from .. import ops
+
+
+class CogVideoXDDIMTables:
+    """The two things the step needs from ``CogVideoXDDIMScheduler``: ``alphas_cumprod`` (fp32 [1000], built exactly as the scheduler's
+    constructor does: scaled-linear betas, SNR shift, optional zero-terminal-SNR rescale) and ``config.num_train_timesteps``."""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.0120, snr_shift_scale: float = 3.0,
+                 rescale_betas_zero_snr: bool = False):
+        self.config = type("Cfg", (), {"num_train_timesteps": num_train_timesteps})()
+        betas = torch.linspace(beta_start**0.5, beta_end**0.5, num_train_timesteps, dtype=torch.float64) ** 2
+        ac = torch.cumprod(1.0 - betas, dim=0)
+        ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)
+        if rescale_betas_zero_snr:
+            a = ac.sqrt()
+            a0, aT = a[0].clone(), a[-1].clone()
+            ac = ((a - aT) * (a0 / (a0 - aT))) ** 2
+        self.alphas_cumprod = ac.float()
+
+    def coefficients(self, timesteps: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(sqrt(alphas_cumprod[t]), sqrt(1 - alphas_cumprod[t])) as the scheduler computes them: the table is cast to the sample dtype FIRST,
+        then indexed and square-rooted in that dtype.  Returned as fp32 tensors holding those bf16 values (what the kernels take)."""
+        ac = self.alphas_cumprod.to(device=timesteps.device, dtype=dtype)
+        return (ac[timesteps] ** 0.5).flatten().float().contiguous(), ((1 - ac[timesteps]) ** 0.5).flatten().float().contiguous()
+
+    def loss_weights(self, timesteps: torch.Tensor) -> torch.Tensor:
+        """utils/diffusion.py:125-128: 1 / (1 - alphas), alphas = scheduler_alphas[timesteps] in fp32 (trainer.py:466)."""
+        return (1 / (1 - self.alphas_cumprod.to(timesteps.device)[timesteps])).float().contiguous()
+
+
+class MI355XCogVideoXSpecOps:
+    """The arithmetic of ``CogVideoXModelSpecification.forward`` around the DiT call, on the GPU.  ``transformer`` is any callable with the
+    reference's signature ``(hidden_states [B,F,C,H,W], encoder_hidden_states, timestep, image_rotary_emb, ofs, return_dict=False)``."""
+
+    def __init__(self, scaling_factor: float = 1.15258426, invert_scale_latents: bool = False, scheduler: Optional[CogVideoXDDIMTables] = None):
+        self.scaling_factor = 1.0 if invert_scale_latents else scaling_factor
+        self.scheduler = scheduler or CogVideoXDDIMTables()
+
+    @property
+    def _resolution_dim_keys(self) -> Dict[str, Tuple[int, ...]]:
+        return {"latents": (1, 3, 4)}  # base_specification.py:118-119 ([B, F, C, H, W])
+
+    def noise_and_target(self, latents: torch.Tensor, sigmas: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                         generator: Optional[torch.Generator] = None):
+        """:283-293: -> (noisy [B,F,C,H,W], target = scaled latents, timesteps [B] long)."""
+        latents = latents.to(torch.bfloat16)
+        timesteps = (sigmas.flatten() * 1000.0).long()
+        if noise is None:
+            noise = torch.zeros_like(latents).normal_(generator=generator)
+        sa, so = self.scheduler.coefficients(timesteps)
+        x0, noisy = ops.ddim_add_noise(latents, noise.to(torch.bfloat16), sa, so, self.scaling_factor)
+        return noisy, x0, timesteps
+
+    def forward(self, transformer: Callable, latents: torch.Tensor, encoder_hidden_states: torch.Tensor, sigmas: torch.Tensor,
+                image_rotary_emb=None, noise: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
+        """-> (pred, target, sigmas) like the reference (:258-333)."""
+        noisy, target, timesteps = self.noise_and_target(latents, sigmas, noise, generator)
+        velocity = transformer(hidden_states=noisy, encoder_hidden_states=encoder_hidden_states, timestep=timesteps, image_rotary_emb=image_rotary_emb,
+                               ofs=None, return_dict=False)[0]
+        sa, so = self.scheduler.coefficients(timesteps)
+        pred = ops.ddim_get_velocity(velocity.to(torch.bfloat16), noisy, sa, so)  # scheduler.get_velocity(velocity, noisy_latents, timesteps)
+        return pred, target, sigmas
+
+    def loss(self, pred: torch.Tensor, target: torch.Tensor, sigmas: torch.Tensor) -> torch.Tensor:
+        """trainer.py:463-481 with the DDIM weights: device fp32 scalar (and d loss / d pred via ops.mse_loss when training)."""
+        timesteps = (sigmas.flatten() * 1000.0).long()
+        loss, _ = ops.mse_loss(pred.contiguous(), target.contiguous(), self.scheduler.loss_weights(timesteps), want_grad=False)
+        return loss.reshape(())

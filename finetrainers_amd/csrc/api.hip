@@ -371,6 +371,19 @@ int ftmi_ltx_noise_pack(const void* latents, const void* noise, const float* mea
                       (bf16_t*)target, B, C, S, (hipStream_t)stream);
 }
 
+int ftmi_ddim_add_noise(const void* latents, const void* noise, const float* sqrt_alpha, const float* sqrt_one_minus_alpha, float scaling_factor,
+                        void* x0, void* noisy, int B, long per_sample, ftmi_stream stream) {
+    if (!latents || !noise || !sqrt_alpha || !sqrt_one_minus_alpha || !noisy || B <= 0) return set_error(FTMI_ERR_INVALID, "ftmi_ddim_add_noise: bad argument");
+    return ddim_mix((const bf16_t*)latents, (const bf16_t*)noise, sqrt_alpha, sqrt_one_minus_alpha, scaling_factor, (bf16_t*)x0, (bf16_t*)noisy, B, per_sample, 0,
+                    (hipStream_t)stream);
+}
+
+int ftmi_ddim_get_velocity(const void* sample, const void* noise, const float* sqrt_alpha, const float* sqrt_one_minus_alpha, void* out, int B,
+                           long per_sample, ftmi_stream stream) {
+    if (!sample || !noise || !sqrt_alpha || !sqrt_one_minus_alpha || !out || B <= 0) return set_error(FTMI_ERR_INVALID, "ftmi_ddim_get_velocity: bad argument");
+    return ddim_mix((const bf16_t*)sample, (const bf16_t*)noise, sqrt_alpha, sqrt_one_minus_alpha, 1.0f, nullptr, (bf16_t*)out, B, per_sample, 1, (hipStream_t)stream);
+}
+
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample, float grad_scale,
                   ftmi_stream stream) {
     if (!pred || !target || !loss) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");

@@ -567,6 +567,45 @@ int adamw_clip_step(float* p, const float* g, float* m, float* v, long n, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// CogVideoX spec-level elementwise ops: DDIM add_noise / get_velocity as CogVideoXModelSpecification.forward applies them
+// (finetrainers/models/cogvideox/base_specification.py:283-293,326-329 around [upstream] CogVideoXDDIMScheduler).  One kernel does both
+// forms (mode 0: x0 = bf(lat * scale); out = bf(bf(sa * x0) + bf(so * noise)), x0 also stored = the training target;
+//        mode 1: out = bf(bf(sa * noise_arg) - bf(so * sample)) = get_velocity(sample, noise_arg)).
+// sa / so are sqrt(alphas_cumprod[t]) / sqrt(1 - alphas_cumprod[t]) per sample, already rounded to bf16 by the host exactly as the
+// scheduler does (it casts alphas_cumprod to the sample dtype first); every product / sum is one bf16 torch op in the reference.
+__global__ __launch_bounds__(256) void ddim_mix_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const float* __restrict__ sa,
+                                                       const float* __restrict__ so, float scale, bf16_t* __restrict__ x0_out,
+                                                       bf16_t* __restrict__ out, long per_sample, int mode) {
+    const int bi = blockIdx.y;
+    const float ca = sa[bi], co = so[bi];
+    const long base = (long)bi * per_sample;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < per_sample; i += (long)gridDim.x * blockDim.x * 8) {
+        float av[8], bv[8], o[8], x0[8];
+        unpack8(*reinterpret_cast<const s16x8*>(a + base + i), av);
+        unpack8(*reinterpret_cast<const s16x8*>(b + base + i), bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (mode == 0) {
+                x0[e] = rbf(av[e] * scale);
+                o[e] = rbf(ca * x0[e]) + rbf(co * bv[e]);
+            } else {
+                o[e] = rbf(ca * bv[e]) - rbf(co * av[e]);
+            }
+        }
+        *reinterpret_cast<s16x8*>(out + base + i) = pack8(o);
+        if (mode == 0 && x0_out) *reinterpret_cast<s16x8*>(x0_out + base + i) = pack8(x0);
+    }
+}
+int ddim_mix(const bf16_t* a, const bf16_t* b, const float* sa, const float* so, float scale, bf16_t* x0_out, bf16_t* out, int B, long per_sample,
+             int mode, hipStream_t st) {
+    if (per_sample % 8) return set_error(FTMI_ERR_UNSUPPORTED, "ddim_mix: elements per sample must be a multiple of 8");
+    long blocks = (per_sample / 8 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ddim_mix_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, a, b, sa, so, scale, x0_out, out, per_sample, mode);
+    return check_launch("ddim_mix");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // transposes (LoRA working copies; frozen-weight transposes for dgrad are made once at load time)
 template <typename TIN>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out_same, bf16_t* __restrict__ out_t,

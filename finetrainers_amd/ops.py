@@ -205,6 +205,27 @@ def noise_pack(latents, noise, mean, std, sigma, sigma_first=None, first_frame_t
     return xt, target
 
 
+def ddim_add_noise(latents, noise, sqrt_alpha, sqrt_one_minus_alpha, scaling_factor: float = 1.0):
+    """CogVideoX noising: (x0 = bf16(latents * scaling_factor), noisy = scheduler.add_noise(x0, noise, t)); per-sample coefficients fp32 [B]."""
+    require_gpu_tensor(latents, "latents", bf16)
+    latents, noise = latents.contiguous(), noise.contiguous()
+    B = latents.shape[0]
+    x0, noisy = torch.empty_like(latents), torch.empty_like(latents)
+    check(_lib.load().ftmi_ddim_add_noise(ptr(latents), ptr(noise), ptr(sqrt_alpha), ptr(sqrt_one_minus_alpha), float(scaling_factor), ptr(x0), ptr(noisy), B,
+                                           latents[0].numel(), stream_ptr()), "ftmi_ddim_add_noise")
+    return x0, noisy
+
+
+def ddim_get_velocity(sample, noise, sqrt_alpha, sqrt_one_minus_alpha):
+    """scheduler.get_velocity(sample, noise, t) = sqrt(a) noise - sqrt(1 - a) sample (bf16 op by op)."""
+    require_gpu_tensor(sample, "sample", bf16)
+    sample, noise = sample.contiguous(), noise.contiguous()
+    out = torch.empty_like(sample)
+    check(_lib.load().ftmi_ddim_get_velocity(ptr(sample), ptr(noise), ptr(sqrt_alpha), ptr(sqrt_one_minus_alpha), ptr(out), sample.shape[0], sample[0].numel(),
+                                              stream_ptr()), "ftmi_ddim_get_velocity")
+    return out
+
+
 def mse_loss(pred, target, weight: Optional[torch.Tensor], want_grad: bool = True, grad_scale: float = 1.0):
     B = pred.shape[0]
     per = pred[0].numel()

@@ -217,6 +217,20 @@ int ftmi_ltx_noise_pack(const void* latents, const void* noise, const float* mea
                         const float* sigma_first, int first_frame_tokens, void* x_t, void* target, int B, int C, int S,
                         ftmi_stream stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * CogVideoX spec level (first kernels of the next model family): the DDIM noising and the velocity -> x0 conversion of
+ * CogVideoXModelSpecification.forward (finetrainers/models/cogvideox/base_specification.py:283-293 and :326-329; scheduler ops
+ * add_noise / get_velocity of [upstream] CogVideoXDDIMScheduler).  latents / noise / sample / outputs: bf16 [B, per_sample];
+ * sqrt_alpha, sqrt_one_minus_alpha: fp32 [B] holding the scheduler's bf16-rounded sqrt(alphas_cumprod[t]), sqrt(1 - alphas_cumprod[t]).
+ *   add_noise:    x0 = bf16(latents * scaling_factor)  (the training target, may be NULL);  noisy = bf16(bf16(sa x0) + bf16(so noise))
+ *   get_velocity: out = bf16(bf16(sa noise) - bf16(so sample))      (the reference calls it as get_velocity(model_out, noisy, t))
+ * The loss weight 1 / (1 - alphas_cumprod[t]) (utils/diffusion.py:125-128) goes through ftmi_mse_loss's per-sample weight.
+ * ------------------------------------------------------------------------------------------------------------ */
+int ftmi_ddim_add_noise(const void* latents, const void* noise, const float* sqrt_alpha, const float* sqrt_one_minus_alpha,
+                        float scaling_factor, void* x0, void* noisy, int B, long per_sample, ftmi_stream stream);
+int ftmi_ddim_get_velocity(const void* sample, const void* noise, const float* sqrt_alpha, const float* sqrt_one_minus_alpha, void* out,
+                           int B, long per_sample, ftmi_stream stream);
+
 /* loss (device fp32 scalar) = mean_b mean w_b (pred-target)^2 ; dpred = d(loss*grad_scale)/dpred (bf16), may be NULL */
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample,
                   float grad_scale, ftmi_stream stream);
