@@ -37,7 +37,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARC
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)  # ~2 s of GPU time; long enough that one box-level stall does not move the mean
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (BASELINE configs[1]: 2)")
     ap.add_argument("--layers", type=int, default=28)
@@ -293,9 +293,12 @@ def main():
                             "to the per-block launch counts, cycles through every shape; compare with the gemm_nt_kernel<...> rows of profiles/r02_*_kernel_stats.csv)",
                 }
                 mf = _profile_json("r02_pmc_mfma.json")
-                if mf:  # counter-derived MFMA utilisation of the same command (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ..., tools/gpu_pmc.sh)
-                    res["roofline"]["mfma_busy_counter"] = mf.get("gemm_nt_kernel")
-                    res["mfma_utilisation_counters"] = mf.get("step")
+                if mf:  # counter-derived figures of the same command (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ..., tools/gpu_profile_r02.sh)
+                    keep = ("mfma_util", "valu_issue_share_of_simd_time", "wave_wait_share", "wave_issue_stall_share", "launches_in_trace")
+                    res["roofline"]["counters"] = {k: mf.get("gemm_nt_kernel", {}).get(k) for k in keep}
+                    res["roofline"]["counters"]["source"] = "profiles/r02_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+                    res["mfma_utilisation_counters"] = {"step": mf.get("step", {}).get("mfma_util_over_kernel_time"),
+                                                        **{k: v.get("mfma_util") for k, v in mf.items() if isinstance(v, dict) and v.get("mfma_util")}}
                 if "attn_fwd" in kern and "attn_bwd" in kern:
                     a_ms = kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["ms_per_step"]
                     a_fl = kern["attn_fwd"]["tflops"] * kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["tflops"] * kern["attn_bwd"]["ms_per_step"]

@@ -624,11 +624,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
             delr = (i < a.Sq) ? delbase[i] : 0.f;
         }
     };
+    // The per-query-row terms of  p = exp2(s * sl + bias_j - lse_i)  and  dS = p * (dP - delta_i)  enter through the ACCUMULATOR INPUT of the
+    // MFMA chains: the S chain starts from -lse_i / sl and the dP chain from -delta_i (both indexed by the accumulator ROW, so they come
+    // straight out of LDS as the four 16-byte reads the kernel did anyway) -- the matrix pipe does the two subtractions per score that
+    // were VALU instructions in a loop bound by VALU issue.
+    const float inv_sl = 1.0f / sl;
     auto stage_commit = [&](int buf) {
         if (tid < 64) {
             float* st = reinterpret_cast<float*>(smem + 2 * 16384) + buf * 128;
-            st[tid] = lser;
-            st[64 + tid] = delr;
+            st[tid] = -lser * inv_sl;  // (+inf for padded query rows -> -inf -> p = 0)
+            st[64 + tid] = -delr;
         }
     };
 
@@ -653,9 +658,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
         for (int is = 0; is < 2; ++is) {
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = 0.f;
-                dp[r] = 0.f;
+            for (int rq = 0; rq < 4; ++rq) {  // accumulator inputs: -lse / sl and -delta of the row each register holds
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + is * 32 + rq * 8 + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + is * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[rq * 4 + j] = l4[j];
+                    dp[rq * 4 + j] = d4[j];
+                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -665,17 +675,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 dp = mfma32(dof, vf[c], dp);
             }
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + is * 32 + rq * 8 + 4 * g);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + is * 32 + rq * 8 + 4 * g);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = rq * 4 + j;
-                    float p = fast_exp2(__builtin_fmaf(s[r], sl, bias_j - l4[j]));
-                    float ds = p * (dp[r] - d4[j]);
-                    s[r] = p;
-                    dp[r] = ds;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(__builtin_fmaf(s[r], sl, bias_j));
+                dp[r] = p * dp[r];
+                s[r] = p;
             }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -768,11 +771,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
             delr = (i < a.Sq) ? delbase[i] : 0.f;
         }
     };
-    auto stage_commit = [&](int buf) {
+    const float inv_sl = 1.0f / sl;
+    auto stage_commit = [&](int buf) {  // (-lse / sl, -delta): the accumulator inputs of the S and dP chains, see attn_bwd_dkdv_kernel
         if (tid < 128) {
             float* st = reinterpret_cast<float*>(smem + 2 * 32768) + buf * 256;
-            st[tid] = lser;
-            st[128 + tid] = delr;
+            st[tid] = -lser * inv_sl;
+            st[128 + tid] = -delr;
         }
     };
 
@@ -796,9 +800,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
         if (t + 1 < nb) stage(t + 1, cur ^ 1);
         f32x16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = 0.f;
-            dp[r] = 0.f;
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + rq * 8 + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + rq * 8 + 4 * g);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                s[rq * 4 + jj] = l4[jj];
+                dp[rq * 4 + jj] = d4[jj];
+            }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -808,17 +817,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
             dp = mfma32(dof, vf[c], dp);
         }
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + rq * 8 + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + rq * 8 + 4 * g);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int r = rq * 4 + jj;
-                float p = fast_exp2(__builtin_fmaf(s[r], sl, bias_j - l4[jj]));
-                float ds = p * (dp[r] - d4[jj]);
-                s[r] = p;
-                dp[r] = ds;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float p = fast_exp2(__builtin_fmaf(s[r], sl, bias_j));
+            dp[r] = p * dp[r];
+            s[r] = p;
         }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {

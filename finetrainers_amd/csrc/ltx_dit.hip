@@ -387,29 +387,8 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
         return lora_down(dY, lddy, rows, lbt, nadp * r, D, r, s, dxa_out, st, nadp > 1 ? D : 0);
     };
 
-    // LoRA weight gradients dB += dY^T XA, dA += dXA^T X only feed the gradient buffer.  Default: ONE batched launch per adapter
-    // group over all blocks after the loop.  FTMI_TN_GROUP=g > 0 instead launches them per g finished blocks on a side stream,
-    // concurrently with the blocks still in flight (measured: 70.2 vs 69.6 ms/step -- the HBM-bound TN kernels slow the
-    // co-running GEMMs by more than their own 2.2 ms, so it is off; kept because per-group completion is what a bucketed
-    // gradient all-reduce would hook into).
-    static const int tn_group = env_int("FTMI_TN_GROUP", 0);
-    const bool use_side = r > 0 && tn_group > 0;
-    struct Side {
-        hipStream_t stream = nullptr;
-        hipEvent_t ready = nullptr, done = nullptr;
-        bool ok = false;
-        Side() {
-            ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess;
-        }
-    };
-    hipStream_t side = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-    if (use_side) {
-        static Side s_side;  // created once, thread-safe (function-local static)
-        if (!s_side.ok) return set_error(FTMI_ERR_LAUNCH, "ltx_backward: cannot create the side stream");
-        side = s_side.stream; ev_ready = s_side.ready; ev_done = s_side.done;
-    }
+    // LoRA weight gradients dB += dY^T XA, dA += dXA^T X only feed the gradient buffer: ONE batched launch per adapter group over all
+    // blocks of this call's range, after its block loop (fills the GPU instead of 28 latency-bound launches per adapter).
     auto lora_wgrad = [&](int l0, int nb, hipStream_t s2) -> int {
         char* blk0 = reinterpret_cast<char*>(ws) + L.blk0 + L.blk_stride * l0;
         const long bs = (long)(L.blk_stride / 2);  // block stride in bf16 elements
@@ -438,8 +417,6 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
         }
         return 0;
     };
-    int wgrad_pending_hi = l_hi;  // blocks [l, wgrad_pending_hi) have finished backward but not their weight gradients
-
     for (int l = l_hi - 1; l >= l_lo; --l) {
         char* blk = reinterpret_cast<char*>(ws) + L.blk0 + L.blk_stride * l;
         const bf16_t* h0 = W(ws, L.hs) + (size_t)l * M * D;
@@ -533,14 +510,8 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
             FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st, ada_prev + 5 * D, ab, dO));
             cur ^= 1;
         }
-        if (use_side && (wgrad_pending_hi - l >= tn_group || l == l_lo)) {
-            if (hipEventRecord(ev_ready, st) != hipSuccess || hipStreamWaitEvent(side, ev_ready, 0) != hipSuccess)
-                return set_error(FTMI_ERR_LAUNCH, "ltx_backward: side-stream hand-off failed");
-            FTMI_TRY(lora_wgrad(l, wgrad_pending_hi - l, side));
-            wgrad_pending_hi = l;
-        }
     }
-    if (r > 0 && !use_side) FTMI_TRY(lora_wgrad(l_lo, l_hi - l_lo, st));
+    if (r > 0) FTMI_TRY(lora_wgrad(l_lo, l_hi - l_lo, st));
     const int nb = l_hi - l_lo;
 
     // ---- text side of the cross-attention, all blocks at once (nothing upstream of `e` needs a gradient) ----
@@ -571,10 +542,6 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
             u.batch = nb; u.u_bstride = 6L * r; u.v_bstride = 0; u.c_bstride = 8L * r * D;
             FTMI_TRY(gemm_tn(u, st));
         }
-    }
-    if (use_side) {  // the caller's stream owns the gradients again
-        if (hipEventRecord(ev_done, side) != hipSuccess || hipStreamWaitEvent(st, ev_done, 0) != hipSuccess)
-            return set_error(FTMI_ERR_LAUNCH, "ltx_backward: side-stream join failed");
     }
     return 0;
 }

@@ -87,15 +87,21 @@ def test_dp_step_on_rccl_single_rank():
         for use_par in (False, True):
             spec, model, cond, latd, sig, noise = _model_and_batch(4, 2, 2, 4, 4)
             step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99), parallel=par if use_par else None, grad_bucket_blocks=1)
+            first = None
             for _ in range(2):
                 o = step.step(cond, latd, sigmas=sig, noise=noise, force_first_frame_branch=False)
+                first = first or (o["loss"].item(), o["grad_norm"].item())
             torch.cuda.synchronize()
-            outs.append((o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().clone(), step.reducer))
-        (l0, g0, p0, _), (l1, g1, p1, red) = outs
-        print(f"[dp-1rank] loss {l0:.6f} / {l1:.6f}  grad_norm {g0:.6e} / {g1:.6e}  buckets {red.buckets_issued}")
+            outs.append((first, o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().clone(), step.reducer))
+        (f0, l0, g0, p0, _), (f1, l1, g1, p1, red) = outs
+        print(f"[dp-1rank] step 1 loss {f0[0]:.6f} / {f1[0]:.6f} grad_norm {f0[1]:.6e} / {f1[1]:.6e};  step 2 loss {l0:.6f} / {l1:.6f} grad_norm {g0:.6e} / {g1:.6e}  buckets {red.buckets_issued}")
         assert red is not None and red.buckets_issued == 8  # 4 buckets per step x 2 steps
-        assert abs(l0 - l1) <= 1e-6 * abs(l0) and abs(g0 - g1) <= 1e-4 * g0
-        assert ((p0 - p1).norm() / p0.norm()).item() < 1e-4  # fp32 atomics order (bucketed vs single-call weight gradients), amplified by AdamW's sign-like first steps
+        # step 1: same weights, same data -> the same loss up to the order of its fp32 atomic sum; gradients differ only by the fp32 atomic order of the per-bucket
+        # weight-gradient launches.  Step 2 starts from parameters that differ where AdamW's sign-like first update saw a near-zero
+        # gradient with the other sign (an update of +-lr either way), so it agrees to ~1e-4, not to rounding.
+        assert abs(f0[0] - f1[0]) <= 1e-6 * abs(f0[0]) and abs(f0[1] - f1[1]) <= 1e-5 * f0[1]  # (the loss scalar is an atomic fp32 sum)
+        assert abs(l0 - l1) <= 2e-4 * abs(l0) and abs(g0 - g1) <= 1e-3 * g0
+        assert ((p0 - p1).norm() / p0.norm()).item() < 1e-4
         m = par.reduce_step_metrics(o["loss"], o["grad_norm"])
         assert abs(m["global_avg_loss"].item() - l1) < 1e-7
     finally:
