@@ -147,11 +147,15 @@ def main():
     from finetrainers_amd.parallel import DataParallelBackend
     from finetrainers_amd.trainer import MI355XSFTStep
 
+    # FTMI_BENCH_SHARE_GPU=1: rehearsal of the multi-rank launch on a one-GPU box -- the N ranks time-share GPU 0 and exchange through gloo
+    # (RCCL refuses two ranks on one device).  It executes the spawn, broadcast, bucketed exchange, barrier and max-over-ranks code; the
+    # line it prints is marked "rehearsal" and its numbers mean nothing.
+    share = os.environ.get("FTMI_BENCH_SHARE_GPU") == "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and not share:
             raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} MI355X visible")
         raise SystemExit(_self_spawn(args))
-    par = DataParallelBackend()
+    par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0)) if share and args.gpus > 1 else DataParallelBackend()
     if par.world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={par.world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = par.device
@@ -239,6 +243,7 @@ def main():
             "ms_per_step": ms,
             "higher_is_better": True,
             "scaling": "weak",
+            **({"rehearsal": "FTMI_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo -- code-path check only, not a measurement"} if share and args.gpus > 1 else {}),
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic latents [B,128,7,16,24] + random text embeds, random-init weights of the production LTX-Video DiT",

@@ -100,8 +100,13 @@ class DataParallelBackend:
         pair = torch.stack([loss.reshape(()).float(), grad_norm.reshape(()).float()])
         if self.world_size == 1:
             return {"global_avg_loss": pair[0], "global_max_loss": pair[0], "grad_norm": pair[1]}
-        gathered = torch.empty(self.world_size, 2, dtype=torch.float32, device=pair.device)
-        dist.all_gather_into_tensor(gathered, pair) if self.backend == "nccl" else dist.all_gather(list(gathered.unbind(0)), pair)
+        if self.backend == "nccl":
+            gathered = torch.empty(self.world_size, 2, dtype=torch.float32, device=pair.device)
+            dist.all_gather_into_tensor(gathered, pair)
+        else:  # gloo has no all-gather for device tensors: sum of one-hot rows (works on CPU and on a GPU alike)
+            gathered = torch.zeros(self.world_size, 2, dtype=torch.float32, device=pair.device)
+            gathered[self.rank] = pair
+            dist.all_reduce(gathered, op=dist.ReduceOp.SUM)
         return {"global_avg_loss": gathered[:, 0].mean(), "global_max_loss": gathered[:, 0].max(), "grad_norm": gathered[:, 1].mean()}
 
     @torch.no_grad()

@@ -171,27 +171,26 @@ def test_gradient_accumulation_matches_oracle():
     assert step.step_count == 1 and not torch.equal(gmodel.lora_flat, before) and gmodel.lora_A.grad is None
 
 
-def _two_rank_worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+def _two_rank_worker(rank, world, port, q, backend="nccl", one_gpu=False):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(0 if one_gpu else rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
 
     from finetrainers_amd.parallel import DataParallelBackend
     from finetrainers_amd.trainer import MI355XSFTStep
 
-    par = DataParallelBackend(backend="nccl")
+    par = DataParallelBackend(backend=backend, device=torch.device("cuda", 0) if one_gpu else None)
     try:
         spec, model, cond, latd, sig, noise = _model_and_batch(4, 1, 2, 4, 4, seed=3 + rank, dev=par.device, data_seed=200 + rank)  # different LoRA init per rank
         step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99), parallel=par, grad_bucket_blocks=2)  # rank 0's adapter is broadcast
         o = step.step(cond, latd, sigmas=sig, noise=noise, force_first_frame_branch=False)
         torch.cuda.synchronize()
-        q.put((rank, o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().cpu()))
+        q.put((rank, o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().cpu(), step.reducer.buckets_issued))
     finally:
         par.destroy()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the round-end driver's multi-GPU node); single-GPU boxes run the one-rank RCCL test above")
-def test_dp_step_two_ranks_equals_concatenated_batch():
+def _run_two_ranks(backend, one_gpu):
     """Two ranks, same weights, different data: after one step both hold the parameters a single rank gets from the concatenated batch."""
     import torch.multiprocessing as mp
 
@@ -199,26 +198,43 @@ def test_dp_step_two_ranks_equals_concatenated_batch():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + os.getpid() % 200
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + os.getpid() % 200 + (50 if one_gpu else 0)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, backend, one_gpu)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, l0, g0, p0), (_, l1, g1, p1) = res
+    (_, l0, g0, p0, nb0), (_, l1, g1, p1, nb1) = res
     assert torch.equal(p0, p1) and g0 == g1  # replicas stay bit-identical
+    assert nb0 == nb1 == 2  # 4 blocks in buckets of 2: two bucketed exchanges issued from inside the backward
     # single rank, both samples in one batch
     spec, model, cond0, lat0, sig0, n0 = _model_and_batch(4, 1, 2, 4, 4, seed=3, data_seed=200)
     _, _, cond1, lat1, sig1, n1 = _model_and_batch(4, 1, 2, 4, 4, seed=3, data_seed=201)
     cond = {k: torch.cat([cond0[k], cond1[k]]) for k in cond0}
     latd = dict(lat0, latents=torch.cat([lat0["latents"], lat1["latents"]]))
     step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99))
+    before = model.lora_flat.detach().cpu().clone()
     o = step.step(cond, latd, sigmas=torch.cat([sig0, sig1]), noise=torch.cat([n0, n1]), force_first_frame_branch=False)
     torch.cuda.synchronize()
     assert abs(o["loss"].item() - (l0 + l1) / 2) < 1e-5 * abs(o["loss"].item())
     assert abs(o["grad_norm"].item() - g0) < 1e-3 * g0
-    rel = ((model.lora_flat.cpu() - p0).norm() / p0.norm()).item()
-    print(f"[dp-2rank] parameter rel diff vs concatenated batch: {rel:.2e}")
-    assert rel < 1e-5
+    # the first AdamW step moves every entry by ~lr * sign(g): entries whose tiny gradient changes sign between the two summation orders
+    # differ by 2 lr, so compare the UPDATES (relative to the update's own norm), not the parameters to 1e-5
+    upd_ref, upd = model.lora_flat.cpu() - before, p0 - before
+    rel = ((upd - upd_ref).norm() / upd_ref.norm()).item()
+    print(f"[dp-2rank {backend}{' one GPU' if one_gpu else ''}] update rel diff vs concatenated batch: {rel:.2e}; grad_norm {g0:.5e} vs {o['grad_norm'].item():.5e}")
+    assert rel < 2e-2
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the round-end driver's multi-GPU node); single-GPU boxes run the gloo variant below")
+def test_dp_step_two_ranks_equals_concatenated_batch():
+    _run_two_ranks("nccl", one_gpu=False)
+
+
+def test_dp_step_two_ranks_sharing_one_gpu_gloo():
+    """The same world-size-2 step on ONE MI355X: two processes share cuda:0 and exchange through gloo (RCCL refuses two ranks on one
+    device).  Everything but the transport is the product path: LoRA broadcast, block-range backward, bucket hooks, async handles,
+    finish(), metric reduction."""
+    _run_two_ranks("gloo", one_gpu=True)
