@@ -510,8 +510,13 @@ int small_linear(const bf16_t* x, const bf16_t* W, const bf16_t* bias, bf16_t* y
 // ---------------------------------------------------------------------------------------------------
 // optimiser: global grad-norm clip + AdamW over the flat LoRA buffer (reference: utils/torch.py:99-161 clip,
 // torch.optim.AdamW(fused=False) via optimizer.py:117-125)
+// Deterministic: every block leaves its partial sum in scratch[2 + block]; the block that takes the last ticket adds the partials in a
+// fixed order.  (A float atomicAdd per block gave totals that differed in the last bit from run to run -- and therefore between the
+// ranks of a data-parallel job, whose clip coefficients and parameters would then drift apart.)
+static constexpr int kSumsqMaxBlocks = 2048;  // = FTMI_CLIP_SCRATCH_FLOATS - 2
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
     __shared__ float red[4];
+    __shared__ bool last;
     float acc = 0.f;
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -523,11 +528,24 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        out[2 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<unsigned*>(out) + 1, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __hip_atomic_load(out + 2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // device-scope load, fixed order per thread
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 int sumsq(const float* g, long n, float* out, hipStream_t st) {
     long blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kSumsqMaxBlocks) blocks = kSumsqMaxBlocks;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, out);
     return check_launch("sumsq");

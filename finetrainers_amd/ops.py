@@ -236,12 +236,17 @@ def mse_loss(pred, target, weight: Optional[torch.Tensor], want_grad: bool = Tru
     return loss, dpred
 
 
+CLIP_SCRATCH_FLOATS = 2050  # include/ftmi355.h FTMI_CLIP_SCRATCH_FLOATS
+
+
 def clip_adamw_step(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, betas=(0.9, 0.95), eps: float = 1e-8,
                     weight_decay: float = 1e-4, max_norm: float = 1.0, scratch: Optional[torch.Tensor] = None,
                     grad_norm_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     n = params.numel()
     if scratch is None:
-        scratch = torch.empty((2,), dtype=torch.float32, device=params.device)
+        scratch = torch.empty((CLIP_SCRATCH_FLOATS,), dtype=torch.float32, device=params.device)
+    elif scratch.numel() < CLIP_SCRATCH_FLOATS or scratch.dtype != torch.float32:
+        raise ValueError(f"clip_adamw_step: scratch must hold {CLIP_SCRATCH_FLOATS} fp32 values (FTMI_CLIP_SCRATCH_FLOATS)")
     if grad_norm_out is None:
         grad_norm_out = torch.empty((1,), dtype=torch.float32, device=params.device)
     check(_lib.load().ftmi_clip_adamw_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), n, float(max_norm), float(lr),

@@ -81,7 +81,7 @@ class MI355XSFTStep:
         self.n_a, self.n_b = transformer.lora_A.numel(), transformer.lora_B.numel()
         self.exp_avg = torch.zeros(self.n_a + self.n_b, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
-        self._scratch = torch.zeros(2, dtype=torch.float32, device=dev)
+        self._scratch = torch.zeros(ops.CLIP_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.reducer = None
         if parallel is not None and parallel.active:

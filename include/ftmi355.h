@@ -235,8 +235,11 @@ int ftmi_ddim_get_velocity(const void* sample, const void* noise, const float* s
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample,
                   float grad_scale, ftmi_stream stream);
 
-/* Global L2 clip (max_norm <= 0 disables) + AdamW over flat fp32 buffers; scratch: >= 2 floats (device).
+/* Global L2 clip (max_norm <= 0 disables) + AdamW over flat fp32 buffers; scratch: >= FTMI_CLIP_SCRATCH_FLOATS floats (device).
+ * The norm is reduced in a fixed order (block partials in scratch, last block adds them): the same gradients give the same
+ * bits on every call and on every rank, so data-parallel replicas keep identical clip coefficients.
  * grad_norm_out (device fp32, may be NULL) receives the pre-clip total norm. */
+#define FTMI_CLIP_SCRATCH_FLOATS 2050
 int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, float* grad_norm_out,
                          ftmi_stream stream);

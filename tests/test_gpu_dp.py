@@ -185,7 +185,7 @@ def _two_rank_worker(rank, world, port, q, backend="nccl", one_gpu=False):
         step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99), parallel=par, grad_bucket_blocks=2)  # rank 0's adapter is broadcast
         o = step.step(cond, latd, sigmas=sig, noise=noise, force_first_frame_branch=False)
         torch.cuda.synchronize()
-        q.put((rank, o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().cpu(), step.reducer.buckets_issued))
+        q.put((rank, o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().cpu().numpy(), step.reducer.buckets_issued))  # numpy: pickled by value (a torch CPU tensor travels as a file descriptor of a process that may be gone)
     finally:
         par.destroy()
 
@@ -207,7 +207,8 @@ def _run_two_ranks(backend, one_gpu):
         p.join(timeout=120)
         assert p.exitcode == 0
     (_, l0, g0, p0, nb0), (_, l1, g1, p1, nb1) = res
-    assert torch.equal(p0, p1) and g0 == g1  # replicas stay bit-identical
+    p0, p1 = torch.from_numpy(p0), torch.from_numpy(p1)
+    assert torch.equal(p0, p1) and g0 == g1  # replicas stay bit-identical (the norm reduction is order-fixed)
     assert nb0 == nb1 == 2  # 4 blocks in buckets of 2: two bucketed exchanges issued from inside the backward
     # single rank, both samples in one batch
     spec, model, cond0, lat0, sig0, n0 = _model_and_batch(4, 1, 2, 4, 4, seed=3, data_seed=200)

@@ -311,6 +311,24 @@ def test_clip_adamw_matches_torch():
         torch.testing.assert_close(p.cpu(), p_ref.detach(), rtol=2e-6, atol=1e-9)
 
 
+def test_grad_norm_is_bitwise_reproducible():
+    """The clip's total norm is reduced in a fixed order: the same gradients give the same bits on every call (and on every rank of a
+    data-parallel job -- a last-bit difference in the clip coefficient would let replicas drift apart)."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    n = 58_720_256  # the full LoRA buffer of the production model (2048 blocks in the first pass)
+    g = torch.randn(n, generator=torch.Generator(device=dev).manual_seed(11), device=dev) * 1e-3
+    p, m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    scratch = torch.zeros(ops.CLIP_SCRATCH_FLOATS, device=dev)
+    norms = {ops.clip_adamw_step(p, g, m, v, 1, lr=0.0, max_norm=1.0, scratch=scratch).item() for _ in range(20)}
+    assert len(norms) == 1, norms
+    ref = g.double().norm().item()
+    assert abs(norms.pop() - ref) <= 2e-6 * ref
+    with pytest.raises(ValueError):
+        ops.clip_adamw_step(p, g, m, v, 1, lr=0.0, scratch=torch.zeros(2, device=dev))
+
+
 def test_lora_refresh_layouts():
     """The bf16 (hi, lo) working copies of the flat fp32 LoRA buffer (include/ftmi355.h: ftmi_ltx_weights)."""
     from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoTransformer3DModel
