@@ -139,7 +139,10 @@ static constexpr int kFwdLds = 2 * 16384 + 2 * 256;  // two (K, V) tile buffers 
 // FL: AF_LAZY | AF_MAX16 is what ships; the other flags are experiments.  1: row sums by VALU adds instead of 4 all-ones MFMAs; 2: lazy rescale (skip the O rescale pass
 // unless the running max of some lane's row grew by more than 2^8); 4 / 8 / 16: timing ablations (no exp / no P.V / no tile reload) whose
 // results are WRONG by construction -- compiled only with -DFTMI_EXPERIMENTAL.
-enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_ABL_NOLOAD = 16, AF_MAX16 = 32 };
+enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_ABL_NOLOAD = 16, AF_MAX16 = 32, AF_TIMING = 64 };
+// AF_TIMING (experimental build only, tools/attn_phase_timing.py): every wave sums the s_memtime ticks it spends between four program points
+// of the tile loop (scores issued, softmax done, P.V issued, barrier passed) and overwrites lse2[row .. row+3] of its first rows with the totals.
+FTMI_DEVICE unsigned tick32() { return (unsigned)__builtin_readcyclecounter(); }
 
 template <bool HAS_KB, int FL = 0, int MINW = 1>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     stage_commit(0);
     tile_dma_wait();
     __syncthreads();
+    unsigned tacc[4] = {0u, 0u, 0u, 0u};
     auto body = [&](int t, auto CUR) {
         constexpr int cur = decltype(CUR)::value;
         const char* ks = smem + cur * 16384;
@@ -207,6 +211,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
             if (t + 1 < nt) stage(t + 1, cur ^ 1);
         }
 
+        unsigned tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0;
+        if constexpr (FL & AF_TIMING) { __builtin_amdgcn_sched_barrier(0); tp0 = tick32(); }
         f32x16 st[2];
 #pragma unroll
         for (int js = 0; js < 2; ++js) {
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
                 st[js] = mfma32(kf, qf[c], st[js]);
             }
         }
+        if constexpr (FL & AF_TIMING) { __builtin_amdgcn_sched_barrier(0); tp1 = tick32(); __builtin_amdgcn_sched_barrier(0); }
         // scores in the log2 domain: x = s * (scale * log2 e) + bias;  row max / exp2 per lane (= per query row)
         float mx = -INFINITY;
         if constexpr (HAS_KB) {
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
         }
+        if constexpr (FL & AF_TIMING) { __builtin_amdgcn_sched_barrier(0); tp2 = tick32(); __builtin_amdgcn_sched_barrier(0); }
 
         // The row sum of P rides on the matrix pipe: an all-ones A-slot fragment makes every row of the product the column
         // sums of P^T (= per-query sums over this tile's keys, both half-waves included), so the 32 adds + cross-half
@@ -321,10 +329,16 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
         } else {
             l_run = l_run * alpha + lsum[0];
         }
+        if constexpr (FL & AF_TIMING) { __builtin_amdgcn_sched_barrier(0); tp3 = tick32(); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (!(FL & AF_ABL_NOLOAD)) {
             if (t + 1 < nt) stage_commit(cur ^ 1);
             tile_dma_wait();
             __syncthreads();  // tile t+1 landed (the barrier drains this wave's DMA first) and tile t's buffer is free again
+        }
+        if constexpr (FL & AF_TIMING) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned tp4 = tick32();
+            tacc[0] += tp1 - tp0; tacc[1] += tp2 - tp1; tacc[2] += tp3 - tp2; tacc[3] += tp4 - tp3;
         }
     };
     for (int t = 0; t < nt; t += 2) {
@@ -337,6 +351,12 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
         bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
         store_rows_via_lds(smem + wave * 4096, oacc, inv, ob, a.o_ss, blk.tile * 128 + wave * 32, a.Sq, lane);
         if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
+        if constexpr (FL & AF_TIMING) {
+            const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));  // HW_REG_HW_ID[3:0]: wave slot within the SIMD
+            if (lane < 5 && a.lse2)
+                a.lse2[((long)b * a.H + h) * a.Sq + blk.tile * 128 + wave * 32 + lane] =
+                    (float)(lane == 0 ? tacc[0] : lane == 1 ? tacc[1] : lane == 2 ? tacc[2] : lane == 3 ? tacc[3] : slot);
+        }
     }
 }
 
@@ -549,6 +569,7 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
             FTMI_AF(16, AF_LAZY | AF_MAX16, 1)
             FTMI_AF(17, AF_MAX16, 1)
             FTMI_AF(18, AF_LAZY | AF_MAX16, 2)
+            FTMI_AF(19, AF_LAZY | AF_MAX16 | AF_TIMING, 1)
 #undef FTMI_AF
             default: break;
         }

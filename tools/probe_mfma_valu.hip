@@ -29,7 +29,7 @@ __device__ __forceinline__ void valu_op(float (&x)[16], float2 (&x2)[8], int j, 
 
 // ROLE: 0 = every wave does both (same-wave interleave), 1 = waves 0-3 MFMA only / waves 4-7 VALU only (two waves per SIMD, split roles),
 // 2 = reversed (waves 0-3 VALU, 4-7 MFMA), 3 = reversed + s_setprio 3 in the MFMA waves, 4 = reversed + s_setprio 3 in the VALU waves
-template <bool DO_M, bool DO_V, int R, int VOP, int ROLE>
+template <bool DO_M, bool DO_V, int R, int VOP, int ROLE, int NACC = 4>
 __global__ __launch_bounds__(512) void probe(float* out, int iters) {
     const int wave = threadIdx.x >> 6;
     const bool m_on = DO_M && (ROLE == 0 || (ROLE == 1 ? wave < 4 : wave >= 4)), v_on = DO_V && (ROLE == 0 || (ROLE == 1 ? wave >= 4 : wave < 4));
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                MFMA(acc[g & 3]);
+                MFMA(acc[g & (NACC - 1)]);
 #pragma unroll
                 for (int j = 0; j < R; ++j) valu_op<VOP>(x, x2, g * R + j, c, d, c2, sinkr);
             }
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
     } else if (m_on) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int g = 0; g < 8; ++g) MFMA(acc[g & 3]);
+            for (int g = 0; g < 8; ++g) MFMA(acc[g & (NACC - 1)]);
         }
     } else if (v_on) {
         for (int it = 0; it < iters; ++it) {
@@ -77,14 +77,14 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)sinkr;
 }
 
-template <bool DO_M, bool DO_V, int R, int VOP, int ROLE>
+template <bool DO_M, bool DO_V, int R, int VOP, int ROLE, int NACC = 4>
 static double run(int threads, const char* label, float* out) {
     const int iters = 4000, grid = 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<DO_M, DO_V, R, VOP, ROLE>), dim3(grid), dim3(threads), 0, 0, out, 50);
+    hipLaunchKernelGGL((probe<DO_M, DO_V, R, VOP, ROLE, NACC>), dim3(grid), dim3(threads), 0, 0, out, 50);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((probe<DO_M, DO_V, R, VOP, ROLE>), dim3(grid), dim3(threads), 0, 0, out, iters);
+    hipLaunchKernelGGL((probe<DO_M, DO_V, R, VOP, ROLE, NACC>), dim3(grid), dim3(threads), 0, 0, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double ns_per_group = ms * 1e6 / (iters * 8.0);
@@ -127,5 +127,17 @@ int main() {
     run<true, true, 16, 0, 3>(512, "reversed, MFMA waves at s_setprio 3: v_fma x16 || MFMA", out);
     run<true, true, 8, 0, 4>(512, "reversed, VALU waves at s_setprio 3: v_fma x8 || MFMA", out);
     run<true, true, 8, 1, 3>(512, "reversed, MFMA waves at s_setprio 3: v_exp x8 || MFMA", out);
+    printf("dependent MFMA chains (NACC = accumulators used round-robin; 1 = every MFMA waits for the previous one):\n");
+    run<true, false, 8, 0, 0, 1>(256, "1 wave/SIMD, MFMA only, 1 accumulator", out);
+    run<true, false, 8, 0, 0, 2>(256, "1 wave/SIMD, MFMA only, 2 accumulators", out);
+    run<true, true, 8, 0, 0, 1>(256, "1 wave/SIMD, MFMA (1 acc) + 8 v_fma interleaved", out);
+    run<true, true, 8, 0, 0, 2>(256, "1 wave/SIMD, MFMA (2 acc) + 8 v_fma interleaved", out);
+    run<true, false, 8, 0, 1, 1>(512, "split roles: MFMA (1 acc) wave alone", out);
+    run<true, true, 8, 0, 1, 1>(512, "split roles: MFMA (1 acc)  ||  v_fma x8", out);
+    run<true, true, 8, 0, 1, 2>(512, "split roles: MFMA (2 acc)  ||  v_fma x8", out);
+    run<true, true, 16, 0, 1, 1>(512, "split roles: MFMA (1 acc)  ||  v_fma x16", out);
+    run<true, true, 8, 1, 1, 1>(512, "split roles: MFMA (1 acc)  ||  v_exp x8", out);
+    run<true, false, 8, 0, 0, 1>(512, "both waves MFMA only (1 acc each)", out);
+    run<true, true, 8, 0, 0, 1>(512, "both waves MFMA (1 acc) + 8 v_fma interleaved", out);
     return 0;
 }
