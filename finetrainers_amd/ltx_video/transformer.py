@@ -126,7 +126,7 @@ class _LTXDiTFunction(torch.autograd.Function):
         # ONE flat fp32 gradient buffer [A | B] -- a contiguous all-reduce per block range and a single clip+AdamW launch downstream.
         # The buffer IS lora_A.grad / lora_B.grad: the kernels write (or, under gradient accumulation, add) straight into it and
         # autograd gets None for the two parameters, so nothing is copied or re-added on the way.
-        n_a, n_b = module.lora_A.numel(), module.lora_B.numel()
+        n_a, n_b = module._lora_A_full.numel(), module._lora_B_full.numel()  # padded rank (== the parameters' own size unless r % 64 != 0)
         ga_live, gb_live = module.lora_A.grad, module.lora_B.grad
         gflat = module._grad_flat_buf
         own = gflat is not None and gflat.numel() == n_a + n_b and gflat.device == dpred.device
@@ -141,8 +141,9 @@ class _LTXDiTFunction(torch.autograd.Function):
         else:  # somebody installed their own .grad tensors: compute into a scratch buffer and let autograd accumulate
             foreign = gflat = torch.empty(n_a + n_b, dtype=torch.float32, device=dpred.device)
             accumulate = 0
-        ga = gflat[:n_a].view_as(module.lora_A)
-        gb = gflat[n_a:].view_as(module.lora_B)
+        ga = gflat[:n_a].view_as(module._lora_A_full)
+        gb = gflat[n_a:].view_as(module._lora_B_full)
+        r_user = module.lora_rank  # the parameters (and their .grad) are the first r_user rows / columns of the padded storage
         _, text, key_bias, _, _, _ = ctx.keep
         lib = _lib.load()
         hook = module._grad_bucket_hook if foreign is None else None
@@ -159,10 +160,10 @@ class _LTXDiTFunction(torch.autograd.Function):
         module._release_workspace(ctx.ws)
         ctx.ws = None
         if foreign is not None:
-            return None, None, None, None, None, None, None, ga, gb
+            return None, None, None, None, None, None, None, ga[:, :, :r_user, :], gb[:, :, :, :r_user]
         module._grad_flat = gflat
         if ga_live is None:
-            module.lora_A.grad, module.lora_B.grad = ga, gb
+            module.lora_A.grad, module.lora_B.grad = ga[:, :, :r_user, :], gb[:, :, :, :r_user]
         return (None,) * 9
 
 
@@ -204,6 +205,8 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         self.lora_A: Optional[nn.Parameter] = None
         self.lora_B: Optional[nn.Parameter] = None
         self.lora_rank = 0
+        self.lora_rank_padded = 0
+        self._lora_A_full = self._lora_B_full = None
         self.lora_alpha = 0.0
         self._lora_versions = None
         self._rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -319,19 +322,29 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
             if not all(hit):
                 raise ValueError("the MI355X LTX backend fuses LoRA into to_q/to_k/to_v/to_out.0 of attn1+attn2; "
                                  f"target_modules={target_modules!r} does not cover exactly that set")
-        if r is None or r <= 0 or r % 64 != 0:
-            raise ValueError(f"LoRA rank must be a positive multiple of 64 for the gfx950 kernels, got {r}")
+        if r is None or r <= 0:
+            raise ValueError(f"LoRA rank must be positive, got {r}")
         if self.lora_A is not None:
             raise ValueError(f"adapter {adapter_name!r}: an adapter is already attached")
         L, D = self.config.num_layers, self.config.inner_dim
-        n = L * 8 * r * D
+        # The gfx950 kernels work on ranks that are multiples of 64 (one MFMA K-extension step).  Any other rank -- the reference's LTX
+        # example trains with --rank 32 (examples/training/sft/ltx_video/crush_smol_lora/train.sh:75) -- is stored padded: the extra rows
+        # of A and columns of B are zero and STAY zero (their gradients are exact zeros: x A_pad^T = 0 and dY B_pad = 0; AdamW and weight
+        # decay leave a zero parameter with zero gradient at zero), so the padded model is the rank-r model bit for bit.  The Parameters
+        # the trainer sees are the [.., :r, :] / [.., :r] views.
+        rp = -(-int(r) // 64) * 64
+        n = L * 8 * rp * D
         # one flat fp32 buffer [A | B]; the two Parameters are views into it
         self.lora_flat = torch.zeros(2 * n, dtype=torch.float32, device=self.device)
+        self._lora_A_full = self.lora_flat[:n].view(L, 8, rp, D)
+        self._lora_B_full = self.lora_flat[n:].view(L, 8, D, rp)
         bound = math.sqrt(6.0 / ((1 + 5.0) * D))  # kaiming_uniform_(a=sqrt(5)) on [r, D]: bound = sqrt(6/((1+a^2) fan_in))
-        self.lora_flat[:n].uniform_(-bound, bound)
-        self.lora_A = nn.Parameter(self.lora_flat[:n].view(L, 8, r, D))
-        self.lora_B = nn.Parameter(self.lora_flat[n:].view(L, 8, D, r))
+        self._lora_A_full[:, :, :r, :].uniform_(-bound, bound)
+        self.lora_A = nn.Parameter(self._lora_A_full[:, :, :r, :])
+        self.lora_B = nn.Parameter(self._lora_B_full[:, :, :, :r])
         self.lora_rank, self.lora_alpha = int(r), float(lora_alpha if lora_alpha is not None else r)
+        self.lora_rank_padded = rp
+        r = rp  # working copies and kernels: padded rank
         # bf16 (hi, lo) working copies for the fp32-equivalent LoRA branch (include/ftmi355.h, ftmi_ltx_weights)
         for n, shp in (("lora_a_sp", (L, 8, 2 * r, D)), ("lora_bt_sp", (L, 8, 2 * r, D)), ("lora_b_ext", (L, 8, D, 3 * r)),
                        ("lora_at_ext", (L, 8, D, 3 * r)), ("lora_at_qkv_ext", (L, D, 9 * r))):
@@ -430,7 +443,7 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
     def _assert_flat_aliasing(self) -> None:
         """The fused clip+AdamW updates ``lora_flat`` in place; lora_A / lora_B must still be views of it (``model.to(...)`` or a foreign
         ``load_state_dict(assign=True)`` would silently detach them)."""
-        n = self.lora_A.numel()
+        n = self._lora_A_full.numel()
         if self.lora_A.data_ptr() != self.lora_flat.data_ptr() or self.lora_B.data_ptr() != self.lora_flat.data_ptr() + 4 * n:
             raise RuntimeError("lora_A / lora_B no longer alias transformer.lora_flat (the module was moved or re-assigned after add_adapter); "
                                "re-attach the adapter on the target device")
@@ -453,8 +466,8 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         if not force and ver == self._lora_versions:
             return
         c = self.config
-        check(_lib.load().ftmi_lora_refresh(ptr(self.lora_A), ptr(self.lora_B), ptr(self.lora_a_sp), ptr(self.lora_bt_sp), ptr(self.lora_b_ext),
-                                             ptr(self.lora_at_ext), ptr(self.lora_at_qkv_ext), c.num_layers, self.lora_rank, c.inner_dim, stream_ptr()),
+        check(_lib.load().ftmi_lora_refresh(ptr(self._lora_A_full), ptr(self._lora_B_full), ptr(self.lora_a_sp), ptr(self.lora_bt_sp), ptr(self.lora_b_ext),
+                                             ptr(self.lora_at_ext), ptr(self.lora_at_qkv_ext), c.num_layers, self.lora_rank_padded, c.inner_dim, stream_ptr()),
               "ftmi_lora_refresh")
         self._lora_versions = ver
 
@@ -462,7 +475,7 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
     def _c_config(self, B: int, S: int, T: int) -> LtxConfig:
         c = self.config
         return LtxConfig(B=B, S=S, T=T, D=c.inner_dim, H=c.num_attention_heads, L=c.num_layers, C_in=c.in_channels, C_out=c.out_channels,
-                         D_ff=c.inner_dim * c.ff_mult, D_cap=c.caption_channels, r=self.lora_rank,
+                         D_ff=c.inner_dim * c.ff_mult, D_cap=c.caption_channels, r=self.lora_rank_padded,
                          lora_scale=(self.lora_alpha / self.lora_rank) if self.lora_rank else 0.0, eps_norm=c.norm_eps, eps_qk=c.qk_norm_eps,
                          gemm_variant=self.gemm_variant)
 

@@ -78,7 +78,7 @@ class MI355XSFTStep:
         dev = transformer.device
         transformer._assert_flat_aliasing()
         # flat fp32 optimiser state matching transformer.lora_flat = [A | B]
-        self.n_a, self.n_b = transformer.lora_A.numel(), transformer.lora_B.numel()
+        self.n_a, self.n_b = transformer._lora_A_full.numel(), transformer._lora_B_full.numel()  # storage size (rank padded to a multiple of 64)
         self.exp_avg = torch.zeros(self.n_a + self.n_b, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self._scratch = torch.zeros(ops.CLIP_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
@@ -153,7 +153,11 @@ class MI355XSFTStep:
         if self.reducer is not None:
             raise RuntimeError("data-parallel step: lora_A.grad / lora_B.grad are not the backend's flat gradient buffer (foreign .grad tensors "
                                "were installed); the bucketed exchange would have missed them")
-        return torch.cat([ga.reshape(-1), gb.reshape(-1)])
+        tr = self.transformer  # foreign .grad tensors (single GPU only): lay them out like the (rank-padded) parameter storage
+        flat = torch.zeros(self.n_a + self.n_b, dtype=torch.float32, device=ga.device)
+        flat[:self.n_a].view_as(tr._lora_A_full)[:, :, :tr.lora_rank, :].copy_(ga)
+        flat[self.n_a:].view_as(tr._lora_B_full)[:, :, :, :tr.lora_rank].copy_(gb)
+        return flat
 
     def _clip_adamw(self, gflat: torch.Tensor) -> torch.Tensor:
         tr = self.transformer

@@ -104,12 +104,12 @@ def _oracle_trace(model, inp):
     return tr
 
 
-def _build(num_layers, B, F_, H_, W_, first_frame, seed):
+def _build(num_layers, B, F_, H_, W_, first_frame, seed, rank=64, alpha=64.0):
     from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
     from oracle import ltx
 
     cfg = ltx.LTXConfig.production(num_layers=num_layers)
-    omodel = ltx.build_model(cfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
+    omodel = ltx.build_model(cfg, seed=0, rank=rank, alpha=float(alpha), lora_b_std=0.02)
     mask_lens = [32, 96][:B]
     inp = ltx.synth_inputs(cfg, B, F_, H_, W_, seed=seed, mask_lens=mask_lens, sigmas=[0.25, 0.7][:B])
     inp.latents_mean = torch.randn(cfg.in_channels, generator=torch.Generator().manual_seed(5)) * 0.1
@@ -118,7 +118,7 @@ def _build(num_layers, B, F_, H_, W_, first_frame, seed):
         inp.first_frame_sigma = torch.tensor([0.1, 0.6][:B])
     spec = MI355XLTXVideoModelSpecification(transformer_config=LTXTransformerConfig(num_layers=num_layers))
     gmodel = spec.load_diffusion_models(state_dict=omodel.state_dict(), device=_dev())["transformer"]
-    gmodel.add_adapter(r=64, lora_alpha=64)
+    gmodel.add_adapter(r=rank, lora_alpha=alpha)
     gmodel.load_lora_state_dict({k: v for k, v in omodel.state_dict().items() if "lora_" in k})
     return cfg, omodel, inp, spec, gmodel
 
@@ -148,11 +148,11 @@ CASES = [
 ]
 
 
-def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trace_activations, tag):
+def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trace_activations, tag, rank=64, alpha=64.0):
     from finetrainers_amd.trainer import sft_loss
     from oracle import ltx
 
-    cfg, omodel, inp, spec, gmodel = _build(num_layers, B, F_, H_, W_, first_frame, seed=3)
+    cfg, omodel, inp, spec, gmodel = _build(num_layers, B, F_, H_, W_, first_frame, seed=3, rank=rank, alpha=alpha)
     S = F_ * H_ * W_
     D = 2048
 
@@ -255,6 +255,46 @@ def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
     glob, worst_adapter, floor_glob, floor_worst = _run_parity_case(num_layers, B, F_, H_, W_, first_frame, True, True, tag)
     assert glob < FLOOR_FACTOR * floor_glob, f"global LoRA gradient error {glob:.3e} vs summation-order floor {floor_glob:.3e}"
     assert worst_adapter < FLOOR_FACTOR_WORST * floor_worst, f"worst adapter {worst_adapter:.3e} vs floor {floor_worst:.3e}"
+
+
+@pytest.mark.parametrize("rank,alpha", [(128, 128.0), (64, 32.0), (32, 32.0)])
+def test_dit_parity_other_ranks(rank, alpha):
+    """Rank 128 (two K-extension steps per plane);
+    alpha != rank exercises the LoRA scale (alpha / rank) that rank 64 / alpha 64 leaves at 1; rank 32 (the reference's LTX example,
+    examples/training/sft/ltx_video/crush_smol_lora/train.sh:75-76) runs on zero-padded rank-64 storage."""
+    tag = f"L2_B2_S72_r{rank}_a{int(alpha)}"
+    glob, worst_adapter, floor_glob, floor_worst = _run_parity_case(2, 2, 3, 4, 6, False, True, False, tag, rank=rank, alpha=alpha)
+    assert glob < FLOOR_FACTOR * floor_glob, f"global LoRA gradient error {glob:.3e} vs summation-order floor {floor_glob:.3e}"
+    assert worst_adapter < FLOOR_FACTOR_WORST * floor_worst, f"worst adapter {worst_adapter:.3e} vs floor {floor_worst:.3e}"
+
+
+def test_rank32_padding_stays_zero_through_optimiser_steps():
+    """Rank 32 on rank-64 storage: after fused clip + AdamW steps (weight decay on) the padded rows of A / columns of B are still exact
+    zeros, the parameters' gradients have the rank-32 shape, and the padded gradient entries the kernels produced are exact zeros."""
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    cfg, omodel, inp, spec, gmodel = _build(1, 2, 2, 4, 4, False, seed=5, rank=32, alpha=32.0)
+    dev = _dev()
+    step = MI355XSFTStep(gmodel, spec, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0)
+    cond = {"encoder_hidden_states": inp.encoder_hidden_states.to(dev), "encoder_attention_mask": inp.encoder_attention_mask.to(dev)}
+    lat = {"latents": inp.latents.to(dev), "latents_mean": inp.latents_mean, "latents_std": inp.latents_std,
+           "num_frames": inp.latents.shape[2], "height": inp.latents.shape[3], "width": inp.latents.shape[4]}
+    before = gmodel.lora_A.detach().clone()
+    for _ in range(3):
+        pred, target, sig = spec.forward(transformer=gmodel, condition_model_conditions=dict(cond), latent_model_conditions=dict(lat),
+                                         sigmas=inp.sigmas.view(-1, 1, 1, 1, 1).to(dev), noise=inp.noise.to(dev))
+        ((pred.float() - target.float()) ** 2).mean().backward()  # the reference loop's own loss.backward(): autograd edge, foreign-free .grad
+        assert gmodel.lora_A.grad.shape == (1, 8, 32, 2048) and gmodel.lora_B.grad.shape == (1, 8, 2048, 32)
+        gfull = gmodel._grad_flat
+        n = gmodel._lora_A_full.numel()
+        assert gfull[:n].view_as(gmodel._lora_A_full)[:, :, 32:, :].abs().max().item() == 0.0
+        assert gfull[n:].view_as(gmodel._lora_B_full)[:, :, :, 32:].abs().max().item() == 0.0
+        gmodel.lora_A.grad = gmodel.lora_B.grad = None
+        out = step.step(cond, lat, sigmas=inp.sigmas.to(dev), noise=inp.noise.to(dev))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["loss"]).item() and out["grad_norm"].item() > 0
+    assert gmodel._lora_A_full[:, :, 32:, :].abs().max().item() == 0.0 and gmodel._lora_B_full[:, :, :, 32:].abs().max().item() == 0.0
+    assert not torch.equal(gmodel.lora_A.detach(), before)
 
 
 def test_full_depth_config2_parity():

@@ -108,7 +108,7 @@ def test_adapter_surface_is_peft_compatible():
 
     model = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=2), device=torch.device("cpu"))
     with pytest.raises(ValueError):
-        model.add_adapter(r=48, lora_alpha=48)  # rank must be a multiple of 64
+        model.add_adapter(r=0, lora_alpha=1)
     with pytest.raises(ValueError):
         model.add_adapter(SimpleNamespace(r=64, lora_alpha=64, target_modules="ff.net.0.proj"))
     model.add_adapter(SimpleNamespace(r=64, lora_alpha=64, target_modules=DEFAULT_TARGET_MODULES, init_lora_weights=True))
@@ -128,6 +128,31 @@ def test_adapter_surface_is_peft_compatible():
     assert 28 * 8 == 224 and 28 * 8 * 2 * 64 * 2048 == 58_720_256
     with pytest.raises(ValueError):
         model.add_adapter(r=64, lora_alpha=64)  # already attached
+
+
+def test_adapter_rank_that_is_not_a_multiple_of_64_is_zero_padded():
+    """The reference's LTX example trains with --rank 32 --lora_alpha 32 (examples/training/sft/ltx_video/crush_smol_lora/train.sh:75-76): the
+    parameters, their state dict and the saved file have rank 32; the storage the kernels see is padded to 64 with zeros."""
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoTransformer3DModel
+
+    model = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=2), device=torch.device("cpu"))
+    model.add_adapter(r=32, lora_alpha=32)
+    assert model.lora_rank == 32 and model.lora_rank_padded == 64
+    assert model.lora_A.shape == (2, 8, 32, 2048) and model.lora_B.shape == (2, 8, 2048, 32)
+    assert model.lora_flat.numel() == 2 * 2 * 8 * 64 * 2048
+    assert model._lora_A_full[:, :, 32:, :].abs().max() == 0 and model._lora_A_full[:, :, :32, :].abs().max() > 0
+    model._assert_flat_aliasing()
+    with torch.no_grad():
+        model.lora_B.normal_(0, 0.02)  # writes through the view: only the real columns change
+    assert model._lora_B_full[:, :, :, 32:].abs().max() == 0 and model._lora_B_full[:, :, :, :32].abs().max() > 0
+    sd = model.lora_state_dict()
+    assert sd["transformer_blocks.1.attn2.to_out.0.lora_B.weight"].shape == (2048, 32)
+    assert sd["transformer_blocks.0.attn1.to_q.lora_A.weight"].shape == (32, 2048)
+    other = MI355XLTXVideoTransformer3DModel(LTXTransformerConfig(num_layers=2), device=torch.device("cpu"))
+    other.add_adapter(r=32, lora_alpha=32)
+    other.load_lora_state_dict(sd)
+    assert torch.equal(other.lora_flat, model.lora_flat)
+    assert model._c_config(1, 32, 128).r == 64 and abs(model._c_config(1, 32, 128).lora_scale - 1.0) < 1e-7
 
 
 def test_rope_tables_match_upstream_formula():
