@@ -60,7 +60,7 @@ class MI355XSFTStep:
     def __init__(self, transformer, specification, lr: float = 5e-5, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
                  max_grad_norm: float = 1.0, flow_weighting_scheme: str = "none", flow_logit_mean: float = 0.0, flow_logit_std: float = 1.0,
                  flow_mode_scale: float = 1.29, parallel=None, generator: Optional[torch.Generator] = None,
-                 gradient_accumulation_steps: int = 1, grad_bucket_blocks: int = 7):
+                 gradient_accumulation_steps: int = 1, grad_bucket_blocks: int = 7, lr_scheduler=None):
         if transformer.lora_A is None:
             raise ValueError("attach a LoRA adapter first (transformer.add_adapter)")
         if gradient_accumulation_steps < 1:
@@ -74,6 +74,9 @@ class MI355XSFTStep:
         self.parallel = parallel
         self.generator = generator
         self.gradient_accumulation_steps = gradient_accumulation_steps
+        # ``finetrainers_amd.utils.lr_schedule.LRSchedule`` (or anything with current_lr() / step()): its rate is read for every optimiser step
+        # and it is stepped right after, as trainer.py:500-503 does with the LambdaLR
+        self.lr_scheduler = lr_scheduler
         self._micro_step = 0
         dev = transformer.device
         transformer._assert_flat_aliasing()
@@ -146,6 +149,24 @@ class MI355XSFTStep:
         tr.lora_B.grad = None
         return {"loss": loss.detach(), "grad_norm": grad_norm}
 
+    # ---- resume (reference: utils/state_checkpoint.py saves optimizer + scheduler state next to the model's) ------------------------------
+    def state_dict(self) -> Dict[str, Any]:
+        """Optimiser-side state of the fused step: AdamW moments laid out like ``transformer.lora_flat`` ([A | B], rank-padded storage),
+        the step counters and the schedule clock.  The LoRA parameters themselves travel in ``transformer.state_dict()``."""
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "micro_step": self._micro_step,
+                "lr_scheduler": None if self.lr_scheduler is None else self.lr_scheduler.state_dict(),
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "max_grad_norm": self.max_grad_norm}}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        if sd["exp_avg"].numel() != self.exp_avg.numel():
+            raise ValueError(f"optimizer state holds {sd['exp_avg'].numel()} values, the attached adapter needs {self.exp_avg.numel()}")
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count, self._micro_step = int(sd["step"]), int(sd.get("micro_step", 0))
+        if self.lr_scheduler is not None and sd.get("lr_scheduler") is not None:
+            self.lr_scheduler.load_state_dict(sd["lr_scheduler"])
+
     def _flat_grad(self, ga: torch.Tensor, gb: torch.Tensor) -> torch.Tensor:
         gflat = self.transformer._grad_flat
         if gflat is not None and ga.data_ptr() == gflat.data_ptr() and gb.data_ptr() == gflat.data_ptr() + 4 * self.n_a:
@@ -162,7 +183,10 @@ class MI355XSFTStep:
     def _clip_adamw(self, gflat: torch.Tensor) -> torch.Tensor:
         tr = self.transformer
         gn = torch.empty(1, dtype=torch.float32, device=gflat.device)
-        ops.clip_adamw_step(tr.lora_flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas, self.eps,
+        lr = self.lr if self.lr_scheduler is None else self.lr_scheduler.current_lr()
+        ops.clip_adamw_step(tr.lora_flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, lr, self.betas, self.eps,
                             self.weight_decay, self.max_grad_norm, scratch=self._scratch, grad_norm_out=gn)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
         tr._lora_versions = None  # parameters changed in place by the library: refresh the bf16 working copies next forward
         return gn

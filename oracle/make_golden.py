@@ -105,6 +105,22 @@ def main() -> None:
     tensors["rms.out_affine"] = ref_rms(types.SimpleNamespace(weight=w, eps=1e-5, bias=None), x)
     tensors["rms.out_plain"] = ref_rms(types.SimpleNamespace(weight=None, eps=1e-6, bias=None), x)
 
+    # ---- learning-rate multipliers (finetrainers/optimizer.py: the seven functions get_lr_scheduler chooses from) ------------------
+    lr_ns = dict(TYPING_NS, Callable=__import__("typing").Callable)
+    steps = list(range(0, 60))
+    sched = {
+        "constant": extract("finetrainers/optimizer.py", "get_constant_schedule", lr_ns)(),
+        "constant_with_warmup": extract("finetrainers/optimizer.py", "get_constant_schedule_with_warmup", lr_ns)(7),
+        "piecewise_constant": extract("finetrainers/optimizer.py", "get_piecewise_constant_schedule", lr_ns)("1:10,0.1:20,0.01:30,0.005"),
+        "linear": extract("finetrainers/optimizer.py", "get_linear_schedule_with_warmup", lr_ns)(5, 50),
+        "cosine": extract("finetrainers/optimizer.py", "get_cosine_schedule_with_warmup", lr_ns)(5, 50, 1),
+        "cosine_half": extract("finetrainers/optimizer.py", "get_cosine_schedule_with_warmup", lr_ns)(5, 50, 0.5),
+        "cosine_with_restarts": extract("finetrainers/optimizer.py", "get_cosine_with_hard_restarts_schedule_with_warmup", lr_ns)(5, 50, 3),
+        "polynomial": extract("finetrainers/optimizer.py", "get_polynomial_decay_schedule_with_warmup", lr_ns)(5, 50, 5e-5, 1e-7, 2.0),
+    }
+    for k_, f_ in sched.items():
+        tensors[f"lr.{k_}"] = torch.tensor([f_(t_) for t_ in steps], dtype=torch.float64)
+
     # ---- spec.forward driving the reference's patched transformer forward --------------
     spec_ns = dict(TYPING_NS, random=types.SimpleNamespace(random=lambda: 1.0), FF=FF,
                    DiagonalGaussianDistribution=None, LTXVideoTransformer3DModel=object)

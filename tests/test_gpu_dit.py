@@ -297,6 +297,49 @@ def test_rank32_padding_stays_zero_through_optimiser_steps():
     assert not torch.equal(gmodel.lora_A.detach(), before)
 
 
+def test_step_state_resume_and_lr_schedule():
+    """Save after two optimiser steps (parameters via transformer.state_dict(), AdamW moments / counters / schedule clock via
+    MI355XSFTStep.state_dict()), rebuild everything from the saved state, take the third step: the same update as the run that
+    never stopped (to fp32-atomic rounding).  The schedule is the reference example's constant_with_warmup: step 1 runs at lr = 0 and must leave the parameters alone."""
+    import copy
+
+    from finetrainers_amd.trainer import MI355XSFTStep
+    from finetrainers_amd.utils.lr_schedule import LRSchedule
+
+    def fresh():
+        cfg, omodel, inp, spec, gmodel = _build(1, 2, 2, 4, 4, False, seed=5)
+        sched = LRSchedule.from_args(1e-3, "constant_with_warmup", num_warmup_steps=2)
+        return inp, spec, gmodel, MI355XSFTStep(gmodel, spec, lr=1e-3, betas=(0.9, 0.99), weight_decay=1e-2, lr_scheduler=sched)
+
+    dev = _dev()
+    inp, spec, gmodel, step = fresh()
+    cond = {"encoder_hidden_states": inp.encoder_hidden_states.to(dev), "encoder_attention_mask": inp.encoder_attention_mask.to(dev)}
+    lat = {"latents": inp.latents.to(dev), "latents_mean": inp.latents_mean, "latents_std": inp.latents_std,
+           "num_frames": inp.latents.shape[2], "height": inp.latents.shape[3], "width": inp.latents.shape[4]}
+    kw = dict(sigmas=inp.sigmas.to(dev), noise=inp.noise.to(dev), force_first_frame_branch=False)
+    p0 = gmodel.lora_flat.clone()
+    step.step(cond, lat, **kw)
+    assert torch.equal(gmodel.lora_flat, p0) and step.lr_scheduler.current_lr() == 5e-4  # warm-up: lr(0) = 0, then 0.5 * base
+    step.step(cond, lat, **kw)
+    saved_model = {k: v.clone() for k, v in gmodel.state_dict().items() if "lora_" in k}
+    saved_step = copy.deepcopy(step.state_dict())
+    step.step(cond, lat, **kw)
+    torch.cuda.synchronize()
+    want = gmodel.lora_flat.clone()
+    assert step.lr_scheduler.current_lr() == 1e-3 and not torch.equal(want, p0)
+
+    _, spec2, gmodel2, step2 = fresh()
+    gmodel2.load_state_dict(saved_model, strict=False)
+    step2.load_state_dict(saved_step)
+    assert step2.step_count == 2 and step2.lr_scheduler.current_lr() == 1e-3
+    step2.step(cond, lat, **kw)
+    torch.cuda.synchronize()
+    # the weight-gradient GEMMs add their token splits with fp32 atomics: two runs agree to rounding, not bit for bit
+    rel = ((gmodel2.lora_flat - want).norm() / (want - p0).norm()).item()
+    print(f"[resume] third step after reload vs uninterrupted: update rel diff {rel:.2e}")
+    assert rel < 2e-2
+
+
 def test_full_depth_config2_parity():
     """BASELINE config 2 EXACTLY: 28 blocks, batch 2, latents [2,128,7,16,24] (2688 tokens), text masks {32, 96}, sigma {0.25, 0.7},
     LoRA rank 64 -- loss and every LoRA gradient against the CPU oracle run on this box's host cores (a few minutes with torch's default

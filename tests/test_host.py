@@ -155,6 +155,43 @@ def test_adapter_rank_that_is_not_a_multiple_of_64_is_zero_padded():
     assert model._c_config(1, 32, 128).r == 64 and abs(model._c_config(1, 32, 128).lora_scale - 1.0) < 1e-7
 
 
+def test_lr_schedules_match_reference(golden):
+    """finetrainers/optimizer.py:191-226: the seven --lr_scheduler multipliers, pinned to values produced by the reference's own functions,
+    and the LambdaLR clock (rate before the first step = base * f(0); one step() per optimiser step)."""
+    from finetrainers_amd.utils.lr_schedule import LRSchedule, lr_multiplier
+
+    cases = {
+        "constant": dict(name="constant"),
+        "constant_with_warmup": dict(name="constant_with_warmup", num_warmup_steps=7),
+        "piecewise_constant": dict(name="piecewise_constant", step_rules="1:10,0.1:20,0.01:30,0.005"),
+        "linear": dict(name="linear", num_warmup_steps=5, num_training_steps=50),
+        "cosine": dict(name="cosine", num_warmup_steps=5, num_training_steps=50, num_cycles=1),
+        "cosine_half": dict(name="cosine", num_warmup_steps=5, num_training_steps=50, num_cycles=0.5),
+        "cosine_with_restarts": dict(name="cosine_with_restarts", num_warmup_steps=5, num_training_steps=50, num_cycles=3),
+        "polynomial": dict(name="polynomial", num_warmup_steps=5, num_training_steps=50, lr_init=5e-5, lr_end=1e-7, power=2.0),
+    }
+    for key, kw in cases.items():
+        f = lr_multiplier(**kw)
+        ref = golden[f"lr.{key}"]
+        got = torch.tensor([f(t) for t in range(ref.numel())], dtype=torch.float64)
+        assert torch.equal(got, ref), (key, (got - ref).abs().max())
+    with pytest.raises(ValueError):
+        lr_multiplier("nope")
+    # clock: identical to torch's LambdaLR around a real optimiser
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=5e-5)
+    ref = torch.optim.lr_scheduler.LambdaLR(opt, lr_multiplier("constant_with_warmup", num_warmup_steps=4))
+    mine = LRSchedule.from_args(5e-5, "constant_with_warmup", num_warmup_steps=4)
+    for _ in range(8):
+        assert mine.get_last_lr() == ref.get_last_lr()
+        opt.step()
+        ref.step()
+        mine.step()
+    again = LRSchedule.from_args(5e-5, "constant_with_warmup", num_warmup_steps=4)
+    again.load_state_dict(mine.state_dict())
+    assert again.current_lr() == mine.current_lr()
+
+
 def test_rope_tables_match_upstream_formula():
     from finetrainers_amd.ltx_video.transformer import ltx_rope_tables
     from oracle import ltx
