@@ -91,6 +91,7 @@ _SIGS = {
     "ftmi_ltx_noise_pack": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ftmi_ddim_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "ftmi_ddim_get_velocity": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "ftmi_posterior_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "ftmi_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p]),
     "ftmi_clip_adamw_step": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 6 + [c_int, c_void_p, c_void_p, c_void_p]),
     "ftmi_lora_refresh": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),

@@ -384,6 +384,11 @@ int ftmi_ddim_get_velocity(const void* sample, const void* noise, const float* s
     return ddim_mix((const bf16_t*)sample, (const bf16_t*)noise, sqrt_alpha, sqrt_one_minus_alpha, 1.0f, nullptr, (bf16_t*)out, B, per_sample, 1, (hipStream_t)stream);
 }
 
+int ftmi_posterior_sample(const void* moments, const void* eps, void* out, int B, long per_sample, ftmi_stream stream) {
+    if (!moments || !eps || !out || B <= 0 || per_sample <= 0) return set_error(FTMI_ERR_INVALID, "ftmi_posterior_sample: bad argument");
+    return posterior_sample((const bf16_t*)moments, (const bf16_t*)eps, (bf16_t*)out, B, per_sample, (hipStream_t)stream);
+}
+
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample, float grad_scale,
                   ftmi_stream stream) {
     if (!pred || !target || !loss) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");

@@ -175,6 +175,8 @@ int mse_loss_fwd_bwd(const bf16_t* pred, const bf16_t* target, const float* weig
 // CogVideoX DDIM noising (mode 0: x0 = bf(a * scale), out = bf(sa x0) + bf(so b)) / get_velocity (mode 1: out = bf(sa b) - bf(so a))
 int ddim_mix(const bf16_t* a, const bf16_t* b, const float* sa, const float* so, float scale, bf16_t* x0_out, bf16_t* out, int B, long per_sample,
              int mode, hipStream_t st);
+// x = mean + exp(0.5 * clamp(logvar)) * eps from moments [B][2][half] (mean | logvar), bf16 op by op
+int posterior_sample(const bf16_t* moments, const bf16_t* eps, bf16_t* out, int B, long half, hipStream_t st);
 
 // timestep sinusoid (256 channels, flip_sin_to_cos) of t = float(timestep)
 int timestep_sinusoid(const float* tval, bf16_t* out, int B, hipStream_t st);

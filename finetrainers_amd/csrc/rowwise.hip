@@ -624,6 +624,37 @@ int ddim_mix(const bf16_t* a, const bf16_t* b, const float* sa, const float* so,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Precomputed-latent path (trainer.py:374: --enable_precomputation => compute_posterior = False): the stored "latents" are the VAE's
+// posterior moments [B, 2C, ...] = (mean | logvar) and every step draws  x = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps
+// (base_specification.py:285-289 -> [upstream] diffusers DiagonalGaussianDistribution.sample), one bf16 torch op at a time.
+__global__ __launch_bounds__(256) void posterior_sample_kernel(const bf16_t* __restrict__ moments, const bf16_t* __restrict__ eps,
+                                                               bf16_t* __restrict__ out, long half) {
+    const int bi = blockIdx.y;
+    const bf16_t* mean = moments + (long)bi * 2 * half;
+    const bf16_t* logvar = mean + half;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < half; i += (long)gridDim.x * blockDim.x * 8) {
+        float mv[8], lv[8], ev[8], o[8];
+        unpack8(*reinterpret_cast<const s16x8*>(mean + i), mv);
+        unpack8(*reinterpret_cast<const s16x8*>(logvar + i), lv);
+        unpack8(*reinterpret_cast<const s16x8*>(eps + (long)bi * half + i), ev);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float l = fminf(fmaxf(lv[e], -30.0f), 20.0f);
+            const float sd = rbf(expf(rbf(0.5f * l)));
+            o[e] = mv[e] + rbf(sd * ev[e]);
+        }
+        *reinterpret_cast<s16x8*>(out + (long)bi * half + i) = pack8(o);
+    }
+}
+int posterior_sample(const bf16_t* moments, const bf16_t* eps, bf16_t* out, int B, long half, hipStream_t st) {
+    if (half % 8) return set_error(FTMI_ERR_UNSUPPORTED, "posterior_sample: elements per sample must be a multiple of 8");
+    long blocks = (half / 8 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(posterior_sample_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, moments, eps, out, half);
+    return check_launch("posterior_sample");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // transposes (LoRA working copies; frozen-weight transposes for dgrad are made once at load time)
 template <typename TIN>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out_same, bf16_t* __restrict__ out_t,

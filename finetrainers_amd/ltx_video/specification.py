@@ -172,9 +172,16 @@ class MI355XLTXVideoModelSpecification:
         Extra keyword-only hooks for parity runs (the reference draws the branch from Python's global
         RNG): ``noise`` injects the N(0,1) draw, ``first_frame_sigma`` ([B] fp32) injects the first-frame sigma,
         ``force_first_frame_branch`` pins the 10 % branch on/off."""
-        if not compute_posterior:
-            raise NotImplementedError("precomputed latents (compute_posterior=True) are the supported SFT path")
         latents = latent_model_conditions.pop("latents")
+        if not compute_posterior:
+            # --enable_precomputation (trainer.py:374): "latents" are the VAE posterior's moments [B, 2C, F, H, W]; draw the sample here
+            # (base_specification.py:285-289).  ``posterior_noise`` injects the N(0,1) draw for parity runs.
+            moments = latents.to(torch.bfloat16)
+            eps = kwargs.pop("posterior_noise", None)
+            if eps is None:
+                shp = (moments.shape[0], moments.shape[1] // 2) + tuple(moments.shape[2:])
+                eps = torch.randn(shp, generator=generator, device=moments.device, dtype=torch.bfloat16)
+            latents = ops.posterior_sample(moments, eps.to(device=moments.device, dtype=torch.bfloat16))
         latents_mean = latent_model_conditions.pop("latents_mean")
         latents_std = latent_model_conditions.pop("latents_std")
         num_frames = latent_model_conditions.get("num_frames", latents.shape[2])

@@ -226,6 +226,18 @@ def ddim_get_velocity(sample, noise, sqrt_alpha, sqrt_one_minus_alpha):
     return out
 
 
+def posterior_sample(moments, eps):
+    """moments [B, 2C, ...] (mean | logvar along dim 1), eps [B, C, ...] ~ N(0,1) -> mean + exp(0.5 * clamp(logvar, -30, 20)) * eps."""
+    require_gpu_tensor(moments, "moments", bf16)
+    require_gpu_tensor(eps, "eps", bf16)
+    if moments.shape[1] != 2 * eps.shape[1] or moments.shape[2:] != eps.shape[2:] or moments.shape[0] != eps.shape[0]:
+        raise ValueError(f"posterior_sample: moments {tuple(moments.shape)} do not hold (mean | logvar) for eps {tuple(eps.shape)}")
+    moments, eps = moments.contiguous(), eps.contiguous()
+    out = torch.empty_like(eps)
+    check(_lib.load().ftmi_posterior_sample(ptr(moments), ptr(eps), ptr(out), eps.shape[0], eps[0].numel(), stream_ptr()), "ftmi_posterior_sample")
+    return out
+
+
 def mse_loss(pred, target, weight: Optional[torch.Tensor], want_grad: bool = True, grad_scale: float = 1.0):
     B = pred.shape[0]
     per = pred[0].numel()

@@ -60,7 +60,7 @@ class MI355XSFTStep:
     def __init__(self, transformer, specification, lr: float = 5e-5, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
                  max_grad_norm: float = 1.0, flow_weighting_scheme: str = "none", flow_logit_mean: float = 0.0, flow_logit_std: float = 1.0,
                  flow_mode_scale: float = 1.29, parallel=None, generator: Optional[torch.Generator] = None,
-                 gradient_accumulation_steps: int = 1, grad_bucket_blocks: int = 7, lr_scheduler=None):
+                 gradient_accumulation_steps: int = 1, grad_bucket_blocks: int = 7, lr_scheduler=None, compute_posterior: bool = True):
         if transformer.lora_A is None:
             raise ValueError("attach a LoRA adapter first (transformer.add_adapter)")
         if gradient_accumulation_steps < 1:
@@ -77,6 +77,8 @@ class MI355XSFTStep:
         # ``finetrainers_amd.utils.lr_schedule.LRSchedule`` (or anything with current_lr() / step()): its rate is read for every optimiser step
         # and it is stepped right after, as trainer.py:500-503 does with the LambdaLR
         self.lr_scheduler = lr_scheduler
+        # False = the batches carry the VAE posterior's moments (what --enable_precomputation stores, trainer.py:374) and every step samples them
+        self.compute_posterior = compute_posterior
         self._micro_step = 0
         dev = transformer.device
         transformer._assert_flat_aliasing()
@@ -124,7 +126,7 @@ class MI355XSFTStep:
         # 3. forward (trainer.py:452-461)
         pred, target, sig = self.spec.forward(
             transformer=tr, condition_model_conditions=dict(condition_model_conditions), latent_model_conditions=dict(latent_model_conditions),
-            sigmas=sigmas, generator=self.generator, compute_posterior=True, **spec_kwargs,
+            sigmas=sigmas, generator=self.generator, compute_posterior=self.compute_posterior, **spec_kwargs,
         )
         # 4. loss + backward (trainer.py:463-481): loss and d loss / d pred come out of one kernel and the DiT backward is seeded with
         # that gradient directly (what loss.backward() would hand it, without the unit-seed multiply)

@@ -231,6 +231,12 @@ int ftmi_ddim_add_noise(const void* latents, const void* noise, const float* sqr
 int ftmi_ddim_get_velocity(const void* sample, const void* noise, const float* sqrt_alpha, const float* sqrt_one_minus_alpha, void* out,
                            int B, long per_sample, ftmi_stream stream);
 
+/* Precomputed-latent path (finetrainers/trainer/sft_trainer/trainer.py:374: --enable_precomputation => compute_posterior = False):
+ * moments [B, 2, per_sample] bf16 = the VAE posterior (mean | logvar) as finetrainers-precomputed-data stores it, eps [B, per_sample] bf16
+ * the N(0,1) draw; out = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps, one bf16 rounding per torch op of
+ * models/ltx_video/base_specification.py:285-289 ([upstream] diffusers DiagonalGaussianDistribution.sample). */
+int ftmi_posterior_sample(const void* moments, const void* eps, void* out, int B, long per_sample, ftmi_stream stream);
+
 /* loss (device fp32 scalar) = mean_b mean w_b (pred-target)^2 ; dpred = d(loss*grad_scale)/dpred (bf16), may be NULL */
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample,
                   float grad_scale, ftmi_stream stream);

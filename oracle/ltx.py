@@ -637,6 +637,16 @@ def normalize_latents(latents, latents_mean, latents_std, scaling_factor: float 
     return ((latents.float() - latents_mean) * scaling_factor / latents_std).to(latents)
 
 
+def posterior_sample(moments: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+    """base_specification.py:285-289 (compute_posterior = False, the --enable_precomputation path): [upstream, unpinned] diffusers
+    ``DiagonalGaussianDistribution(moments).sample()`` -- mean, logvar = chunk(moments, 2, dim=1); logvar clamped to [-30, 20];
+    std = exp(0.5 * logvar); x = mean + std * eps, every op in the moments' dtype (bf16: one rounding per op)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    std = torch.exp(0.5 * logvar)
+    return mean + std * eps.to(moments.dtype)
+
+
 def pack_latents(latents, patch_size: int = 1, patch_size_t: int = 1):
     """base_specification.py:438-459."""
     b, c, f, h, w = latents.shape

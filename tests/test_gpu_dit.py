@@ -340,6 +340,31 @@ def test_step_state_resume_and_lr_schedule():
     assert rel < 2e-2
 
 
+def test_precomputed_posterior_path_equals_sampled_latents():
+    """compute_posterior = False (what --enable_precomputation runs, trainer.py:374): the spec draws the latents from the stored moments,
+    then proceeds exactly as with ready-made latents."""
+    from finetrainers_amd import ops
+
+    cfg, omodel, inp, spec, gmodel = _build(1, 2, 2, 4, 4, False, seed=9)
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    mean = inp.latents.to(bf16)
+    logvar = (torch.randn(mean.shape, generator=g) * 0.5 - 3.0).to(bf16)
+    moments = torch.cat([mean, logvar], dim=1).to(dev)
+    eps = torch.randn(mean.shape, generator=g).to(bf16).to(dev)
+    cond = {"encoder_hidden_states": inp.encoder_hidden_states.to(dev), "encoder_attention_mask": inp.encoder_attention_mask.to(dev)}
+    lat = {"latents_mean": inp.latents_mean, "latents_std": inp.latents_std, "num_frames": mean.shape[2], "height": mean.shape[3], "width": mean.shape[4]}
+    kw = dict(sigmas=inp.sigmas.view(-1, 1, 1, 1, 1).to(dev), noise=inp.noise.to(dev), force_first_frame_branch=False)
+    with torch.no_grad():
+        p1, t1, _ = spec.forward(transformer=gmodel, condition_model_conditions=dict(cond), latent_model_conditions=dict(lat, latents=moments),
+                                 compute_posterior=False, posterior_noise=eps, **kw)
+        sampled = ops.posterior_sample(moments, eps)
+        p2, t2, _ = spec.forward(transformer=gmodel, condition_model_conditions=dict(cond), latent_model_conditions=dict(lat, latents=sampled),
+                                 compute_posterior=True, **kw)
+    assert torch.equal(t1, t2) and torch.equal(p1, p2)
+    assert not torch.equal(sampled.cpu(), mean)
+
+
 def test_full_depth_config2_parity():
     """BASELINE config 2 EXACTLY: 28 blocks, batch 2, latents [2,128,7,16,24] (2688 tokens), text masks {32, 96}, sigma {0.25, 0.7},
     LoRA rank 64 -- loss and every LoRA gradient against the CPU oracle run on this box's host cores (a few minutes with torch's default

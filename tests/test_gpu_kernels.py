@@ -288,6 +288,28 @@ def test_mse_loss_matches_oracle():
         report(f"mse dpred {scheme}", dpred, p.grad, 2e-3)
 
 
+def test_posterior_sample_matches_eager_bf16():
+    """compute_posterior = False (precomputed moments): mean + exp(0.5 * clamp(logvar)) * eps against the eager bf16 graph on the CPU."""
+    from finetrainers_amd import ops
+    from oracle import ltx
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    mom = torch.randn(2, 256, 3, 4, 6, generator=g)
+    mom[:, 128:] = mom[:, 128:] * 6.0 - 4.0  # log-variances, a few beyond the clamp on either side
+    mom[0, 128, 0, 0, :3] = torch.tensor([-45.0, 25.0, 20.0])
+    mom = mom.to(bf16)
+    eps = torch.randn(2, 128, 3, 4, 6, generator=g).to(bf16)
+    ref = ltx.posterior_sample(mom, eps)
+    out = ops.posterior_sample(mom.to(dev), eps.to(dev)).cpu()
+    # expf on the two sides may differ in the last fp32 bit: at most one bf16 ulp on a handful of entries
+    diff = (out.float() - ref.float()).abs()
+    tol = ref.float().abs() * 2.0 ** -7 + 1e-30
+    assert (diff <= tol).all() and (diff > 0).float().mean().item() < 5e-3, ((diff > 0).float().mean().item(), (diff / tol).max().item())
+    with pytest.raises(ValueError):
+        ops.posterior_sample(mom.to(dev)[:, :200], eps.to(dev))
+
+
 def test_clip_adamw_matches_torch():
     from finetrainers_amd import ops
     from oracle import ltx
