@@ -406,6 +406,15 @@ int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, floa
     return adamw_clip_step(params, grads, exp_avg, exp_avg_sq, n, scratch, max_norm, lr, beta1, beta2, eps, weight_decay, step, grad_norm_out, st);
 }
 
+int ftmi_clip_grad_norm(float* grads, long n, float max_norm, float* scratch, float* grad_norm_out, ftmi_stream stream) {
+    if (!grads || !scratch || n <= 0) return set_error(FTMI_ERR_INVALID, "ftmi_clip_grad_norm: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0, 2 * sizeof(float), st) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "ftmi_clip_grad_norm: memset failed");
+    int rc = sumsq(grads, n, scratch, st);
+    if (rc) return rc;
+    return clip_scale(grads, n, scratch, max_norm, grad_norm_out, st);
+}
+
 int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
                       void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream) {
     if (!a_f32 || !b_f32 || !lora_a_sp || !lora_bt_sp || !lora_b_ext || !lora_at_ext || !lora_at_qkv_ext)

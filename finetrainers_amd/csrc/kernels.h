@@ -186,6 +186,7 @@ int small_linear(const bf16_t* x, const bf16_t* W, const bf16_t* bias, bf16_t* y
 
 // ---- optimiser ---------------------------------------------------------------------------------------
 int sumsq(const float* g, long n, float* out /* [0] result, [1] ticket (both zeroed by the caller), [2..2049] block partials */, hipStream_t st);
+int clip_scale(float* g, long n, const float* sumsq_in, float max_norm, float* grad_norm_out, hipStream_t st);  // in-place clip by a precomputed sum of squares
 int adamw_clip_step(float* p, const float* g, float* m, float* v, long n, const float* sumsq_in, float max_norm, float lr,
                     float beta1, float beta2, float eps, float wd, int step, float* grad_norm_out, hipStream_t st);
 // bf16 (hi, lo) working copies of nmat fp32 matrices W [rows, cols] (hi = bf16(w), lo = bf16(w - hi); hi + lo carries 16 mantissa bits):

@@ -551,6 +551,24 @@ int sumsq(const float* g, long n, float* out, hipStream_t st) {
     return check_launch("sumsq");
 }
 
+// In-place global-norm clip (utils/torch.py:99-161 as trainer.py:487-492 calls it after EVERY backward, also on the micro-steps of a
+// gradient-accumulation window, where the optimiser does not step): g *= min(1, max_norm / (norm + 1e-6)).  Nothing is touched when the
+// norm is inside the bound (the usual case): every block reads the scalar and leaves.
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ sumsq_in, float max_norm,
+                                                         float* __restrict__ grad_norm_out) {
+    const float total_norm = sqrtf(*sumsq_in);
+    if (grad_norm_out && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm_out = total_norm;
+    const float coef = max_norm / (total_norm + 1e-6f);
+    if (!(coef < 1.0f) || max_norm <= 0.f) return;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] *= coef;
+}
+int clip_scale(float* g, long n, const float* sumsq_in, float max_norm, float* grad_norm_out, hipStream_t st) {
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, n, sumsq_in, max_norm, grad_norm_out);
+    return check_launch("clip_scale");
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, const float* __restrict__ sumsq_in, float max_norm,
                                                     float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,

@@ -248,6 +248,19 @@ def mse_loss(pred, target, weight: Optional[torch.Tensor], want_grad: bool = Tru
     return loss, dpred
 
 
+def clip_grad_norm_(grads: torch.Tensor, max_norm: float, scratch: Optional[torch.Tensor] = None, grad_norm_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """In-place global-norm clip of a flat fp32 gradient buffer; returns the pre-clip norm (device scalar)."""
+    require_gpu_tensor(grads, "grads", torch.float32)
+    if not grads.is_contiguous():
+        raise ValueError("clip_grad_norm_: the flat gradient buffer must be contiguous")
+    if scratch is None:
+        scratch = torch.empty((CLIP_SCRATCH_FLOATS,), dtype=torch.float32, device=grads.device)
+    if grad_norm_out is None:
+        grad_norm_out = torch.empty((1,), dtype=torch.float32, device=grads.device)
+    check(_lib.load().ftmi_clip_grad_norm(ptr(grads), grads.numel(), float(max_norm), ptr(scratch), ptr(grad_norm_out), stream_ptr()), "ftmi_clip_grad_norm")
+    return grad_norm_out
+
+
 CLIP_SCRATCH_FLOATS = 2050  # include/ftmi355.h FTMI_CLIP_SCRATCH_FLOATS
 
 

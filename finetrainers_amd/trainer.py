@@ -54,13 +54,13 @@ class MI355XSFTStep:
     Data parallelism (reference: ``apply_ddp`` -> ``replicate``, parallel/ptd.py:462-463): on construction the LoRA parameters are
     broadcast from rank 0 (DDP broadcasts module state the same way), every step each rank runs its own samples, and the LoRA
     gradients are averaged bucket by bucket WHILE the backward is still running (``GradBucketReducer``).  With
-    ``gradient_accumulation_steps`` > 1 only the last micro-step of a group exchanges gradients (DDP's ``no_sync`` for the others) and
-    applies clip + AdamW (trainer.py:479-503)."""
+    ``gradient_accumulation_steps`` > 1 only the last micro-step of a group applies AdamW; every micro-step exchanges and clips, as the
+    reference loop does (trainer.py:479-503), unless ``no_sync_accumulation``."""
 
     def __init__(self, transformer, specification, lr: float = 5e-5, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
                  max_grad_norm: float = 1.0, flow_weighting_scheme: str = "none", flow_logit_mean: float = 0.0, flow_logit_std: float = 1.0,
                  flow_mode_scale: float = 1.29, parallel=None, generator: Optional[torch.Generator] = None,
-                 gradient_accumulation_steps: int = 1, grad_bucket_blocks: int = 7, lr_scheduler=None, compute_posterior: bool = True):
+                 gradient_accumulation_steps: int = 1, grad_bucket_blocks: int = 7, lr_scheduler=None, compute_posterior: bool = True, no_sync_accumulation: bool = False):
         if transformer.lora_A is None:
             raise ValueError("attach a LoRA adapter first (transformer.add_adapter)")
         if gradient_accumulation_steps < 1:
@@ -79,6 +79,11 @@ class MI355XSFTStep:
         self.lr_scheduler = lr_scheduler
         # False = the batches carry the VAE posterior's moments (what --enable_precomputation stores, trainer.py:374) and every step samples them
         self.compute_posterior = compute_posterior
+        # Data parallelism x gradient accumulation: the reference wraps the model with replicate() and never enters no_sync (trainer.py:479-503,
+        # "TODO revisit no_sync"), so EVERY backward all-reduces the accumulated .grad and the per-backward clip sees the same averaged sums on
+        # all ranks.  That is the default here too; True skips the exchange (and the clip) on the non-stepping micro-steps -- equal results
+        # whenever no partial sum exceeds max_grad_norm, half the traffic.
+        self.no_sync_accumulation = no_sync_accumulation
         self._micro_step = 0
         dev = transformer.device
         transformer._assert_flat_aliasing()
@@ -134,12 +139,19 @@ class MI355XSFTStep:
         weights = diffusion_utils.compute_loss_weighting_for_sd3(self.scheme, per_sample_sigma).float().contiguous()
         loss, dpred = ops.mse_loss(pred.detach(), target, weights, want_grad=True, grad_scale=1.0 / gas)
         loss = loss.reshape(()) / gas if gas > 1 else loss.reshape(())
-        tr._grad_bucket_hook = self.reducer.bucket_ready if (self.reducer is not None and sync) else None
+        exchange = self.reducer is not None and (sync or not self.no_sync_accumulation)
+        tr._grad_bucket_hook = self.reducer.bucket_ready if exchange else None
         try:
             pred.backward(dpred)  # DP: buckets of finished blocks are all-reduced (AVG) on RCCL's stream while this still runs
         finally:
             tr._grad_bucket_hook = None
         if not sync:
+            # the reference clips after every backward (trainer.py:487-492), i.e. also the partial sums of an accumulation window -- in place
+            # on .grad (under DP on the all-reduced sums, see no_sync_accumulation)
+            if exchange:
+                self.reducer.finish()
+            if self.max_grad_norm and self.max_grad_norm > 0 and (self.reducer is None or exchange):
+                ops.clip_grad_norm_(self._flat_grad(tr.lora_A.grad, tr.lora_B.grad), self.max_grad_norm, scratch=self._scratch)
             return {"loss": loss.detach(), "grad_norm": None}
         gflat = self._flat_grad(tr.lora_A.grad, tr.lora_B.grad)
         if self.reducer is not None:

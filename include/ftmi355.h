@@ -250,6 +250,12 @@ int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, floa
                          float beta1, float beta2, float eps, float weight_decay, int step, float* scratch, float* grad_norm_out,
                          ftmi_stream stream);
 
+/* In-place global L2 clip of a flat fp32 gradient buffer: grads *= min(1, max_norm / (norm + 1e-6)) (finetrainers/utils/torch.py:99-161).
+ * The reference loop clips after EVERY backward (trainer/sft_trainer/trainer.py:487-492), also on the micro-steps of a gradient-
+ * accumulation window where no optimiser step follows; ftmi_clip_adamw_step covers the stepping micro-step, this call the others.
+ * scratch: >= FTMI_CLIP_SCRATCH_FLOATS floats; grad_norm_out (may be NULL) receives the pre-clip norm; order-fixed reduction. */
+int ftmi_clip_grad_norm(float* grads, long n, float max_norm, float* scratch, float* grad_norm_out, ftmi_stream stream);
+
 /* fp32 flat LoRA params (A region [L,8,r,D] then B region [L,8,D,r]) -> the bf16 (hi, lo) working copies of ftmi_ltx_weights */
 int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
                       void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream);

@@ -171,6 +171,36 @@ def test_gradient_accumulation_matches_oracle():
     assert step.step_count == 1 and not torch.equal(gmodel.lora_flat, before) and gmodel.lora_A.grad is None
 
 
+def test_accumulation_clips_after_every_backward():
+    """The reference clips after every backward (trainer.py:487-492), also on the micro-steps of an accumulation window: with a bound the
+    partial sum exceeds, .grad is rescaled in place after micro-step 1, and the norm reported at the stepping micro-step is that of
+    clip(g/2) + g/2, not of g."""
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    spec, model, cond, latd, sig, noise = _model_and_batch(2, 1, 2, 4, 4, seed=3)
+    kw = dict(sigmas=sig, noise=noise, force_first_frame_branch=False)
+    raw_step = MI355XSFTStep(model, spec, lr=0.0, max_grad_norm=1e9, gradient_accumulation_steps=2)
+    raw_step.step(cond, latd, **kw)
+    raw = model._grad_flat.clone()  # g / 2, unclipped
+    raw_norm = raw.norm().item()
+    model.lora_A.grad = model.lora_B.grad = None
+
+    bound = 0.25 * raw_norm
+    step = MI355XSFTStep(model, spec, lr=0.0, max_grad_norm=bound, gradient_accumulation_steps=2)
+    o1 = step.step(cond, latd, **kw)
+    torch.cuda.synchronize()
+    assert o1["grad_norm"] is None and step.step_count == 0
+    coef = bound / (raw_norm + 1e-6)
+    after1 = model._grad_flat.clone()
+    assert abs(after1.norm().item() - coef * raw_norm) <= 1e-5 * bound  # rescaled in place to the bound
+    o2 = step.step(cond, latd, **kw)  # same batch, lr = 0: the second backward adds the same g / 2
+    torch.cuda.synchronize()
+    want = (1.0 + coef) * raw_norm
+    got = o2["grad_norm"].item()
+    print(f"[accumulate-clip] reported norm {got:.6e} vs clip(g/2) + g/2 = {want:.6e} (raw g/2 norm {raw_norm:.6e})")
+    assert abs(got - want) <= 2e-3 * want and step.step_count == 1
+
+
 def _two_rank_worker(rank, world, port, q, backend="nccl", one_gpu=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(0 if one_gpu else rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -333,6 +333,23 @@ def test_clip_adamw_matches_torch():
         torch.testing.assert_close(p.cpu(), p_ref.detach(), rtol=2e-6, atol=1e-9)
 
 
+def test_clip_grad_norm_in_place():
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.randn(3_000_003, generator=torch.Generator(device=dev).manual_seed(2), device=dev) * 1e-3
+    ref_norm = g.double().norm().item()
+    keep = g.clone()
+    n = ops.clip_grad_norm_(g, max_norm=10.0)  # inside the bound: untouched
+    assert torch.equal(g, keep) and abs(n.item() - ref_norm) <= 2e-6 * ref_norm
+    n = ops.clip_grad_norm_(g, max_norm=0.5 * ref_norm)
+    assert abs(n.item() - ref_norm) <= 2e-6 * ref_norm
+    coef = 0.5 * ref_norm / (ref_norm + 1e-6)
+    torch.testing.assert_close(g, keep * coef, rtol=2e-7, atol=0)
+    with pytest.raises(ValueError):
+        ops.clip_grad_norm_(g.cpu(), 1.0)
+
+
 def test_grad_norm_is_bitwise_reproducible():
     """The clip's total norm is reduced in a fixed order: the same gradients give the same bits on every call (and on every rank of a
     data-parallel job -- a last-bit difference in the clip coefficient would let replicas drift apart)."""
