@@ -389,6 +389,49 @@ int ftmi_posterior_sample(const void* moments, const void* eps, void* out, int B
     return posterior_sample((const bf16_t*)moments, (const bf16_t*)eps, (bf16_t*)out, B, per_sample, (hipStream_t)stream);
 }
 
+int ftmi_cog_ln_mod_fwd(const void* x, const void* w, const void* b, const void* shift, const void* onep, void* y, int rows, int D,
+                        int rows_per_batch, int text_len, float eps, ftmi_stream stream) {
+    if (!x || !w || !b || !shift || !onep || !y) return set_error(FTMI_ERR_INVALID, "ftmi_cog_ln_mod_fwd: null argument");
+    CogLnArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b; a.shift = (const bf16_t*)shift; a.onep = (const bf16_t*)onep;
+    a.y = (bf16_t*)y; a.rows = rows; a.D = D; a.rows_per_batch = rows_per_batch; a.seg0 = text_len; a.eps = eps;
+    return cog_ln_mod_fwd(a, (hipStream_t)stream);
+}
+
+int ftmi_cog_ln_mod_bwd(const void* x, const void* w, const void* onep, const void* dy, const void* dres, void* dx, int rows, int D,
+                        int rows_per_batch, int text_len, float eps, ftmi_stream stream) {
+    if (!x || !w || !onep || !dy || !dx) return set_error(FTMI_ERR_INVALID, "ftmi_cog_ln_mod_bwd: null argument");
+    CogLnArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.onep = (const bf16_t*)onep; a.dy = (const bf16_t*)dy; a.dres = (const bf16_t*)dres;
+    a.dx = (bf16_t*)dx; a.rows = rows; a.D = D; a.rows_per_batch = rows_per_batch; a.seg0 = text_len; a.eps = eps;
+    return cog_ln_mod_bwd(a, (hipStream_t)stream);
+}
+
+int ftmi_cog_head_ln_fwd(const void* x, long ld, const void* w, const void* b, void* y, int rows, int D, float eps, ftmi_stream stream) {
+    if (!x || !w || !b || !y || ld < D || (ld % 8)) return set_error(FTMI_ERR_INVALID, "ftmi_cog_head_ln_fwd: bad argument");
+    CogLnArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b; a.y = (bf16_t*)y; a.rows = rows; a.D = D; a.ld = ld; a.eps = eps;
+    a.rows_per_batch = rows > 0 ? rows : 1;
+    return cog_head_ln_fwd(a, (hipStream_t)stream);
+}
+
+int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, void* dx, int rows, int D, float eps, ftmi_stream stream) {
+    if (!x || !w || !dy || !dx || ld < D || (ld % 8)) return set_error(FTMI_ERR_INVALID, "ftmi_cog_head_ln_bwd: bad argument");
+    CogLnArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.dy = (const bf16_t*)dy; a.dx = (bf16_t*)dx; a.rows = rows; a.D = D; a.ld = ld; a.eps = eps;
+    a.rows_per_batch = rows > 0 ? rows : 1;
+    return cog_head_ln_bwd(a, (hipStream_t)stream);
+}
+
+int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, void* out, int rows, int D, int rows_per_batch, int text_len,
+                           ftmi_stream stream) {
+    if (!y || !gate || !out) return set_error(FTMI_ERR_INVALID, "ftmi_cog_gate_residual: null argument");
+    CogLnArgs a;
+    a.x = (const bf16_t*)y; a.onep = (const bf16_t*)gate; a.dres = (const bf16_t*)res; a.y = (bf16_t*)out; a.rows = rows; a.D = D;
+    a.rows_per_batch = rows_per_batch; a.seg0 = text_len;
+    return cog_gate_residual(a, (hipStream_t)stream);
+}
+
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample, float grad_scale,
                   ftmi_stream stream) {
     if (!pred || !target || !loss) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");

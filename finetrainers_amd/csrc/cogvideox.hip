@@ -1,0 +1,298 @@
+// CogVideoX row-wise kernels of the DiT block, any row width D that is a multiple of 64 (CogVideoX-2b: 1920 = 30 heads x 64).
+// HBM-bound: one wavefront per token row, 16-byte loads, shuffle reductions, one pass over [M, D]; every point where the reference's eager
+// bf16 graph materialises a tensor is a bf16 round in registers (rbf), so the chain  LayerNorm -> * (1 + scale) -> + shift  costs one
+// read and one write instead of three of each.
+//
+// Reference ([upstream] diffusers, restated in oracle/cogvideox.py and anchored on the reference's call sites
+// finetrainers/models/cogvideox/base_specification.py:296-333):
+//   CogVideoXLayerNormZero   y = LN(x; w, b) * (1 + scale) + shift          text rows and video rows carry different (shift, scale, gate)
+//   Attention(qk_norm="layer_norm")   q, k <- LN over each head's 64 channels (affine, eps 1e-6)
+//   CogVideoXBlock           h <- h + gate * f(...)                            (again per segment)
+// Token layout: one buffer [B, T + S, D], the T text tokens of a sample first (the order the joint attention concatenates them in).
+// Only x-gradients are produced: with LoRA on the attention projections nothing upstream of shift / scale / gate / w / b is trainable.
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace ftmi {
+
+namespace {
+
+constexpr int kMaxChunks = 8;  // 64 lanes x 8 chunks x 8 elements: D <= 4096
+
+FTMI_DEVICE float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+FTMI_DEVICE float gsum8(float v) {  // sum over an aligned group of 8 lanes (= one 64-channel head)
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+FTMI_DEVICE void up8(const bf16_t* p, float (&f)[8]) {
+    const s16x8 r = *reinterpret_cast<const s16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = bf2f((bf16_t)r[e]);
+}
+FTMI_DEVICE void st8(bf16_t* p, const float (&f)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack2bf(f[2 * e], f[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(p) = w;
+}
+// modulation row of a token: [B, D] (seg0 == 0) or [B, 2, D] with the first seg0 tokens of a sample using row 0 (text), the rest row 1
+FTMI_DEVICE long mod_row(int row, int rows_per_batch, int seg0) {
+    const int b = row / rows_per_batch, pos = row - b * rows_per_batch;
+    return seg0 > 0 ? (long)b * 2 + (pos >= seg0 ? 1 : 0) : (long)b;
+}
+
+// ---- y = bf(bf(LN(x; w, b)) * onep) + shift ------------------------------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(CogLnArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int nchunk = a.D / 8;
+    const bf16_t* xp = a.x + (long)row * a.D;
+    float xv[NC][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            up8(xp + c * 8, xv[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1 += xv[it][e];
+        }
+    }
+    const float mean = wsum(s1) / a.D;
+    float v = 0.f;
+#pragma unroll
+    for (int it = 0; it < NC; ++it)
+        if (lane + 64 * it < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = xv[it][e] - mean;
+                v += d * d;
+            }
+    const float rstd = rsqrtf(wsum(v) / a.D + a.eps);
+    const long mr = mod_row(row, a.rows_per_batch, a.seg0) * a.D;
+    bf16_t* yp = a.y + (long)row * a.D;
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            float wv[8], bv[8], ov[8], sv[8], o[8];
+            up8(a.w + c * 8, wv);
+            up8(a.b + c * 8, bv);
+            up8(a.onep + mr + c * 8, ov);
+            up8(a.shift + mr + c * 8, sv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = rbf((xv[it][e] - mean) * rstd * wv[e] + bv[e]);
+                o[e] = rbf(n * ov[e]) + sv[e];
+            }
+            st8(yp + c * 8, o);
+        }
+    }
+}
+
+// ---- dx = bf(dres + LN'(x)[bf(dy * onep) * w])  (dres: the gradient arriving on the residual branch, may be null) -------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(CogLnArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int nchunk = a.D / 8;
+    const bf16_t* xp = a.x + (long)row * a.D;
+    const bf16_t* dyp = a.dy + (long)row * a.D;
+    const long mr = mod_row(row, a.rows_per_batch, a.seg0) * a.D;
+    float xv[NC][8], gv[NC][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            float dv[8], ov[8], wv[8];
+            up8(xp + c * 8, xv[it]);
+            up8(dyp + c * 8, dv);
+            up8(a.onep + mr + c * 8, ov);
+            up8(a.w + c * 8, wv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gv[it][e] = rbf(dv[e] * ov[e]) * wv[e];  // d / d xhat: the gradient of the bf16 LayerNorm output times the affine weight
+                s1 += xv[it][e];
+            }
+        }
+    }
+    const float mean = wsum(s1) / a.D;
+    float v = 0.f;
+#pragma unroll
+    for (int it = 0; it < NC; ++it)
+        if (lane + 64 * it < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = xv[it][e] - mean;
+                v += d * d;
+            }
+    const float rstd = rsqrtf(wsum(v) / a.D + a.eps);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NC; ++it)
+        if (lane + 64 * it < nchunk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                c1 += gv[it][e];
+                c2 += gv[it][e] * ((xv[it][e] - mean) * rstd);
+            }
+    c1 = wsum(c1) / a.D;
+    c2 = wsum(c2) / a.D;
+    bf16_t* dxp = a.dx + (long)row * a.D;
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            float o[8], rv[8];
+            if (a.dres) up8(a.dres + (long)row * a.D + c * 8, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[it][e] - mean) * rstd;
+                const float d = rstd * (gv[it][e] - c1 - xh * c2);
+                o[e] = a.dres ? rv[e] + rbf(d) : d;
+            }
+            st8(dxp + c * 8, o);
+        }
+    }
+}
+
+// ---- per-head LayerNorm over 64 channels (affine), forward and x-gradient ----------------------------------------------------------------
+template <int NC, bool BWD>
+__global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int nchunk = a.D / 8;
+    const long ro = (long)row * a.ld;
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+        const int c = lane + 64 * it;  // chunk c covers channels 8 (c % 8) .. +7 of head c / 8; the 8 lanes of a head are adjacent
+        const bool on = c < nchunk;
+        float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wv[8], bv[8];
+        if (on) {
+            up8(a.x + ro + c * 8, xv);
+            up8(a.w + (c & 7) * 8, wv);
+            if (!BWD) up8(a.b + (c & 7) * 8, bv);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += xv[e];
+        const float mean = gsum8(s) * (1.0f / 64);
+        float v = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v += (xv[e] - mean) * (xv[e] - mean);
+        const float rstd = rsqrtf(gsum8(v) * (1.0f / 64) + a.eps);
+        float o[8];
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = on ? (xv[e] - mean) * rstd * wv[e] + bv[e] : 0.f;
+            if (on) st8(a.y + ro + c * 8, o);
+        } else {
+            float gv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8];
+            if (on) {
+                up8(a.dy + ro + c * 8, dv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[e] = dv[e] * wv[e];
+            }
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                c1 += gv[e];
+                c2 += gv[e] * ((xv[e] - mean) * rstd);
+            }
+            c1 = gsum8(c1) * (1.0f / 64);
+            c2 = gsum8(c2) * (1.0f / 64);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[e] - c1 - (xv[e] - mean) * rstd * c2);
+            if (on) st8(a.dx + ro + c * 8, o);
+        }
+    }
+}
+
+// ---- out = res + bf(gate * y)   (res null: out = bf(gate * y), the y-gradient of the same op) --------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(256) void gate_residual_kernel(CogLnArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const int nchunk = a.D / 8;
+    const long mr = mod_row(row, a.rows_per_batch, a.seg0) * a.D;
+#pragma unroll
+    for (int it = 0; it < NC; ++it) {
+        const int c = lane + 64 * it;
+        if (c < nchunk) {
+            float yv[8], gv[8], rv[8], o[8];
+            up8(a.x + (long)row * a.D + c * 8, yv);
+            up8(a.onep + mr + c * 8, gv);
+            if (a.dres) up8(a.dres + (long)row * a.D + c * 8, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = a.dres ? rv[e] + rbf(gv[e] * yv[e]) : gv[e] * yv[e];
+            st8(a.y + (long)row * a.D + c * 8, o);
+        }
+    }
+}
+
+int check_args(const CogLnArgs& a, const char* who) {
+    if (a.rows <= 0) return 0;
+    if (a.D <= 0 || a.D % 64 != 0 || a.D > kMaxChunks * 512) return set_error(FTMI_ERR_UNSUPPORTED, "cogvideox row-wise kernels: row width must be a multiple of 64, at most 4096");
+    if (a.rows_per_batch <= 0 || a.seg0 < 0 || a.seg0 > a.rows_per_batch) return set_error(FTMI_ERR_INVALID, "cogvideox row-wise kernels: bad segment description");
+    (void)who;
+    return 0;
+}
+
+}  // namespace
+
+#define FTMI_COG_DISPATCH(KERNEL, ...)                                                                           \
+    switch ((a.D + 511) / 512) {                                                                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<1 __VA_ARGS__>), grid, dim3(256), 0, st, a); break;                    \
+        case 2: hipLaunchKernelGGL((KERNEL<2 __VA_ARGS__>), grid, dim3(256), 0, st, a); break;                    \
+        case 3: hipLaunchKernelGGL((KERNEL<3 __VA_ARGS__>), grid, dim3(256), 0, st, a); break;                    \
+        case 4: hipLaunchKernelGGL((KERNEL<4 __VA_ARGS__>), grid, dim3(256), 0, st, a); break;                    \
+        default: hipLaunchKernelGGL((KERNEL<8 __VA_ARGS__>), grid, dim3(256), 0, st, a); break;                   \
+    }
+
+int cog_ln_mod_fwd(const CogLnArgs& a, hipStream_t st) {
+    if (int rc = check_args(a, "ln_mod_fwd")) return rc;
+    if (a.rows <= 0) return 0;
+    const dim3 grid((a.rows + 3) / 4);
+    FTMI_COG_DISPATCH(ln_mod_fwd_kernel)
+    return check_launch("cog_ln_mod_fwd");
+}
+int cog_ln_mod_bwd(const CogLnArgs& a, hipStream_t st) {
+    if (int rc = check_args(a, "ln_mod_bwd")) return rc;
+    if (a.rows <= 0) return 0;
+    const dim3 grid((a.rows + 3) / 4);
+    FTMI_COG_DISPATCH(ln_mod_bwd_kernel)
+    return check_launch("cog_ln_mod_bwd");
+}
+int cog_head_ln_fwd(const CogLnArgs& a, hipStream_t st) {
+    if (int rc = check_args(a, "head_ln_fwd")) return rc;
+    if (a.rows <= 0) return 0;
+    const dim3 grid((a.rows + 3) / 4);
+#define COMMA_FALSE , false
+    FTMI_COG_DISPATCH(head_ln_kernel, COMMA_FALSE)
+    return check_launch("cog_head_ln_fwd");
+}
+int cog_head_ln_bwd(const CogLnArgs& a, hipStream_t st) {
+    if (int rc = check_args(a, "head_ln_bwd")) return rc;
+    if (a.rows <= 0) return 0;
+    const dim3 grid((a.rows + 3) / 4);
+#define COMMA_TRUE , true
+    FTMI_COG_DISPATCH(head_ln_kernel, COMMA_TRUE)
+    return check_launch("cog_head_ln_bwd");
+}
+int cog_gate_residual(const CogLnArgs& a, hipStream_t st) {
+    if (int rc = check_args(a, "gate_residual")) return rc;
+    if (a.rows <= 0) return 0;
+    const dim3 grid((a.rows + 3) / 4);
+    FTMI_COG_DISPATCH(gate_residual_kernel)
+    return check_launch("cog_gate_residual");
+}
+
+}  // namespace ftmi

@@ -691,7 +691,8 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
     const int m0 = (grp * 8 + lid % in_grp) * 32, n0 = (lid / in_grp) * 64;
     const bf16_t* X = p.X;
     if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-    const int kq = p.K / 4, k0 = wave * kq, nch = kq / 64;
+    // the four waves split the K / 64 chunks as evenly as they divide (K = 1920: 8, 7, 8, 7)
+    const int nck = p.K / 64, c_lo = (nck * wave) / 4, k0 = c_lo * 64, nch = (nck * (wave + 1)) / 4 - c_lo;
     char* ring = smem + wave * (NST * CH);
 
     uint32_t off[12];
@@ -830,8 +831,8 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 8) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
     if (a.split_r > 0) {  // fp32-equivalent LoRA down-projection: always the LDS-ring skinny kernel (any M, any N, grouped W allowed)
-        if (a.K2 != 0 || a.epi != EPI_STORE || a.bias || a.K % 256 != 0 || a.split_r % 64 != 0 || (a.N / 2) % a.split_r != 0)
-            return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: split (hi/lo) mode needs a plain store, K % 256 == 0 and whole groups of split_r outputs");
+        if (a.K2 != 0 || a.epi != EPI_STORE || a.bias || a.K < 256 || a.split_r % 64 != 0 || (a.N / 2) % a.split_r != 0)
+            return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: split (hi/lo) mode needs a plain store, K >= 256 and whole groups of split_r outputs");
         if ((a.w_grp_n > 0 && a.w_grp_n % 64) || (a.xk_grp_n > 0 && a.xk_grp_n % 64)) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
         ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
         constexpr int kSmem = 4 * 3 * 12288;

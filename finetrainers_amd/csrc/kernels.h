@@ -209,4 +209,27 @@ int lora_split(const LoraSplitArgs& a, hipStream_t st);
 // plain bf16 transpose [rows, cols] -> [cols, rows]
 int transpose_bf16(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t st);
 
+// ---- CogVideoX row-wise kernels (cogvideox.hip): any row width D % 64 == 0, D <= 4096 ----------------------------------------------
+// Tokens [B, rows_per_batch, D]; seg0 > 0: the first seg0 tokens of a sample (text) use modulation row 2b, the others (video) row 2b + 1 of
+// [B, 2, D] tables; seg0 == 0: one row per sample, tables [B, D].
+struct CogLnArgs {
+    const bf16_t* x = nullptr;      // input rows (head_ln: row stride ld)
+    const bf16_t* w = nullptr;      // LayerNorm weight [D] (head_ln: [64])
+    const bf16_t* b = nullptr;      // LayerNorm bias
+    const bf16_t* shift = nullptr;  // modulation shift
+    const bf16_t* onep = nullptr;   // modulation (1 + scale), or the gate of gate_residual
+    const bf16_t* dy = nullptr;
+    const bf16_t* dres = nullptr;   // ln_mod_bwd: gradient on the residual branch; gate_residual: the residual input
+    bf16_t* y = nullptr;
+    bf16_t* dx = nullptr;
+    int rows = 0, D = 0, rows_per_batch = 1, seg0 = 0;
+    long ld = 0;
+    float eps = 1e-5f;
+};
+int cog_ln_mod_fwd(const CogLnArgs& a, hipStream_t st);    // y = bf(bf(LN(x; w, b)) * onep) + shift
+int cog_ln_mod_bwd(const CogLnArgs& a, hipStream_t st);    // dx = [dres +] LN'(x)[bf(dy * onep) * w]
+int cog_head_ln_fwd(const CogLnArgs& a, hipStream_t st);   // per 64-channel head: y = LN(x; w[64], b[64])
+int cog_head_ln_bwd(const CogLnArgs& a, hipStream_t st);
+int cog_gate_residual(const CogLnArgs& a, hipStream_t st); // y = [dres +] bf(onep * x)
+
 }  // namespace ftmi

@@ -226,6 +226,67 @@ def ddim_get_velocity(sample, noise, sqrt_alpha, sqrt_one_minus_alpha):
     return out
 
 
+# ---- CogVideoX block, row-wise stages (include/ftmi355.h: ftmi_cog_*) ------------------------------------------------------------------
+def _cog_rows(x):
+    require_gpu_tensor(x, "x", bf16)
+    if x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("expected a contiguous [B, tokens, D] bf16 tensor (text tokens of a sample first)")
+    return x.shape[0] * x.shape[1], x.shape[2], x.shape[1]
+
+
+def cog_ln_mod(x, w, b, shift, onep, text_len: int, eps: float = 1e-5):
+    """CogVideoXLayerNormZero body: bf(bf(LayerNorm(x; w, b)) * onep) + shift; shift / onep [B, 2, D] (text, video) or [B, D] (text_len = 0)."""
+    rows, D, rpb = _cog_rows(x)
+    y = torch.empty_like(x)
+    check(_lib.load().ftmi_cog_ln_mod_fwd(ptr(x), ptr(w), ptr(b), ptr(shift.contiguous()), ptr(onep.contiguous()), ptr(y), rows, D, rpb, int(text_len),
+                                          float(eps), stream_ptr()), "ftmi_cog_ln_mod_fwd")
+    return y
+
+
+def cog_ln_mod_bwd(x, w, onep, dy, text_len: int, eps: float = 1e-5, dres=None):
+    rows, D, rpb = _cog_rows(x)
+    dx = torch.empty_like(x)
+    check(_lib.load().ftmi_cog_ln_mod_bwd(ptr(x), ptr(w), ptr(onep.contiguous()), ptr(dy.contiguous()), ptr(dres), ptr(dx), rows, D, rpb, int(text_len),
+                                          float(eps), stream_ptr()), "ftmi_cog_ln_mod_bwd")
+    return dx
+
+
+def cog_head_ln(x2d, w, b, eps: float = 1e-6, out=None):
+    """LayerNorm over each 64-channel head of the rows of x2d [M, D] (a column slice of a wider buffer is fine: row stride = x2d.stride(0))."""
+    require_gpu_tensor(x2d, "x", bf16)
+    M, D = x2d.shape
+    if x2d.stride(1) != 1:
+        raise ValueError("head LayerNorm: channels must be contiguous")
+    y = torch.empty((M, D), dtype=bf16, device=x2d.device) if out is None else out
+    if y.stride(0) != x2d.stride(0):
+        y_c = torch.empty_strided((M, D), (x2d.stride(0), 1), dtype=bf16, device=x2d.device)
+    else:
+        y_c = y
+    check(_lib.load().ftmi_cog_head_ln_fwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(b), ptr(y_c), M, D, float(eps), stream_ptr()), "ftmi_cog_head_ln_fwd")
+    if y_c is not y:
+        y.copy_(y_c)
+    return y
+
+
+def cog_head_ln_bwd(x2d, w, dy2d, eps: float = 1e-6):
+    require_gpu_tensor(x2d, "x", bf16)
+    M, D = x2d.shape
+    if x2d.stride(0) != dy2d.stride(0) or x2d.stride(1) != 1 or dy2d.stride(1) != 1:
+        raise ValueError("head LayerNorm backward: x and dy must share one row stride")
+    dx = torch.empty_strided((M, D), (x2d.stride(0), 1), dtype=bf16, device=x2d.device)
+    check(_lib.load().ftmi_cog_head_ln_bwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(dy2d), ptr(dx), M, D, float(eps), stream_ptr()), "ftmi_cog_head_ln_bwd")
+    return dx
+
+
+def cog_gate_residual(res, y, gate, text_len: int):
+    """res + bf(gate * y) per segment (res None: bf(gate * y))."""
+    rows, D, rpb = _cog_rows(y)
+    out = torch.empty_like(y)
+    check(_lib.load().ftmi_cog_gate_residual(ptr(res), ptr(y), ptr(gate.contiguous()), ptr(out), rows, D, rpb, int(text_len), stream_ptr()),
+          "ftmi_cog_gate_residual")
+    return out
+
+
 def posterior_sample(moments, eps):
     """moments [B, 2C, ...] (mean | logvar along dim 1), eps [B, C, ...] ~ N(0,1) -> mean + exp(0.5 * clamp(logvar, -30, 20)) * eps."""
     require_gpu_tensor(moments, "moments", bf16)

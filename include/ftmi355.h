@@ -231,6 +231,25 @@ int ftmi_ddim_add_noise(const void* latents, const void* noise, const float* sqr
 int ftmi_ddim_get_velocity(const void* sample, const void* noise, const float* sqrt_alpha, const float* sqrt_one_minus_alpha, void* out,
                            int B, long per_sample, ftmi_stream stream);
 
+/* ---- CogVideoX DiT block, row-wise stages (call sites finetrainers/models/cogvideox/base_specification.py:296-333, arithmetic
+ * [upstream] diffusers CogVideoXBlock / CogVideoXLayerNormZero / Attention(qk_norm="layer_norm"), restated in oracle/cogvideox.py).
+ * Tokens are one bf16 buffer [B, rows_per_batch, D] with the text_len text tokens of a sample first (the order the joint attention
+ * concatenates them in); D % 64 == 0, D <= 4096.  text_len > 0: modulation tables are [B, 2, D] (row 0 text, row 1 video);
+ * text_len == 0: [B, D].  Every tensor the eager bf16 graph materialises is one bf16 rounding here.  Only x-gradients exist: with LoRA on
+ * the attention projections nothing upstream of the modulation / affine parameters is trainable. */
+/* y = bf(bf(LayerNorm(x; w, b, eps)) * onep) + shift        (onep = bf(1 + scale), prepared by the caller like the reference's (1 + scale)) */
+int ftmi_cog_ln_mod_fwd(const void* x, const void* w, const void* b, const void* shift, const void* onep, void* y, int rows, int D,
+                        int rows_per_batch, int text_len, float eps, ftmi_stream stream);
+/* dx = [dres +] LayerNorm'(x)[bf(dy * onep) * w]            (dres: gradient arriving on the residual branch, may be NULL) */
+int ftmi_cog_ln_mod_bwd(const void* x, const void* w, const void* onep, const void* dy, const void* dres, void* dx, int rows, int D,
+                        int rows_per_batch, int text_len, float eps, ftmi_stream stream);
+/* q / k LayerNorm over each head's 64 channels (w, b: [64]); x, y, dy, dx: rows of D channels, row stride ld elements */
+int ftmi_cog_head_ln_fwd(const void* x, long ld, const void* w, const void* b, void* y, int rows, int D, float eps, ftmi_stream stream);
+int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, void* dx, int rows, int D, float eps, ftmi_stream stream);
+/* out = res + bf(gate * y)   (res NULL: out = bf(gate * y), which is also the y-gradient of the same op) */
+int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, void* out, int rows, int D, int rows_per_batch, int text_len,
+                           ftmi_stream stream);
+
 /* Precomputed-latent path (finetrainers/trainer/sft_trainer/trainer.py:374: --enable_precomputation => compute_posterior = False):
  * moments [B, 2, per_sample] bf16 = the VAE posterior (mean | logvar) as finetrainers-precomputed-data stores it, eps [B, per_sample] bf16
  * the N(0,1) draw; out = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps, one bf16 rounding per torch op of
