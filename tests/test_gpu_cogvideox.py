@@ -173,3 +173,87 @@ def test_gate_residual_is_bit_exact():
     assert torch.equal(ops.cog_gate_residual(None, y.to(dev), gate.to(dev), T).cpu(), gt * y)
     with pytest.raises(ValueError):
         ops.cog_ln_mod(torch.zeros(1, 4, 100, dtype=bf16, device=dev), y, y, y, y, 0)  # row width must be a multiple of 64
+
+
+BLOCK_GRAD_GLOBAL, BLOCK_GRAD_WORST = 4.8e-3, 8e-3
+
+
+def _block_pair(rank=64):
+    """A CogVideoX-2b-width block (1920 = 30 x 64, time_embed_dim 512) with LoRA on to_q / to_k / to_v / to_out.0: the oracle module and the
+    MI355X block holding the same weights."""
+    from finetrainers_amd.cogvideox import MI355XCogVideoXBlock
+    from oracle import cogvideox as cvx
+
+    cfg = cvx.CogVideoXConfig(num_layers=1, sample_width=8, sample_height=8, sample_frames=5, max_text_seq_length=8)
+    model = cvx.build_model(cfg, seed=0, rank=rank, alpha=float(rank), lora_b_std=0.02)
+    oblk = model.transformer_blocks[0]
+    with torch.no_grad():  # non-trivial affine parameters (default init leaves LayerNorm weights at 1 / biases at 0)
+        g = torch.Generator().manual_seed(7)
+        for n, p in oblk.named_parameters():
+            if "norm" in n and n.endswith("weight") and p.dim() == 1:
+                p.copy_((1 + 0.1 * torch.randn(p.shape, generator=g)).to(p.dtype))
+            elif "norm" in n and n.endswith("bias") and p.dim() == 1 and "linear" not in n:
+                p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(p.dtype))
+    # the oracle names its feed-forward Linears proj_in / proj_out; diffusers: ff.net.0.proj / ff.net.2
+    sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2."): v for k, v in oblk.state_dict().items()}
+    gblk = MI355XCogVideoXBlock(dim=cfg.inner_dim, heads=cfg.num_attention_heads, time_embed_dim=cfg.time_embed_dim, device=_dev())
+    gblk.load_diffusers_state_dict({k: v for k, v in sd.items() if "lora_" not in k})
+    gblk.add_adapter(r=rank, lora_alpha=float(rank))
+    names = ("attn1.to_q", "attn1.to_k", "attn1.to_v", "attn1.to_out.0")
+    with torch.no_grad():
+        for i, n in enumerate(names):
+            gblk.lora_A[i].copy_(sd[f"{n}.lora_A.default.weight"])
+            gblk.lora_B[i].copy_(sd[f"{n}.lora_B.default.weight"])
+    return cfg, oblk, gblk, names
+
+
+@pytest.mark.parametrize("B,T,S", [(2, 8, 40), (1, 16, 150)])
+def test_block_forward_backward_parity(B, T, S):
+    """One CogVideoX block at the 2b width, forward and backward (dx for both token streams + the 8 LoRA gradients), against the oracle block
+    on the CPU; the LoRA-gradient bound is the oracle's own summation-order floor on the same inputs x 1.5, as for LTX."""
+    from oracle import ltx
+
+    cfg, oblk, gblk, names = _block_pair()
+    dev = _dev()
+    D = cfg.inner_dim
+    g = torch.Generator().manual_seed(B * 100 + S)
+    text = torch.randn(B, T, D, generator=g).to(bf16)
+    video = torch.randn(B, S, D, generator=g).to(bf16)
+    temb = torch.randn(B, cfg.time_embed_dim, generator=g).to(bf16)
+    dvid = torch.randn(B, S, D, generator=g).to(bf16)
+    dtxt = torch.randn(B, T, D, generator=g).to(bf16)
+
+    def run_oracle():
+        for p in oblk.parameters():
+            p.grad = None
+        vr, tr = video.clone().requires_grad_(True), text.clone().requires_grad_(True)
+        hv, ht = oblk(vr, tr, temb)
+        torch.autograd.backward([hv, ht], [dvid, dtxt])
+        grads = {n: p.grad.detach().clone() for n, p in oblk.named_parameters() if p.grad is not None}
+        return hv.detach(), ht.detach(), vr.grad, tr.grad, grads
+
+    hv_ref, ht_ref, dv_ref, dt_ref, g_ref = run_oracle()
+    with ltx.accumulation_order_variant(512):
+        _, _, _, _, g_alt = run_oracle()
+    floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
+
+    tokens = torch.cat([text, video], 1).to(dev).requires_grad_(True)
+    out = gblk(tokens, temb.to(dev), T)
+    out.backward(torch.cat([dtxt, dvid], 1).to(dev))
+    torch.cuda.synchronize()
+    e_hv, e_ht = _rel(out[:, T:].cpu(), hv_ref), _rel(out[:, :T].cpu(), ht_ref)
+    e_dv, e_dt = _rel(tokens.grad[:, T:].cpu(), dv_ref), _rel(tokens.grad[:, :T].cpu(), dt_ref)
+    got = {}
+    for i, n in enumerate(names):
+        got[f"{n}.lora_A.default.weight"] = gblk.lora_A.grad[i].cpu()
+        got[f"{n}.lora_B.default.weight"] = gblk.lora_B.grad[i].cpu()
+    assert set(got) == set(g_ref)
+    glob, worst = ltx.grads_rel_l2(got, g_ref)
+    print(f"[cog-block B={B} T={T} S={S}] out video {e_hv:.2e} text {e_ht:.2e} | dx video {e_dv:.2e} text {e_dt:.2e} | LoRA grads {glob:.2e} (worst {worst:.2e}); "
+          f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
+    assert e_hv < 5e-3 and e_ht < 5e-3
+    assert e_dv < 1e-2 and e_dt < 1e-2
+    # the floor only reorders the frozen Linears; the block's remaining difference is the attention (bf16 P / dS on the MFMA, its own tile
+    # order).  Bounds = the residuals measured on an MI355X x 1.5 (3.2e-3 / 5.1e-3 at B=2, S=40), and never more than 2.5 floors.
+    assert glob < BLOCK_GRAD_GLOBAL and worst < BLOCK_GRAD_WORST
+    assert glob < 2.5 * floor and worst < 2.5 * floor_worst
