@@ -98,6 +98,8 @@ _SIGS = {
     "ftmi_cog_head_ln_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ftmi_cog_head_ln_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ftmi_cog_gate_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ftmi_cog_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ftmi_cog_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ftmi_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p]),
     "ftmi_clip_adamw_step": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 6 + [c_int, c_void_p, c_void_p, c_void_p]),
     "ftmi_lora_refresh": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),

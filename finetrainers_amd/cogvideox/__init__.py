@@ -1,2 +1,3 @@
 from .specification import CogVideoXDDIMTables, MI355XCogVideoXSpecOps  # noqa: F401
 from .block import MI355XCogVideoXBlock  # noqa: F401
+from .model import CogVideoXTransformerConfig, MI355XCogVideoXTransformer3DModel  # noqa: F401

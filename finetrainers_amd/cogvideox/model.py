@@ -1,0 +1,230 @@
+"""CogVideoX-2b DiT for LoRA SFT on the gfx950 kernels: patch embed + sincos table, time embedding, the blocks of ``block.py``, final norms,
+``proj_out`` and un-patchify -- forward, and the backward that reaches the LoRA adapters (everything outside the blocks is frozen, and nothing
+below block 0 needs a gradient).
+
+Reference: [upstream] diffusers ``CogVideoXTransformer3DModel`` as the reference drives it (``finetrainers/models/cogvideox/base_specification.py:
+296-333``), restated in ``oracle/cogvideox.py``.  This is the sincos-table variant (CogVideoX-2b, ``use_rotary_positional_embeddings = False``,
+BASELINE config 3); the rotary variant (5b) needs RoPE on the video part of q / k and is not wired yet.
+
+Token layout: ONE buffer ``[B, T + S, D]``, the T = ``max_text_seq_length`` text tokens first.  Orchestration is Python over C-ABI calls (see
+``block.py``); torch ops touch only per-sample conditioning vectors ([B, 1920] / [B, 512]) and the host-built constant tables.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .block import MI355XCogVideoXBlock
+
+bf16 = torch.bfloat16
+
+
+@dataclass
+class CogVideoXTransformerConfig:
+    """[upstream] CogVideoX-2b ``transformer/config.json`` values."""
+
+    num_attention_heads: int = 30
+    attention_head_dim: int = 64
+    in_channels: int = 16
+    out_channels: int = 16
+    time_embed_dim: int = 512
+    text_embed_dim: int = 4096
+    num_layers: int = 30
+    sample_width: int = 90
+    sample_height: int = 60
+    sample_frames: int = 49
+    patch_size: int = 2
+    temporal_compression_ratio: int = 4
+    max_text_seq_length: int = 226
+    norm_eps: float = 1e-5
+    spatial_interpolation_scale: float = 1.875
+    temporal_interpolation_scale: float = 1.0
+    ff_mult: int = 4
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+
+def _sincos_1d(dim: int, pos: torch.Tensor) -> torch.Tensor:
+    omega = 1.0 / 10000 ** (torch.arange(dim // 2, dtype=torch.float64) / (dim / 2.0))
+    ang = torch.outer(pos.reshape(-1).to(torch.float64), omega)
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+
+
+def sincos_position_table(cfg: CogVideoXTransformerConfig, height: int, width: int, frames: int) -> torch.Tensor:
+    """[upstream] ``get_3d_sincos_pos_embed`` as ``CogVideoXPatchEmbed`` lays it out: rows = latent frames x (height/p) x (width/p) patches; the first
+    D/4 channels encode the frame, the other 3D/4 the 2-D position (width half, then height half); spatial grid divided by the interpolation scale."""
+    D, p = cfg.inner_dim, cfg.patch_size
+    ph, pw = height // p, width // p
+    d_sp, d_t = 3 * D // 4, D // 4
+    gh = torch.arange(ph, dtype=torch.float32) / cfg.spatial_interpolation_scale
+    gw = torch.arange(pw, dtype=torch.float32) / cfg.spatial_interpolation_scale
+    mw, mh = torch.meshgrid(gw, gh, indexing="xy")  # [ph, pw] each: width varies fastest
+    pos_sp = torch.cat([_sincos_1d(d_sp // 2, mw), _sincos_1d(d_sp // 2, mh)], dim=1)  # [ph * pw, d_sp]
+    pos_t = _sincos_1d(d_t, torch.arange(frames, dtype=torch.float32) / cfg.temporal_interpolation_scale)  # [frames, d_t]
+    table = torch.cat([pos_t[:, None, :].expand(frames, ph * pw, d_t), pos_sp[None].expand(frames, ph * pw, d_sp)], dim=-1)
+    return table.reshape(frames * ph * pw, D).float()
+
+
+def timestep_embedding(timesteps: torch.Tensor, dim: int) -> torch.Tensor:
+    """[upstream] ``get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)``: [cos | sin] of t * 10000^(-i / (dim/2))."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half)
+    ang = timesteps[:, None].float() * freqs[None, :]
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+
+class _HeadFunction(torch.autograd.Function):
+    """Video tokens of the last block -> norm_final -> AdaLayerNorm(norm_out) -> proj_out -> un-patchify.  Backward: d tokens (text rows zero)."""
+
+    @staticmethod
+    def forward(ctx, m: "MI355XCogVideoXTransformer3DModel", tokens, onep_out, shift_out, geom):
+        B, N, D = tokens.shape
+        F_, H, W = geom
+        T, S, p, C = m.config.max_text_seq_length, N - m.config.max_text_seq_length, m.config.patch_size, m.config.out_channels
+        nf = torch.empty((B, S, D), dtype=bf16, device=tokens.device)
+        no = torch.empty_like(nf)
+        for b in range(B):  # the video rows of a sample are contiguous, the samples are T rows apart
+            ops.cog_ln_mod(tokens[b:b + 1, T:], m.norm_final_w, m.norm_final_b, m._zeros_row, m._ones_row, 0, m.config.norm_eps, out=nf[b:b + 1])
+        ops.cog_ln_mod(nf, m.norm_out_w, m.norm_out_b, shift_out, onep_out, 0, m.config.norm_eps, out=no)
+        y = ops.gemm_nt(no.view(B * S, D), m.proj_out_w, m.proj_out_b)
+        ctx.m, ctx.geom = m, geom
+        ctx.save_for_backward(tokens, nf, onep_out)
+        return ops.cog_unpatchify(y.view(B, S, p * p * C), F_, C, H, W, p)
+
+    @staticmethod
+    def backward(ctx, dvel):
+        m = ctx.m
+        tokens, nf, onep_out = ctx.saved_tensors
+        B, N, D = tokens.shape
+        T, S, p = m.config.max_text_seq_length, N - m.config.max_text_seq_length, m.config.patch_size
+        dy = ops.cog_patchify(dvel.contiguous(), p)  # the un-patchify's transpose is the patchify
+        dno = ops.gemm_nt(dy.view(B * S, -1), m.proj_out_w_t, None)
+        dnf = ops.cog_ln_mod_bwd(nf, m.norm_out_w, onep_out, dno.view(B, S, D), 0, m.config.norm_eps)
+        dtok = torch.zeros_like(tokens)  # the text stream does not reach the output
+        for b in range(B):
+            dx = ops.cog_ln_mod_bwd(tokens[b:b + 1, T:], m.norm_final_w, m._ones_row, dnf[b:b + 1], 0, m.config.norm_eps)
+            dtok[b, T:].copy_(dx[0])
+        return None, dtok, None, None, None
+
+
+class MI355XCogVideoXTransformer3DModel(nn.Module):
+    """Same call contract as the diffusers model for the SFT path: ``forward(hidden_states [B, F, C, H, W], encoder_hidden_states [B, T, 4096],
+    timestep [B])`` -> ``(velocity [B, F, C, H, W],)``."""
+
+    def __init__(self, config: Optional[CogVideoXTransformerConfig] = None, device: Optional[torch.device] = None):
+        super().__init__()
+        self.config = c = config or CogVideoXTransformerConfig()
+        if c.attention_head_dim != 64:
+            raise ValueError("the gfx950 attention kernels need head_dim 64")
+        dev = device or torch.device("cuda", 0)
+        D, p = c.inner_dim, c.patch_size
+        z = lambda *shape: torch.zeros(shape, dtype=bf16, device=dev)
+        for name, shape in (("patch_w", (D, c.in_channels * p * p)), ("patch_b", (D,)), ("text_w", (D, c.text_embed_dim)), ("text_b", (D,)),
+                            ("time1_w", (c.time_embed_dim, D)), ("time1_b", (c.time_embed_dim,)), ("time2_w", (c.time_embed_dim, c.time_embed_dim)),
+                            ("time2_b", (c.time_embed_dim,)), ("norm_final_w", (D,)), ("norm_final_b", (D,)), ("norm_out_lin_w", (2 * D, c.time_embed_dim)),
+                            ("norm_out_lin_b", (2 * D,)), ("norm_out_w", (D,)), ("norm_out_b", (D,)), ("proj_out_w", (p * p * c.out_channels, D)),
+                            ("proj_out_b", (p * p * c.out_channels,))):
+            self.register_buffer(name, z(*shape))
+        self.register_buffer("proj_out_w_t", None, persistent=False)
+        self.register_buffer("_ones_row", torch.ones(1, D, dtype=bf16, device=dev), persistent=False)
+        self.register_buffer("_zeros_row", torch.zeros(1, D, dtype=bf16, device=dev), persistent=False)
+        self.transformer_blocks = nn.ModuleList([MI355XCogVideoXBlock(D, c.num_attention_heads, c.time_embed_dim, c.ff_mult, c.norm_eps, dev)
+                                                 for _ in range(c.num_layers)])
+        self._pos_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
+
+    @property
+    def device(self) -> torch.device:
+        return self.patch_w.device
+
+    _KEYS = {
+        "patch_embed.proj.bias": "patch_b", "patch_embed.text_proj.weight": "text_w", "patch_embed.text_proj.bias": "text_b",
+        "time_embedding.linear_1.weight": "time1_w", "time_embedding.linear_1.bias": "time1_b", "time_embedding.linear_2.weight": "time2_w",
+        "time_embedding.linear_2.bias": "time2_b", "norm_final.weight": "norm_final_w", "norm_final.bias": "norm_final_b",
+        "norm_out.linear.weight": "norm_out_lin_w", "norm_out.linear.bias": "norm_out_lin_b", "norm_out.norm.weight": "norm_out_w",
+        "norm_out.norm.bias": "norm_out_b", "proj_out.weight": "proj_out_w", "proj_out.bias": "proj_out_b",
+    }
+
+    @torch.no_grad()
+    def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """A diffusers ``CogVideoXTransformer3DModel`` state dict (peft ``.base_layer.`` infix accepted, LoRA tensors ignored here)."""
+        sd = {k.replace(".base_layer.", "."): v for k, v in sd.items() if "lora_" not in k}
+        for k, name in self._KEYS.items():
+            getattr(self, name).copy_(sd[k].to(bf16))
+        self.patch_w.copy_(sd["patch_embed.proj.weight"].reshape(self.patch_w.shape).to(bf16))  # Conv2d [D, C, p, p] -> [D, C p p]
+        self.proj_out_w_t = ops.transpose_bf16(self.proj_out_w)
+        for i, blk in enumerate(self.transformer_blocks):
+            pre = f"transformer_blocks.{i}."
+            blk.load_diffusers_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+
+    def add_adapter(self, r: int = 64, lora_alpha: float = 64.0) -> None:
+        for blk in self.transformer_blocks:
+            blk.add_adapter(r, lora_alpha)
+
+    def lora_state_dict(self) -> Dict[str, torch.Tensor]:
+        """peft-format keys: ``transformer_blocks.N.attn1.to_q.lora_A.weight`` ..."""
+        out = {}
+        for i, blk in enumerate(self.transformer_blocks):
+            for j, n in enumerate(("to_q", "to_k", "to_v", "to_out.0")):
+                out[f"transformer_blocks.{i}.attn1.{n}.lora_A.weight"] = blk.lora_A[j]
+                out[f"transformer_blocks.{i}.attn1.{n}.lora_B.weight"] = blk.lora_B[j]
+        return out
+
+    @torch.no_grad()
+    def load_lora_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        sd = {k.replace(".default.", "."): v for k, v in sd.items()}
+        for k, v in self.lora_state_dict().items():
+            v.copy_(sd[k].to(v))
+
+    def lora_parameters(self) -> List[nn.Parameter]:
+        return [p for blk in self.transformer_blocks for p in (blk.lora_A, blk.lora_B) if p is not None]
+
+    def _pos_table(self, frames: int, height: int, width: int) -> torch.Tensor:
+        key = (frames, height, width)
+        if key not in self._pos_cache:
+            c = self.config
+            tab = torch.zeros(1, c.max_text_seq_length + frames * (height // c.patch_size) * (width // c.patch_size), c.inner_dim)
+            tab[0, c.max_text_seq_length:] = sincos_position_table(c, height, width, frames)
+            self._pos_cache[key] = tab.to(device=self.device, dtype=bf16)
+        return self._pos_cache[key]
+
+    @torch.no_grad()
+    def _embed(self, hidden_states, encoder_hidden_states, timestep):
+        c = self.config
+        B, F_, C, H, W = hidden_states.shape
+        T, D, p = c.max_text_seq_length, c.inner_dim, c.patch_size
+        if encoder_hidden_states.shape[1] != T:
+            raise ValueError(f"CogVideoX expects {T} text tokens (max_text_seq_length), got {encoder_hidden_states.shape[1]}")
+        S = F_ * (H // p) * (W // p)
+        tokens = torch.empty((B, T + S, D), dtype=bf16, device=self.device)
+        patches = ops.cog_patchify(hidden_states.to(bf16), p)
+        text = encoder_hidden_states.to(bf16).contiguous()
+        pos = self._pos_table(F_, H, W)
+        for b in range(B):
+            ops.gemm_nt(text[b], self.text_w, self.text_b, out=tokens[b, :T])
+            ops.gemm_nt(patches[b], self.patch_w, self.patch_b, out=tokens[b, T:])
+            ops.cog_gate_residual(pos, tokens[b:b + 1], self._ones_row, 0, out=tokens[b:b + 1])  # + sincos table (text rows: + 0)
+        t_emb = timestep_embedding(timestep.to(self.device), D).to(bf16)
+        emb = ops.gemm_nt(torch.nn.functional.silu(ops.gemm_nt(t_emb, self.time1_w, self.time1_b)), self.time2_w, self.time2_b)
+        mod = ops.gemm_nt(torch.nn.functional.silu(emb), self.norm_out_lin_w, self.norm_out_lin_b)  # AdaLayerNorm: shift, scale = chunk(2)
+        return tokens, emb, (1 + mod[:, D:]).contiguous(), mod[:, :D].contiguous()
+
+    def forward(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb=None, ofs=None, return_dict: bool = False, **kwargs):
+        if image_rotary_emb is not None or ofs is not None:
+            raise NotImplementedError("the rotary / ofs variants (CogVideoX-5b, 1.5) are not wired yet")
+        if self.proj_out_w_t is None:
+            raise RuntimeError("load_diffusers_state_dict first")
+        tokens, emb, onep_out, shift_out = self._embed(hidden_states, encoder_hidden_states, timestep)
+        T = self.config.max_text_seq_length
+        for blk in self.transformer_blocks:
+            tokens = blk(tokens, emb, T)
+        B, F_, C, H, W = hidden_states.shape
+        vel = _HeadFunction.apply(self, tokens, onep_out, shift_out, (F_, H, W))
+        return {"sample": vel} if return_dict else (vel,)

@@ -4,9 +4,8 @@ DP = 8).  What exists: the spec-level arithmetic of ``CogVideoXModelSpecificatio
 ``get_velocity`` (velocity -> x0), the ``1 / (1 - alphas_cumprod[t])`` loss weight (finetrainers/utils/diffusion.py:117-130) -- as gfx950
 kernels behind the C ABI (``ftmi_ddim_add_noise`` / ``ftmi_ddim_get_velocity`` / ``ftmi_mse_loss``), and the joint text + video attention
 of every CogVideoX block through the ``mi355x`` attention provider (``ftmi_attn_fwd`` / ``_bwd``; 226 + 17 550 tokens, 30 heads of 64).
-What does NOT exist yet: the CogVideoX DiT block orchestrator (LayerNorm-zero modulation at width 1920, patch embed, fused LoRA
-projections) -- ``MI355XCogVideoXSpecOps.forward`` therefore takes the transformer as a callable (the reference's diffusers model with the
-``mi355x`` attention provider today, the native DiT later).  The oracle for all of it is ``oracle/cogvideox.py``.
+``MI355XCogVideoXSpecOps.forward`` takes the transformer as a callable: the native DiT of ``model.py`` (CogVideoX-2b variant), or the
+reference's diffusers model with the ``mi355x`` attention provider.  The oracle for all of it is ``oracle/cogvideox.py``.
 """
 
 from __future__ import annotations
@@ -45,6 +44,22 @@ class CogVideoXDDIMTables:
         return (1 / (1 - self.alphas_cumprod.to(timesteps.device)[timesteps])).float().contiguous()
 
 
+class _GetVelocity(torch.autograd.Function):
+    """``scheduler.get_velocity(sample=velocity, noise=noisy_latents, t)`` = sqrt(a) noisy - sqrt(1 - a) velocity, differentiable in the model
+    output: d velocity = bf(-sqrt(1 - a) * d pred), through the same kernel."""
+
+    @staticmethod
+    def forward(ctx, velocity, noisy, sa, so):
+        ctx.save_for_backward(sa, so)
+        return ops.ddim_get_velocity(velocity, noisy, sa, so)
+
+    @staticmethod
+    def backward(ctx, dpred):
+        sa, so = ctx.saved_tensors
+        dpred = dpred.contiguous()
+        return ops.ddim_get_velocity(dpred, torch.zeros_like(dpred), torch.zeros_like(sa), so), None, None, None
+
+
 class MI355XCogVideoXSpecOps:
     """The arithmetic of ``CogVideoXModelSpecification.forward`` around the DiT call, on the GPU.  ``transformer`` is any callable with the
     reference's signature ``(hidden_states [B,F,C,H,W], encoder_hidden_states, timestep, image_rotary_emb, ofs, return_dict=False)``."""
@@ -75,7 +90,7 @@ class MI355XCogVideoXSpecOps:
         velocity = transformer(hidden_states=noisy, encoder_hidden_states=encoder_hidden_states, timestep=timesteps, image_rotary_emb=image_rotary_emb,
                                ofs=None, return_dict=False)[0]
         sa, so = self.scheduler.coefficients(timesteps)
-        pred = ops.ddim_get_velocity(velocity.to(torch.bfloat16), noisy, sa, so)  # scheduler.get_velocity(velocity, noisy_latents, timesteps)
+        pred = _GetVelocity.apply(velocity.to(torch.bfloat16), noisy, sa, so)  # scheduler.get_velocity(velocity, noisy_latents, timesteps)
         return pred, target, sigmas
 
     def loss(self, pred: torch.Tensor, target: torch.Tensor, sigmas: torch.Tensor) -> torch.Tensor:
@@ -83,3 +98,11 @@ class MI355XCogVideoXSpecOps:
         timesteps = (sigmas.flatten() * 1000.0).long()
         loss, _ = ops.mse_loss(pred.contiguous(), target.contiguous(), self.scheduler.loss_weights(timesteps), want_grad=False)
         return loss.reshape(())
+
+    def loss_backward(self, pred: torch.Tensor, target: torch.Tensor, sigmas: torch.Tensor, grad_scale: float = 1.0) -> torch.Tensor:
+        """Loss and ``loss.backward()`` in one: loss and d loss / d pred come out of one kernel and seed the backward of ``pred``'s graph (the DiT)."""
+        timesteps = (sigmas.flatten() * 1000.0).long()
+        loss, dpred = ops.mse_loss(pred.detach().contiguous(), target.contiguous(), self.scheduler.loss_weights(timesteps), want_grad=True,
+                                   grad_scale=grad_scale)
+        pred.backward(dpred)
+        return loss.reshape(()) * grad_scale

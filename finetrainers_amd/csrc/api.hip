@@ -432,6 +432,16 @@ int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, voi
     return cog_gate_residual(a, (hipStream_t)stream);
 }
 
+int ftmi_cog_patchify(const void* latents, void* tokens, int B, int F, int C, int H, int W, int patch, ftmi_stream stream) {
+    if (!latents || !tokens) return set_error(FTMI_ERR_INVALID, "ftmi_cog_patchify: null argument");
+    return cog_patch_permute((const bf16_t*)latents, (bf16_t*)tokens, B, F, C, H, W, patch, 1, (hipStream_t)stream);
+}
+
+int ftmi_cog_unpatchify(const void* tokens, void* latents, int B, int F, int C, int H, int W, int patch, ftmi_stream stream) {
+    if (!latents || !tokens) return set_error(FTMI_ERR_INVALID, "ftmi_cog_unpatchify: null argument");
+    return cog_patch_permute((const bf16_t*)tokens, (bf16_t*)latents, B, F, C, H, W, patch, 0, (hipStream_t)stream);
+}
+
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample, float grad_scale,
                   ftmi_stream stream) {
     if (!pred || !target || !loss) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");

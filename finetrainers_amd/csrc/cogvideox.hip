@@ -246,7 +246,37 @@ int check_args(const CogLnArgs& a, const char* who) {
     return 0;
 }
 
+// ---- patch (p x p) gather / scatter between latents [B, F, C, H, W] and tokens [B, F (H/p) (W/p), C p p] -----------------------------------
+// tokens[b, (f h + hy) w + wx, (c p + py) p + px] <-> lat[b, f, c, hy p + py, wx p + px]: the im2col of CogVideoXPatchEmbed's Conv2d(kernel = stride
+// = p) (its weight flattens as [D, C p p] in the same (c, py, px) order) and, in the other direction, the model's final un-patchify
+// (x.reshape(b, f, h, w, C, p, p).permute(0, 1, 4, 2, 5, 3, 6)).
+__global__ __launch_bounds__(256) void patch_permute_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int F, int C, int H, int W, int p,
+                                                            long total, int to_tokens) {
+    const int h = H / p, w = W / p, E = C * p * p;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        long t = i / E;
+        const int wx = (int)(t % w); t /= w;
+        const int hy = (int)(t % h); t /= h;
+        const int f = (int)(t % F);
+        const long b = t / F;
+        const int px = e % p, py = (e / p) % p, c = e / (p * p);
+        const long li = (((b * F + f) * C + c) * H + (hy * p + py)) * (long)W + (wx * p + px);
+        if (to_tokens) dst[i] = src[li];
+        else dst[li] = src[i];
+    }
+}
+
 }  // namespace
+
+int cog_patch_permute(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W, int p, int to_tokens, hipStream_t st) {
+    if (B <= 0 || F <= 0 || C <= 0 || p <= 0 || H % p || W % p) return set_error(FTMI_ERR_INVALID, "cog_patch_permute: bad geometry");
+    const long total = (long)B * F * C * H * W;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(patch_permute_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, F, C, H, W, p, total, to_tokens);
+    return check_launch("cog_patch_permute");
+}
 
 #define FTMI_COG_DISPATCH(KERNEL, ...)                                                                           \
     switch ((a.D + 511) / 512) {                                                                                  \

@@ -231,5 +231,6 @@ int cog_ln_mod_bwd(const CogLnArgs& a, hipStream_t st);    // dx = [dres +] LN'(
 int cog_head_ln_fwd(const CogLnArgs& a, hipStream_t st);   // per 64-channel head: y = LN(x; w[64], b[64])
 int cog_head_ln_bwd(const CogLnArgs& a, hipStream_t st);
 int cog_gate_residual(const CogLnArgs& a, hipStream_t st); // y = [dres +] bf(onep * x)
+int cog_patch_permute(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W, int p, int to_tokens, hipStream_t st);  // latents <-> patch tokens
 
 }  // namespace ftmi

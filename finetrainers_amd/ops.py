@@ -79,15 +79,18 @@ def attn_bwd(q, k, v, out, lse, dout, key_bias=None, scale=None):
 
 def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0, epilogue: int = 0,
             resid: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, rows_per_batch: int = 0,
-            aux: Optional[torch.Tensor] = None, want_out2: bool = False, variant: int = 8):
-    """out[M,N] = epilogue(alpha * x[M,K] @ w[N,K]^T + bias)."""
+            aux: Optional[torch.Tensor] = None, want_out2: bool = False, variant: int = 8, out: Optional[torch.Tensor] = None):
+    """out[M,N] = epilogue(alpha * x[M,K] @ w[N,K]^T + bias).  ``out``: write into an existing [M, N] bf16 view (row stride free, a multiple of 8)."""
     require_gpu_tensor(x, "x", bf16)
     require_gpu_tensor(w, "w", bf16)
     M, K = x.shape
     N = w.shape[0]
-    out = torch.empty((M, N), dtype=bf16, device=x.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=bf16, device=x.device)
+    elif out.shape != (M, N) or out.dtype != bf16 or out.stride(1) != 1:
+        raise ValueError("gemm_nt: out must be an [M, N] bf16 view with contiguous columns")
     out2 = torch.empty((M, N), dtype=bf16, device=x.device) if want_out2 else None
-    check(_lib.load().ftmi_gemm_nt(M, N, K, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), float(alpha), ptr(out), N, epilogue,
+    check(_lib.load().ftmi_gemm_nt(M, N, K, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), float(alpha), ptr(out), out.stride(0), epilogue,
                                     ptr(out2), ptr(resid), ptr(gate), rows_per_batch, ptr(aux), variant, stream_ptr()), "ftmi_gemm_nt")
     return (out, out2) if want_out2 else out
 
@@ -234,10 +237,12 @@ def _cog_rows(x):
     return x.shape[0] * x.shape[1], x.shape[2], x.shape[1]
 
 
-def cog_ln_mod(x, w, b, shift, onep, text_len: int, eps: float = 1e-5):
+def cog_ln_mod(x, w, b, shift, onep, text_len: int, eps: float = 1e-5, out=None):
     """CogVideoXLayerNormZero body: bf(bf(LayerNorm(x; w, b)) * onep) + shift; shift / onep [B, 2, D] (text, video) or [B, D] (text_len = 0)."""
     rows, D, rpb = _cog_rows(x)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
+    if y.shape != x.shape or not y.is_contiguous():
+        raise ValueError("cog_ln_mod: out must be a contiguous tensor of x's shape")
     check(_lib.load().ftmi_cog_ln_mod_fwd(ptr(x), ptr(w), ptr(b), ptr(shift.contiguous()), ptr(onep.contiguous()), ptr(y), rows, D, rpb, int(text_len),
                                           float(eps), stream_ptr()), "ftmi_cog_ln_mod_fwd")
     return y
@@ -278,12 +283,36 @@ def cog_head_ln_bwd(x2d, w, dy2d, eps: float = 1e-6):
     return dx
 
 
-def cog_gate_residual(res, y, gate, text_len: int):
-    """res + bf(gate * y) per segment (res None: bf(gate * y))."""
+def cog_gate_residual(res, y, gate, text_len: int, out=None):
+    """res + bf(gate * y) per segment (res None: bf(gate * y)); ``out`` may be ``y`` or ``res`` themselves (element-wise, in place)."""
     rows, D, rpb = _cog_rows(y)
-    out = torch.empty_like(y)
+    out = torch.empty_like(y) if out is None else out
+    if out.shape != y.shape or not out.is_contiguous() or (res is not None and (res.shape != y.shape or not res.is_contiguous())):
+        raise ValueError("cog_gate_residual: res / out must be contiguous tensors of y's shape")
     check(_lib.load().ftmi_cog_gate_residual(ptr(res), ptr(y), ptr(gate.contiguous()), ptr(out), rows, D, rpb, int(text_len), stream_ptr()),
           "ftmi_cog_gate_residual")
+    return out
+
+
+def cog_patchify(latents, patch: int):
+    """latents [B, F, C, H, W] bf16 -> tokens [B, F (H/p) (W/p), C p p] (channel order (c, py, px): the flattened Conv2d weight's)."""
+    require_gpu_tensor(latents, "latents", bf16)
+    B, F_, C, H, W = latents.shape
+    latents = latents.contiguous()
+    out = torch.empty((B, F_ * (H // patch) * (W // patch), C * patch * patch), dtype=bf16, device=latents.device)
+    check(_lib.load().ftmi_cog_patchify(ptr(latents), ptr(out), B, F_, C, H, W, int(patch), stream_ptr()), "ftmi_cog_patchify")
+    return out
+
+
+def cog_unpatchify(tokens, F_: int, C: int, H: int, W: int, patch: int):
+    """tokens [B, F (H/p) (W/p), C p p] bf16 -> latents [B, F, C, H, W]."""
+    require_gpu_tensor(tokens, "tokens", bf16)
+    B = tokens.shape[0]
+    if tokens.shape[1:] != (F_ * (H // patch) * (W // patch), C * patch * patch):
+        raise ValueError(f"cog_unpatchify: tokens {tuple(tokens.shape)} do not match F={F_} C={C} H={H} W={W} p={patch}")
+    tokens = tokens.contiguous()
+    out = torch.empty((B, F_, C, H, W), dtype=bf16, device=tokens.device)
+    check(_lib.load().ftmi_cog_unpatchify(ptr(tokens), ptr(out), B, F_, C, H, W, int(patch), stream_ptr()), "ftmi_cog_unpatchify")
     return out
 
 

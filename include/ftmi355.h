@@ -250,6 +250,11 @@ int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, 
 int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, void* out, int rows, int D, int rows_per_batch, int text_len,
                            ftmi_stream stream);
 
+/* latents [B, F, C, H, W] -> tokens [B, F (H/p) (W/p), C p p] (the im2col of CogVideoXPatchEmbed's Conv2d(kernel = stride = p), channel order
+ * (c, py, px) like the flattened conv weight), and back (the model's final un-patchify).  [upstream] CogVideoXPatchEmbed / CogVideoXTransformer3DModel. */
+int ftmi_cog_patchify(const void* latents, void* tokens, int B, int F, int C, int H, int W, int patch, ftmi_stream stream);
+int ftmi_cog_unpatchify(const void* tokens, void* latents, int B, int F, int C, int H, int W, int patch, ftmi_stream stream);
+
 /* Precomputed-latent path (finetrainers/trainer/sft_trainer/trainer.py:374: --enable_precomputation => compute_posterior = False):
  * moments [B, 2, per_sample] bf16 = the VAE posterior (mean | logvar) as finetrainers-precomputed-data stores it, eps [B, per_sample] bf16
  * the N(0,1) draw; out = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps, one bf16 rounding per torch op of

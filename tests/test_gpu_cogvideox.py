@@ -257,3 +257,89 @@ def test_block_forward_backward_parity(B, T, S):
     # order).  Bounds = the residuals measured on an MI355X x 1.5 (3.2e-3 / 5.1e-3 at B=2, S=40), and never more than 2.5 floors.
     assert glob < BLOCK_GRAD_GLOBAL and worst < BLOCK_GRAD_WORST
     assert glob < 2.5 * floor and worst < 2.5 * floor_worst
+
+
+def test_patchify_roundtrip_and_position_table():
+    from finetrainers_amd import ops
+    from finetrainers_amd.cogvideox.model import CogVideoXTransformerConfig, sincos_position_table, timestep_embedding
+    from oracle import cogvideox as cvx
+    from oracle import ltx
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(2, 3, 16, 8, 12, generator=g).to(bf16)
+    tok = ops.cog_patchify(lat.to(dev), 2)
+    ref = lat.view(2, 3, 16, 4, 2, 6, 2).permute(0, 1, 3, 5, 2, 4, 6).reshape(2, 3 * 4 * 6, 64)  # im2col of Conv2d(kernel = stride = 2)
+    assert torch.equal(tok.cpu(), ref)
+    assert torch.equal(ops.cog_unpatchify(tok, 3, 16, 8, 12, 2).cpu(), lat)
+    # un-patchify as the model writes it
+    y = torch.randn(2, 3 * 4 * 6, 64, generator=g).to(bf16)
+    ref_out = y.reshape(2, 3, 4, 6, -1, 2, 2).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+    assert torch.equal(ops.cog_unpatchify(y.to(dev), 3, 16, 8, 12, 2).cpu(), ref_out)
+    ocfg = cvx.CogVideoXConfig()
+    cfg = CogVideoXTransformerConfig()
+    pe_ref = cvx.get_3d_sincos_pos_embed(ocfg.inner_dim, (7, 5), 3, ocfg.spatial_interpolation_scale, ocfg.temporal_interpolation_scale).flatten(0, 1)
+    assert torch.equal(sincos_position_table(cfg, 10, 14, 3), pe_ref)
+    t = torch.tensor([0, 31, 874, 999])
+    assert torch.equal(timestep_embedding(t, 1920), ltx.get_timestep_embedding(t, 1920))
+
+
+def test_model_step_parity_two_blocks():
+    """The whole CogVideoX-2b-width SFT forward + backward at 2 blocks: spec ops (scaling, DDIM noising), patch embed + sincos table, time
+    embedding, blocks, final norms, proj_out, un-patchify, velocity -> x0, weighted loss, and every LoRA gradient, against oracle/cogvideox.py."""
+    from finetrainers_amd.cogvideox import CogVideoXTransformerConfig, MI355XCogVideoXSpecOps, MI355XCogVideoXTransformer3DModel
+    from oracle import cogvideox as cvx
+    from oracle import ltx
+
+    dev = _dev()
+    kw = dict(num_layers=2, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
+    ocfg = cvx.CogVideoXConfig(**kw)
+    omodel = cvx.build_model(ocfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(7)
+        for n, p in omodel.named_parameters():
+            if "norm" in n and "linear" not in n and p.dim() == 1:
+                p.copy_(((1.0 if n.endswith("weight") else 0.0) + 0.1 * torch.randn(p.shape, generator=g)).to(p.dtype))
+    sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2."): v for k, v in omodel.state_dict().items()}
+    gmodel = MI355XCogVideoXTransformer3DModel(CogVideoXTransformerConfig(**kw), device=dev)
+    gmodel.load_diffusers_state_dict(sd)
+    gmodel.add_adapter(r=64, lora_alpha=64.0)
+    gmodel.load_lora_state_dict({k: v for k, v in sd.items() if "lora_" in k})
+
+    g = torch.Generator().manual_seed(11)
+    B, F_, C, H, W = 2, 3, 16, 8, 12
+    lat = torch.randn(B, F_, C, H, W, generator=g).to(bf16)
+    noise = torch.randn(B, F_, C, H, W, generator=g).to(bf16)
+    text = torch.randn(B, 16, 4096, generator=g).to(bf16)
+    sig = torch.tensor([0.21, 0.77])
+    osch = cvx.CogVideoXDDIMScheduler()
+
+    def run_oracle():
+        for p in omodel.parameters():
+            p.grad = None
+        pred, target, _ = cvx.spec_forward(omodel, osch, lat, text, sig, noise=noise)
+        loss = cvx.sft_loss(pred, target, sig, osch)
+        loss.backward()
+        return loss.item(), pred.detach(), {n: p.grad.detach().clone() for n, p in omodel.named_parameters() if p.grad is not None}
+
+    loss_ref, pred_ref, g_ref = run_oracle()
+    with ltx.accumulation_order_variant(512):
+        _, _, g_alt = run_oracle()
+    floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
+
+    spec = MI355XCogVideoXSpecOps()
+    pred, target, _ = spec.forward(gmodel, lat.to(dev), text.to(dev), sig.to(dev), noise=noise.to(dev))
+    loss = spec.loss_backward(pred, target, sig.to(dev))
+    torch.cuda.synchronize()
+    got = {k.replace(".lora_A.", ".lora_A.default.").replace(".lora_B.", ".lora_B.default."): None for k in gmodel.lora_state_dict()}
+    for i, blk in enumerate(gmodel.transformer_blocks):
+        for j, n in enumerate(("to_q", "to_k", "to_v", "to_out.0")):
+            got[f"transformer_blocks.{i}.attn1.{n}.lora_A.default.weight"] = blk.lora_A.grad[j].cpu()
+            got[f"transformer_blocks.{i}.attn1.{n}.lora_B.default.weight"] = blk.lora_B.grad[j].cpu()
+    assert set(got) == set(g_ref)
+    glob, worst = ltx.grads_rel_l2(got, g_ref)
+    e_pred, e_loss = _rel(pred.cpu(), pred_ref), abs(loss.item() - loss_ref) / abs(loss_ref)
+    print(f"[cog-model L=2] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref:.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
+          f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
+    assert e_pred < 1e-2 and e_loss < 1e-3
+    assert glob < 2.5 * floor + 1e-3 and worst < 2.5 * floor_worst + 2e-3
