@@ -153,14 +153,21 @@ class MI355XCogVideoXBlock(nn.Module):
         for name in ("wq", "wk", "wv", "wo", "ff1_w", "ff2_w"):
             setattr(self, name + "_t", ops.transpose_bf16(getattr(self, name)))
 
-    def add_adapter(self, r: int = 64, lora_alpha: float = 64.0) -> None:
+    def add_adapter(self, r: int = 64, lora_alpha: float = 64.0, storage_a: Optional[torch.Tensor] = None, storage_b: Optional[torch.Tensor] = None) -> None:
+        """``storage_a`` [4, r, D] / ``storage_b`` [4, D, r] fp32: views of a model-wide flat buffer (so one fused clip + AdamW launch covers every
+        block); allocated here when absent."""
         if r % 64 != 0:
             raise ValueError("this first cut takes ranks that are multiples of 64 (the LTX model shows the zero-padding route for the others)")
         dev, D = self.wq.device, self.dim
-        a = torch.empty(4, r, D, dtype=torch.float32, device=dev)
-        a.uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
+        a = torch.empty(4, r, D, dtype=torch.float32, device=dev) if storage_a is None else storage_a
+        b = torch.empty(4, D, r, dtype=torch.float32, device=dev) if storage_b is None else storage_b
+        if a.shape != (4, r, D) or b.shape != (4, D, r) or not a.is_contiguous() or not b.is_contiguous():
+            raise ValueError("adapter storage must be contiguous [4, r, D] / [4, D, r] fp32")
+        with torch.no_grad():
+            a.uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
+            b.zero_()
         self.lora_A = nn.Parameter(a)
-        self.lora_B = nn.Parameter(torch.zeros(4, D, r, dtype=torch.float32, device=dev))
+        self.lora_B = nn.Parameter(b)
         self.lora_scale = float(lora_alpha) / r
 
     def _ones(self, B: int, D: int, dev) -> torch.Tensor:

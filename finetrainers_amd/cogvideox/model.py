@@ -139,6 +139,8 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([MI355XCogVideoXBlock(D, c.num_attention_heads, c.time_embed_dim, c.ff_mult, c.norm_eps, dev)
                                                  for _ in range(c.num_layers)])
         self._pos_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self.lora_flat: Optional[torch.Tensor] = None
+        self.lora_rank = 0
 
     @property
     def device(self) -> torch.device:
@@ -165,8 +167,20 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
             blk.load_diffusers_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
 
     def add_adapter(self, r: int = 64, lora_alpha: float = 64.0) -> None:
-        for blk in self.transformer_blocks:
-            blk.add_adapter(r, lora_alpha)
+        """LoRA on to_q / to_k / to_v / to_out.0 of every block (the default target regex, sft_trainer/config.py:24-26).  All adapters live in ONE
+        flat fp32 buffer ``lora_flat`` = [A of every block | B of every block]; the blocks' Parameters are views."""
+        L, D = len(self.transformer_blocks), self.config.inner_dim
+        n = L * 4 * r * D
+        self.lora_flat = torch.zeros(2 * n, dtype=torch.float32, device=self.device)
+        a_all, b_all = self.lora_flat[:n].view(L, 4, r, D), self.lora_flat[n:].view(L, 4, D, r)
+        for i, blk in enumerate(self.transformer_blocks):
+            blk.add_adapter(r, lora_alpha, a_all[i], b_all[i])
+        self.lora_rank = r
+
+    def flat_lora_grad(self) -> torch.Tensor:
+        """The blocks' ``.grad`` tensors laid out like ``lora_flat`` (one copy of 2 L 4 r D floats: 118 MB at the 2b size)."""
+        blocks = self.transformer_blocks
+        return torch.cat([blk.lora_A.grad.reshape(-1) for blk in blocks] + [blk.lora_B.grad.reshape(-1) for blk in blocks])
 
     def lora_state_dict(self) -> Dict[str, torch.Tensor]:
         """peft-format keys: ``transformer_blocks.N.attn1.to_q.lora_A.weight`` ..."""

@@ -343,3 +343,20 @@ def test_model_step_parity_two_blocks():
           f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
     assert e_pred < 1e-2 and e_loss < 1e-3
     assert glob < 2.5 * floor + 1e-3 and worst < 2.5 * floor_worst + 2e-3
+
+    # the fused step on top: sigma table, DDIM noising, forward, loss, backward, flat gradient, clip + AdamW over the model-wide LoRA buffer
+    from finetrainers_amd.cogvideox import MI355XCogVideoXSFTStep
+
+    for blk in gmodel.transformer_blocks:
+        blk.lora_A.grad = blk.lora_B.grad = None
+    step = MI355XCogVideoXSFTStep(gmodel, spec, lr=1e-3, betas=(0.9, 0.99), generator=torch.Generator(device=dev).manual_seed(3))
+    sg = step.sample_sigmas(4096)
+    assert sg.min() >= 0 and sg.max() < 0.9995 and torch.isin(sg, step.sigma_table).all()  # values of timesteps / 1000
+    before = gmodel.lora_flat.clone()
+    out = step.step(lat.to(dev), text.to(dev), sigmas=sig.to(dev), noise=noise.to(dev))
+    torch.cuda.synchronize()
+    gn_ref = math.sqrt(sum(float(v.double().pow(2).sum()) for v in g_ref.values()))
+    print(f"[cog-step] loss {out['loss'].item():.6f} grad_norm {out['grad_norm'].item():.5e} vs oracle {gn_ref:.5e}")
+    assert abs(out["loss"].item() - loss_ref) < 1e-3 * abs(loss_ref) and abs(out["grad_norm"].item() - gn_ref) < 5e-3 * gn_ref
+    assert not torch.equal(gmodel.lora_flat, before) and gmodel.transformer_blocks[0].lora_A.grad is None
+    assert gmodel.transformer_blocks[1].lora_B.data_ptr() == gmodel.lora_flat[gmodel.lora_flat.numel() // 2:].view(2, 4, 1920, 64)[1].data_ptr()

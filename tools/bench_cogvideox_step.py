@@ -1,0 +1,58 @@
+"""BASELINE config 3 on one GPU: CogVideoX-2b LoRA r = 64 SFT optimisation step, 49 x 480 x 720 clip (latents [1, 13, 16, 60, 90]: 226 text + 17 550
+video tokens), 30 blocks, random-init weights of the 2b architecture, synthetic latents / text embeddings, bf16 base + fp32-equivalent LoRA, nothing
+recomputed.  Not the bench.py line (that is BASELINE's metric on configs[1]); this is config 3's measurement.
+    python tools/bench_cogvideox_step.py [steps] [layers]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from finetrainers_amd.cogvideox import (CogVideoXTransformerConfig, MI355XCogVideoXSFTStep, MI355XCogVideoXTransformer3DModel)  # noqa: E402
+
+dev = torch.device("cuda", 0)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+layers = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+bf16 = torch.bfloat16
+cfg = CogVideoXTransformerConfig(num_layers=layers)
+model = MI355XCogVideoXTransformer3DModel(cfg, device=dev)
+g = torch.Generator(device=dev).manual_seed(0)
+sd = {}
+
+
+def rnd(shape, fan_in):
+    return (torch.randn(shape, generator=g, device=dev) / fan_in ** 0.5).to(bf16)
+
+
+D = cfg.inner_dim
+for k, name in model._KEYS.items():
+    shp = getattr(model, name).shape
+    sd[k] = rnd(shp, shp[1]) if len(shp) == 2 else (torch.ones(shp, device=dev, dtype=bf16) if "norm" in k and k.endswith("weight") else 0.02 * rnd(shp, 1))
+sd["patch_embed.proj.weight"] = rnd((D, cfg.in_channels, 2, 2), 64)
+for i, blk in enumerate(model.transformer_blocks):
+    for k, name in blk._KEYS.items():
+        shp = getattr(blk, name).shape
+        sd[f"transformer_blocks.{i}.{k}"] = rnd(shp, shp[1]) if len(shp) == 2 else (torch.ones(shp, device=dev, dtype=bf16) if "norm" in k and k.endswith("weight") else 0.02 * rnd(shp, 1))
+model.load_diffusers_state_dict(sd)
+del sd
+model.add_adapter(r=64, lora_alpha=64.0)
+with torch.no_grad():
+    n = model.lora_flat.numel() // 2
+    model.lora_flat[n:].normal_(0, 0.01, generator=g)  # B != 0 so every gradient path carries data
+step = MI355XCogVideoXSFTStep(model, lr=5e-5, betas=(0.9, 0.99), generator=torch.Generator(device=dev).manual_seed(1))
+lat = torch.randn((1, 13, 16, 60, 90), generator=g, device=dev).to(bf16)
+text = torch.randn((1, 226, 4096), generator=g, device=dev).to(bf16)
+for _ in range(2):
+    out = step.step(lat, text)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    out = step.step(lat, text)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / steps * 1e3
+N, L = 226 + 17550, layers
+flop = L * (2.0 * N * D * D * 12 * 2 + 4.0 * N * N * D * 3.5)  # linears forward + dgrad, attention forward + 2.5 x backward (LoRA / embed / head terms omitted)
+print(f"CogVideoX-2b LoRA r=64 SFT step, 49x480x720 (226 + 17550 tokens), {L} blocks, batch 1: {ms:.1f} ms/step = {1e3 / ms:.3f} samples/s; "
+      f"{flop / ms / 1e9:.0f} TF/s algorithmic = {flop / ms / 1e9 / 2500:.3f} of the dense bf16 peak; loss {out['loss'].item():.4f} grad_norm {out['grad_norm'].item():.4e}; "
+      f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
