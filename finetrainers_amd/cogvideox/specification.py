@@ -106,3 +106,102 @@ class MI355XCogVideoXSpecOps:
                                    grad_scale=grad_scale)
         pred.backward(dpred)
         return loss.reshape(()) * grad_scale
+
+
+class MI355XCogVideoXModelSpecification(MI355XCogVideoXSpecOps):
+    """Mirror of ``CogVideoXModelSpecification`` (finetrainers/models/cogvideox/base_specification.py:80-420) for the SFT hot path: same constructor
+    keywords, ``_resolution_dim_keys``, ``load_diffusion_models``, ``collate_*``, ``forward`` with the reference's signature, ``_save_lora_weights``.
+    Text encoder, VAE, pipeline and validation stay with the reference."""
+
+    def __init__(self, pretrained_model_name_or_path: Optional[str] = "THUDM/CogVideoX-5b", tokenizer_id: Optional[str] = None,
+                 text_encoder_id: Optional[str] = None, transformer_id: Optional[str] = None, vae_id: Optional[str] = None,
+                 text_encoder_dtype: torch.dtype = torch.bfloat16, transformer_dtype: torch.dtype = torch.bfloat16, vae_dtype: torch.dtype = torch.bfloat16,
+                 revision: Optional[str] = None, cache_dir: Optional[str] = None, condition_model_processors: Optional[list] = None,
+                 latent_model_processors: Optional[list] = None, transformer_config=None, vae_scaling_factor: float = 1.15258426,
+                 invert_scale_latents: bool = False, **kwargs) -> None:
+        if transformer_dtype != torch.bfloat16:
+            raise ValueError("the MI355X backend computes in bf16 (fp32 accumulation); transformer_dtype must be torch.bfloat16")
+        super().__init__(scaling_factor=vae_scaling_factor, invert_scale_latents=invert_scale_latents)
+        self.pretrained_model_name_or_path = pretrained_model_name_or_path
+        self.tokenizer_id, self.text_encoder_id, self.transformer_id, self.vae_id = tokenizer_id, text_encoder_id, transformer_id, vae_id
+        self.text_encoder_dtype, self.transformer_dtype, self.vae_dtype = text_encoder_dtype, transformer_dtype, vae_dtype
+        self.revision, self.cache_dir = revision, cache_dir
+        self.condition_model_processors = condition_model_processors or []
+        self.latent_model_processors = latent_model_processors or []
+        self.transformer_config = transformer_config
+
+    def load_diffusion_models(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, device: Optional[torch.device] = None) -> Dict[str, object]:
+        """-> {"transformer", "scheduler"} (base_specification.py:150-170).  With no ``state_dict`` the frozen weights come from ``transformer_id`` or
+        ``<pretrained_model_name_or_path>/transformer`` (a local diffusers directory); a path that does not resolve RAISES -- never random weights."""
+        from .. import wire
+        from .model import CogVideoXTransformerConfig, MI355XCogVideoXTransformer3DModel
+
+        cfg = self.transformer_config
+        if state_dict is None:
+            directory = wire.resolve_transformer_dir(self.pretrained_model_name_or_path, self.transformer_id)
+            disk = wire.load_transformer_config(directory)
+            if disk.get("use_rotary_positional_embeddings") or disk.get("ofs_embed_dim") is not None or disk.get("patch_size_t") is not None:
+                raise NotImplementedError("this checkpoint is a rotary / 1.5 CogVideoX variant; the MI355X DiT covers the sincos-table 2b architecture so far")
+            if disk:
+                fields = CogVideoXTransformerConfig.__dataclass_fields__
+                cfg = CogVideoXTransformerConfig(**{k: disk[k] for k in fields if k in disk})
+            state_dict = wire.load_transformer_state_dict(directory)
+        cfg = cfg or CogVideoXTransformerConfig()
+        self.transformer_config = cfg
+        transformer = MI355XCogVideoXTransformer3DModel(cfg, device=device)
+        transformer.load_diffusers_state_dict(state_dict)
+        return {"transformer": transformer, "scheduler": self.scheduler}
+
+    @staticmethod
+    def _collate(data):
+        out = {}
+        for k in data[0]:
+            vals = [d[k] for d in data]
+            out[k] = torch.cat([v if v.dim() > 0 else v[None] for v in vals], dim=0) if torch.is_tensor(vals[0]) else vals[0]
+        return out
+
+    def collate_conditions(self, data):
+        return self._collate(data)
+
+    def collate_latents(self, data):
+        return self._collate(data)
+
+    def forward(self, transformer, condition_model_conditions: Dict[str, torch.Tensor], latent_model_conditions: Dict[str, torch.Tensor],
+                sigmas: torch.Tensor, scheduler=None, generator: Optional[torch.Generator] = None, compute_posterior: bool = True,
+                noise: Optional[torch.Tensor] = None, posterior_noise: Optional[torch.Tensor] = None, **kwargs):
+        """base_specification.py:258-333: -> (pred, target, sigmas).  ``compute_posterior = False``: "latents" are the VAE posterior's moments
+        [B, F, 2C, H, W] (what --enable_precomputation stores) and are sampled here (``DiagonalGaussianDistribution(..., _dim=2).sample``)."""
+        latents = latent_model_conditions.pop("latents")
+        if not compute_posterior:
+            B, F_, C2, H, W = latents.shape
+            mom = latents.to(torch.bfloat16).reshape(B * F_, C2, H, W)  # per (sample, frame): (mean | logvar) along the channel axis
+            if posterior_noise is None:
+                posterior_noise = torch.randn((B * F_, C2 // 2, H, W), generator=generator, device=mom.device, dtype=torch.bfloat16)
+            latents = ops.posterior_sample(mom, posterior_noise.reshape(B * F_, C2 // 2, H, W).to(mom)).view(B, F_, C2 // 2, H, W)
+        return MI355XCogVideoXSpecOps.forward(self, transformer, latents, condition_model_conditions["encoder_hidden_states"], sigmas, noise=noise,
+                                              generator=generator)
+
+    def _save_lora_weights(self, directory: str, transformer_state_dict: Optional[Dict[str, torch.Tensor]] = None, scheduler=None,
+                           metadata: Optional[Dict[str, str]] = None, *args, **kwargs) -> None:
+        """base_specification.py:366-384: ``pytorch_lora_weights.safetensors`` (``transformer.``-prefixed peft keys + metadata) and the scheduler config."""
+        import json
+        import os
+
+        from .. import wire
+
+        if transformer_state_dict is not None:
+            wire.save_lora_weights(directory, transformer_state_dict, metadata)
+        if scheduler is not None:
+            os.makedirs(os.path.join(directory, "scheduler"), exist_ok=True)
+            with open(os.path.join(directory, "scheduler", "scheduler_config.json"), "w") as f:
+                json.dump({"_class_name": "CogVideoXDDIMScheduler", "num_train_timesteps": scheduler.config.num_train_timesteps, "beta_start": 0.00085,
+                           "beta_end": 0.012, "beta_schedule": "scaled_linear", "snr_shift_scale": 3.0, "prediction_type": "v_prediction"}, f, indent=2)
+
+    def load_condition_models(self):
+        raise NotImplementedError("text encoders are outside the MI355X hot path; use the reference specification")
+
+    def load_latent_models(self):
+        raise NotImplementedError("the VAE is outside the MI355X hot path; use the reference specification")
+
+    def validation(self, *a, **k):
+        raise NotImplementedError("inference / validation is outside the MI355X hot path; use the reference specification")

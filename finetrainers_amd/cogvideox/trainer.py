@@ -46,7 +46,7 @@ class MI355XCogVideoXSFTStep:
         tr = self.transformer
         if sigmas is None:
             sigmas = self.sample_sigmas(latents.shape[0])
-        pred, target, _ = self.spec.forward(tr, latents, encoder_hidden_states, sigmas, noise=noise, generator=self.generator)
+        pred, target, _ = MI355XCogVideoXSpecOps.forward(self.spec, tr, latents, encoder_hidden_states, sigmas, noise=noise, generator=self.generator)
         loss = self.spec.loss_backward(pred, target, sigmas)
         gflat = tr.flat_lora_grad()
         if self.parallel is not None and self.parallel.active:

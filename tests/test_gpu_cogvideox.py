@@ -360,3 +360,105 @@ def test_model_step_parity_two_blocks():
     assert abs(out["loss"].item() - loss_ref) < 1e-3 * abs(loss_ref) and abs(out["grad_norm"].item() - gn_ref) < 5e-3 * gn_ref
     assert not torch.equal(gmodel.lora_flat, before) and gmodel.transformer_blocks[0].lora_A.grad is None
     assert gmodel.transformer_blocks[1].lora_B.data_ptr() == gmodel.lora_flat[gmodel.lora_flat.numel() // 2:].view(2, 4, 1920, 64)[1].data_ptr()
+
+
+def test_specification_mirror_loads_a_diffusers_directory_and_saves_lora(tmp_path):
+    """B1 for CogVideoX: the spec built with the reference's constructor keywords loads ``<root>/transformer`` (config.json + safetensors), refuses a path
+    that does not resolve, runs forward with the reference's dict arguments (also from stored posterior moments), and writes the LoRA file."""
+    import json
+
+    from safetensors.torch import save_file
+
+    from finetrainers_amd import ops, wire
+    from finetrainers_amd.cogvideox import MI355XCogVideoXModelSpecification
+    from oracle import cogvideox as cvx
+
+    dev = _dev()
+    kw = dict(num_layers=1, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
+    omodel = cvx.build_model(cvx.CogVideoXConfig(**kw), seed=0, rank=0)
+    sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2."): v.contiguous() for k, v in omodel.state_dict().items()
+          if "pos_embedding" not in k}
+    tdir = tmp_path / "snap" / "transformer"
+    tdir.mkdir(parents=True)
+    save_file(sd, str(tdir / "diffusion_pytorch_model.safetensors"))
+    (tdir / "config.json").write_text(json.dumps(dict(kw, num_attention_heads=30, attention_head_dim=64, use_rotary_positional_embeddings=False)))
+    with pytest.raises(FileNotFoundError):
+        MI355XCogVideoXModelSpecification(pretrained_model_name_or_path=str(tmp_path / "nope")).load_diffusion_models(device=dev)
+    spec = MI355XCogVideoXModelSpecification(pretrained_model_name_or_path=str(tmp_path / "snap"), transformer_dtype=bf16)
+    comps = spec.load_diffusion_models(device=dev)
+    model = comps["transformer"]
+    assert model.config.num_layers == 1 and spec._resolution_dim_keys == {"latents": (1, 3, 4)}
+    model.add_adapter(r=64, lora_alpha=64.0)
+    g = torch.Generator().manual_seed(1)
+    B, F_, C, H, W = 1, 3, 16, 8, 12
+    mean = torch.randn(B, F_, C, H, W, generator=g).to(bf16)
+    logvar = (torch.randn(B, F_, C, H, W, generator=g) * 0.3 - 3).to(bf16)
+    eps = torch.randn(B, F_, C, H, W, generator=g).to(bf16)
+    noise = torch.randn(B, F_, C, H, W, generator=g).to(bf16).to(dev)
+    text = torch.randn(B, 16, 4096, generator=g).to(bf16).to(dev)
+    sig = torch.tensor([0.4], device=dev)
+    cond = spec.collate_conditions([{"encoder_hidden_states": text}])
+    with torch.no_grad():
+        p1, t1, _ = spec.forward(model, dict(cond), spec.collate_latents([{"latents": torch.cat([mean, logvar], 2).to(dev)}]), sig, scheduler=comps["scheduler"],
+                                 compute_posterior=False, posterior_noise=eps.to(dev), noise=noise)
+        sampled = ops.posterior_sample(torch.cat([mean, logvar], 2).to(dev).view(B * F_, 2 * C, H, W), eps.to(dev).view(B * F_, C, H, W)).view(B, F_, C, H, W)
+        p2, t2, _ = spec.forward(model, dict(cond), {"latents": sampled}, sig, noise=noise)
+    assert torch.equal(p1, p2) and torch.equal(t1, t2) and p1.shape == (B, F_, C, H, W)
+    out = tmp_path / "ckpt"
+    spec._save_lora_weights(str(out), model.lora_state_dict(), comps["scheduler"], wire.lora_config_metadata(64, 64.0, ["to_q", "to_k", "to_v", "to_out.0"]))
+    tensors, meta = wire.load_lora_weights(str(out))
+    assert set(tensors) == {f"transformer.{k}" for k in model.lora_state_dict()} or set(tensors) == set(model.lora_state_dict())
+    assert (out / "scheduler" / "scheduler_config.json").exists()
+
+
+def _cog_two_rank_worker(rank, port, q):
+    import os
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+
+    from finetrainers_amd.cogvideox import CogVideoXTransformerConfig, MI355XCogVideoXSFTStep, MI355XCogVideoXTransformer3DModel
+    from finetrainers_amd.parallel import DataParallelBackend
+    from oracle import cogvideox as cvx
+
+    par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0))
+    try:
+        kw = dict(num_layers=1, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
+        omodel = cvx.build_model(cvx.CogVideoXConfig(**kw), seed=0, rank=0)
+        sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2."): v for k, v in omodel.state_dict().items()}
+        model = MI355XCogVideoXTransformer3DModel(CogVideoXTransformerConfig(**kw), device=par.device)
+        model.load_diffusers_state_dict(sd)
+        torch.manual_seed(100 + rank)  # different adapter init per rank: the step object broadcasts rank 0's
+        model.add_adapter(r=64, lora_alpha=64.0)
+        with torch.no_grad():
+            model.lora_flat[model.lora_flat.numel() // 2:].normal_(0, 0.02)
+        step = MI355XCogVideoXSFTStep(model, lr=1e-3, betas=(0.9, 0.99), parallel=par)
+        g = torch.Generator().manual_seed(50 + rank)
+        lat = torch.randn(1, 3, 16, 8, 12, generator=g).to(torch.bfloat16).to(par.device)
+        text = torch.randn(1, 16, 4096, generator=g).to(torch.bfloat16).to(par.device)
+        noise = torch.randn(1, 3, 16, 8, 12, generator=g).to(torch.bfloat16).to(par.device)
+        out = step.step(lat, text, sigmas=torch.tensor([0.3 + 0.4 * rank], device=par.device), noise=noise)
+        torch.cuda.synchronize()
+        q.put((rank, out["grad_norm"].item(), model.lora_flat.detach().cpu().numpy()))
+    finally:
+        par.destroy()
+
+
+def test_cogvideox_dp_step_two_ranks_on_one_gpu():
+    """World size 2 over gloo on one GPU: rank 0's adapter is broadcast, the flat LoRA gradient is averaged, both replicas end the step bit-identical."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_cog_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, g0, p0), (_, g1, p1) = res
+    assert g0 == g1 and (p0 == p1).all() and g0 > 0

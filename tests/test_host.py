@@ -513,3 +513,23 @@ def test_loss_weighting_and_density_schemes_match_oracle():
         b = ltx.compute_density_for_timestep_sampling(scheme, 16, logit_mean=0.0, logit_std=1.0, mode_scale=1.29, generator=g2)
         assert torch.equal(a, b), scheme
         assert (a >= 0).all() and (a <= 1).all()
+
+
+def test_cogvideox_host_tables_match_oracle():
+    """CogVideoX host-side constants (no kernels): the 3-D sincos position table, the timestep embedding, the DDIM alphas and the sigma table."""
+    from finetrainers_amd.cogvideox import CogVideoXDDIMTables, CogVideoXTransformerConfig
+    from finetrainers_amd.cogvideox.model import sincos_position_table, timestep_embedding
+    from oracle import cogvideox as cvx
+    from oracle import ltx
+
+    ocfg, cfg = cvx.CogVideoXConfig(), CogVideoXTransformerConfig()
+    for (h, w, f) in ((60, 90, 13), (10, 14, 3)):
+        ref = cvx.get_3d_sincos_pos_embed(ocfg.inner_dim, (w // 2, h // 2), f, ocfg.spatial_interpolation_scale, ocfg.temporal_interpolation_scale).flatten(0, 1)
+        assert torch.equal(sincos_position_table(cfg, h, w, f), ref)
+    t = torch.tensor([0, 31, 874, 999])
+    assert torch.equal(timestep_embedding(t, 1920), ltx.get_timestep_embedding(t, 1920))
+    tab, osch = CogVideoXDDIMTables(), cvx.CogVideoXDDIMScheduler()
+    assert torch.equal(tab.alphas_cumprod, osch.alphas_cumprod)
+    ts = torch.tensor([3, 500, 998])
+    assert torch.equal(tab.loss_weights(ts), 1 / (1 - osch.alphas_cumprod[ts]))
+    assert dict(cfg.__dict__, use_rotary_positional_embeddings=False, patch_size_t=None, ofs_embed_dim=None) == ocfg.__dict__  # the 2b defaults agree
