@@ -95,8 +95,8 @@ _SIGS = {
     "ftmi_clip_grad_norm": (c_int, [c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p]),
     "ftmi_cog_ln_mod_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ftmi_cog_ln_mod_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "ftmi_cog_head_ln_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
-    "ftmi_cog_head_ln_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "ftmi_cog_head_ln_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ftmi_cog_head_ln_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ftmi_cog_gate_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ftmi_cog_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ftmi_cog_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -6,8 +6,8 @@ gated residual -> CogVideoXLayerNormZero -> GELU-tanh feed-forward over the conc
 
 First cut of SURVEY 8f-1's block: the kernels are the product (MFMA GEMMs with fused LoRA / GELU / GELU' epilogues, flash attention over
 the 226 + 17 550 joint tokens, the row-wise stages of ``csrc/cogvideox.hip``); the ORCHESTRATION is still Python -- ~35 C-ABI calls per
-block and direction -- where the LTX path has a C++ orchestrator with a caller-owned workspace (that, the fused q|k|v projection and the
-CogVideoX-5b rotary variant are the next steps).  Tokens live in one buffer ``[B, T + S, D]``, text first: the joint attention's own order,
+block and direction -- where the LTX path has a C++ orchestrator with a caller-owned workspace (that and the fused q|k|v projection are the
+next steps).  Both checkpoint families are covered: sincos-table (2b) and rotary (5b: RoPE on the video rows of q / k, fused into the head norm).  Tokens live in one buffer ``[B, T + S, D]``, text first: the joint attention's own order,
 so nothing is ever concatenated or split.  The only torch ops are on per-sample conditioning vectors (``silu(temb)`` [B, 512], ``1 + scale``
 [B, 2, D]) -- no token-sized tensor is touched outside a kernel.
 """
@@ -27,7 +27,7 @@ LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0")
 
 class _BlockFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, blk: "MI355XCogVideoXBlock", x, temb_silu, text_len, lora_a, lora_b):
+    def forward(ctx, blk: "MI355XCogVideoXBlock", x, temb_silu, text_len, lora_a, lora_b, rope_cos=None, rope_sin=None):
         B, N, D = x.shape
         M, H, T = B * N, blk.heads, int(text_len)
         s = blk.lora_scale
@@ -46,8 +46,9 @@ class _BlockFunction(torch.autograd.Function):
         q, xa_q = ops.linear_lora_fwd(n1_2d, blk.wq, blk.bq, A(0), Bm(0), s)
         k, xa_k = ops.linear_lora_fwd(n1_2d, blk.wk, blk.bk, A(1), Bm(1), s)
         v, xa_v = ops.linear_lora_fwd(n1_2d, blk.wv, blk.bv, A(2), Bm(2), s)
-        qn = ops.cog_head_ln(q, blk.norm_q_w, blk.norm_q_b, blk.qk_eps)
-        kn = ops.cog_head_ln(k, blk.norm_k_w, blk.norm_k_b, blk.qk_eps)
+        rope = None if rope_cos is None else (rope_cos, rope_sin)  # rotary checkpoints: applied to the video rows of q and k after the norm
+        qn = ops.cog_head_ln(q, blk.norm_q_w, blk.norm_q_b, blk.qk_eps, rope=rope, rows_per_batch=N, text_len=T)
+        kn = ops.cog_head_ln(k, blk.norm_k_w, blk.norm_k_b, blk.qk_eps, rope=rope, rows_per_batch=N, text_len=T)
         heads = lambda t: t.view(B, N, H, 64).permute(0, 2, 1, 3)
         o, lse = ops.attn_fwd(heads(qn), heads(kn), heads(v))
         o_2d = o.permute(0, 2, 1, 3).reshape(M, D)  # a view: the kernel wrote [B, N, H, 64]
@@ -59,7 +60,7 @@ class _BlockFunction(torch.autograd.Function):
         f = ops.gemm_nt(act, blk.ff2_w, blk.ff2_b)
         out = ops.cog_gate_residual(h1, f.view(B, N, D), gate2, T)
 
-        ctx.blk, ctx.T = blk, T
+        ctx.blk, ctx.T, ctx.rope = blk, T, rope
         ctx.has_lora = lora_a is not None
         ctx.save_for_backward(x, n1, q, k, qn, kn, v, o, lse, h1, n2, pre, onep1, gate1, onep2, gate2, xa_q, xa_k, xa_v, xa_o,
                               lora_a if lora_a is not None else x.new_empty(0), lora_b if lora_b is not None else x.new_empty(0))
@@ -93,8 +94,8 @@ class _BlockFunction(torch.autograd.Function):
         heads = lambda t: t.view(B, N, H, 64).permute(0, 2, 1, 3)
         dqn, dkn, dv = ops.attn_bwd(heads(qn), heads(kn), heads(v), o, lse, heads(do))
         flat = lambda t: t.permute(0, 2, 1, 3).reshape(M, D)
-        dq = ops.cog_head_ln_bwd(q, blk.norm_q_w, flat(dqn), blk.qk_eps)
-        dk = ops.cog_head_ln_bwd(k, blk.norm_k_w, flat(dkn), blk.qk_eps)
+        dq = ops.cog_head_ln_bwd(q, blk.norm_q_w, flat(dqn), blk.qk_eps, rope=ctx.rope, rows_per_batch=N, text_len=T)
+        dk = ops.cog_head_ln_bwd(k, blk.norm_k_w, flat(dkn), blk.qk_eps, rope=ctx.rope, rows_per_batch=N, text_len=T)
         n1_2d = n1.view(M, D)
         dn_q, _, _ = ops.linear_lora_bwd(n1_2d, dq, xa_q, blk.wq_t, A(0), Bm(0), s, GA(0), GB(0))
         dn_k, _, _ = ops.linear_lora_bwd(n1_2d, dk, xa_k, blk.wk_t, A(1), Bm(1), s, GA(1), GB(1))
@@ -105,7 +106,7 @@ class _BlockFunction(torch.autograd.Function):
         dn1 = ops.cog_gate_residual(dn_v.view(B, N, D), dn_k.view(B, N, D), ones, 0)
         dn1 = ops.cog_gate_residual(dn1, dn_q.view(B, N, D), ones, 0)
         dx = ops.cog_ln_mod_bwd(x, blk.norm1_w, onep1, dn1, T, blk.norm_eps, dres=dh1)
-        return None, dx, None, None, ga, gb
+        return None, dx, None, None, ga, gb, None, None
 
 
 class MI355XCogVideoXBlock(nn.Module):
@@ -176,10 +177,11 @@ class MI355XCogVideoXBlock(nn.Module):
             self._ones_cache[key] = torch.ones(B, D, dtype=bf16, device=dev)
         return self._ones_cache[key]
 
-    def forward(self, tokens: torch.Tensor, temb: torch.Tensor, text_len: int) -> torch.Tensor:
+    def forward(self, tokens: torch.Tensor, temb: torch.Tensor, text_len: int, image_rotary_emb=None) -> torch.Tensor:
         """``tokens`` [B, T + S, D] bf16 (text first), ``temb`` [B, time_embed_dim] bf16 -> the block's output tokens in the same layout
         (``[:, :T]`` = encoder_hidden_states, ``[:, T:]`` = hidden_states of the reference block)."""
         if self.wq_t is None:
             raise RuntimeError("load_diffusers_state_dict first (it also builds the transposed weights the dgrads use)")
         temb_silu = torch.nn.functional.silu(temb.to(bf16)).contiguous()
-        return _BlockFunction.apply(self, tokens.contiguous(), temb_silu, int(text_len), self.lora_A, self.lora_B)
+        cos, sin = (None, None) if image_rotary_emb is None else image_rotary_emb
+        return _BlockFunction.apply(self, tokens.contiguous(), temb_silu, int(text_len), self.lora_A, self.lora_B, cos, sin)

@@ -3,8 +3,8 @@
 below block 0 needs a gradient).
 
 Reference: [upstream] diffusers ``CogVideoXTransformer3DModel`` as the reference drives it (``finetrainers/models/cogvideox/base_specification.py:
-296-333``), restated in ``oracle/cogvideox.py``.  This is the sincos-table variant (CogVideoX-2b, ``use_rotary_positional_embeddings = False``,
-BASELINE config 3); the rotary variant (5b) needs RoPE on the video part of q / k and is not wired yet.
+296-333``), restated in ``oracle/cogvideox.py``.  Both the sincos-table checkpoints (CogVideoX-2b, BASELINE config 3) and the rotary ones (5b: ``use_rotary_positional_embeddings``, RoPE on the
+video rows of q / k) are covered; the 1.5 family (``patch_size_t``, ``ofs``) is not.
 
 Token layout: ONE buffer ``[B, T + S, D]``, the T = ``max_text_seq_length`` text tokens first.  Orchestration is Python over C-ABI calls (see
 ``block.py``); torch ops touch only per-sample conditioning vectors ([B, 1920] / [B, 512]) and the host-built constant tables.
@@ -46,6 +46,7 @@ class CogVideoXTransformerConfig:
     spatial_interpolation_scale: float = 1.875
     temporal_interpolation_scale: float = 1.0
     ff_mult: int = 4
+    use_rotary_positional_embeddings: bool = False  # 2b: sincos table added in the patch embed; 5b: rotary embedding inside the attention
 
     @property
     def inner_dim(self) -> int:
@@ -71,6 +72,34 @@ def sincos_position_table(cfg: CogVideoXTransformerConfig, height: int, width: i
     pos_t = _sincos_1d(d_t, torch.arange(frames, dtype=torch.float32) / cfg.temporal_interpolation_scale)  # [frames, d_t]
     table = torch.cat([pos_t[:, None, :].expand(frames, ph * pw, d_t), pos_sp[None].expand(frames, ph * pw, d_sp)], dim=-1)
     return table.reshape(frames * ph * pw, D).float()
+
+
+def rotary_tables(cfg: CogVideoXTransformerConfig, height: int, width: int, frames: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``prepare_rotary_positional_embeddings`` (finetrainers/models/cogvideox/utils.py:8-51, the ``patch_size_t is None`` branch) for LATENT sizes:
+    (cos, sin) fp32 [frames * gh * gw, 64]; head channels split t : h : w = 16 : 24 : 24, each frequency repeated for its channel pair; spatial positions
+    are a linspace over the crop of the base grid (sample_height / sample_width) that matches this clip's aspect ratio."""
+    p, d = cfg.patch_size, cfg.attention_head_dim
+    gh, gw, bh, bw = height // p, width // p, cfg.sample_height // p, cfg.sample_width // p
+    if gh / gw > bh / bw:  # get_resize_crop_region_for_grid((gh, gw), bw, bh)
+        rh, rw = bh, int(round(bh / gh * gw))
+    else:
+        rw, rh = bw, int(round(bw / gw * gh))
+    top, left = int(round((bh - rh) / 2.0)), int(round((bw - rw) / 2.0))
+    grid_h = torch.linspace(top, (top + rh) * (gh - 1) / gh, gh, dtype=torch.float32)
+    grid_w = torch.linspace(left, (left + rw) * (gw - 1) / gw, gw, dtype=torch.float32)
+    grid_t = torch.linspace(0, frames * (frames - 1) / frames, frames, dtype=torch.float32)
+
+    def one(dim, pos):
+        ang = torch.outer(pos, 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim)))
+        return ang.cos().repeat_interleave(2, dim=1).float(), ang.sin().repeat_interleave(2, dim=1).float()
+
+    (ct, st), (ch, sh), (cw, sw) = one(d // 4, grid_t), one(d // 8 * 3, grid_h), one(d // 8 * 3, grid_w)
+
+    def combine(t, h, w):
+        return torch.cat([t[:, None, None, :].expand(-1, gh, gw, -1), h[None, :, None, :].expand(frames, -1, gw, -1),
+                          w[None, None, :, :].expand(frames, gh, -1, -1)], dim=-1).reshape(frames * gh * gw, -1).contiguous()
+
+    return combine(ct, ch, cw), combine(st, sh, sw)
 
 
 def timestep_embedding(timesteps: torch.Tensor, dim: int) -> torch.Tensor:
@@ -220,25 +249,31 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
         tokens = torch.empty((B, T + S, D), dtype=bf16, device=self.device)
         patches = ops.cog_patchify(hidden_states.to(bf16), p)
         text = encoder_hidden_states.to(bf16).contiguous()
-        pos = self._pos_table(F_, H, W)
+        pos = None if c.use_rotary_positional_embeddings else self._pos_table(F_, H, W)
         for b in range(B):
             ops.gemm_nt(text[b], self.text_w, self.text_b, out=tokens[b, :T])
             ops.gemm_nt(patches[b], self.patch_w, self.patch_b, out=tokens[b, T:])
-            ops.cog_gate_residual(pos, tokens[b:b + 1], self._ones_row, 0, out=tokens[b:b + 1])  # + sincos table (text rows: + 0)
+            if pos is not None:
+                ops.cog_gate_residual(pos, tokens[b:b + 1], self._ones_row, 0, out=tokens[b:b + 1])  # + sincos table (text rows: + 0)
         t_emb = timestep_embedding(timestep.to(self.device), D).to(bf16)
         emb = ops.gemm_nt(torch.nn.functional.silu(ops.gemm_nt(t_emb, self.time1_w, self.time1_b)), self.time2_w, self.time2_b)
         mod = ops.gemm_nt(torch.nn.functional.silu(emb), self.norm_out_lin_w, self.norm_out_lin_b)  # AdaLayerNorm: shift, scale = chunk(2)
         return tokens, emb, (1 + mod[:, D:]).contiguous(), mod[:, :D].contiguous()
 
     def forward(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb=None, ofs=None, return_dict: bool = False, **kwargs):
-        if image_rotary_emb is not None or ofs is not None:
-            raise NotImplementedError("the rotary / ofs variants (CogVideoX-5b, 1.5) are not wired yet")
+        if ofs is not None:
+            raise NotImplementedError("the ofs / patch_size_t variants (CogVideoX 1.5) are not wired yet")
+        c = self.config
+        if c.use_rotary_positional_embeddings != (image_rotary_emb is not None):
+            raise ValueError("image_rotary_emb must be given exactly for the rotary checkpoints (use_rotary_positional_embeddings)")
+        if image_rotary_emb is not None:
+            image_rotary_emb = tuple(t.to(device=self.device, dtype=torch.float32).contiguous() for t in image_rotary_emb)
         if self.proj_out_w_t is None:
             raise RuntimeError("load_diffusers_state_dict first")
         tokens, emb, onep_out, shift_out = self._embed(hidden_states, encoder_hidden_states, timestep)
         T = self.config.max_text_seq_length
         for blk in self.transformer_blocks:
-            tokens = blk(tokens, emb, T)
+            tokens = blk(tokens, emb, T, image_rotary_emb)
         B, F_, C, H, W = hidden_states.shape
         vel = _HeadFunction.apply(self, tokens, onep_out, shift_out, (F_, H, W))
         return {"sample": vel} if return_dict else (vel,)

@@ -87,6 +87,11 @@ class MI355XCogVideoXSpecOps:
                 image_rotary_emb=None, noise: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
         """-> (pred, target, sigmas) like the reference (:258-333)."""
         noisy, target, timesteps = self.noise_and_target(latents, sigmas, noise, generator)
+        tcfg = getattr(transformer, "config", None)
+        if image_rotary_emb is None and getattr(tcfg, "use_rotary_positional_embeddings", False):  # base_specification.py:302-317
+            from .model import rotary_tables
+
+            image_rotary_emb = tuple(t.to(noisy.device) for t in rotary_tables(tcfg, noisy.shape[3], noisy.shape[4], noisy.shape[1]))
         velocity = transformer(hidden_states=noisy, encoder_hidden_states=encoder_hidden_states, timestep=timesteps, image_rotary_emb=image_rotary_emb,
                                ofs=None, return_dict=False)[0]
         sa, so = self.scheduler.coefficients(timesteps)
@@ -140,8 +145,8 @@ class MI355XCogVideoXModelSpecification(MI355XCogVideoXSpecOps):
         if state_dict is None:
             directory = wire.resolve_transformer_dir(self.pretrained_model_name_or_path, self.transformer_id)
             disk = wire.load_transformer_config(directory)
-            if disk.get("use_rotary_positional_embeddings") or disk.get("ofs_embed_dim") is not None or disk.get("patch_size_t") is not None:
-                raise NotImplementedError("this checkpoint is a rotary / 1.5 CogVideoX variant; the MI355X DiT covers the sincos-table 2b architecture so far")
+            if disk.get("ofs_embed_dim") is not None or disk.get("patch_size_t") is not None:
+                raise NotImplementedError("this checkpoint is a CogVideoX 1.5 variant (patch_size_t / ofs); the MI355X DiT covers the 2b and 5b architectures")
             if disk:
                 fields = CogVideoXTransformerConfig.__dataclass_fields__
                 cfg = CogVideoXTransformerConfig(**{k: disk[k] for k in fields if k in disk})

@@ -407,19 +407,25 @@ int ftmi_cog_ln_mod_bwd(const void* x, const void* w, const void* onep, const vo
     return cog_ln_mod_bwd(a, (hipStream_t)stream);
 }
 
-int ftmi_cog_head_ln_fwd(const void* x, long ld, const void* w, const void* b, void* y, int rows, int D, float eps, ftmi_stream stream) {
-    if (!x || !w || !b || !y || ld < D || (ld % 8)) return set_error(FTMI_ERR_INVALID, "ftmi_cog_head_ln_fwd: bad argument");
+int ftmi_cog_head_ln_fwd(const void* x, long ld, const void* w, const void* b, void* y, int rows, int D, float eps, const float* rope_cos,
+                         const float* rope_sin, int rows_per_batch, int text_len, ftmi_stream stream) {
+    if (!x || !w || !b || !y || ld < D || (ld % 8) || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_cog_head_ln_fwd: bad argument");
     CogLnArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.b = (const bf16_t*)b; a.y = (bf16_t*)y; a.rows = rows; a.D = D; a.ld = ld; a.eps = eps;
-    a.rows_per_batch = rows > 0 ? rows : 1;
+    a.cos = rope_cos; a.sin = rope_sin; a.seg0 = rope_cos ? text_len : 0;
+    a.rows_per_batch = rope_cos ? rows_per_batch : (rows > 0 ? rows : 1);
     return cog_head_ln_fwd(a, (hipStream_t)stream);
 }
 
-int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, void* dx, int rows, int D, float eps, ftmi_stream stream) {
-    if (!x || !w || !dy || !dx || ld < D || (ld % 8)) return set_error(FTMI_ERR_INVALID, "ftmi_cog_head_ln_bwd: bad argument");
+int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, void* dx, int rows, int D, float eps, const float* rope_cos,
+                         const float* rope_sin, int rows_per_batch, int text_len, ftmi_stream stream) {
+    if (!x || !w || !dy || !dx || ld < D || (ld % 8) || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_cog_head_ln_bwd: bad argument");
     CogLnArgs a;
     a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.dy = (const bf16_t*)dy; a.dx = (bf16_t*)dx; a.rows = rows; a.D = D; a.ld = ld; a.eps = eps;
-    a.rows_per_batch = rows > 0 ? rows : 1;
+    a.cos = rope_cos; a.sin = rope_sin; a.seg0 = rope_cos ? text_len : 0;
+    a.rows_per_batch = rope_cos ? rows_per_batch : (rows > 0 ? rows : 1);
     return cog_head_ln_bwd(a, (hipStream_t)stream);
 }
 

@@ -164,22 +164,38 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(CogLnArgs a) {
     }
 }
 
-// ---- per-head LayerNorm over 64 channels (affine), forward and x-gradient ----------------------------------------------------------------
+// ---- per-head LayerNorm over 64 channels (affine) [+ rotary embedding on the video rows], forward and x-gradient -------------------------
+// CogVideoXAttnProcessor2_0: q, k <- norm_q / norm_k (LayerNorm per head), then -- rotary checkpoints (CogVideoX-5b) -- apply_rotary_emb on the video
+// tokens only: channel pairs (2i, 2i+1) of a head rotate by the angle of (position, i); cos / sin are fp32 [S, 64] with every frequency repeated
+// twice (embeddings.apply_rotary_emb(use_real=True, use_real_unbind_dim=-1)):  out = bf(n * cos + rot(n) * sin),  rot(n) = (-n[2i+1], n[2i]).
 template <int NC, bool BWD>
 __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const int nchunk = a.D / 8;
     const long ro = (long)row * a.ld;
+    const int pos = row % a.rows_per_batch;
+    const bool rope = a.cos != nullptr && pos >= a.seg0;
+    const float* cp = rope ? a.cos + (long)(pos - a.seg0) * 64 : nullptr;
+    const float* sp = rope ? a.sin + (long)(pos - a.seg0) * 64 : nullptr;
 #pragma unroll
     for (int it = 0; it < NC; ++it) {
         const int c = lane + 64 * it;  // chunk c covers channels 8 (c % 8) .. +7 of head c / 8; the 8 lanes of a head are adjacent
         const bool on = c < nchunk;
-        float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wv[8], bv[8];
+        float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wv[8], bv[8], cv[8], sv[8];
         if (on) {
             up8(a.x + ro + c * 8, xv);
             up8(a.w + (c & 7) * 8, wv);
             if (!BWD) up8(a.b + (c & 7) * 8, bv);
+            if (rope) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp + (c & 7) * 8), c1 = *reinterpret_cast<const f32x4*>(cp + (c & 7) * 8 + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + (c & 7) * 8), s1 = *reinterpret_cast<const f32x4*>(sp + (c & 7) * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cv[e] = c0[e]; cv[4 + e] = c1[e];
+                    sv[e] = s0[e]; sv[4 + e] = s1[e];
+                }
+            }
         }
         float s = 0.f;
 #pragma unroll
@@ -193,11 +209,31 @@ __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
         if constexpr (!BWD) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = on ? (xv[e] - mean) * rstd * wv[e] + bv[e] : 0.f;
+            if (rope && on) {
+                float n[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) n[e] = rbf(o[e]);  // the LayerNorm output is a bf16 tensor
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    o[e] = n[e] * cv[e] - n[e + 1] * sv[e];
+                    o[e + 1] = n[e + 1] * cv[e + 1] + n[e] * sv[e + 1];
+                }
+            }
             if (on) st8(a.y + ro + c * 8, o);
         } else {
             float gv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8];
             if (on) {
                 up8(a.dy + ro + c * 8, dv);
+                if (rope) {  // gradient of the bf16 LayerNorm output: the cos term and the (bf16-path) rotated term, each a bf16 tensor, added in bf16
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        t[e] = rbf(rbf(dv[e] * cv[e]) + rbf(dv[e + 1] * sv[e + 1]));
+                        t[e + 1] = rbf(rbf(dv[e + 1] * cv[e + 1]) - rbf(dv[e] * sv[e]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dv[e] = t[e];
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) gv[e] = dv[e] * wv[e];
             }

@@ -220,6 +220,8 @@ struct CogLnArgs {
     const bf16_t* onep = nullptr;   // modulation (1 + scale), or the gate of gate_residual
     const bf16_t* dy = nullptr;
     const bf16_t* dres = nullptr;   // ln_mod_bwd: gradient on the residual branch; gate_residual: the residual input
+    const float* cos = nullptr;     // head_ln: rotary tables fp32 [S, 64] for the rows at position >= seg0 of a sample (null: no rotary embedding)
+    const float* sin = nullptr;
     bf16_t* y = nullptr;
     bf16_t* dx = nullptr;
     int rows = 0, D = 0, rows_per_batch = 1, seg0 = 0;

@@ -256,10 +256,23 @@ def cog_ln_mod_bwd(x, w, onep, dy, text_len: int, eps: float = 1e-5, dres=None):
     return dx
 
 
-def cog_head_ln(x2d, w, b, eps: float = 1e-6, out=None):
-    """LayerNorm over each 64-channel head of the rows of x2d [M, D] (a column slice of a wider buffer is fine: row stride = x2d.stride(0))."""
+def _rope_args(rope, rows_per_batch, text_len):
+    if rope is None:
+        return None, None, 0, 0
+    cos, sin = rope
+    require_gpu_tensor(cos, "rope cos", torch.float32)
+    require_gpu_tensor(sin, "rope sin", torch.float32)
+    if cos.shape != sin.shape or cos.dim() != 2 or cos.shape[1] != 64 or cos.shape[0] != rows_per_batch - text_len or not cos.is_contiguous() or not sin.is_contiguous():
+        raise ValueError(f"rotary tables must be contiguous fp32 [video tokens = {rows_per_batch - text_len}, 64], got {tuple(cos.shape)}")
+    return cos, sin, int(rows_per_batch), int(text_len)
+
+
+def cog_head_ln(x2d, w, b, eps: float = 1e-6, out=None, rope=None, rows_per_batch: int = 0, text_len: int = 0):
+    """LayerNorm over each 64-channel head of the rows of x2d [M, D] (a column slice of a wider buffer is fine: row stride = x2d.stride(0));
+    ``rope = (cos, sin)`` fp32 [S, 64]: rotary embedding on the rows at position >= text_len of every rows_per_batch-token sample."""
     require_gpu_tensor(x2d, "x", bf16)
     M, D = x2d.shape
+    cos, sin, rpb, tl = _rope_args(rope, rows_per_batch, text_len)
     if x2d.stride(1) != 1:
         raise ValueError("head LayerNorm: channels must be contiguous")
     y = torch.empty((M, D), dtype=bf16, device=x2d.device) if out is None else out
@@ -267,19 +280,22 @@ def cog_head_ln(x2d, w, b, eps: float = 1e-6, out=None):
         y_c = torch.empty_strided((M, D), (x2d.stride(0), 1), dtype=bf16, device=x2d.device)
     else:
         y_c = y
-    check(_lib.load().ftmi_cog_head_ln_fwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(b), ptr(y_c), M, D, float(eps), stream_ptr()), "ftmi_cog_head_ln_fwd")
+    check(_lib.load().ftmi_cog_head_ln_fwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(b), ptr(y_c), M, D, float(eps), ptr(cos), ptr(sin), rpb, tl, stream_ptr()),
+          "ftmi_cog_head_ln_fwd")
     if y_c is not y:
         y.copy_(y_c)
     return y
 
 
-def cog_head_ln_bwd(x2d, w, dy2d, eps: float = 1e-6):
+def cog_head_ln_bwd(x2d, w, dy2d, eps: float = 1e-6, rope=None, rows_per_batch: int = 0, text_len: int = 0):
     require_gpu_tensor(x2d, "x", bf16)
     M, D = x2d.shape
+    cos, sin, rpb, tl = _rope_args(rope, rows_per_batch, text_len)
     if x2d.stride(0) != dy2d.stride(0) or x2d.stride(1) != 1 or dy2d.stride(1) != 1:
         raise ValueError("head LayerNorm backward: x and dy must share one row stride")
     dx = torch.empty_strided((M, D), (x2d.stride(0), 1), dtype=bf16, device=x2d.device)
-    check(_lib.load().ftmi_cog_head_ln_bwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(dy2d), ptr(dx), M, D, float(eps), stream_ptr()), "ftmi_cog_head_ln_bwd")
+    check(_lib.load().ftmi_cog_head_ln_bwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(dy2d), ptr(dx), M, D, float(eps), ptr(cos), ptr(sin), rpb, tl, stream_ptr()),
+          "ftmi_cog_head_ln_bwd")
     return dx
 
 

@@ -243,9 +243,14 @@ int ftmi_cog_ln_mod_fwd(const void* x, const void* w, const void* b, const void*
 /* dx = [dres +] LayerNorm'(x)[bf(dy * onep) * w]            (dres: gradient arriving on the residual branch, may be NULL) */
 int ftmi_cog_ln_mod_bwd(const void* x, const void* w, const void* onep, const void* dy, const void* dres, void* dx, int rows, int D,
                         int rows_per_batch, int text_len, float eps, ftmi_stream stream);
-/* q / k LayerNorm over each head's 64 channels (w, b: [64]); x, y, dy, dx: rows of D channels, row stride ld elements */
-int ftmi_cog_head_ln_fwd(const void* x, long ld, const void* w, const void* b, void* y, int rows, int D, float eps, ftmi_stream stream);
-int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, void* dx, int rows, int D, float eps, ftmi_stream stream);
+/* q / k LayerNorm over each head's 64 channels (w, b: [64]); x, y, dy, dx: rows of D channels, row stride ld elements.
+ * rope_cos / rope_sin (fp32 [S, 64], every frequency repeated twice; NULL for the sincos-table checkpoints): rotary embedding of the rotary
+ * checkpoints (CogVideoX-5b), applied after the norm to the video rows only -- token position >= text_len within its rows_per_batch-token sample --
+ * as diffusers' apply_rotary_emb(use_real=True, use_real_unbind_dim=-1) does on channel pairs (2i, 2i+1). */
+int ftmi_cog_head_ln_fwd(const void* x, long ld, const void* w, const void* b, void* y, int rows, int D, float eps, const float* rope_cos,
+                         const float* rope_sin, int rows_per_batch, int text_len, ftmi_stream stream);
+int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, void* dx, int rows, int D, float eps, const float* rope_cos,
+                         const float* rope_sin, int rows_per_batch, int text_len, ftmi_stream stream);
 /* out = res + bf(gate * y)   (res NULL: out = bf(gate * y), which is also the y-gradient of the same op) */
 int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, void* out, int rows, int D, int rows_per_batch, int text_len,
                            ftmi_stream stream);

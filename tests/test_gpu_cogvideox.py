@@ -159,6 +159,36 @@ def test_head_layernorm_fwd_bwd(D):
     assert e_y < 1.5e-3 and e_dx < 4e-3
 
 
+def test_head_layernorm_with_rotary_embedding_fwd_bwd():
+    """Rotary checkpoints (CogVideoX-5b): per-head LayerNorm followed by apply_rotary_emb on the video rows only, fused; against the eager graph
+    (oracle/cogvideox.py apply_rotary_emb = diffusers' use_real, unbind_dim=-1 form)."""
+    from finetrainers_amd import ops
+    from oracle import cogvideox as cvx
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    B, T, S, H = 2, 3, 10, 6
+    D, N = H * 64, T + S
+    x = (torch.randn(B * N, D, generator=g) * 2).to(bf16)
+    w = (1 + 0.1 * torch.randn(64, generator=g)).to(bf16)
+    b = (0.1 * torch.randn(64, generator=g)).to(bf16)
+    dy = torch.randn(B * N, D, generator=g).to(bf16)
+    cos, sin = cvx._rotary_1d(64, torch.arange(S) * 0.37)
+    xr = x.clone().requires_grad_(True)
+    n = torch.nn.functional.layer_norm(xr.view(B, N, H, 64).transpose(1, 2), (64,), w, b, 1e-6)  # [B, H, N, 64]
+    y_ref = torch.cat([n[:, :, :T], cvx.apply_rotary_emb(n[:, :, T:], (cos, sin))], dim=2)
+    y_ref.backward(dy.view(B, N, H, 64).transpose(1, 2))
+    rope = (cos.to(dev), sin.to(dev))
+    y = ops.cog_head_ln(x.to(dev), w.to(dev), b.to(dev), rope=rope, rows_per_batch=N, text_len=T)
+    dx = ops.cog_head_ln_bwd(x.to(dev), w.to(dev), dy.to(dev), rope=rope, rows_per_batch=N, text_len=T)
+    e_y = _rel(y.cpu().view(B, N, H, 64).transpose(1, 2), y_ref)
+    e_dx = _rel(dx.cpu(), xr.grad)
+    print(f"[cog-head-ln+rope] y {e_y:.2e} dx {e_dx:.2e}")
+    assert e_y < 1.5e-3 and e_dx < 4e-3
+    plain = ops.cog_head_ln(x.to(dev), w.to(dev), b.to(dev))
+    assert torch.equal(y.view(B, N, D)[:, :T], plain.view(B, N, D)[:, :T]) and not torch.equal(y.view(B, N, D)[:, T:], plain.view(B, N, D)[:, T:])
+
+
 def test_gate_residual_is_bit_exact():
     from finetrainers_amd import ops
 
@@ -284,15 +314,17 @@ def test_patchify_roundtrip_and_position_table():
     assert torch.equal(timestep_embedding(t, 1920), ltx.get_timestep_embedding(t, 1920))
 
 
-def test_model_step_parity_two_blocks():
-    """The whole CogVideoX-2b-width SFT forward + backward at 2 blocks: spec ops (scaling, DDIM noising), patch embed + sincos table, time
+@pytest.mark.parametrize("rotary", [False, True])
+def test_model_step_parity_two_blocks(rotary):
+    """(rotary = False: the 2b sincos-table architecture, BASELINE config 3; True: the 5b-style rotary embedding on the video rows of q / k.)
+    The whole CogVideoX-2b-width SFT forward + backward at 2 blocks: spec ops (scaling, DDIM noising), patch embed + sincos table, time
     embedding, blocks, final norms, proj_out, un-patchify, velocity -> x0, weighted loss, and every LoRA gradient, against oracle/cogvideox.py."""
     from finetrainers_amd.cogvideox import CogVideoXTransformerConfig, MI355XCogVideoXSpecOps, MI355XCogVideoXTransformer3DModel
     from oracle import cogvideox as cvx
     from oracle import ltx
 
     dev = _dev()
-    kw = dict(num_layers=2, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
+    kw = dict(num_layers=2, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16, use_rotary_positional_embeddings=rotary)
     ocfg = cvx.CogVideoXConfig(**kw)
     omodel = cvx.build_model(ocfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
     with torch.no_grad():
@@ -339,7 +371,7 @@ def test_model_step_parity_two_blocks():
     assert set(got) == set(g_ref)
     glob, worst = ltx.grads_rel_l2(got, g_ref)
     e_pred, e_loss = _rel(pred.cpu(), pred_ref), abs(loss.item() - loss_ref) / abs(loss_ref)
-    print(f"[cog-model L=2] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref:.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
+    print(f"[cog-model L=2 rotary={rotary}] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref:.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
           f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
     assert e_pred < 1e-2 and e_loss < 1e-3
     assert glob < 2.5 * floor + 1e-3 and worst < 2.5 * floor_worst + 2e-3
