@@ -1,7 +1,10 @@
 """BASELINE config 3 on one GPU: CogVideoX-2b LoRA r = 64 SFT optimisation step, 49 x 480 x 720 clip (latents [1, 13, 16, 60, 90]: 226 text + 17 550
 video tokens), 30 blocks, random-init weights of the 2b architecture, synthetic latents / text embeddings, bf16 base + fp32-equivalent LoRA, nothing
 recomputed.  Not the bench.py line (that is BASELINE's metric on configs[1]); this is config 3's measurement.
-    python tools/bench_cogvideox_step.py [steps] [layers]"""
+    python tools/bench_cogvideox_step.py [steps] [layers] [--cpu-baseline]
+--cpu-baseline: also time the oracle (CPU restatement of the reference step, kind "port") on the box's host threads on a bounded sample of the same
+workload -- ONE block forward + backward at the full 17 776 tokens, 1 warm-up + 1 timed, scaled by the block count (the embed / head / optimiser share of
+the GPU step is < 2 %).  tools/ may import oracle/ for exactly this (it is the checker and the baseline, never the product)."""
 import os
 import sys
 import time
@@ -12,8 +15,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finetrainers_amd.cogvideox import (CogVideoXTransformerConfig, MI355XCogVideoXSFTStep, MI355XCogVideoXTransformer3DModel)  # noqa: E402
 
 dev = torch.device("cuda", 0)
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-layers = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+steps = int(argv[0]) if len(argv) > 0 else 5
+layers = int(argv[1]) if len(argv) > 1 else 30
 bf16 = torch.bfloat16
 cfg = CogVideoXTransformerConfig(num_layers=layers)
 model = MI355XCogVideoXTransformer3DModel(cfg, device=dev)
@@ -56,3 +60,26 @@ flop = L * (2.0 * N * D * D * 12 * 2 + 4.0 * N * N * D * 3.5)  # linears forward
 print(f"CogVideoX-2b LoRA r=64 SFT step, 49x480x720 (226 + 17550 tokens), {L} blocks, batch 1: {ms:.1f} ms/step = {1e3 / ms:.3f} samples/s; "
       f"{flop / ms / 1e9:.0f} TF/s algorithmic = {flop / ms / 1e9 / 2500:.3f} of the dense bf16 peak; loss {out['loss'].item():.4f} grad_norm {out['grad_norm'].item():.4e}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+
+if "--cpu-baseline" in sys.argv:
+    from oracle import cogvideox as cvx  # noqa: E402
+
+    ocfg = cvx.CogVideoXConfig(num_layers=1)
+    omodel = cvx.build_model(ocfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
+    oblk = omodel.transformer_blocks[0]
+    gcpu = torch.Generator().manual_seed(0)
+    vid = torch.randn(1, 17550, D, generator=gcpu).to(bf16)
+    txt = torch.randn(1, 226, D, generator=gcpu).to(bf16)
+    temb = torch.randn(1, 512, generator=gcpu).to(bf16)
+    times = []
+    for it in range(2):
+        for p_ in oblk.parameters():
+            p_.grad = None
+        vr, tr_ = vid.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        hv, ht = oblk(vr, tr_, temb)
+        torch.autograd.backward([hv, ht], [torch.ones_like(hv), torch.ones_like(ht)])
+        times.append(time.perf_counter() - t0)
+    per_block = times[-1]
+    print(f"cpu_baseline (kind port, {torch.get_num_threads()} threads): oracle block forward + backward at 17 776 tokens {per_block:.1f} s (warm-up {times[0]:.1f} s) "
+          f"-> x{layers} blocks = {per_block * layers:.0f} s per sample-step = {1.0 / (per_block * layers):.5f} samples/s; GPU / CPU = {per_block * layers * 1e3 / ms:.0f}x")
