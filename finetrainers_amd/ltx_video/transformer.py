@@ -24,7 +24,7 @@ import ctypes
 import math
 import re
 from dataclasses import dataclass
-from typing import Dict, Iterable, Optional, Tuple
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -90,6 +90,10 @@ def ltx_rope_tables(num_frames: int, height: int, width: int, rope_interpolation
     cos = torch.cat([pad_c, freqs.cos()], dim=-1).contiguous()
     sin = torch.cat([pad_s, freqs.sin()], dim=-1).contiguous()
     return cos, sin
+
+
+# finetrainers/args.py:395 (layerwise_upcasting_skip_modules_pattern default)
+LAYERWISE_UPCASTING_SKIP_PATTERNS = ("patch_embed", "pos_embed", "x_embedder", "context_embedder", "time_embed", "^proj_in$", "^proj_out$", "norm")
 
 
 class _LTXDiTFunction(torch.autograd.Function):
@@ -265,6 +269,32 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
             src, dst = getattr(self, name), getattr(self, name + "_t")
             for l in range(L):
                 dst[l].copy_(ops.transpose_bf16(src[l]))
+
+    @torch.no_grad()
+    def apply_layerwise_casting(self, storage_dtype: torch.dtype = torch.float8_e4m3fn, compute_dtype: torch.dtype = bf16,
+                                skip_modules_pattern=LAYERWISE_UPCASTING_SKIP_PATTERNS, non_blocking: bool = False) -> List[str]:
+        """The reference's ``--layerwise_upcasting_modules transformer`` (trainer/sft_trainer/trainer.py:111-118 -> [upstream] diffusers
+        ``apply_layerwise_casting``): every Linear whose module name matches none of ``skip_modules_pattern`` (regex search; default = args.py:395)
+        keeps weight AND bias in ``storage_dtype`` (float8_e4m3fn) and casts them up to ``compute_dtype`` for each forward.  The up-cast is exact,
+        so the arithmetic is that of bf16 weights that hold fp8-representable values: here the frozen weights are rounded to the storage dtype once
+        and kept in bf16 (the 1.9 GB the reference saves on a 24-80 GB card are not what limits a 288 GB one).  Call it where the reference does:
+        after loading, before ``add_adapter``.  Returns the diffusers module names that were cast."""
+        if compute_dtype != bf16:
+            raise ValueError("the MI355X backend computes in bf16")
+        cast = []
+        for key, view in self._base_views().items():
+            mod, _, leaf = key.replace(".base_layer.", ".").rpartition(".")
+            if leaf not in ("weight", "bias") or view.dim() == 0:
+                continue
+            if mod.endswith(("norm_q", "norm_k")) or key.endswith("scale_shift_table"):  # RMSNorm / block Parameters: not a layer type the hook supports
+                continue
+            if any(re.search(p, mod) for p in skip_modules_pattern):
+                continue
+            view.copy_(view.to(storage_dtype).to(bf16))
+            if leaf == "weight":
+                cast.append(mod)
+        self._make_transposes()
+        return cast
 
     @torch.no_grad()
     def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:

@@ -569,6 +569,26 @@ def grads_rel_l2(a: Dict[str, torch.Tensor], b: Dict[str, torch.Tensor]) -> Tupl
 LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0")
 
 
+LAYERWISE_UPCASTING_SKIP_PATTERNS = ("patch_embed", "pos_embed", "x_embedder", "context_embedder", "time_embed", "^proj_in$", "^proj_out$", "norm")  # args.py:395
+
+
+def apply_layerwise_casting(model: nn.Module, storage_dtype: torch.dtype = torch.float8_e4m3fn, skip_modules_pattern=LAYERWISE_UPCASTING_SKIP_PATTERNS) -> List[str]:
+    """trainer/sft_trainer/trainer.py:111-118 -> [upstream, unpinned] diffusers ``apply_layerwise_casting``: Linear layers whose module name matches none of
+    the skip patterns (regex search) store weight and bias in ``storage_dtype`` and up-cast to the compute dtype for every forward.  The up-cast is exact,
+    so the model computes with bf16 tensors holding storage-dtype-representable values: restated as a one-time rounding.  Call before ``add_lora``."""
+    import re
+
+    cast = []
+    for name, mod in model.named_modules():
+        if isinstance(mod, nn.Linear) and not any(re.search(p, name) for p in skip_modules_pattern):
+            with torch.no_grad():
+                mod.weight.copy_(mod.weight.to(storage_dtype).to(mod.weight.dtype))
+                if mod.bias is not None:
+                    mod.bias.copy_(mod.bias.to(storage_dtype).to(mod.bias.dtype))
+            cast.append(name)
+    return cast
+
+
 def add_lora(model: LTXVideoTransformer3DModel, rank: int = 64, alpha: float = 64.0) -> List[str]:
     """Wrap to_q/to_k/to_v/to_out.0 of attn1+attn2 in every block (the default target regex),
     freeze everything else, LoRA params fp32 (``cast_training_params``)."""

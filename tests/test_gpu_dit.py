@@ -365,6 +365,34 @@ def test_precomputed_posterior_path_equals_sampled_latents():
     assert not torch.equal(sampled.cpu(), mean)
 
 
+def test_layerwise_upcasting_fp8_storage_semantics():
+    """--layerwise_upcasting_modules transformer with float8_e4m3fn storage (trainer.py:111-118): the same Linears as the reference's skip patterns
+    leave (args.py:395) hold fp8-representable weights and biases afterwards, bit-identical to the oracle's restatement of the cast; the step
+    still matches the (equally cast) oracle."""
+    from oracle import ltx
+
+    cfg = ltx.LTXConfig.production(num_layers=1)
+    torch.manual_seed(0)
+    omodel = ltx.LTXVideoTransformer3DModel(cfg).to(bf16)
+    plain = {k: v.clone() for k, v in omodel.state_dict().items()}
+    names = ltx.apply_layerwise_casting(omodel)
+    assert "transformer_blocks.0.attn1.to_q" in names and "transformer_blocks.0.ff.net.2" in names and "caption_projection.linear_1" in names
+    assert not any(n.startswith(("proj_in", "proj_out", "time_embed")) or "norm" in n for n in names)
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
+
+    spec = MI355XLTXVideoModelSpecification(transformer_config=LTXTransformerConfig(num_layers=1))
+    gmodel = spec.load_diffusion_models(state_dict=plain, device=_dev())["transformer"]
+    cast = gmodel.apply_layerwise_casting(torch.float8_e4m3fn, torch.bfloat16)
+    assert sorted(cast) == sorted(names)
+    osd = omodel.state_dict()
+    changed = 0
+    for k, v in gmodel.state_dict().items():
+        assert torch.equal(v.cpu(), osd[k]), k
+        changed += int(not torch.equal(osd[k], plain[k]))
+    assert changed >= 2 * len(names) - 2  # weights and biases of the cast Linears moved (a bias may survive by chance), nothing else did
+    assert torch.equal(gmodel.w_o_t[0].cpu(), osd["transformer_blocks.0.attn1.to_out.0.weight"].t())  # the dgrad copies follow
+
+
 def test_full_depth_config2_parity():
     """BASELINE config 2 EXACTLY: 28 blocks, batch 2, latents [2,128,7,16,24] (2688 tokens), text masks {32, 96}, sigma {0.25, 0.7},
     LoRA rank 64 -- loss and every LoRA gradient against the CPU oracle run on this box's host cores (a few minutes with torch's default
