@@ -314,8 +314,8 @@ def test_patchify_roundtrip_and_position_table():
     assert torch.equal(timestep_embedding(t, 1920), ltx.get_timestep_embedding(t, 1920))
 
 
-@pytest.mark.parametrize("rotary", [False, True])
-def test_model_step_parity_two_blocks(rotary):
+@pytest.mark.parametrize("rotary,layers", [(False, 2), (True, 2), (False, 30)])
+def test_model_step_parity_two_blocks(rotary, layers):
     """(rotary = False: the 2b sincos-table architecture, BASELINE config 3; True: the 5b-style rotary embedding on the video rows of q / k.)
     The whole CogVideoX-2b-width SFT forward + backward at 2 blocks: spec ops (scaling, DDIM noising), patch embed + sincos table, time
     embedding, blocks, final norms, proj_out, un-patchify, velocity -> x0, weighted loss, and every LoRA gradient, against oracle/cogvideox.py."""
@@ -324,7 +324,8 @@ def test_model_step_parity_two_blocks(rotary):
     from oracle import ltx
 
     dev = _dev()
-    kw = dict(num_layers=2, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16, use_rotary_positional_embeddings=rotary)
+    # layers = 30: the CogVideoX-2b architecture of BASELINE config 3 at its full depth (width 1920, 30 heads, 30 blocks), small clip
+    kw = dict(num_layers=layers, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16, use_rotary_positional_embeddings=rotary)
     ocfg = cvx.CogVideoXConfig(**kw)
     omodel = cvx.build_model(ocfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
     with torch.no_grad():
@@ -371,9 +372,9 @@ def test_model_step_parity_two_blocks(rotary):
     assert set(got) == set(g_ref)
     glob, worst = ltx.grads_rel_l2(got, g_ref)
     e_pred, e_loss = _rel(pred.cpu(), pred_ref), abs(loss.item() - loss_ref) / abs(loss_ref)
-    print(f"[cog-model L=2 rotary={rotary}] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref:.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
+    print(f"[cog-model L={layers} rotary={rotary}] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref:.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
           f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
-    assert e_pred < 1e-2 and e_loss < 1e-3
+    assert e_pred < 1e-2 * max(1.0, layers / 8) and e_loss < 1e-3
     assert glob < 2.5 * floor + 1e-3 and worst < 2.5 * floor_worst + 2e-3
 
     # the fused step on top: sigma table, DDIM noising, forward, loss, backward, flat gradient, clip + AdamW over the model-wide LoRA buffer
@@ -391,7 +392,7 @@ def test_model_step_parity_two_blocks(rotary):
     print(f"[cog-step] loss {out['loss'].item():.6f} grad_norm {out['grad_norm'].item():.5e} vs oracle {gn_ref:.5e}")
     assert abs(out["loss"].item() - loss_ref) < 1e-3 * abs(loss_ref) and abs(out["grad_norm"].item() - gn_ref) < 5e-3 * gn_ref
     assert not torch.equal(gmodel.lora_flat, before) and gmodel.transformer_blocks[0].lora_A.grad is None
-    assert gmodel.transformer_blocks[1].lora_B.data_ptr() == gmodel.lora_flat[gmodel.lora_flat.numel() // 2:].view(2, 4, 1920, 64)[1].data_ptr()
+    assert gmodel.transformer_blocks[1].lora_B.data_ptr() == gmodel.lora_flat[gmodel.lora_flat.numel() // 2:].view(layers, 4, 1920, 64)[1].data_ptr()
 
 
 def test_specification_mirror_loads_a_diffusers_directory_and_saves_lora(tmp_path):
