@@ -77,8 +77,18 @@ class _BlockFunction(torch.autograd.Function):
         dout = dout.contiguous()
         A = lambda i: None if lora_a is None else lora_a[i]
         Bm = lambda i: None if lora_b is None else lora_b[i]
-        ga = torch.zeros_like(lora_a) if lora_a is not None else None
-        gb = torch.zeros_like(lora_b) if lora_b is not None else None
+        # LoRA gradients: inside a model they go straight into this block's slice of the model-wide flat gradient buffer, which IS lora_A.grad /
+        # lora_B.grad (added to when a gradient is already there, i.e. under gradient accumulation) -- one flat buffer for the bucketed all-reduce
+        # and the fused clip + AdamW, and nothing for autograd to copy.  A stand-alone block hands fresh tensors to autograd instead.
+        own = lora_a is not None and blk._grad_a_view is not None
+        if own:
+            ga, gb = blk._grad_a_view, blk._grad_b_view
+            if blk.lora_A.grad is None or blk.lora_A.grad.data_ptr() != ga.data_ptr():
+                ga.zero_()
+                gb.zero_()
+        else:
+            ga = torch.zeros_like(lora_a) if lora_a is not None else None
+            gb = torch.zeros_like(lora_b) if lora_b is not None else None
         GA = lambda i: None if ga is None else ga[i]
         GB = lambda i: None if gb is None else gb[i]
 
@@ -106,6 +116,11 @@ class _BlockFunction(torch.autograd.Function):
         dn1 = ops.cog_gate_residual(dn_v.view(B, N, D), dn_k.view(B, N, D), ones, 0)
         dn1 = ops.cog_gate_residual(dn1, dn_q.view(B, N, D), ones, 0)
         dx = ops.cog_ln_mod_bwd(x, blk.norm1_w, onep1, dn1, T, blk.norm_eps, dres=dh1)
+        if own:
+            blk.lora_A.grad, blk.lora_B.grad = ga, gb
+            if blk._grad_hook is not None:
+                blk._grad_hook(ga, gb)  # data parallelism: this block's LoRA gradients are final -- start averaging them while the earlier blocks run
+            return None, dx, None, None, None, None, None, None
         return None, dx, None, None, ga, gb, None, None
 
 
@@ -132,6 +147,8 @@ class MI355XCogVideoXBlock(nn.Module):
         self.lora_B: Optional[nn.Parameter] = None  # [4, D, r]
         self.lora_scale = 0.0
         self._ones_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._grad_hook = None  # callable(grad_a, grad_b), set by the data-parallel step
+        self._grad_a_view = self._grad_b_view = None  # this block's slices of the model's flat gradient buffer
 
     _KEYS = {  # diffusers CogVideoXBlock parameter name -> buffer
         "norm1.linear.weight": "norm1_lin_w", "norm1.linear.bias": "norm1_lin_b", "norm1.norm.weight": "norm1_w", "norm1.norm.bias": "norm1_b",

@@ -202,14 +202,16 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
         n = L * 4 * r * D
         self.lora_flat = torch.zeros(2 * n, dtype=torch.float32, device=self.device)
         a_all, b_all = self.lora_flat[:n].view(L, 4, r, D), self.lora_flat[n:].view(L, 4, D, r)
+        self.lora_grad_flat = torch.zeros_like(self.lora_flat)  # laid out like lora_flat; the blocks' .grad tensors are views of it
+        ga_all, gb_all = self.lora_grad_flat[:n].view(L, 4, r, D), self.lora_grad_flat[n:].view(L, 4, D, r)
         for i, blk in enumerate(self.transformer_blocks):
             blk.add_adapter(r, lora_alpha, a_all[i], b_all[i])
+            blk._grad_a_view, blk._grad_b_view = ga_all[i], gb_all[i]
         self.lora_rank = r
 
     def flat_lora_grad(self) -> torch.Tensor:
-        """The blocks' ``.grad`` tensors laid out like ``lora_flat`` (one copy of 2 L 4 r D floats: 118 MB at the 2b size)."""
-        blocks = self.transformer_blocks
-        return torch.cat([blk.lora_A.grad.reshape(-1) for blk in blocks] + [blk.lora_B.grad.reshape(-1) for blk in blocks])
+        """The flat fp32 gradient buffer the blocks' backward wrote (``blk.lora_A.grad`` / ``lora_B.grad`` are its views)."""
+        return self.lora_grad_flat
 
     def lora_state_dict(self) -> Dict[str, torch.Tensor]:
         """peft-format keys: ``transformer_blocks.N.attn1.to_q.lora_A.weight`` ..."""

@@ -1,7 +1,8 @@
 """One CogVideoX LoRA SFT optimisation step (reference loop: finetrainers/trainer/sft_trainer/trainer.py:430-503 with the CogVideoX
 specification): sigma draw -> DDIM noising -> DiT forward -> velocity -> x0 -> 1 / (1 - alphas_cumprod) weighted MSE -> backward -> LoRA-gradient
 average over the data-parallel ranks -> global-norm clip -> AdamW, the last two fused over the model-wide flat LoRA buffer.  First cut: the
-gradient exchange is one all-reduce of the flat buffer after the backward (the LTX path overlaps per-block buckets with the backward)."""
+gradients of a block are all-reduced (AVG, asynchronously on RCCL's stream) as soon as that block's backward has produced them, while the earlier
+blocks still compute; the step waits for the outstanding collectives before the flat gradient is assembled."""
 
 from __future__ import annotations
 
@@ -47,10 +48,28 @@ class MI355XCogVideoXSFTStep:
         if sigmas is None:
             sigmas = self.sample_sigmas(latents.shape[0])
         pred, target, _ = MI355XCogVideoXSpecOps.forward(self.spec, tr, latents, encoder_hidden_states, sigmas, noise=noise, generator=self.generator)
-        loss = self.spec.loss_backward(pred, target, sigmas)
+        dp = self.parallel is not None and self.parallel.active
+        pending = []
+
+        def exchange(ga, gb):  # called from inside the backward, block by block (last block first): every rank issues the same sequence
+            for t in (ga, gb):
+                h = self.parallel.all_reduce_mean_async(t)
+                if h is not None:
+                    pending.append(h)
+
+        for blk in tr.transformer_blocks:
+            blk._grad_hook = exchange if dp else None
+        try:
+            loss = self.spec.loss_backward(pred, target, sigmas)
+        finally:
+            for blk in tr.transformer_blocks:
+                blk._grad_hook = None
+        for work, div in pending:  # device-side wait on RCCL; gloo: host wait + divide
+            work.wait()
+            if div is not None:
+                div.div_(self.parallel.world_size)
+        self.buckets_issued = len(pending) // 2
         gflat = tr.flat_lora_grad()
-        if self.parallel is not None and self.parallel.active:
-            self.parallel.all_reduce_mean_(gflat)
         self.step_count += 1
         lr = self.lr if self.lr_scheduler is None else self.lr_scheduler.current_lr()
         gn = torch.empty(1, dtype=torch.float32, device=gflat.device)
