@@ -185,6 +185,10 @@ ATTN_CASES = [
     (2, 4, 2688, 128, True),   # cfg 2 cross-attention with text mask (few keys: split-query dK/dV kernel)
     (1, 2, 600, 77, True),     # split-query dK/dV kernel, ragged queries (last 128-block holds 88) and keys
     (1, 1, 520, 33, False),    # split-query dK/dV kernel, second 64-row tile of the last block wholly past the end
+    (3, 5, 257, 65, False),    # one row / one key past a tile boundary; B * H = 15 is not a multiple of the 8 XCDs (plain block order)
+    (1, 1, 1, 1, False),       # a single query and a single key
+    (2, 2, 129, 191, True),    # ragged both ways with per-sample masks, keys one short of three tiles
+    (1, 3, 64, 4097, False),   # one query tile against many key tiles plus one key
 ]
 
 
