@@ -139,7 +139,9 @@ static constexpr int kFwdLds = 2 * 16384 + 2 * 256;  // two (K, V) tile buffers 
 // FL: AF_LAZY | AF_MAX16 is what ships; the other flags are experiments.  1: row sums by VALU adds instead of 4 all-ones MFMAs; 2: lazy rescale (skip the O rescale pass
 // unless the running max of some lane's row grew by more than 2^8); 4 / 8 / 16: timing ablations (no exp / no P.V / no tile reload) whose
 // results are WRONG by construction -- compiled only with -DFTMI_EXPERIMENTAL.
-enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_ABL_NOLOAD = 16, AF_MAX16 = 32, AF_TIMING = 64 };
+enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_ABL_NOLOAD = 16, AF_MAX16 = 32, AF_TIMING = 64, AF_RAGGED = 128 };
+// AF_RAGGED (shipped, with HAS_KB = false): Sk is not a multiple of the 64-key tile and there is no key bias -- the fast loop runs unchanged and only the
+// LAST tile sets the scores of its padded keys to -inf (CogVideoX's 17 776 joint tokens; before, one ragged tile put the whole launch on the bias path).
 // AF_TIMING (experimental build only, tools/attn_phase_timing.py): every wave sums the s_memtime ticks it spends between four program points
 // of the tile loop (scores issued, softmax done, P.V issued, barrier passed) and overwrites lse2[row .. row+3] of its first rows with the totals.
 FTMI_DEVICE unsigned tick32() { return (unsigned)__builtin_readcyclecounter(); }
@@ -225,6 +227,15 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         if constexpr (FL & AF_TIMING) { __builtin_amdgcn_sched_barrier(0); tp1 = tick32(); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr ((FL & AF_RAGGED) && !HAS_KB) {
+            if (t == nt - 1) {  // register r of sub-tile js holds key t*64 + js*32 + crow(r, g)
+#pragma unroll
+                for (int js = 0; js < 2; ++js)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * 64 + js * 32 + crow(r, g) >= a.Sk) st[js][r] = -INFINITY;
+            }
+        }
         // scores in the log2 domain: x = s * (scale * log2 e) + bias;  row max / exp2 per lane (= per query row)
         float mx = -INFINITY;
         if constexpr (HAS_KB) {
@@ -586,8 +597,10 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     }
 #endif
     // lazy rescale + single-statement row max: 148 us against 159 us for the exact running max (cfg-2 self-attention, profiles/README.md)
-    if (a.kbias || (a.Sk % 64) != 0)
+    if (a.kbias)
         hipLaunchKernelGGL((attn_fwd_kernel<true, AF_LAZY | AF_MAX16>), grid, dim3(256), kFwdLds, st, a);
+    else if ((a.Sk % 64) != 0)
+        hipLaunchKernelGGL((attn_fwd_kernel<false, AF_LAZY | AF_MAX16 | AF_RAGGED>), grid, dim3(256), kFwdLds, st, a);
     else
         hipLaunchKernelGGL((attn_fwd_kernel<false, AF_LAZY | AF_MAX16>), grid, dim3(256), kFwdLds, st, a);
     return check_launch("attn_fwd");
@@ -1041,7 +1054,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // non-matrix instructions, so every K / V row fragment and every K^T fragment read from LDS now feeds two MFMAs).  Per 32 keys and
 // wave: 24 MFMAs, 16 LDS reads (first generation: 12 MFMAs per 16 reads).  delta = rowsum(dO * O) is still produced here.
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_KB>
+template <bool HAS_KB, bool RAGGED = false>  // RAGGED (with HAS_KB = false): Sk % 64 != 0 without a key bias -- only the last tile masks its padded keys
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1147,6 +1160,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
                 const s16x8 vf = read_row_frag(vs, js * 32 + li, c, g);
                 dp[0] = mfma32(vf, dof[0][c], dp[0]);
                 dp[1] = mfma32(vf, dof[1][c], dp[1]);
+            }
+            if constexpr (RAGGED && !HAS_KB) {
+                if (t == nt - 1) {  // padded keys (their K / V rows are clamped copies of the last real one): score -inf => p = 0 => no dS
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (t * 64 + js * 32 + crow(r, g) >= a.Sk) {
+                            s[0][r] = -INFINITY;
+                            s[1][r] = -INFINITY;
+                        }
+                }
             }
             s16x8 dsf[2][2];
 #pragma unroll
@@ -1363,8 +1386,10 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
 #endif
     if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
-        if (a.kbias || (a.Sk % 64) != 0)
+        if (a.kbias)
             hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, grid2, dim3(256), kDqLds, st, a);
+        else if ((a.Sk % 64) != 0)
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, true>), grid2, dim3(256), kDqLds, st, a);
         else
             hipLaunchKernelGGL(attn_bwd_dq2_kernel<false>, grid2, dim3(256), kDqLds, st, a);
     } else if (a.kbias || (a.Sk % 64) != 0)
