@@ -296,6 +296,39 @@ def main() -> None:
         for i, p in enumerate(ps[:-1]):
             tensors[f"{tag}.out{i}"] = p.grad.clone()
 
+    # ---- Wan: the reference's spec forward, its DiagonalGaussianDistribution and its patched time/text embedding, executed -----------
+    from oracle import wan
+
+    MU = types.ModuleType("ref_models_utils")  # finetrainers/models/utils.py with diffusers' randn_tensor replaced by its torch equivalent
+    MU.__dict__["__name__"] = "ref_models_utils"
+    src = open(os.path.join(REF, "finetrainers/models/utils.py")).read().replace("from diffusers.utils.torch_utils import randn_tensor", "")
+    MU.__dict__["randn_tensor"] = lambda shape, generator=None, device=None, dtype=None: torch.randn(shape, generator=generator, dtype=dtype)
+    exec(compile(src, "models/utils.py", "exec"), MU.__dict__)
+    wan_ns = dict(TYPING_NS, FF=FF, DiagonalGaussianDistribution=MU.DiagonalGaussianDistribution, WanTransformer3DModel=object)
+    wan_fwd = extract("finetrainers/models/wan/base_specification.py", "forward", wan_ns, cls="WanModelSpecification")
+    wan_norm = extract("finetrainers/models/wan/base_specification.py", "_normalize_latents", wan_ns, cls="WanModelSpecification")
+    wcfg = wan.WanConfig.dummy()
+    wmodel = wan.build_model(wcfg, seed=0, dtype=torch.bfloat16)
+    gw = torch.Generator().manual_seed(21)
+    B_, C_, F_, H_, W_ = 2, 16, 3, 8, 12
+    mom = torch.randn(B_, 2 * C_, F_, H_, W_, generator=gw)
+    mom[:, C_:] = mom[:, C_:] * 0.3 - 2.0
+    mom = mom.bfloat16()
+    lmean = (0.2 * torch.randn(C_, generator=gw)).float()
+    lstd = (1.0 / (0.5 + torch.rand(C_, generator=gw))).float()  # the processors store the reciprocal
+    wtext = torch.randn(B_, 7, wcfg.text_dim, generator=gw).bfloat16()
+    wsig = torch.tensor([0.31, 0.84]).view(B_, 1, 1, 1, 1)
+    self_stub = types.SimpleNamespace(_normalize_latents=wan_norm, transformer_config={})
+    with torch.no_grad():
+        pred_w, target_w, _ = wan_fwd(self_stub, wmodel, {"encoder_hidden_states": wtext},
+                                      {"latents": mom.clone(), "latents_mean": lmean, "latents_std": lstd}, wsig, generator=torch.Generator().manual_seed(77))
+    for k_, v_ in (("moments", mom), ("latents_mean", lmean), ("latents_std", lstd), ("text", wtext), ("sigmas", wsig.flatten()), ("pred", pred_w), ("target", target_w)):
+        tensors[f"wan.spec.{k_}"] = v_
+    ref_embed = extract("finetrainers/patches/models/wan/patch.py", "_patched_WanTimeTextImageEmbedding_forward", dict(TYPING_NS))
+    with torch.no_grad():
+        temb_w, tproj_w, text_w, _ = ref_embed(wmodel.condition_embedder, torch.tensor([310, 840]), wtext)
+    tensors["wan.embed.temb"], tensors["wan.embed.timestep_proj"], tensors["wan.embed.text"] = temb_w, tproj_w, text_w
+
     tensors = {k: v.detach().clone().contiguous() for k, v in tensors.items()}
     path = os.path.join(OUT, "reference_fixtures.safetensors")
     save_file(tensors, path, metadata={"generator": "oracle/make_golden.py", "reference": "a-r-r-o-w/finetrainers @ 2025-08-29"})
