@@ -61,6 +61,15 @@ print(f"CogVideoX-2b LoRA r=64 SFT step, 49x480x720 (226 + 17550 tokens), {L} bl
       f"{flop / ms / 1e9:.0f} TF/s algorithmic = {flop / ms / 1e9 / 2500:.3f} of the dense bf16 peak; loss {out['loss'].item():.4f} grad_norm {out['grad_norm'].item():.4e}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 
+import json  # noqa: E402
+
+line = {"metric": "train samples/sec (+ step ms) CogVideoX-2b LoRA 49x480x720 (BASELINE configs[2])", "value": 1e3 / ms, "unit": "samples/s", "n_gpus": 1,
+        "steps": steps, "warmup": 2, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic latents [1,13,16,60,90] + random text embeds [1,226,4096], random-init weights of the CogVideoX-2b DiT",
+        "config": {"workload": f"CogVideoX-2b LoRA rank=64 bf16 SFT step, 49x480x720 clip (226 text + 17550 video tokens), batch 1 per GPU, {layers} blocks",
+                   "global_batch": 1, "seq_len": N, "parallelism": "dp1", "activation_checkpointing": False, "orchestration": "python over the C ABI"},
+        "step_tflop_algorithmic": flop / 1e12, "mfma_utilisation_step": flop / ms / 1e9 / 2500, "final_loss": out["loss"].item(),
+        "peak_memory_gib": torch.cuda.max_memory_allocated() / 2**30}
 if "--cpu-baseline" in sys.argv:
     from oracle import cogvideox as cvx  # noqa: E402
 
@@ -83,3 +92,6 @@ if "--cpu-baseline" in sys.argv:
     per_block = times[-1]
     print(f"cpu_baseline (kind port, {torch.get_num_threads()} threads): oracle block forward + backward at 17 776 tokens {per_block:.1f} s (warm-up {times[0]:.1f} s) "
           f"-> x{layers} blocks = {per_block * layers:.0f} s per sample-step = {1.0 / (per_block * layers):.5f} samples/s; GPU / CPU = {per_block * layers * 1e3 / ms:.0f}x")
+    line["cpu_baseline"] = {"value": 1.0 / (per_block * layers), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                            "sample": f"oracle CogVideoXBlock forward + backward at the full {N} tokens, 1 warm-up + 1 timed = {per_block:.1f} s, scaled x{layers} blocks"}
+print(json.dumps(line))
