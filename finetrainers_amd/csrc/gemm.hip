@@ -870,8 +870,12 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             // plus ~85 issue cycles per 1-KiB direct-to-LDS load, tiles run in rounds of (256 CUs x workgroups per CU):
             //   192 x 128 (2 WG / CU), 192 x 256 and 256 x 256 (8 waves, 1 WG / CU; need 256-wide column groups)
             static const int force192 = env_int("FTMI_NT192", 0), force256 = env_int("FTMI_NT256", 0), use_model = env_int("FTMI_NT_AUTO", 3);
-            if (a.M < 1024) {
-                variant = 44;  // few rows (the text side): 128 x 128 tiles
+            // 192 x 128 tiles leave a half-empty machine when there are few of them (batch 1: M = 2688, N = 2048 gives 224 tiles for 512 slots): the
+            // 336 tiles of 128 x 128 put a second workgroup on a third of the CUs -- 36.6 vs 39.1 us (K = 2048), 110 vs 121 us (K = 8192), tools/bench_gemm.py
+            static const int few192 = env_int("FTMI_NT128_BELOW", 342);
+            const long n192 = (long)((a.M + 191) / 192) * (a.N / 128);
+            if (a.M < 1024 || n192 < few192) {
+                variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
             } else {
                 auto g256 = [](int g) { return g <= 0 || g % 256 == 0; };
                 const bool ok256 = a.N % 256 == 0 && g256(a.w_grp_n) && g256(a.w2_grp_n) && g256(a.xk_grp_n) && g256(a.x2_grp_n);
