@@ -111,7 +111,8 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
 
 static int fill_attn(const ftmi_attn_desc* d, AttnArgs& a) {
     if (!d) return set_error(FTMI_ERR_INVALID, "attention: null descriptor");
-    if (d->d != 64) return set_error(FTMI_ERR_UNSUPPORTED, "attention: head_dim must be 64");
+    if (d->d != 64 && d->d != 128) return set_error(FTMI_ERR_UNSUPPORTED, "attention: head_dim must be 64 (or 128, forward only)");
+    a.d = d->d;
     a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Sk = d->Sk; a.scale = d->scale;
     a.q_sb = d->q_strides[0]; a.q_sh = d->q_strides[1]; a.q_ss = d->q_strides[2];
     a.k_sb = d->k_strides[0]; a.k_sh = d->k_strides[1]; a.k_ss = d->k_strides[2];

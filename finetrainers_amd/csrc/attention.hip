@@ -134,7 +134,8 @@ FTMI_DEVICE float xhalf_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-static constexpr int kFwdLds = 2 * 16384 + 2 * 256;  // two (K, V) tile buffers + two key-bias rows
+static constexpr int kFwdLds = 2 * 16384 + 2 * 256;  // two (K, V) tile buffers + two key-bias rows (head_dim 128: kFwdLds128)
+static constexpr int kFwdLds128 = 2 * 32768 + 2 * 256;
 
 // FL: AF_LAZY | AF_MAX16 is what ships; the other flags are experiments.  1: row sums by VALU adds instead of 4 all-ones MFMAs; 2: lazy rescale (skip the O rescale pass
 // unless the running max of some lane's row grew by more than 2^8); 4 / 8 / 16: timing ablations (no exp / no P.V / no tile reload) whose
@@ -146,7 +147,9 @@ enum { AF_VALU_ROWSUM = 1, AF_LAZY = 2, AF_ABL_NOEXP = 4, AF_ABL_NOPV = 8, AF_AB
 // of the tile loop (scores issued, softmax done, P.V issued, barrier passed) and overwrites lse2[row .. row+3] of its first rows with the totals.
 FTMI_DEVICE unsigned tick32() { return (unsigned)__builtin_readcyclecounter(); }
 
-template <bool HAS_KB, int FL = 0, int MINW = 1>
+// ND = head_dim / 64 (1: LTX / CogVideoX; 2: head_dim 128 of Wan / HunyuanVideo -- twice the matrix work per softmax element: 36 MFMAs against the same
+// ~160 VALU instructions per 64-key tile).  A 128-wide K / V tile is two [64 tok][64 d] LDS images side by side; everything indexed by d loops over them.
+template <bool HAS_KB, int FL = 0, int MINW = 1, int ND = 1>
 __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,9 +161,9 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     const float sl = a.scale * kLog2e;
 
     const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
-    s16x8 qf[4];
+    s16x8 qf[4 * ND];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+    for (int c = 0; c < 4 * ND; ++c) qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
 
     const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
@@ -170,9 +173,9 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     s16x8 ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
-    f32x16 oacc[2];
+    f32x16 oacc[2 * ND];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2 * ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
 
@@ -181,9 +184,12 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     float kbr = 0.f;
     // stage tile t into buffer `buf`: K and V by DMA; the key-bias row (log2 domain, -inf for padded keys) through a register
     auto stage = [&](int t, int buf) {
-        char* tb = smem + buf * 16384;
-        tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
-        tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+        char* tb = smem + buf * (16384 * ND);
+#pragma unroll
+        for (int dh = 0; dh < ND; ++dh) {
+            tile_dma_issue(kd, kbase + 64 * dh, a.k_ss, t, t == nt - 1, tb + dh * 8192, wave);
+            tile_dma_issue(vd, vbase + 64 * dh, a.v_ss, t, t == nt - 1, tb + (ND + dh) * 8192, wave);
+        }
         if constexpr (HAS_KB) {
             if (tid < 64) {
                 int j = t * 64 + tid;
@@ -193,12 +199,12 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     };
     auto stage_commit = [&](int buf) {
         if constexpr (HAS_KB) {
-            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384)[buf * 64 + tid] = kbr;
+            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384 * ND)[buf * 64 + tid] = kbr;
         }
     };
 
 #pragma unroll
-    for (int c = 0; c < 4; ++c) settle(qf[c]);
+    for (int c = 0; c < 4 * ND; ++c) settle(qf[c]);
     stage(0, 0);
     stage_commit(0);
     tile_dma_wait();
@@ -206,9 +212,9 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     unsigned tacc[4] = {0u, 0u, 0u, 0u};
     auto body = [&](int t, auto CUR) {
         constexpr int cur = decltype(CUR)::value;
-        const char* ks = smem + cur * 16384;
-        const char* vs = ks + 8192;
-        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
+        const char* ks = smem + cur * (16384 * ND);
+        const char* vs = ks + 8192 * ND;
+        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384 * ND) + cur * 64;
         if constexpr (!(FL & AF_ABL_NOLOAD)) {
             if (t + 1 < nt) stage(t + 1, cur ^ 1);
         }
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
+            for (int c = 0; c < 4 * ND; ++c) {
+                s16x8 kf = read_row_frag(ks + (c >> 2) * 8192, js * 32 + li, c & 3, g);
                 st[js] = mfma32(kf, qf[c], st[js]);
             }
         }
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
                 const float m_eff0 = (m_new == -INFINITY) ? 0.f : m_new;
                 alpha = fast_exp2(m_run - m_eff0);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2 * ND; ++dt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
             }
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
         m_run = m_new;
         if constexpr (!(FL & AF_LAZY)) {
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2 * ND; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
         }
@@ -321,8 +327,8 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
                     asm volatile("" ::"v"(pf));
                 } else {
 #pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
+                    for (int dt = 0; dt < 2 * ND; ++dt) {
+                        s16x8 vf = read_tr_frag(vs + (dt >> 1) * 8192, (dt & 1) * 32, js * 32 + hh * 16, lane);
                         oacc[dt] = mfma32(vf, pf, oacc[dt]);
                     }
                 }
@@ -360,7 +366,10 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     {
         const float inv = 1.0f / l_run;
         bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
-        store_rows_via_lds(smem + wave * 4096, oacc, inv, ob, a.o_ss, blk.tile * 128 + wave * 32, a.Sq, lane);
+        if constexpr (ND > 1) __syncthreads();  // the per-wave store scratch overlays the tile buffers other waves may still read
+#pragma unroll
+        for (int dh = 0; dh < ND; ++dh)
+            store_rows_via_lds(smem + wave * 4096, *reinterpret_cast<const f32x16(*)[2]>(&oacc[2 * dh]), inv, ob + 64 * dh, a.o_ss, blk.tile * 128 + wave * 32, a.Sq, lane);
         if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
         if constexpr (FL & AF_TIMING) {
             const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));  // HW_REG_HW_ID[3:0]: wave slot within the SIMD
@@ -557,7 +566,7 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8))
         return set_error(FTMI_ERR_INVALID, "attn_fwd: token strides must keep 16-byte alignment");
     dim3 grid(((a.Sq + 127) / 128) * a.H * a.B);
-    ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);
+    ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * a.d, st);
 #ifdef FTMI_EXPERIMENTAL
     const int fv = env_int("FTMI_ATTN_FWD", 0);  // re-read every call: tools/bench_attn.py switches variants inside one process
     if (fv && !(a.kbias || (a.Sk % 64) != 0)) {
@@ -597,6 +606,20 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     }
 #endif
     // lazy rescale + single-statement row max: 148 us against 159 us for the exact running max (cfg-2 self-attention, profiles/README.md)
+    if (a.d == 128) {  // Wan / HunyuanVideo head size: forward only so far
+        static const bool ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<true, AF_LAZY | AF_MAX16, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<false, AF_LAZY | AF_MAX16 | AF_RAGGED, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<false, AF_LAZY | AF_MAX16, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds128) == hipSuccess;
+        if (!ok) return set_error(FTMI_ERR_LAUNCH, "attn_fwd: cannot raise the dynamic LDS limit");
+        if (a.kbias)
+            hipLaunchKernelGGL((attn_fwd_kernel<true, AF_LAZY | AF_MAX16, 2, 2>), grid, dim3(256), kFwdLds128, st, a);
+        else if ((a.Sk % 64) != 0)
+            hipLaunchKernelGGL((attn_fwd_kernel<false, AF_LAZY | AF_MAX16 | AF_RAGGED, 2, 2>), grid, dim3(256), kFwdLds128, st, a);
+        else
+            hipLaunchKernelGGL((attn_fwd_kernel<false, AF_LAZY | AF_MAX16, 2, 2>), grid, dim3(256), kFwdLds128, st, a);
+        return check_launch("attn_fwd");
+    }
     if (a.kbias)
         hipLaunchKernelGGL((attn_fwd_kernel<true, AF_LAZY | AF_MAX16>), grid, dim3(256), kFwdLds, st, a);
     else if ((a.Sk % 64) != 0)
@@ -1375,6 +1398,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv2_kernel(AttnArgs a) {
 int attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_bwd: empty problem");
     if (!a.lse2 || !a.delta || !a.dout || !a.o) return set_error(FTMI_ERR_INVALID, "attn_bwd: missing lse/delta/dout/out");
+    if (a.d != 64) return set_error(FTMI_ERR_UNSUPPORTED, "attn_bwd: head_dim 128 has a forward kernel only so far");
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8) || (a.do_ss % 8) || (a.dq_ss % 8) || (a.dk_ss % 8) || (a.dv_ss % 8))
         return set_error(FTMI_ERR_INVALID, "attn_bwd: token strides must keep 16-byte alignment");
     ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);  // algorithmic: 5 matmuls (2.5x forward)

@@ -111,7 +111,8 @@ int gemm_tn(const GemmTnArgs& a, hipStream_t st);
 
 // ---- attention -----------------------------------------------------------------------------------
 struct AttnArgs {
-    int B = 0, H = 0, Sq = 0, Sk = 0;  // head dim fixed at 64
+    int B = 0, H = 0, Sq = 0, Sk = 0;
+    int d = 64;  // head dim: 64 (forward + backward) or 128 (forward)
     // element strides (d contiguous)
     const bf16_t* q = nullptr;
     long q_sb = 0, q_sh = 0, q_ss = 0;

@@ -24,10 +24,10 @@ def _strides3(t: torch.Tensor) -> Tuple[int, int, int]:
 def _desc(q, k, v, o, scale, dout=None, dq=None, dk=None, dv=None, key_bias=None) -> AttnDesc:
     B, H, Sq, d = q.shape
     Sk = k.shape[2]
-    if d != 64:
-        raise ValueError(f"mi355x attention supports head_dim 64, got {d}")
+    if d not in (64, 128):
+        raise ValueError(f"mi355x attention supports head_dim 64 (and 128 for the forward), got {d}")
     if k.shape != (B, H, Sk, d) or v.shape != (B, H, Sk, d):
-        raise ValueError("mi355x attention: key/value shapes must be [B, H, Sk, 64] (no GQA)")
+        raise ValueError("mi355x attention: key/value shapes must be [B, H, Sk, head_dim] (no GQA)")
     desc = AttnDesc()
     desc.B, desc.H, desc.Sq, desc.Sk, desc.d = B, H, Sq, Sk, d
     desc.scale = float(scale)

@@ -222,6 +222,32 @@ def test_attention_fwd_bwd(B, H, Sq, Sk, biased):
     report(tag + " dv", dv, dv_ref, 1e-2)
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 3, 300, 257, True), (1, 2, 128, 128, False), (1, 2, 200, 330, False), (1, 4, 2688, 2688, False)])
+def test_attention_forward_head_dim_128(B, H, Sq, Sk, biased):
+    """Head size of Wan / HunyuanVideo: forward only so far -- same kernel, twice the matrix work per softmax element.
+    Against fp32 softmax attention on the CPU (and the backward must refuse instead of running the head_dim-64 kernels on it)."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(1)
+    q, k, v = rnd((B, H, Sq, 128), g), rnd((B, H, Sk, 128), g), rnd((B, H, Sk, 128), g)
+    bias = None
+    if biased:
+        mask = torch.zeros(B, Sk)
+        for b in range(B):
+            mask[b, : max(1, (Sk * (b + 1)) // (B + 1))] = 1
+        bias = ((1 - mask.to(bf16)) * -10000.0).float()
+    sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(128.0) + (0 if bias is None else bias[:, None, None, :])
+    o_ref = torch.softmax(sc, dim=-1) @ v.float()
+    out, lse = ops.attn_fwd(q.to(dev), k.to(dev), v.to(dev), None if bias is None else bias.to(dev))
+    tag = f"attn d128 B{B} H{H} {Sq}x{Sk}{' bias' if biased else ''}"
+    report(tag + " fwd", out, o_ref, 6e-3)
+    assert (out.float().cpu() - o_ref).abs().max() < 5e-3 * max(1.0, o_ref.abs().max().item())
+    report(tag + " lse", lse.cpu() * math.log(2.0), torch.logsumexp(sc, dim=-1), 1e-4)
+    with pytest.raises(ValueError):
+        ops.attn_bwd(q.to(dev), k.to(dev), v.to(dev), out, lse, out)
+
+
 def test_attention_strided_layout():
     """[B,S,H*d] storage viewed as [B,H,S,d] (what the DiT uses) == contiguous [B,H,S,d]."""
     from finetrainers_amd import ops

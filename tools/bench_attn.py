@@ -16,19 +16,20 @@ which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 variants = sys.argv[2:] or [""]
 cross = which.startswith("x")
 bwd = which.endswith("bwd")
-B, H, S = 2, 32, 2688
+D = int(os.environ.get("HEAD_DIM", "64"))  # 128: forward only (Wan / HunyuanVideo head size)
+B, H, S = (int(v_) for v_ in os.environ.get("BHS", "2,32,2688").split(","))
 Sk = 128 if cross else S
 g = torch.Generator(device=dev).manual_seed(0)
-q = torch.randn((B, S, H, 64), generator=g, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
-kv = torch.randn((B, Sk, 2, H, 64), generator=g, device=dev).to(torch.bfloat16)
+q = torch.randn((B, S, H, D), generator=g, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
+kv = torch.randn((B, Sk, 2, H, D), generator=g, device=dev).to(torch.bfloat16)
 k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
-dout = torch.randn((B, S, H, 64), generator=g, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
+dout = torch.randn((B, S, H, D), generator=g, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
 bias = None
 if cross:
     bias = torch.zeros((B, Sk), device=dev)
     bias[0, 32:] = -10000.0
     bias[1, 96:] = -10000.0
-flops = 4.0 * B * H * S * Sk * 64 * (2.5 if bwd else 1.0)
+flops = 4.0 * B * H * S * Sk * D * (2.5 if bwd else 1.0)
 KEYS = ("FTMI_ATTN_GEN", "FTMI_ATTN_FWD_GEN", "FTMI_ATTN_DQ_GEN", "FTMI_ATTN_DKV_GEN", "FTMI_ATTN_FWD")
 
 
