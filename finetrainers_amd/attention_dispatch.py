@@ -114,9 +114,10 @@ def _check_qkv_dtype_bf16(query, key, value, **kwargs) -> None:
         raise ValueError("Query, key, and value must be bfloat16 for the mi355x provider.")
 
 
-def _check_head_dim_64(query, key, value, **kwargs) -> None:
-    if query.shape[-1] != 64 or key.shape[-1] != 64 or value.shape[-1] != 64:
-        raise ValueError("The mi355x provider is built for head_dim == 64.")
+def _check_head_dim(query, key, value, **kwargs) -> None:
+    d = query.shape[-1]
+    if d not in (64, 128) or key.shape[-1] != d or value.shape[-1] != d:
+        raise ValueError("The mi355x provider is built for head_dim 64 (LTX-Video, CogVideoX) and 128 (Wan, HunyuanVideo).")
 
 
 def _check_no_dropout_causal_gqa(dropout_p=0.0, is_causal=False, enable_gqa=False, **kwargs) -> None:
@@ -172,7 +173,7 @@ class _MI355XAttention(torch.autograd.Function):
 
 @_AttentionProviderRegistry.register(
     AttentionProvider.MI355X,
-    constraints=[_check_device_gpu, _check_qkv_dtype_bf16, _check_head_dim_64, _check_no_dropout_causal_gqa],
+    constraints=[_check_device_gpu, _check_qkv_dtype_bf16, _check_head_dim, _check_no_dropout_causal_gqa],
     supports_cp=False,
 )
 def _mi355x_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, attn_mask: Optional[torch.Tensor] = None,
@@ -195,7 +196,7 @@ def register_into_finetrainers() -> bool:
     member = getattr(ref.AttentionProvider, "MI355X", None)
     if member is None:
         raise RuntimeError('finetrainers.models.attention_dispatch.AttentionProvider lacks MI355X = "mi355x" (INTEGRATION.md step 1)')
-    ref._AttentionProviderRegistry.register(member, constraints=[_check_device_gpu, _check_qkv_dtype_bf16, _check_head_dim_64], supports_cp=False)(
+    ref._AttentionProviderRegistry.register(member, constraints=[_check_device_gpu, _check_qkv_dtype_bf16, _check_head_dim], supports_cp=False)(
         _mi355x_attention
     )
     return True

@@ -634,6 +634,10 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 static constexpr int kDkvLds = 2 * 16384 + 2 * 512;  // two (Q, dO) tile buffers + two (lse, delta) rows
 
+// ND = head_dim / 64; WHICH: 2 = dK and dV (head_dim 64), 0 = dV only, 1 = dK only -- at head_dim 128 the K / V fragments (64 VGPRs) and the two
+// accumulator sets (128) do not fit one wave's 256 registers together with the scores, so the backward runs the loop twice, once per output (one more S
+// recomputation: 8 executed matmuls for the 5 algorithmic ones).
+template <int ND = 1, int WHICH = 2>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -646,11 +650,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 
     const bf16_t* kp = a.k + (long)b * a.k_sb + (long)h * a.k_sh + (long)jc * a.k_ss;
     const bf16_t* vp = a.v + (long)b * a.v_sb + (long)h * a.v_sh + (long)jc * a.v_ss;
-    s16x8 kf[4], vf[4];
+    constexpr bool DO_V = WHICH != 1, DO_K = WHICH != 0;
+    s16x8 kf[4 * ND], vf[DO_K ? 4 * ND : 1];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 4 * ND; ++c) {
         kf[c] = *reinterpret_cast<const s16x8*>(kp + c * 16 + g * 8);
-        vf[c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
+        if constexpr (DO_K) vf[c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
     }
     const float bias_j = a.kbias ? a.kbias[(long)b * a.kb_sb + (long)h * a.kb_sh + jc] * kLog2e : 0.f;
 
@@ -659,22 +664,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const float* lsebase = a.lse2 + ((long)b * a.H + h) * a.Sq;
     const float* delbase = a.delta + ((long)b * a.H + h) * a.Sq;
 
-    f32x16 dkt[2], dvt[2];
+    f32x16 dkt[DO_K ? 2 * ND : 1], dvt[DO_V ? 2 * ND : 1];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2 * ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            dkt[dt][r] = 0.f;
-            dvt[dt][r] = 0.f;
+            if constexpr (DO_K) dkt[dt][r] = 0.f;
+            if constexpr (DO_V) dvt[dt][r] = 0.f;
         }
 
     const int ni = (a.Sq + 63) / 64;
     const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane);
     float lser = 0.f, delr = 0.f;
     auto stage = [&](int t, int buf) {
-        char* tb = smem + buf * 16384;
-        tile_dma_issue(qd, qbase, a.q_ss, t, t == ni - 1, tb, wave);
-        tile_dma_issue(dod, dobase, a.do_ss, t, t == ni - 1, tb + 8192, wave);
+        char* tb = smem + buf * (16384 * ND);
+#pragma unroll
+        for (int dh = 0; dh < ND; ++dh) {
+            tile_dma_issue(qd, qbase + 64 * dh, a.q_ss, t, t == ni - 1, tb + dh * 8192, wave);
+            tile_dma_issue(dod, dobase + 64 * dh, a.do_ss, t, t == ni - 1, tb + (ND + dh) * 8192, wave);
+        }
         if (tid < 64) {
             int i = t * 64 + tid;
             lser = (i < a.Sq) ? lsebase[i] : INFINITY;  // +inf => p = 0 for padded query rows
@@ -688,16 +696,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     const float inv_sl = 1.0f / sl;
     auto stage_commit = [&](int buf) {
         if (tid < 64) {
-            float* st = reinterpret_cast<float*>(smem + 2 * 16384) + buf * 128;
+            float* st = reinterpret_cast<float*>(smem + 2 * 16384 * ND) + buf * 128;
             st[tid] = -lser * inv_sl;  // (+inf for padded query rows -> -inf -> p = 0)
             st[64 + tid] = -delr;
         }
     };
 
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 4 * ND; ++c) {
         settle(kf[c]);
-        settle(vf[c]);
+        if constexpr (DO_K) settle(vf[c]);
     }
     settle(bias_j);
     stage(0, 0);
@@ -706,9 +714,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     __syncthreads();
     auto body = [&](int t, auto CUR) {
         constexpr int cur = decltype(CUR)::value;
-        const char* qs = smem + cur * 16384;
-        const char* dos = qs + 8192;
-        const float* lses = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 128;
+        const char* qs = smem + cur * (16384 * ND);
+        const char* dos = qs + 8192 * ND;
+        const float* lses = reinterpret_cast<const float*>(smem + 2 * 16384 * ND) + cur * 128;
         const float* dels = lses + 64;
         if (t + 1 < ni) stage(t + 1, cur ^ 1);
 #pragma unroll
@@ -725,28 +733,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s16x8 qf = read_row_frag(qs, is * 32 + li, c, g);
+            for (int c = 0; c < 4 * ND; ++c) {
+                s16x8 qf = read_row_frag(qs + (c >> 2) * 8192, is * 32 + li, c & 3, g);
                 s = mfma32(qf, kf[c], s);
-                s16x8 dof = read_row_frag(dos, is * 32 + li, c, g);
-                dp = mfma32(dof, vf[c], dp);
+                if constexpr (DO_K) {
+                    s16x8 dof = read_row_frag(dos + (c >> 2) * 8192, is * 32 + li, c & 3, g);
+                    dp = mfma32(dof, vf[c], dp);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = fast_exp2(__builtin_fmaf(s[r], sl, bias_j));
-                dp[r] = p * dp[r];
+                if constexpr (DO_K) dp[r] = p * dp[r];
                 s[r] = p;
             }
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                s16x8 pf = pack_frag(s, hh);
-                s16x8 dsf = pack_frag(dp, hh);
+                s16x8 pf, dsf;
+                if constexpr (DO_V) pf = pack_frag(s, hh);
+                if constexpr (DO_K) dsf = pack_frag(dp, hh);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    s16x8 dotf = read_tr_frag(dos, dt * 32, is * 32 + hh * 16, lane);
-                    dvt[dt] = mfma32(dotf, pf, dvt[dt]);
-                    s16x8 qtf = read_tr_frag(qs, dt * 32, is * 32 + hh * 16, lane);
-                    dkt[dt] = mfma32(qtf, dsf, dkt[dt]);
+                for (int dt = 0; dt < 2 * ND; ++dt) {
+                    if constexpr (DO_V) {
+                        s16x8 dotf = read_tr_frag(dos + (dt >> 1) * 8192, (dt & 1) * 32, is * 32 + hh * 16, lane);
+                        dvt[dt] = mfma32(dotf, pf, dvt[dt]);
+                    }
+                    if constexpr (DO_K) {
+                        s16x8 qtf = read_tr_frag(qs + (dt >> 1) * 8192, (dt & 1) * 32, is * 32 + hh * 16, lane);
+                        dkt[dt] = mfma32(qtf, dsf, dkt[dt]);
+                    }
                 }
             }
         }
@@ -762,8 +777,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
     {
         bf16_t* dkb = a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh;
         bf16_t* dvb = a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh;
-        store_rows_via_lds(smem + wave * 4096, dkt, a.scale, dkb, a.dk_ss, blk.tile * 128 + wave * 32, a.Sk, lane);
-        store_rows_via_lds(smem + wave * 4096, dvt, 1.0f, dvb, a.dv_ss, blk.tile * 128 + wave * 32, a.Sk, lane);
+#pragma unroll
+        for (int dh = 0; dh < ND; ++dh) {
+            if constexpr (DO_K)
+                store_rows_via_lds(smem + wave * 4096, *reinterpret_cast<const f32x16(*)[2]>(&dkt[2 * dh]), a.scale, dkb + 64 * dh, a.dk_ss, blk.tile * 128 + wave * 32, a.Sk, lane);
+            if constexpr (DO_V)
+                store_rows_via_lds(smem + wave * 4096, *reinterpret_cast<const f32x16(*)[2]>(&dvt[2 * dh]), 1.0f, dvb + 64 * dh, a.dv_ss, blk.tile * 128 + wave * 32, a.Sk, lane);
+        }
     }
 }
 
@@ -938,8 +958,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 static constexpr int kDqLds = 2 * 16384 + 2 * 256;
 
-template <bool HAS_KB>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+template <bool HAS_KB, int ND = 1>  // ND = head_dim / 64 (2: Wan / HunyuanVideo; 32 query rows per wave keep q, dO and the dQ accumulators inside 256 VGPRs)
+__global__ __launch_bounds__(256, ND) void attn_bwd_dq_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
@@ -951,9 +971,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
     const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
     const bf16_t* dop = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)ic * a.do_ss;
-    s16x8 qf[4], dof[4];
+    s16x8 qf[4 * ND], dof[4 * ND];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 4 * ND; ++c) {
         qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
         dof[c] = *reinterpret_cast<const s16x8*>(dop + c * 16 + g * 8);
     }
@@ -965,7 +985,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     {
         const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)ic * a.o_ss;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 4 * ND; ++c) {
             const s16x8 of = *reinterpret_cast<const s16x8*>(op + c * 16 + g * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) del_i += bf2f((bf16_t)dof[c][e]) * bf2f((bf16_t)of[e]);
@@ -978,9 +998,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
     const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
 
-    f32x16 dqt[2];
+    f32x16 dqt[2 * ND];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2 * ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqt[dt][r] = 0.f;
 
@@ -988,9 +1008,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
     float kbr = 0.f;
     auto stage = [&](int t, int buf) {
-        char* tb = smem + buf * 16384;
-        tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
-        tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+        char* tb = smem + buf * (16384 * ND);
+#pragma unroll
+        for (int dh = 0; dh < ND; ++dh) {
+            tile_dma_issue(kd, kbase + 64 * dh, a.k_ss, t, t == nt - 1, tb + dh * 8192, wave);
+            tile_dma_issue(vd, vbase + 64 * dh, a.v_ss, t, t == nt - 1, tb + (ND + dh) * 8192, wave);
+        }
         if constexpr (HAS_KB) {
             if (tid < 64) {
                 int j = t * 64 + tid;
@@ -1000,12 +1023,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     };
     auto stage_commit = [&](int buf) {
         if constexpr (HAS_KB) {
-            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384)[buf * 64 + tid] = kbr;
+            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384 * ND)[buf * 64 + tid] = kbr;
         }
     };
 
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 4 * ND; ++c) {
         settle(qf[c]);
         settle(dof[c]);
     }
@@ -1017,9 +1040,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     __syncthreads();
     auto body = [&](int t, auto CUR) {
         constexpr int cur = decltype(CUR)::value;
-        const char* ks = smem + cur * 16384;
-        const char* vs = ks + 8192;
-        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
+        const char* ks = smem + cur * (16384 * ND);
+        const char* vs = ks + 8192 * ND;
+        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384 * ND) + cur * 64;
         if (t + 1 < nt) stage(t + 1, cur ^ 1);
 #pragma unroll
         for (int js = 0; js < 2; ++js) {
@@ -1030,10 +1053,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 dp[r] = 0.f;
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
+            for (int c = 0; c < 4 * ND; ++c) {
+                s16x8 kf = read_row_frag(ks + (c >> 2) * 8192, js * 32 + li, c & 3, g);
                 s = mfma32(kf, qf[c], s);
-                s16x8 vf = read_row_frag(vs, js * 32 + li, c, g);
+                s16x8 vf = read_row_frag(vs + (c >> 2) * 8192, js * 32 + li, c & 3, g);
                 dp = mfma32(vf, dof[c], dp);
             }
 #pragma unroll
@@ -1051,8 +1074,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             for (int hh = 0; hh < 2; ++hh) {
                 s16x8 dsf = pack_frag(dp, hh);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    s16x8 ktf = read_tr_frag(ks, dt * 32, js * 32 + hh * 16, lane);
+                for (int dt = 0; dt < 2 * ND; ++dt) {
+                    s16x8 ktf = read_tr_frag(ks + (dt >> 1) * 8192, (dt & 1) * 32, js * 32 + hh * 16, lane);
                     dqt[dt] = mfma32(ktf, dsf, dqt[dt]);
                 }
             }
@@ -1068,7 +1091,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
     {
         bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
-        store_rows_via_lds(smem + wave * 4096, dqt, a.scale, dqb, a.dq_ss, blk.tile * 128 + wave * 32, a.Sq, lane);
+#pragma unroll
+        for (int dh = 0; dh < ND; ++dh)
+            store_rows_via_lds(smem + wave * 4096, *reinterpret_cast<const f32x16(*)[2]>(&dqt[2 * dh]), a.scale, dqb + 64 * dh, a.dq_ss, blk.tile * 128 + wave * 32, a.Sq, lane);
     }
 }
 
@@ -1398,7 +1423,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv2_kernel(AttnArgs a) {
 int attn_bwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_bwd: empty problem");
     if (!a.lse2 || !a.delta || !a.dout || !a.o) return set_error(FTMI_ERR_INVALID, "attn_bwd: missing lse/delta/dout/out");
-    if (a.d != 64) return set_error(FTMI_ERR_UNSUPPORTED, "attn_bwd: head_dim 128 has a forward kernel only so far");
+    if (a.d == 128) {
+        // head_dim 128 (Wan / HunyuanVideo): dQ with 32 query rows per wave (also publishes delta), then dV and dK in two passes of the key-major loop
+        constexpr int kDq128 = 2 * 32768 + 2 * 256, kDkv128 = 2 * 32768 + 2 * 512;
+        static const bool ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kDq128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kDq128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv128) == hipSuccess;
+        if (!ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
+        ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * a.d, st);
+        const dim3 gq(((a.Sq + 127) / 128) * a.H * a.B), gk(((a.Sk + 127) / 128) * a.H * a.B);
+        if (a.kbias || (a.Sk % 64) != 0)
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 2>), gq, dim3(256), kDq128, st, a);
+        else
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 2>), gq, dim3(256), kDq128, st, a);
+        int rc128 = check_launch("attn_bwd_dq");
+        if (rc128) return rc128;
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<2, 0>), gk, dim3(256), kDkv128, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<2, 1>), gk, dim3(256), kDkv128, st, a);
+        return check_launch("attn_bwd_dkdv");
+    }
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8) || (a.do_ss % 8) || (a.dq_ss % 8) || (a.dk_ss % 8) || (a.dv_ss % 8))
         return set_error(FTMI_ERR_INVALID, "attn_bwd: token strides must keep 16-byte alignment");
     ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * 64, st);  // algorithmic: 5 matmuls (2.5x forward)
@@ -1434,7 +1479,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, dim3(((a.Sk + 255) / 256) * a.H * a.B), dim3(256), kDkvLds, st, a);
         else
 #endif
-            hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<1, 2>), dim3(((a.Sk + 127) / 128) * a.H * a.B), dim3(256), kDkvLds, st, a);
     }
     return check_launch("attn_bwd_dkdv");
 }

@@ -25,7 +25,7 @@ def _desc(q, k, v, o, scale, dout=None, dq=None, dk=None, dv=None, key_bias=None
     B, H, Sq, d = q.shape
     Sk = k.shape[2]
     if d not in (64, 128):
-        raise ValueError(f"mi355x attention supports head_dim 64 (and 128 for the forward), got {d}")
+        raise ValueError(f"mi355x attention supports head_dim 64 and 128, got {d}")
     if k.shape != (B, H, Sk, d) or v.shape != (B, H, Sk, d):
         raise ValueError("mi355x attention: key/value shapes must be [B, H, Sk, head_dim] (no GQA)")
     desc = AttnDesc()

@@ -62,7 +62,8 @@ int ftmi_prof_summary(int kernel_class, double* sampled_ms, long* sampled_launch
                       double* all_flops, int reset);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Attention provider level.  q,k,v,out,dout,dq,dk,dv: bf16, head_dim 64 contiguous; element (b,h,s,:) lives at
+ * Attention provider level.  q,k,v,out,dout,dq,dk,dv: bf16, head_dim desc.d = 64 (LTX-Video, CogVideoX) or 128 (Wan, HunyuanVideo)
+ * contiguous; element (b,h,s,:) lives at
  * base + b*stride[0] + h*stride[1] + s*stride[2] (strides in elements).  lse: fp32 [B,H,Sq] (log2 domain,
  * written by fwd, read by bwd).  key_bias: optional fp32 additive bias per (batch, head, key) (an attn_mask that broadcasts over
  * queries; desc.bias_strides = {Sk, 0} for the usual [B,Sk] mask shared by the heads), NULL for none.  A bias of -inf removes the key

@@ -222,30 +222,36 @@ def test_attention_fwd_bwd(B, H, Sq, Sk, biased):
     report(tag + " dv", dv, dv_ref, 1e-2)
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 3, 300, 257, True), (1, 2, 128, 128, False), (1, 2, 200, 330, False), (1, 4, 2688, 2688, False)])
-def test_attention_forward_head_dim_128(B, H, Sq, Sk, biased):
-    """Head size of Wan / HunyuanVideo: forward only so far -- same kernel, twice the matrix work per softmax element.
-    Against fp32 softmax attention on the CPU (and the backward must refuse instead of running the head_dim-64 kernels on it)."""
+@pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 3, 300, 257, True), (1, 2, 128, 128, False), (1, 2, 200, 330, False), (1, 4, 2688, 2688, False),
+                                              (2, 2, 2688, 512, True)])
+def test_attention_head_dim_128_fwd_bwd(B, H, Sq, Sk, biased):
+    """Head size of Wan / HunyuanVideo: the forward kernel templated on head_dim / 64, the 32-row dQ kernel, and dV / dK in two
+    passes of the key-major loop (the accumulators of both do not fit 256 VGPRs next to the K / V fragments).  Against fp32 softmax attention + autograd."""
     from finetrainers_amd import ops
 
     dev = _dev()
     g = torch.Generator().manual_seed(1)
     q, k, v = rnd((B, H, Sq, 128), g), rnd((B, H, Sk, 128), g), rnd((B, H, Sk, 128), g)
+    dout = rnd((B, H, Sq, 128), g)
     bias = None
     if biased:
         mask = torch.zeros(B, Sk)
         for b in range(B):
             mask[b, : max(1, (Sk * (b + 1)) // (B + 1))] = 1
         bias = ((1 - mask.to(bf16)) * -10000.0).float()
-    sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(128.0) + (0 if bias is None else bias[:, None, None, :])
-    o_ref = torch.softmax(sc, dim=-1) @ v.float()
-    out, lse = ops.attn_fwd(q.to(dev), k.to(dev), v.to(dev), None if bias is None else bias.to(dev))
+    o_ref, dq_ref, dk_ref, dv_ref = _attn_ref(q, k, v, bias, dout)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    bd = None if bias is None else bias.to(dev)
+    out, lse = ops.attn_fwd(qd, kd, vd, bd)
     tag = f"attn d128 B{B} H{H} {Sq}x{Sk}{' bias' if biased else ''}"
     report(tag + " fwd", out, o_ref, 6e-3)
     assert (out.float().cpu() - o_ref).abs().max() < 5e-3 * max(1.0, o_ref.abs().max().item())
+    sc = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(128.0) + (0 if bias is None else bias[:, None, None, :])
     report(tag + " lse", lse.cpu() * math.log(2.0), torch.logsumexp(sc, dim=-1), 1e-4)
-    with pytest.raises(ValueError):
-        ops.attn_bwd(q.to(dev), k.to(dev), v.to(dev), out, lse, out)
+    dq, dk, dv = ops.attn_bwd(qd, kd, vd, out, lse, dout.to(dev), bd)
+    report(tag + " dq", dq, dq_ref, 1e-2)
+    report(tag + " dk", dk, dk_ref, 1e-2)
+    report(tag + " dv", dv, dv_ref, 1e-2)
 
 
 def test_attention_strided_layout():

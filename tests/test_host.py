@@ -254,7 +254,7 @@ def test_attention_provider_registry_semantics():
     with pytest.raises(ValueError, match="bfloat16"):
         ad._check_qkv_dtype_bf16(query=q.float(), key=q, value=q)
     with pytest.raises(ValueError, match="head_dim"):
-        ad._check_head_dim_64(query=q[..., :32], key=q, value=q)
+        ad._check_head_dim(query=q[..., :32], key=q, value=q)
     with pytest.raises(ValueError):
         ad._check_no_dropout_causal_gqa(is_causal=True)
     # kwargs the provider does not name are dropped by the dispatcher (attention_dispatch.py:442)
