@@ -61,6 +61,27 @@ class LtxWeights(Structure):
     _fields_ = [(n, c_void_p) for n in LTX_WEIGHT_FIELDS]
 
 
+class CogConfig(Structure):
+    _fields_ = [
+        ("B", c_int), ("T", c_int), ("S", c_int),
+        ("D", c_int), ("H", c_int), ("L", c_int),
+        ("D_ff", c_int), ("D_temb", c_int),
+        ("r", c_int),
+        ("lora_scale", c_float), ("eps_norm", c_float), ("eps_qk", c_float),
+        ("gemm_variant", c_int),
+    ]
+
+
+COG_WEIGHT_FIELDS = [
+    "mod_w", "mod_b", "norm_w", "norm_b", "w_qkv", "b_qkv", "w_o", "b_o", "qk_norm", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
+    "w_qkv_t", "w_o_t", "w_ff1_t", "w_ff2_t", "lora_a_sp", "lora_bt_sp", "lora_b_ext", "lora_at_ext", "lora_at_qkv_ext", "rope_cos", "rope_sin",
+]
+
+
+class CogWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in COG_WEIGHT_FIELDS]
+
+
 _SIGS = {
     "ftmi_version": (c_int, []),
     "ftmi_last_error": (c_int, [c_char_p, c_size_t]),
@@ -103,6 +124,11 @@ _SIGS = {
     "ftmi_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p]),
     "ftmi_clip_adamw_step": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 6 + [c_int, c_void_p, c_void_p, c_void_p]),
     "ftmi_lora_refresh": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    "ftmi_lora_refresh_n": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "ftmi_cog_workspace_bytes": (c_size_t, [POINTER(CogConfig)]),
+    "ftmi_cog_blocks_forward": (c_int, [POINTER(CogConfig), POINTER(CogWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ftmi_cog_blocks_backward": (c_int, [POINTER(CogConfig), POINTER(CogWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         c_int, c_int, c_int, c_void_p]),
     "ftmi_lora_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

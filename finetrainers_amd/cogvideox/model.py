@@ -19,7 +19,10 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import ops
+import ctypes
+
+from .. import _lib, ops
+from .._lib import CogConfig, CogWeights, check, ptr, stream_ptr
 from .block import MI355XCogVideoXBlock
 
 bf16 = torch.bfloat16
@@ -110,6 +113,58 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int) -> torch.Tensor:
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
 
+class _BlockStackFunction(torch.autograd.Function):
+    """All blocks in one C call per direction (``ftmi_cog_blocks_forward`` / ``_backward``, csrc/cog_dit.hip): the workspace holds every activation the
+    backward needs.  The LoRA gradients land in the model's flat gradient buffer (= the blocks' ``.grad`` views); with a data-parallel hook installed the
+    backward runs in block ranges and each finished range is handed to the hook (bucketed all-reduce overlapped with the remaining blocks)."""
+
+    @staticmethod
+    def forward(ctx, m: "MI355XCogVideoXTransformer3DModel", tokens, temb_silu, rope, lora_anchor, keep_activations: bool):
+        B, N, D = tokens.shape
+        cfg = m._c_config(B, N)
+        w = m._c_weights(rope)
+        lib = _lib.load()
+        nbytes = lib.ftmi_cog_workspace_bytes(ctypes.byref(cfg))
+        ws = m._acquire_workspace(nbytes)
+        out = torch.empty_like(tokens)
+        check(lib.ftmi_cog_blocks_forward(ctypes.byref(cfg), ctypes.byref(w), ptr(tokens), ptr(temb_silu), ptr(out), ptr(ws), nbytes, stream_ptr()),
+              "ftmi_cog_blocks_forward")
+        if not keep_activations:  # no_grad evaluation: nothing will come back for the activations
+            m._release_workspace(ws)
+            return out
+        ctx.m, ctx.cfg, ctx.w, ctx.ws, ctx.nbytes, ctx.rope = m, cfg, w, ws, nbytes, rope
+        ctx.save_for_backward(tokens)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.m
+        (tokens,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        L, r, D = m.config.num_layers, m.lora_rank, m.config.inner_dim
+        n = L * 4 * r * D
+        gflat = m.lora_grad_flat
+        ga, gb = gflat[:n].view(L, 4, r, D), gflat[n:].view(L, 4, D, r)
+        blk0 = m.transformer_blocks[0]
+        accumulate = int(blk0.lora_A.grad is not None and blk0.lora_A.grad.data_ptr() == ga[0].data_ptr())
+        hook = m._grad_bucket_hook
+        step = m.grad_bucket_blocks if (hook is not None and m.grad_bucket_blocks > 0) else L
+        lib = _lib.load()
+        hi = L
+        while hi > 0:
+            lo = max(0, hi - step)
+            check(lib.ftmi_cog_blocks_backward(ctypes.byref(ctx.cfg), ctypes.byref(ctx.w), ptr(tokens), ptr(dout), None, ptr(ga), ptr(gb), ptr(ctx.ws),
+                                               ctx.nbytes, hi, lo, accumulate, stream_ptr()), "ftmi_cog_blocks_backward")
+            if hook is not None:
+                hook(lo, hi, ga[lo:hi], gb[lo:hi])
+            hi = lo
+        for i, blk in enumerate(m.transformer_blocks):
+            blk.lora_A.grad, blk.lora_B.grad = ga[i], gb[i]
+        m._release_workspace(ctx.ws)
+        ctx.ws = None
+        return None, None, None, None, None, None  # nothing below block 0 is trainable
+
+
 class _HeadFunction(torch.autograd.Function):
     """Video tokens of the last block -> norm_final -> AdaLayerNorm(norm_out) -> proj_out -> un-patchify.  Backward: d tokens (text rows zero)."""
 
@@ -170,6 +225,13 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
         self._pos_cache: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self.lora_flat: Optional[torch.Tensor] = None
         self.lora_rank = 0
+        self.native_blocks = True  # all blocks as one C call per direction (csrc/cog_dit.hip); False: the per-block Python composition of block.py
+        self._stack: Dict[str, torch.Tensor] = {}
+        self._lora_copies: Optional[Dict[str, torch.Tensor]] = None
+        self._lora_versions = None
+        self._ws_pool: List[torch.Tensor] = []
+        self._grad_bucket_hook = None  # callable(lo, hi, grad_a[lo:hi], grad_b[lo:hi]) set by the data-parallel step
+        self.grad_bucket_blocks = 0
 
     @property
     def device(self) -> torch.device:
@@ -194,6 +256,78 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
         for i, blk in enumerate(self.transformer_blocks):
             pre = f"transformer_blocks.{i}."
             blk.load_diffusers_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+        self._build_stack()
+
+    # ---- stacked weights / C structs of the native block stack --------------------------------------------------------------------------
+    @torch.no_grad()
+    def _build_stack(self) -> None:
+        """Per-kind tensors with a leading layer axis (include/ftmi355.h: ftmi_cog_weights), built from the blocks' buffers at load time."""
+        blocks = self.transformer_blocks
+        cat = lambda f: torch.stack([f(b) for b in blocks]).contiguous()
+        st = {
+            "mod_w": cat(lambda b: torch.stack([b.norm1_lin_w, b.norm2_lin_w])), "mod_b": cat(lambda b: torch.stack([b.norm1_lin_b, b.norm2_lin_b])),
+            "norm_w": cat(lambda b: torch.stack([b.norm1_w, b.norm2_w])), "norm_b": cat(lambda b: torch.stack([b.norm1_b, b.norm2_b])),
+            "w_qkv": cat(lambda b: torch.cat([b.wq, b.wk, b.wv])), "b_qkv": cat(lambda b: torch.cat([b.bq, b.bk, b.bv])),
+            "w_o": cat(lambda b: b.wo), "b_o": cat(lambda b: b.bo),
+            "qk_norm": cat(lambda b: torch.stack([b.norm_q_w, b.norm_q_b, b.norm_k_w, b.norm_k_b])),
+            "w_ff1": cat(lambda b: b.ff1_w), "b_ff1": cat(lambda b: b.ff1_b), "w_ff2": cat(lambda b: b.ff2_w), "b_ff2": cat(lambda b: b.ff2_b),
+            "w_o_t": cat(lambda b: b.wo_t), "w_ff1_t": cat(lambda b: b.ff1_w_t), "w_ff2_t": cat(lambda b: b.ff2_w_t),
+        }
+        st["w_qkv_t"] = torch.stack([ops.transpose_bf16(wl) for wl in st["w_qkv"]]).contiguous()  # [L, D, 3D]
+        self._stack = st
+        D = self.config.inner_dim
+        for i, b in enumerate(blocks):  # one copy of the large matrices: the blocks' buffers become views of the stacks
+            b.wq, b.wk, b.wv = st["w_qkv"][i, :D], st["w_qkv"][i, D:2 * D], st["w_qkv"][i, 2 * D:]
+            b.wo, b.ff1_w, b.ff2_w = st["w_o"][i], st["w_ff1"][i], st["w_ff2"][i]
+            b.wo_t, b.ff1_w_t, b.ff2_w_t = st["w_o_t"][i], st["w_ff1_t"][i], st["w_ff2_t"][i]
+
+    def _c_config(self, B: int, N: int) -> CogConfig:
+        c = self.config
+        return CogConfig(B=B, T=c.max_text_seq_length, S=N - c.max_text_seq_length, D=c.inner_dim, H=c.num_attention_heads, L=c.num_layers,
+                         D_ff=c.ff_mult * c.inner_dim, D_temb=c.time_embed_dim, r=self.lora_rank,
+                         lora_scale=(self.transformer_blocks[0].lora_scale if self.lora_rank else 0.0), eps_norm=c.norm_eps, eps_qk=1e-6, gemm_variant=8)
+
+    @torch.no_grad()
+    def _refresh_lora_copies(self) -> None:
+        """bf16 (hi, lo) working copies of the flat fp32 adapters, rebuilt when the parameters changed (3 launches)."""
+        if self.lora_flat is None:
+            return
+        ver = (self.lora_flat._version, self.lora_flat.data_ptr())
+        if self._lora_copies is not None and ver == self._lora_versions:
+            return
+        L, r, D = self.config.num_layers, self.lora_rank, self.config.inner_dim
+        if self._lora_copies is None:
+            z = lambda *shape: torch.zeros(shape, dtype=bf16, device=self.device)
+            self._lora_copies = {"lora_a_sp": z(L, 4, 2 * r, D), "lora_bt_sp": z(L, 4, 2 * r, D), "lora_b_ext": z(L, 4, D, 3 * r),
+                                 "lora_at_ext": z(L, 4, D, 3 * r), "lora_at_qkv_ext": z(L, D, 9 * r)}
+        n = L * 4 * r * D
+        cp = self._lora_copies
+        check(_lib.load().ftmi_lora_refresh_n(ptr(self.lora_flat[:n]), ptr(self.lora_flat[n:]), ptr(cp["lora_a_sp"]), ptr(cp["lora_bt_sp"]), ptr(cp["lora_b_ext"]),
+                                               ptr(cp["lora_at_ext"]), ptr(cp["lora_at_qkv_ext"]), L, 4, r, D, stream_ptr()), "ftmi_lora_refresh_n")
+        self._lora_versions = ver
+
+    def _c_weights(self, rope) -> CogWeights:
+        w = CogWeights()
+        for k, v in self._stack.items():
+            setattr(w, k, v.data_ptr())
+        if self.lora_rank:
+            self._refresh_lora_copies()
+            for k, v in self._lora_copies.items():
+                setattr(w, k, v.data_ptr())
+        if rope is not None:
+            w.rope_cos, w.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
+        return w
+
+    def _acquire_workspace(self, nbytes: int) -> torch.Tensor:
+        for i, t in enumerate(self._ws_pool):
+            if t.numel() >= nbytes:
+                return self._ws_pool.pop(i)
+        self._ws_pool.clear()
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
+    def _release_workspace(self, ws: Optional[torch.Tensor]) -> None:
+        if ws is not None:
+            self._ws_pool.append(ws)
 
     def add_adapter(self, r: int = 64, lora_alpha: float = 64.0) -> None:
         """LoRA on to_q / to_k / to_v / to_out.0 of every block (the default target regex, sft_trainer/config.py:24-26).  All adapters live in ONE
@@ -274,8 +408,13 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
             raise RuntimeError("load_diffusers_state_dict first")
         tokens, emb, onep_out, shift_out = self._embed(hidden_states, encoder_hidden_states, timestep)
         T = self.config.max_text_seq_length
-        for blk in self.transformer_blocks:
-            tokens = blk(tokens, emb, T, image_rotary_emb)
+        if self.native_blocks and self.lora_flat is not None:
+            temb_silu = torch.nn.functional.silu(emb.to(bf16)).contiguous()
+            # the last argument only tells autograd that this node has trainable inputs: the gradients go straight into lora_grad_flat
+            tokens = _BlockStackFunction.apply(self, tokens, temb_silu, image_rotary_emb, self.transformer_blocks[0].lora_A, torch.is_grad_enabled())
+        else:
+            for blk in self.transformer_blocks:
+                tokens = blk(tokens, emb, T, image_rotary_emb)
         B, F_, C, H, W = hidden_states.shape
         vel = _HeadFunction.apply(self, tokens, onep_out, shift_out, (F_, H, W))
         return {"sample": vel} if return_dict else (vel,)

@@ -19,7 +19,7 @@ from .specification import MI355XCogVideoXSpecOps
 class MI355XCogVideoXSFTStep:
     def __init__(self, transformer: MI355XCogVideoXTransformer3DModel, spec: Optional[MI355XCogVideoXSpecOps] = None, lr: float = 5e-5,
                  betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4, max_grad_norm: float = 1.0, parallel=None,
-                 generator: Optional[torch.Generator] = None, lr_scheduler=None):
+                 generator: Optional[torch.Generator] = None, lr_scheduler=None, grad_bucket_blocks: int = 5):
         if transformer.lora_flat is None:
             raise ValueError("attach a LoRA adapter first (transformer.add_adapter)")
         self.transformer, self.spec = transformer, spec or MI355XCogVideoXSpecOps()
@@ -30,6 +30,7 @@ class MI355XCogVideoXSFTStep:
         self.exp_avg_sq = torch.zeros_like(transformer.lora_flat)
         self._scratch = torch.zeros(ops.CLIP_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
         self.step_count = 0
+        self.grad_bucket_blocks = grad_bucket_blocks  # native block stack: blocks per all-reduce bucket (2 x 5 x 4 x r x D fp32 = 39 MB at rank 128)
         if parallel is not None and parallel.active:
             parallel.broadcast_(transformer.lora_flat, src=0)  # replicas start from rank 0's adapter (DDP does the same)
         # utils/diffusion.py:75-81: the DDIM "sigma" table is scheduler.timesteps / num_train_timesteps, timesteps = 999 ... 0
@@ -57,11 +58,15 @@ class MI355XCogVideoXSFTStep:
                 if h is not None:
                     pending.append(h)
 
-        for blk in tr.transformer_blocks:
+        for blk in tr.transformer_blocks:  # per-block Python composition: one exchange per block
             blk._grad_hook = exchange if dp else None
+        # native block stack: the backward runs in ranges of grad_bucket_blocks blocks, each range's slice of the flat gradient is one bucket
+        tr._grad_bucket_hook = (lambda lo, hi, ga, gb: exchange(ga, gb)) if dp else None
+        tr.grad_bucket_blocks = self.grad_bucket_blocks
         try:
             loss = self.spec.loss_backward(pred, target, sigmas)
         finally:
+            tr._grad_bucket_hook = None
             for blk in tr.transformer_blocks:
                 blk._grad_hook = None
         for work, div in pending:  # device-side wait on RCCL; gloo: host wait + divide
@@ -75,6 +80,7 @@ class MI355XCogVideoXSFTStep:
         gn = torch.empty(1, dtype=torch.float32, device=gflat.device)
         ops.clip_adamw_step(tr.lora_flat, gflat, self.exp_avg, self.exp_avg_sq, self.step_count, lr, self.betas, self.eps, self.weight_decay,
                             self.max_grad_norm, scratch=self._scratch, grad_norm_out=gn)
+        tr._lora_versions = None  # parameters changed in place by the library: refresh the bf16 working copies next forward
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
         for blk in tr.transformer_blocks:

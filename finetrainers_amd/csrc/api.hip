@@ -449,6 +449,22 @@ int ftmi_cog_unpatchify(const void* tokens, void* latents, int B, int F, int C, 
     return cog_patch_permute((const bf16_t*)tokens, (bf16_t*)latents, B, F, C, H, W, patch, 0, (hipStream_t)stream);
 }
 
+size_t ftmi_cog_workspace_bytes(const ftmi_cog_config* cfg) { return cfg ? cog_workspace_bytes(*cfg) : 0; }
+
+int ftmi_cog_blocks_forward(const ftmi_cog_config* cfg, const ftmi_cog_weights* w, const void* tokens_in, const void* temb_silu, void* tokens_out,
+                            void* workspace, size_t workspace_bytes, ftmi_stream stream) {
+    if (!cfg || !w || !tokens_in || !temb_silu || !tokens_out || !workspace) return set_error(FTMI_ERR_INVALID, "ftmi_cog_blocks_forward: null argument");
+    return cog_blocks_forward(*cfg, *w, (const bf16_t*)tokens_in, (const bf16_t*)temb_silu, (bf16_t*)tokens_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int ftmi_cog_blocks_backward(const ftmi_cog_config* cfg, const ftmi_cog_weights* w, const void* tokens_in, const void* d_tokens_out, void* d_tokens_in,
+                             float* grad_a, float* grad_b, void* workspace, size_t workspace_bytes, int l_hi, int l_lo, int accumulate, ftmi_stream stream) {
+    if (!cfg || !w || !tokens_in || !d_tokens_out || !workspace || (cfg->r > 0 && (!grad_a || !grad_b)))
+        return set_error(FTMI_ERR_INVALID, "ftmi_cog_blocks_backward: null argument");
+    return cog_blocks_backward(*cfg, *w, (const bf16_t*)tokens_in, (const bf16_t*)d_tokens_out, (bf16_t*)d_tokens_in, grad_a, grad_b, workspace, workspace_bytes,
+                               l_hi, l_lo, accumulate, (hipStream_t)stream);
+}
+
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample, float grad_scale,
                   ftmi_stream stream) {
     if (!pred || !target || !loss) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");
@@ -477,24 +493,29 @@ int ftmi_clip_grad_norm(float* grads, long n, float max_norm, float* scratch, fl
 
 int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
                       void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream) {
-    if (!a_f32 || !b_f32 || !lora_a_sp || !lora_bt_sp || !lora_b_ext || !lora_at_ext || !lora_at_qkv_ext)
-        return set_error(FTMI_ERR_INVALID, "ftmi_lora_refresh: null argument");
+    return ftmi_lora_refresh_n(a_f32, b_f32, lora_a_sp, lora_bt_sp, lora_b_ext, lora_at_ext, lora_at_qkv_ext, L, 8, r, D, stream);
+}
+
+int ftmi_lora_refresh_n(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
+                        void* lora_at_qkv_ext, int L, int nadp, int r, int D, ftmi_stream stream) {
+    if (!a_f32 || !b_f32 || !lora_a_sp || !lora_bt_sp || !lora_b_ext || !lora_at_ext || !lora_at_qkv_ext || nadp < 3)
+        return set_error(FTMI_ERR_INVALID, "ftmi_lora_refresh: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const long per = (long)r * D;
     LoraSplitArgs a;  // A [r, D]: row planes of A, column planes of A^T
-    a.w = a_f32; a.rows = r; a.cols = D; a.nmat = L * 8; a.in_bstride = per;
+    a.w = a_f32; a.rows = r; a.cols = D; a.nmat = L * nadp; a.in_bstride = per;
     a.sp = (bf16_t*)lora_a_sp; a.sp_bstride = 2 * per;
     a.t_ext = (bf16_t*)lora_at_ext; a.t_ext_bstride = 3 * per; a.ld_t_ext = 3L * r;
     int rc = lora_split(a, st);
     if (rc) return rc;
     LoraSplitArgs b;  // B [D, r]: column planes of B, row planes of B^T
-    b.w = b_f32; b.rows = D; b.cols = r; b.nmat = L * 8; b.in_bstride = per;
+    b.w = b_f32; b.rows = D; b.cols = r; b.nmat = L * nadp; b.in_bstride = per;
     b.ext = (bf16_t*)lora_b_ext; b.ext_bstride = 3 * per; b.ld_ext = 3L * r;
     b.t_sp = (bf16_t*)lora_bt_sp; b.t_sp_bstride = 2 * per;
     rc = lora_split(b, st);
     if (rc) return rc;
     LoraSplitArgs q;  // adapters 0,1,2 of every block side by side: [D, 9r]
-    q.w = a_f32; q.rows = r; q.cols = D; q.nmat = L * 3; q.inner_n = 3; q.in_bstride = 8 * per; q.in_istride = per;
+    q.w = a_f32; q.rows = r; q.cols = D; q.nmat = L * 3; q.inner_n = 3; q.in_bstride = (long)nadp * per; q.in_istride = per;
     q.t_ext = (bf16_t*)lora_at_qkv_ext; q.t_ext_bstride = 9 * per; q.t_ext_istride = 3L * r; q.ld_t_ext = 9L * r;
     return lora_split(q, st);
 }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const int nchunk = a.D / 8;
-    const long ro = (long)row * a.ld;
+    const long ro = (long)row * a.ld, rdy = (long)row * (a.ld_dy ? a.ld_dy : a.ld), rout = (long)row * (a.ld_out ? a.ld_out : a.ld);
     const int pos = row % a.rows_per_batch;
     const bool rope = a.cos != nullptr && pos >= a.seg0;
     const float* cp = rope ? a.cos + (long)(pos - a.seg0) * 64 : nullptr;
@@ -219,11 +219,11 @@ __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
                     o[e + 1] = n[e + 1] * cv[e + 1] + n[e] * sv[e + 1];
                 }
             }
-            if (on) st8(a.y + ro + c * 8, o);
+            if (on) st8(a.y + rout + c * 8, o);
         } else {
             float gv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8];
             if (on) {
-                up8(a.dy + ro + c * 8, dv);
+                up8(a.dy + rdy + c * 8, dv);
                 if (rope) {  // gradient of the bf16 LayerNorm output: the cos term and the (bf16-path) rotated term, each a bf16 tensor, added in bf16
                     float t[8];
 #pragma unroll
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
             c2 = gsum8(c2) * (1.0f / 64);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[e] - c1 - (xv[e] - mean) * rstd * c2);
-            if (on) st8(a.dx + ro + c * 8, o);
+            if (on) st8(a.dx + rout + c * 8, o);
         }
     }
 }
@@ -282,6 +282,23 @@ int check_args(const CogLnArgs& a, const char* who) {
     return 0;
 }
 
+// ---- modulation tables of all blocks: mod [B][L2][6][D] = linear(silu(temb)) of every LayerNorm-zero (L2 = 2 per block), chunks (shift, scale, gate,
+// enc_shift, enc_scale, enc_gate)  ->  tables [L2][3][B][2][D]: (shift, bf(1 + scale), gate) x (text row, video row) ---------------------------------
+__global__ __launch_bounds__(256) void mod_tables_kernel(const bf16_t* __restrict__ mod, bf16_t* __restrict__ tables, int L2, int B, int D) {
+    const long total = (long)L2 * 3 * B * 2 * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        long t = i / D;
+        const int seg = (int)(t % 2); t /= 2;
+        const int b = (int)(t % B); t /= B;
+        const int kind = (int)(t % 3);
+        const int l2 = (int)(t / 3);
+        const int chunk = (seg == 0 ? 3 : 0) + kind;  // text rows use the enc_* chunks
+        const float v = bf2f(mod[(((long)b * L2 + l2) * 6 + chunk) * D + d]);
+        tables[i] = f2bf(kind == 1 ? 1.0f + v : v);
+    }
+}
+
 // ---- patch (p x p) gather / scatter between latents [B, F, C, H, W] and tokens [B, F (H/p) (W/p), C p p] -----------------------------------
 // tokens[b, (f h + hy) w + wx, (c p + py) p + px] <-> lat[b, f, c, hy p + py, wx p + px]: the im2col of CogVideoXPatchEmbed's Conv2d(kernel = stride
 // = p) (its weight flattens as [D, C p p] in the same (c, py, px) order) and, in the other direction, the model's final un-patchify
@@ -304,6 +321,14 @@ __global__ __launch_bounds__(256) void patch_permute_kernel(const bf16_t* __rest
 }
 
 }  // namespace
+
+int cog_mod_tables(const bf16_t* mod, bf16_t* tables, int L2, int B, int D, hipStream_t st) {
+    const long total = (long)L2 * 3 * B * 2 * D;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mod_tables_kernel, dim3((unsigned)blocks), dim3(256), 0, st, mod, tables, L2, B, D);
+    return check_launch("cog_mod_tables");
+}
 
 int cog_patch_permute(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W, int p, int to_tokens, hipStream_t st) {
     if (B <= 0 || F <= 0 || C <= 0 || p <= 0 || H % p || W % p) return set_error(FTMI_ERR_INVALID, "cog_patch_permute: bad geometry");

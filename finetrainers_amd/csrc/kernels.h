@@ -226,7 +226,8 @@ struct CogLnArgs {
     bf16_t* y = nullptr;
     bf16_t* dx = nullptr;
     int rows = 0, D = 0, rows_per_batch = 1, seg0 = 0;
-    long ld = 0;
+    long ld = 0;                 // head_ln: row stride of x
+    long ld_dy = 0, ld_out = 0;  // head_ln: row strides of dy and of the output (y / dx); 0 = ld
     float eps = 1e-5f;
 };
 int cog_ln_mod_fwd(const CogLnArgs& a, hipStream_t st);    // y = bf(bf(LN(x; w, b)) * onep) + shift
@@ -234,6 +235,12 @@ int cog_ln_mod_bwd(const CogLnArgs& a, hipStream_t st);    // dx = [dres +] LN'(
 int cog_head_ln_fwd(const CogLnArgs& a, hipStream_t st);   // per 64-channel head: y = LN(x; w[64], b[64])
 int cog_head_ln_bwd(const CogLnArgs& a, hipStream_t st);
 int cog_gate_residual(const CogLnArgs& a, hipStream_t st); // y = [dres +] bf(onep * x)
+size_t cog_workspace_bytes(const ftmi_cog_config& c);
+int cog_blocks_forward(const ftmi_cog_config& c, const ftmi_cog_weights& w, const bf16_t* tokens_in, const bf16_t* temb_silu, bf16_t* tokens_out, void* ws,
+                       size_t ws_bytes, hipStream_t st);
+int cog_blocks_backward(const ftmi_cog_config& c, const ftmi_cog_weights& w, const bf16_t* tokens_in, const bf16_t* d_out, bf16_t* d_in, float* grad_a,
+                        float* grad_b, void* ws, size_t ws_bytes, int l_hi, int l_lo, int accumulate, hipStream_t st);
+int cog_mod_tables(const bf16_t* mod, bf16_t* tables, int L2, int B, int D, hipStream_t st);  // linear(silu(temb)) rows -> (shift, 1 + scale, gate) x (text, video)
 int cog_patch_permute(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W, int p, int to_tokens, hipStream_t st);  // latents <-> patch tokens
 
 }  // namespace ftmi

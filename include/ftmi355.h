@@ -256,6 +256,39 @@ int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, 
 int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, void* out, int rows, int D, int rows_per_batch, int text_len,
                            ftmi_stream stream);
 
+/* The whole CogVideoX block stack as one call per direction (the LTX orchestrator's design: caller-owned workspace, every activation of the backward
+ * kept, nothing recomputed; the backward runs over block ranges so a data-parallel caller can all-reduce finished ranges while the rest computes).
+ * Weights are stacked per kind along a leading layer axis, bf16; "_t" = transposed copies for the dgrads (made once at load time). */
+typedef struct {
+    int B, T, S;      /* batch, text tokens, video tokens: token buffers are [B, T + S, D], text first */
+    int D, H, L;      /* width = H x 64, blocks */
+    int D_ff, D_temb; /* feed-forward width, time-embedding width */
+    int r;            /* LoRA rank (0: none; multiple of 64) on to_q, to_k, to_v, to_out.0 */
+    float lora_scale, eps_norm, eps_qk;
+    int gemm_variant; /* 8 */
+} ftmi_cog_config;
+typedef struct {
+    const void *mod_w, *mod_b;   /* [L,2,6D,D_temb], [L,2,6D]: norm1.linear and norm2.linear of every block */
+    const void *norm_w, *norm_b; /* [L,2,D]: the LayerNorm affine of norm1, norm2 */
+    const void *w_qkv, *b_qkv;   /* [L,3D,D], [L,3D]: to_q | to_k | to_v */
+    const void *w_o, *b_o;       /* [L,D,D], [L,D] */
+    const void* qk_norm;         /* [L,4,64]: norm_q.weight, norm_q.bias, norm_k.weight, norm_k.bias */
+    const void *w_ff1, *b_ff1, *w_ff2, *b_ff2;       /* [L,D_ff,D], [L,D_ff], [L,D,D_ff], [L,D] */
+    const void *w_qkv_t, *w_o_t, *w_ff1_t, *w_ff2_t; /* [L,D,3D], [L,D,D], [L,D,D_ff], [L,D_ff,D] */
+    /* bf16 (hi, lo) working copies of the fp32 adapters (ftmi_lora_refresh_n with 4 adapters per block), NULL when r == 0 */
+    const void *lora_a_sp, *lora_bt_sp, *lora_b_ext, *lora_at_ext, *lora_at_qkv_ext; /* [L,4,2r,D] x2, [L,4,D,3r] x2, [L,D,9r] */
+    const float *rope_cos, *rope_sin; /* fp32 [S,64] for the rotary checkpoints, NULL otherwise */
+} ftmi_cog_weights;
+size_t ftmi_cog_workspace_bytes(const ftmi_cog_config* cfg);
+/* tokens_out <- blocks(tokens_in); temb_silu [B, D_temb] bf16 = silu(time embedding) */
+int ftmi_cog_blocks_forward(const ftmi_cog_config* cfg, const ftmi_cog_weights* w, const void* tokens_in, const void* temb_silu, void* tokens_out,
+                            void* workspace, size_t workspace_bytes, ftmi_stream stream);
+/* blocks [l_lo, l_hi) of the backward, last block first; ranges in descending order share the workspace.  d_tokens_out: gradient of the stack's output
+ * (read when l_hi == L).  d_tokens_in (may be NULL): gradient of the stack's input (written when l_lo == 0).  grad_a [L,4,r,D] / grad_b [L,4,D,r] fp32: the
+ * range's slices are overwritten (accumulate = 0) or added to (1) and are final when the call returns (stream order). */
+int ftmi_cog_blocks_backward(const ftmi_cog_config* cfg, const ftmi_cog_weights* w, const void* tokens_in, const void* d_tokens_out, void* d_tokens_in,
+                             float* grad_a, float* grad_b, void* workspace, size_t workspace_bytes, int l_hi, int l_lo, int accumulate, ftmi_stream stream);
+
 /* latents [B, F, C, H, W] -> tokens [B, F (H/p) (W/p), C p p] (the im2col of CogVideoXPatchEmbed's Conv2d(kernel = stride = p), channel order
  * (c, py, px) like the flattened conv weight), and back (the model's final un-patchify).  [upstream] CogVideoXPatchEmbed / CogVideoXTransformer3DModel. */
 int ftmi_cog_patchify(const void* latents, void* tokens, int B, int F, int C, int H, int W, int patch, ftmi_stream stream);
@@ -289,6 +322,9 @@ int ftmi_clip_grad_norm(float* grads, long n, float max_norm, float* scratch, fl
 /* fp32 flat LoRA params (A region [L,8,r,D] then B region [L,8,D,r]) -> the bf16 (hi, lo) working copies of ftmi_ltx_weights */
 int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
                       void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream);
+/* the same for a model with n_adapters adapters per block, the first three being q, k, v (CogVideoX: 4) */
+int ftmi_lora_refresh_n(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
+                        void* lora_at_qkv_ext, int L, int n_adapters, int r, int D, ftmi_stream stream);
 
 /* The same split for ONE fp32 matrix w [rows, cols] (building block of ftmi_linear_lora_fwd/_bwd callers): any of the four outputs
  * may be NULL.  sp [2 rows, cols]: (hi, lo) row planes interleaved per 32 rows; ext [rows, 3 cols]: [hi | hi | lo];

@@ -314,8 +314,8 @@ def test_patchify_roundtrip_and_position_table():
     assert torch.equal(timestep_embedding(t, 1920), ltx.get_timestep_embedding(t, 1920))
 
 
-@pytest.mark.parametrize("rotary,layers", [(False, 2), (True, 2), (False, 30)])
-def test_model_step_parity_two_blocks(rotary, layers):
+@pytest.mark.parametrize("rotary,layers,native", [(False, 2, True), (True, 2, True), (False, 30, True), (True, 2, False)])
+def test_model_step_parity_two_blocks(rotary, layers, native):
     """(rotary = False: the 2b sincos-table architecture, BASELINE config 3; True: the 5b-style rotary embedding on the video rows of q / k.)
     The whole CogVideoX-2b-width SFT forward + backward at 2 blocks: spec ops (scaling, DDIM noising), patch embed + sincos table, time
     embedding, blocks, final norms, proj_out, un-patchify, velocity -> x0, weighted loss, and every LoRA gradient, against oracle/cogvideox.py."""
@@ -338,6 +338,7 @@ def test_model_step_parity_two_blocks(rotary, layers):
     gmodel.load_diffusers_state_dict(sd)
     gmodel.add_adapter(r=64, lora_alpha=64.0)
     gmodel.load_lora_state_dict({k: v for k, v in sd.items() if "lora_" in k})
+    gmodel.native_blocks = native  # True: all blocks in one C call per direction (csrc/cog_dit.hip); False: the per-block composition of block.py
 
     g = torch.Generator().manual_seed(11)
     B, F_, C, H, W = 2, 3, 16, 8, 12
@@ -372,7 +373,7 @@ def test_model_step_parity_two_blocks(rotary, layers):
     assert set(got) == set(g_ref)
     glob, worst = ltx.grads_rel_l2(got, g_ref)
     e_pred, e_loss = _rel(pred.cpu(), pred_ref), abs(loss.item() - loss_ref) / abs(loss_ref)
-    print(f"[cog-model L={layers} rotary={rotary}] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref:.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
+    print(f"[cog-model L={layers} rotary={rotary} native={native}] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref:.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
           f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
     assert e_pred < 1e-2 * max(1.0, layers / 8) and e_loss < 1e-3
     assert glob < 2.5 * floor + 1e-3 and worst < 2.5 * floor_worst + 2e-3
@@ -393,6 +394,68 @@ def test_model_step_parity_two_blocks(rotary, layers):
     assert abs(out["loss"].item() - loss_ref) < 1e-3 * abs(loss_ref) and abs(out["grad_norm"].item() - gn_ref) < 5e-3 * gn_ref
     assert not torch.equal(gmodel.lora_flat, before) and gmodel.transformer_blocks[0].lora_A.grad is None
     assert gmodel.transformer_blocks[1].lora_B.data_ptr() == gmodel.lora_flat[gmodel.lora_flat.numel() // 2:].view(layers, 4, 1920, 64)[1].data_ptr()
+
+
+def test_native_block_stack_ranges_accumulation_and_python_composition():
+    """The C block stack (ftmi_cog_blocks_forward / _backward) against the per-block Python composition of the same kernels on the same model; the
+    backward in block ranges with the bucket hook (what the data-parallel step drives) gives the single-range gradients; a second backward without
+    clearing the gradients accumulates; a no_grad forward returns its workspace."""
+    from finetrainers_amd.cogvideox import CogVideoXTransformerConfig, MI355XCogVideoXSpecOps, MI355XCogVideoXTransformer3DModel
+    from oracle import cogvideox as cvx
+
+    dev = _dev()
+    kw = dict(num_layers=3, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16, use_rotary_positional_embeddings=True)
+    omodel = cvx.build_model(cvx.CogVideoXConfig(**kw), seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
+    sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2."): v for k, v in omodel.state_dict().items()}
+    m = MI355XCogVideoXTransformer3DModel(CogVideoXTransformerConfig(**kw), device=dev)
+    m.load_diffusers_state_dict(sd)
+    m.add_adapter(r=64, lora_alpha=64.0)
+    m.load_lora_state_dict({k: v for k, v in sd.items() if "lora_" in k})
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(2, 3, 16, 8, 12, generator=g).to(bf16).to(dev)
+    noise = torch.randn(2, 3, 16, 8, 12, generator=g).to(bf16).to(dev)
+    text = torch.randn(2, 16, 4096, generator=g).to(bf16).to(dev)
+    sig = torch.tensor([0.35, 0.8], device=dev)
+    spec = MI355XCogVideoXSpecOps()
+
+    def run(clear=True):
+        if clear:
+            for blk in m.transformer_blocks:
+                blk.lora_A.grad = blk.lora_B.grad = None
+        pred, target, _ = spec.forward(m, lat, text, sig, noise=noise)
+        loss = spec.loss_backward(pred, target, sig)
+        torch.cuda.synchronize()
+        return pred.detach().clone(), loss.item(), m.flat_lora_grad().clone()
+
+    m.native_blocks = False
+    pred_py, loss_py, g_py = run()
+    m.native_blocks = True
+    pred_c, loss_c, g_c = run()
+    e_pred, e_g = _rel(pred_c.float(), pred_py.float()), _rel(g_c, g_py)
+    print(f"[cog-native vs composition] pred {e_pred:.2e} loss {loss_c:.6f} vs {loss_py:.6f} grads {e_g:.2e}")
+    # same kernels, same order; the C path sums the three d n1 contributions of q / k / v in one fp32 accumulator (the composition adds bf16 tensors)
+    assert e_pred < 1e-3 and abs(loss_c - loss_py) < 1e-4 * abs(loss_py) and e_g < 3e-3
+    for i, blk in enumerate(m.transformer_blocks):
+        assert blk.lora_A.grad.data_ptr() == m.flat_lora_grad()[: g_c.numel() // 2].view(3, 4, 64, 1920)[i].data_ptr()
+
+    seen = []
+    m._grad_bucket_hook, m.grad_bucket_blocks = (lambda lo, hi, ga, gb: seen.append((lo, hi, tuple(ga.shape), tuple(gb.shape)))), 2
+    _, _, g_rng = run()
+    m._grad_bucket_hook = None
+    assert seen == [(1, 3, (2, 4, 64, 1920), (2, 4, 1920, 64)), (0, 1, (1, 4, 64, 1920), (1, 4, 1920, 64))]
+    assert _rel(g_rng, g_c) < 1e-6
+    _, _, g_twice = run(clear=False)  # gradients already there: the second backward adds to them
+    assert _rel(g_twice, 2 * g_rng) < 1e-5
+    with torch.no_grad():
+        pool = len(m._ws_pool)
+        p3 = m(lat, text, torch.tensor([350, 800], device=dev), image_rotary_emb=spec_rope(m, 3, 8, 12))[0]
+        assert len(m._ws_pool) == pool and p3.shape == lat.shape
+
+
+def spec_rope(m, frames, height, width):
+    from finetrainers_amd.cogvideox.model import rotary_tables
+
+    return rotary_tables(m.config, height, width, frames)
 
 
 def test_specification_mirror_loads_a_diffusers_directory_and_saves_lora(tmp_path):
@@ -456,7 +519,7 @@ def _cog_two_rank_worker(rank, port, q):
 
     par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0))
     try:
-        kw = dict(num_layers=1, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
+        kw = dict(num_layers=3, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
         omodel = cvx.build_model(cvx.CogVideoXConfig(**kw), seed=0, rank=0)
         sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2."): v for k, v in omodel.state_dict().items()}
         model = MI355XCogVideoXTransformer3DModel(CogVideoXTransformerConfig(**kw), device=par.device)
@@ -465,13 +528,14 @@ def _cog_two_rank_worker(rank, port, q):
         model.add_adapter(r=64, lora_alpha=64.0)
         with torch.no_grad():
             model.lora_flat[model.lora_flat.numel() // 2:].normal_(0, 0.02)
-        step = MI355XCogVideoXSFTStep(model, lr=1e-3, betas=(0.9, 0.99), parallel=par)
+        step = MI355XCogVideoXSFTStep(model, lr=1e-3, betas=(0.9, 0.99), parallel=par, grad_bucket_blocks=2)  # buckets: blocks [1, 3), [0, 1)
         g = torch.Generator().manual_seed(50 + rank)
         lat = torch.randn(1, 3, 16, 8, 12, generator=g).to(torch.bfloat16).to(par.device)
         text = torch.randn(1, 16, 4096, generator=g).to(torch.bfloat16).to(par.device)
         noise = torch.randn(1, 3, 16, 8, 12, generator=g).to(torch.bfloat16).to(par.device)
         out = step.step(lat, text, sigmas=torch.tensor([0.3 + 0.4 * rank], device=par.device), noise=noise)
         torch.cuda.synchronize()
+        assert step.buckets_issued == 2
         q.put((rank, out["grad_norm"].item(), model.lora_flat.detach().cpu().numpy()))
     finally:
         par.destroy()

@@ -1,7 +1,7 @@
 """BASELINE config 3 on one GPU: CogVideoX-2b LoRA r = 64 SFT optimisation step, 49 x 480 x 720 clip (latents [1, 13, 16, 60, 90]: 226 text + 17 550
 video tokens), 30 blocks, random-init weights of the 2b architecture, synthetic latents / text embeddings, bf16 base + fp32-equivalent LoRA, nothing
 recomputed.  Not the bench.py line (that is BASELINE's metric on configs[1]); this is config 3's measurement.
-    python tools/bench_cogvideox_step.py [steps] [layers] [--cpu-baseline]
+    python tools/bench_cogvideox_step.py [steps] [layers] [--cpu-baseline] [--python-blocks]
 --cpu-baseline: also time the oracle (CPU restatement of the reference step, kind "port") on the box's host threads on a bounded sample of the same
 workload -- ONE block forward + backward at the full 17 776 tokens, 1 warm-up + 1 timed, scaled by the block count (the embed / head / optimiser share of
 the GPU step is < 2 %).  tools/ may import oracle/ for exactly this (it is the checker and the baseline, never the product)."""
@@ -44,6 +44,7 @@ model.add_adapter(r=64, lora_alpha=64.0)
 with torch.no_grad():
     n = model.lora_flat.numel() // 2
     model.lora_flat[n:].normal_(0, 0.01, generator=g)  # B != 0 so every gradient path carries data
+model.native_blocks = "--python-blocks" not in sys.argv  # default: all blocks in one C call per direction (csrc/cog_dit.hip)
 step = MI355XCogVideoXSFTStep(model, lr=5e-5, betas=(0.9, 0.99), generator=torch.Generator(device=dev).manual_seed(1))
 lat = torch.randn((1, 13, 16, 60, 90), generator=g, device=dev).to(bf16)
 text = torch.randn((1, 226, 4096), generator=g, device=dev).to(bf16)
@@ -67,7 +68,7 @@ line = {"metric": "train samples/sec (+ step ms) CogVideoX-2b LoRA 49x480x720 (B
         "steps": steps, "warmup": 2, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic latents [1,13,16,60,90] + random text embeds [1,226,4096], random-init weights of the CogVideoX-2b DiT",
         "config": {"workload": f"CogVideoX-2b LoRA rank=64 bf16 SFT step, 49x480x720 clip (226 text + 17550 video tokens), batch 1 per GPU, {layers} blocks",
-                   "global_batch": 1, "seq_len": N, "parallelism": "dp1", "activation_checkpointing": False, "orchestration": "python over the C ABI"},
+                   "global_batch": 1, "seq_len": N, "parallelism": "dp1", "activation_checkpointing": False, "orchestration": "C block stack (ftmi_cog_blocks_forward / _backward)" if model.native_blocks else "python, per block over the C ABI"},
         "step_tflop_algorithmic": flop / 1e12, "mfma_utilisation_step": flop / ms / 1e9 / 2500, "final_loss": out["loss"].item(),
         "peak_memory_gib": torch.cuda.max_memory_allocated() / 2**30}
 if "--cpu-baseline" in sys.argv:
