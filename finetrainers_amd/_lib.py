@@ -82,6 +82,17 @@ class CogWeights(Structure):
     _fields_ = [(n, c_void_p) for n in COG_WEIGHT_FIELDS]
 
 
+class WanRowArgs(Structure):
+    """include/ftmi355.h: ftmi_wan_row_args."""
+
+    _fields_ = [
+        ("x", c_void_p), ("ld_x", c_long), ("w", c_void_p), ("b", c_void_p), ("shift", c_void_p), ("scale", c_void_p), ("mod_bstride", c_long),
+        ("dy", c_void_p), ("ld_dy", c_long), ("dres", c_void_p), ("y", c_void_p), ("ld_y", c_long), ("red1", c_void_p), ("red2", c_void_p),
+        ("red_per_batch", c_int), ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("head_dim", c_int), ("rows", c_int), ("D", c_int),
+        ("rows_per_batch", c_int), ("eps", c_float),
+    ]
+
+
 _SIGS = {
     "ftmi_version": (c_int, []),
     "ftmi_last_error": (c_int, [c_char_p, c_size_t]),
@@ -124,6 +135,11 @@ _SIGS = {
     "ftmi_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p]),
     "ftmi_clip_adamw_step": (c_int, [c_void_p] * 4 + [c_long] + [c_float] * 6 + [c_int, c_void_p, c_void_p, c_void_p]),
     "ftmi_lora_refresh": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_void_p]),
+    **{f"ftmi_wan_{n}": (c_int, [POINTER(WanRowArgs), c_void_p]) for n in ("ln_fwd", "ln_bwd", "rms_rope_fwd", "rms_rope_bwd", "gate_res_fwd",
+                                                                           "gate_res_bwd", "colsum")},
+    "ftmi_grad_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "ftmi_adamw_bf16_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
+                                     c_void_p, c_void_p]),
     "ftmi_lora_refresh_n": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p]),
     "ftmi_cog_workspace_bytes": (c_size_t, [POINTER(CogConfig)]),
     "ftmi_cog_blocks_forward": (c_int, [POINTER(CogConfig), POINTER(CogWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

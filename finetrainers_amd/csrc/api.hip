@@ -491,6 +491,45 @@ int ftmi_clip_grad_norm(float* grads, long n, float max_norm, float* scratch, fl
     return clip_scale(grads, n, scratch, max_norm, grad_norm_out, st);
 }
 
+int ftmi_grad_sumsq(const float* grads, long n, float* scratch, ftmi_stream stream) {
+    if (!grads || !scratch || n <= 0) return set_error(FTMI_ERR_INVALID, "ftmi_grad_sumsq: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0, 2 * sizeof(float), st) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "ftmi_grad_sumsq: memset failed");
+    return sumsq(grads, n, scratch, st);
+}
+
+int ftmi_adamw_bf16_step(void* params, const float* grads, void* exp_avg, void* exp_avg_sq, long n, const float* sumsq_in, float max_norm, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int step, float* grad_norm_out, ftmi_stream stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return set_error(FTMI_ERR_INVALID, "ftmi_adamw_bf16_step: bad argument");
+    return adamw_bf16_step((bf16_t*)params, grads, (bf16_t*)exp_avg, (bf16_t*)exp_avg_sq, n, sumsq_in, max_norm, lr, beta1, beta2, eps, weight_decay, step,
+                           grad_norm_out, (hipStream_t)stream);
+}
+
+namespace {
+WanRowArgs wan_args(const ftmi_wan_row_args* p) {
+    WanRowArgs a;
+    a.x = (const bf16_t*)p->x; a.ld_x = p->ld_x; a.w = (const bf16_t*)p->w; a.b = (const bf16_t*)p->b; a.shift = p->shift; a.scale = p->scale;
+    a.mod_bstride = p->mod_bstride; a.dy = (const bf16_t*)p->dy; a.ld_dy = p->ld_dy; a.dres = (const bf16_t*)p->dres; a.y = (bf16_t*)p->y; a.ld_y = p->ld_y;
+    a.red1 = p->red1; a.red2 = p->red2; a.red_per_batch = p->red_per_batch; a.rope_cos = p->rope_cos; a.rope_sin = p->rope_sin; a.head_dim = p->head_dim;
+    a.rows = p->rows; a.D = p->D; a.rows_per_batch = p->rows_per_batch; a.eps = p->eps;
+    return a;
+}
+}  // namespace
+
+#define FTMI_WAN_ENTRY(NAME)                                                                        \
+    int ftmi_##NAME(const ftmi_wan_row_args* args, ftmi_stream stream) {                            \
+        if (!args) return set_error(FTMI_ERR_INVALID, "ftmi_" #NAME ": null argument block");      \
+        return NAME(wan_args(args), (hipStream_t)stream);                                           \
+    }
+FTMI_WAN_ENTRY(wan_ln_fwd)
+FTMI_WAN_ENTRY(wan_ln_bwd)
+FTMI_WAN_ENTRY(wan_rms_rope_fwd)
+FTMI_WAN_ENTRY(wan_rms_rope_bwd)
+FTMI_WAN_ENTRY(wan_gate_res_fwd)
+FTMI_WAN_ENTRY(wan_gate_res_bwd)
+FTMI_WAN_ENTRY(wan_colsum)
+#undef FTMI_WAN_ENTRY
+
 int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
                       void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream) {
     return ftmi_lora_refresh_n(a_f32, b_f32, lora_a_sp, lora_bt_sp, lora_b_ext, lora_at_ext, lora_at_qkv_ext, L, 8, r, D, stream);

@@ -241,6 +241,39 @@ int cog_blocks_forward(const ftmi_cog_config& c, const ftmi_cog_weights& w, cons
 int cog_blocks_backward(const ftmi_cog_config& c, const ftmi_cog_weights& w, const bf16_t* tokens_in, const bf16_t* d_out, bf16_t* d_in, float* grad_a,
                         float* grad_b, void* ws, size_t ws_bytes, int l_hi, int l_lo, int accumulate, hipStream_t st);
 int cog_mod_tables(const bf16_t* mod, bf16_t* tables, int L2, int B, int D, hipStream_t st);  // linear(silu(temb)) rows -> (shift, 1 + scale, gate) x (text, video)
+// ---- Wan-T2V row-wise kernels (wan.hip): one argument block for the seven launchers --------------------------------------------------------
+struct WanRowArgs {
+    const bf16_t* x = nullptr;   // input rows [rows, ld_x]   (gate_res_bwd: d out)
+    long ld_x = 0;
+    const bf16_t* w = nullptr;   // LayerNorm / RMSNorm weight [D] (LayerNorm: null = no affine)
+    const bf16_t* b = nullptr;   // LayerNorm bias [D]
+    const float* shift = nullptr;  // fp32 [B, mod_bstride]: modulation shift (null = not modulated)
+    const float* scale = nullptr;  // fp32: modulation scale (ln) / gate (gate_res)
+    long mod_bstride = 0;
+    const bf16_t* dy = nullptr;  // backward: gradient of the output rows; gate_res: the y operand
+    long ld_dy = 0;
+    const bf16_t* dres = nullptr;  // ln_bwd: gradient arriving on the residual branch (row stride ld_y), added in bf16
+    bf16_t* y = nullptr;         // output rows (forward: y, backward: dx / dy)
+    long ld_y = 0;
+    float* red1 = nullptr;       // column sums, += (see wan.hip)
+    float* red2 = nullptr;
+    int red_per_batch = 0;       // 1: one row of sums per sample ([B, D]), 0: one row for all
+    const float* rope_cos = nullptr;  // fp32 [rows_per_batch, head_dim / 2]
+    const float* rope_sin = nullptr;
+    int head_dim = 0;
+    int rows = 0, D = 0, rows_per_batch = 0;
+    float eps = 1e-6f;
+};
+int wan_ln_fwd(const WanRowArgs& a, hipStream_t st);
+int wan_ln_bwd(const WanRowArgs& a, hipStream_t st);
+int wan_rms_rope_fwd(const WanRowArgs& a, hipStream_t st);
+int wan_rms_rope_bwd(const WanRowArgs& a, hipStream_t st);
+int wan_gate_res_fwd(const WanRowArgs& a, hipStream_t st);
+int wan_gate_res_bwd(const WanRowArgs& a, hipStream_t st);
+int wan_colsum(const WanRowArgs& a, hipStream_t st);
+int adamw_bf16_step(bf16_t* p, const float* g, bf16_t* m, bf16_t* v, long n, const float* sumsq_in, float max_norm, float lr, float beta1, float beta2,
+                    float eps, float wd, int step, float* grad_norm_out, hipStream_t st);
+
 int cog_patch_permute(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W, int p, int to_tokens, hipStream_t st);  // latents <-> patch tokens
 
 }  // namespace ftmi

@@ -602,6 +602,49 @@ int adamw_clip_step(float* p, const float* g, float* m, float* v, long n, const 
     return check_launch("adamw");
 }
 
+// AdamW on bf16 parameters with bf16 moments: what torch.optim.AdamW does to a model that is trained in bf16 (the reference's full fine-tune,
+// BASELINE config 4: transformer_dtype bf16, optimizer.py:17-46) -- every torch op of the update is one fp32 computation rounded to bf16:
+//   p *= 1 - lr wd;  m = lerp(m, g, 1 - b1);  v *= b2;  v += (1 - b2) g g;  d = sqrt(v);  d /= sqrt(bc2);  d += eps;  p += -(lr / bc1) m / d
+// g arrives in fp32 (the reduce-scattered gradient shard) and is scaled by the clip coefficient and rounded to bf16 first: the reference's
+// sharded gradient is a bf16 tensor (FSDP-2 casts the fp32 reduce result back to the parameter dtype) that clip_grad_norm_ multiplies in place.
+__global__ __launch_bounds__(256) void adamw_bf16_kernel(bf16_t* __restrict__ p, const float* __restrict__ g, bf16_t* __restrict__ m,
+                                                         bf16_t* __restrict__ v, long n, const float* __restrict__ sumsq_in, float max_norm, float decay,
+                                                         float w1, float beta2, float omb2, float eps, float step_size, float bc2_sqrt,
+                                                         float* __restrict__ grad_norm_out) {
+    float coef = 1.0f;
+    if (sumsq_in) {
+        const float total_norm = sqrtf(*sumsq_in);
+        coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
+        if (grad_norm_out && blockIdx.x == 0 && threadIdx.x == 0) *grad_norm_out = total_norm;
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = rbf(g[i]);
+        if (coef < 1.0f) gi = rbf(gi * coef);
+        float pi = rbf(bf2f(p[i]) * decay);
+        const float mi0 = bf2f(m[i]);
+        const float mi = rbf(w1 < 0.5f ? mi0 + w1 * (gi - mi0) : gi - (gi - mi0) * (1.0f - w1));  // at::lerp
+        float vi = rbf(bf2f(v[i]) * beta2);
+        vi = rbf(vi + omb2 * gi * gi);
+        float d = rbf(sqrtf(vi));
+        d = rbf(d / bc2_sqrt);
+        d = rbf(d + eps);
+        pi = rbf(pi + step_size * (mi / d));
+        p[i] = f2bf(pi);
+        m[i] = f2bf(mi);
+        v[i] = f2bf(vi);
+    }
+}
+int adamw_bf16_step(bf16_t* p, const float* g, bf16_t* m, bf16_t* v, long n, const float* sumsq_in, float max_norm, float lr, float beta1,
+                    float beta2, float eps, float wd, int step, float* grad_norm_out, hipStream_t st) {
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, sumsq_in, max_norm, (float)(1.0 - (double)lr * wd),
+                       (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps, (float)(-((double)lr / bc1)), (float)sqrt(bc2), grad_norm_out);
+    return check_launch("adamw_bf16");
+}
+
 // ---------------------------------------------------------------------------------------------------
 // CogVideoX spec-level elementwise ops: DDIM add_noise / get_velocity as CogVideoXModelSpecification.forward applies them
 // (finetrainers/models/cogvideox/base_specification.py:283-293,326-329 around [upstream] CogVideoXDDIMScheduler).  One kernel does both

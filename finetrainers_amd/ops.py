@@ -61,7 +61,8 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, key_bias: Option
     return out, lse
 
 
-def attn_bwd(q, k, v, out, lse, dout, key_bias=None, scale=None):
+def attn_bwd(q, k, v, out, lse, dout, key_bias=None, scale=None, dv_out=None):
+    """``dv_out``: an existing [B, H, Sk, d] bf16 view (head_dim contiguous) that receives dV, e.g. the value third of a fused d(q|k|v) buffer."""
     B, H, Sq, d = q.shape
     Sk = k.shape[2]
     scale = (1.0 / d**0.5) if scale is None else scale
@@ -69,7 +70,9 @@ def attn_bwd(q, k, v, out, lse, dout, key_bias=None, scale=None):
         dout = dout.contiguous()
     dq = torch.empty((B, Sq, H, d), dtype=bf16, device=q.device).permute(0, 2, 1, 3)
     dk = torch.empty((B, Sk, H, d), dtype=bf16, device=q.device).permute(0, 2, 1, 3)
-    dv = torch.empty((B, Sk, H, d), dtype=bf16, device=q.device).permute(0, 2, 1, 3)
+    dv = torch.empty((B, Sk, H, d), dtype=bf16, device=q.device).permute(0, 2, 1, 3) if dv_out is None else dv_out
+    if dv.shape != (B, H, Sk, d) or dv.dtype != bf16:
+        raise ValueError("attn_bwd: dv_out must be a [B, H, Sk, head_dim] bf16 view")
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     desc = _desc(q, k, v, out, scale, dout, dq, dk, dv, key_bias=key_bias)
     check(_lib.load().ftmi_attn_bwd(ctypes.byref(desc), ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(dout), ptr(dq), ptr(dk), ptr(dv),
@@ -384,3 +387,135 @@ def clip_adamw_step(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, be
                                             float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), ptr(scratch),
                                             ptr(grad_norm_out), stream_ptr()), "ftmi_clip_adamw_step")
     return grad_norm_out
+
+
+# ---- Wan-T2V full fine-tune (include/ftmi355.h: ftmi_wan_*; csrc/wan.hip) --------------------------------------------------------------------
+def _rows2d(t: torch.Tensor, name: str) -> torch.Tensor:
+    require_gpu_tensor(t, name, bf16)
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 != 0:
+        raise ValueError(f"{name}: a 2-D bf16 view with contiguous columns and a row stride that is a multiple of 8")
+    return t
+
+
+def _f32(t: Optional[torch.Tensor], name: str, shape=None) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    require_gpu_tensor(t, name, torch.float32)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: contiguous columns required")
+    return t
+
+
+def _wan_call(name: str, x, y, rows_per_batch, eps=1e-6, w=None, b=None, shift=None, scale=None, dy=None, dres=None, red1=None, red2=None, red_per_batch=False,
+              rope=None, head_dim=0):
+    rows, D = x.shape
+    a = _lib.WanRowArgs()
+    a.x, a.ld_x = x.data_ptr(), x.stride(0)
+    a.w, a.b = ptr(w), ptr(b)
+    a.shift, a.scale = ptr(shift), ptr(scale)
+    a.mod_bstride = scale.stride(0) if scale is not None else 0
+    if shift is not None and scale is not None and shift.stride(0) != scale.stride(0):
+        raise ValueError("shift and scale must share their sample stride")
+    a.dy, a.ld_dy = ptr(dy), (dy.stride(0) if dy is not None else 0)
+    a.dres = ptr(dres)
+    a.y, a.ld_y = ptr(y), (y.stride(0) if y is not None else 0)
+    a.red1, a.red2, a.red_per_batch = ptr(red1), ptr(red2), int(bool(red_per_batch))
+    if rope is not None:
+        cos, sin = rope
+        _f32(cos, "rope cos", (rows_per_batch, head_dim // 2))
+        _f32(sin, "rope sin", (rows_per_batch, head_dim // 2))
+        if not (cos.is_contiguous() and sin.is_contiguous()):
+            raise ValueError("rope tables must be contiguous")
+        a.rope_cos, a.rope_sin, a.head_dim = cos.data_ptr(), sin.data_ptr(), int(head_dim)
+    a.rows, a.D, a.rows_per_batch, a.eps = rows, D, int(rows_per_batch), float(eps)
+    check(getattr(_lib.load(), f"ftmi_wan_{name}")(ctypes.byref(a), stream_ptr()), f"ftmi_wan_{name}")
+
+
+def wan_ln(x, rows_per_batch: int, w=None, b=None, shift=None, scale=None, eps: float = 1e-6, out=None):
+    """y = bf(LN(float(x)) [* w + b] [* (1 + scale_b) + shift_b]); x [rows, D] bf16, shift / scale fp32 [B, D] views (sample stride free)."""
+    x = _rows2d(x, "x")
+    B = x.shape[0] // rows_per_batch
+    out = torch.empty(x.shape, dtype=bf16, device=x.device) if out is None else _rows2d(out, "out")
+    _wan_call("ln_fwd", x, out, rows_per_batch, eps, w=w, b=b, shift=_f32(shift, "shift", (B, x.shape[1])), scale=_f32(scale, "scale", (B, x.shape[1])))
+    return out
+
+
+def wan_ln_bwd(x, dy, rows_per_batch: int, w=None, scale=None, eps: float = 1e-6, dres=None, red1=None, red2=None, red_per_batch: bool = False):
+    """dx = bf([dres +] bf(LN'(x)[dy * (w | 1 + scale_b)])); red1 += sum dy, red2 += sum dy * xhat (fp32 [B, D] views when red_per_batch, else [D])."""
+    x, dy = _rows2d(x, "x"), _rows2d(dy, "dy")
+    dx = torch.empty(x.shape, dtype=bf16, device=x.device)
+    if dres is not None and (_rows2d(dres, "dres").stride(0) != dx.stride(0)):
+        raise ValueError("dres must be contiguous like dx")
+    B, D = x.shape[0] // rows_per_batch, x.shape[1]
+    if red_per_batch:
+        for r in (red1, red2):
+            if r is not None and (tuple(r.shape) != (B, D) or r.stride(0) != D):
+                raise ValueError("per-sample column sums must be contiguous [B, D] fp32")
+    _wan_call("ln_bwd", x, dx, rows_per_batch, eps, w=w, scale=_f32(scale, "scale", (B, D)), dy=dy, dres=dres, red1=_f32(red1, "red1"), red2=_f32(red2, "red2"),
+              red_per_batch=red_per_batch)
+    return dx
+
+
+def wan_rms_rope(x, w, rows_per_batch: int, rope=None, head_dim: int = 128, eps: float = 1e-6, out=None):
+    x = _rows2d(x, "x")
+    out = torch.empty(x.shape, dtype=bf16, device=x.device) if out is None else _rows2d(out, "out")
+    _wan_call("rms_rope_fwd", x, out, rows_per_batch, eps, w=w, rope=rope, head_dim=head_dim)
+    return out
+
+
+def wan_rms_rope_bwd(x, w, dy, rows_per_batch: int, rope=None, head_dim: int = 128, eps: float = 1e-6, dweight=None, out=None):
+    """dx of the RMSNorm (+ rotary) above; dweight (fp32 [D]) += sum dn * xhat."""
+    x, dy = _rows2d(x, "x"), _rows2d(dy, "dy")
+    out = torch.empty(x.shape, dtype=bf16, device=x.device) if out is None else _rows2d(out, "out")
+    _wan_call("rms_rope_bwd", x, out, rows_per_batch, eps, w=w, dy=dy, rope=rope, head_dim=head_dim, red2=_f32(dweight, "dweight", (x.shape[1],)))
+    return out
+
+
+def wan_gate_res(x, y, rows_per_batch: int, gate=None, out=None):
+    """out = bf(float(x) + float(y) * gate_b)  (gate fp32 [B, D]; None: bf(x + y))."""
+    x, y = _rows2d(x, "x"), _rows2d(y, "y")
+    out = torch.empty(x.shape, dtype=bf16, device=x.device) if out is None else _rows2d(out, "out")
+    _wan_call("gate_res_fwd", x, out, rows_per_batch, scale=_f32(gate, "gate", (x.shape[0] // rows_per_batch, x.shape[1])), dy=y)
+    return out
+
+
+def wan_gate_res_bwd(dout, y, gate, rows_per_batch: int, dgate=None):
+    """dy = bf(d out * gate_b); dgate (fp32 contiguous [B, D]) += sum_rows d out * y."""
+    dout, y = _rows2d(dout, "dout"), _rows2d(y, "y")
+    B, D = dout.shape[0] // rows_per_batch, dout.shape[1]
+    if dgate is not None and (tuple(dgate.shape) != (B, D) or dgate.stride(0) != D):
+        raise ValueError("dgate must be contiguous [B, D] fp32")
+    dy = torch.empty(dout.shape, dtype=bf16, device=dout.device)
+    _wan_call("gate_res_bwd", dout, dy, rows_per_batch, scale=_f32(gate, "gate", (B, D)), dy=y, red1=_f32(dgate, "dgate"), red_per_batch=True)
+    return dy
+
+
+def wan_colsum(x, out):
+    """out (fp32 [N]) += sum over the rows of x [rows, N] (bias gradients)."""
+    x = _rows2d(x, "x")
+    _wan_call("colsum", x, None, x.shape[0], red1=_f32(out, "out", (x.shape[1],)))
+    return out
+
+
+def grad_sumsq(grads: torch.Tensor, scratch: torch.Tensor) -> torch.Tensor:
+    """scratch[0] <- sum g^2 of a flat fp32 gradient (shard), order-fixed; returns scratch[:1]."""
+    require_gpu_tensor(grads, "grads", torch.float32)
+    if scratch.numel() < CLIP_SCRATCH_FLOATS or scratch.dtype != torch.float32:
+        raise ValueError(f"grad_sumsq: scratch must hold {CLIP_SCRATCH_FLOATS} fp32 values")
+    check(_lib.load().ftmi_grad_sumsq(ptr(grads), grads.numel(), ptr(scratch), stream_ptr()), "ftmi_grad_sumsq")
+    return scratch[:1]
+
+
+def adamw_bf16_step(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 1e-4,
+                    sumsq: Optional[torch.Tensor] = None, max_norm: float = 1.0, grad_norm_out: Optional[torch.Tensor] = None) -> None:
+    """torch.optim.AdamW on flat bf16 parameters / moments with an fp32 gradient (clipped by the global norm sqrt(sumsq[0]) when given)."""
+    for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        require_gpu_tensor(t, n, bf16)
+    require_gpu_tensor(grads, "grads", torch.float32)
+    if not (params.numel() == grads.numel() == exp_avg.numel() == exp_avg_sq.numel()):
+        raise ValueError("adamw_bf16_step: size mismatch")
+    check(_lib.load().ftmi_adamw_bf16_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), ptr(sumsq), float(max_norm), float(lr),
+                                            float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), ptr(grad_norm_out), stream_ptr()),
+          "ftmi_adamw_bf16_step")

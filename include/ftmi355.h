@@ -319,6 +319,50 @@ int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, floa
  * scratch: >= FTMI_CLIP_SCRATCH_FLOATS floats; grad_norm_out (may be NULL) receives the pre-clip norm; order-fixed reduction. */
 int ftmi_clip_grad_norm(float* grads, long n, float max_norm, float* scratch, float* grad_norm_out, ftmi_stream stream);
 
+/* ---- Wan-T2V full fine-tune (BASELINE config 4; finetrainers/models/wan/base_specification.py:433-493 driving [upstream]
+ * diffusers transformer_wan.py; restated in oracle/wan.py).  Every parameter trains, so the backward kernels also produce the column sums the
+ * parameter gradients need; they ADD to red1 / red2 (fp32, zeroed or kept by the caller; atomics: the summation order is not fixed).
+ * One argument block for the seven row-wise launchers; rows = whole samples of rows_per_batch tokens, D a multiple of 64 (<= 4096, colsum: any),
+ * row strides multiples of 8.
+ *   ftmi_wan_ln_fwd        y = bf(LN(float(x)) [* w + b] [* (1 + scale_b) + shift_b])     FP32LayerNorm (+ affine | + modulation), one rounding
+ *   ftmi_wan_ln_bwd        y = dx = bf([dres +] bf(LN'(x)[dy * (w | 1 + scale_b)]));  red1 += sum dy (d shift | d bias), red2 += sum dy * xhat
+ *                          (d scale | d weight); red_per_batch = 1 for the modulated norms ([B, D] sums)
+ *   ftmi_wan_rms_rope_fwd  n = bf(x * rstd(x) * w) over the WHOLE row (qk_norm = "rms_norm_across_heads"), y = bf(n rotated by rope_cos/sin
+ *                          [rows_per_batch, head_dim / 2], the complex pair (2k, 2k+1) of every head times cos_k + i sin_k); rope null: y = n
+ *   ftmi_wan_rms_rope_bwd  y = dx;  red2 += sum dn * xhat (d weight)
+ *   ftmi_wan_gate_res_fwd  y = bf(float(x) + float(dy) * scale_b)   ("dy" = the branch output; scale = fp32 gate [B, D], null: bf(x + dy))
+ *   ftmi_wan_gate_res_bwd  x = d out, dy = the branch output of the forward: y = bf(d out * scale_b), red1 += sum d out * branch (d gate)
+ *   ftmi_wan_colsum        red1 += sum over rows of x   (Linear bias gradients) */
+typedef struct ftmi_wan_row_args {
+    const void* x; long ld_x;
+    const void* w; const void* b;            /* bf16 [D] */
+    const float* shift; const float* scale;  /* fp32 [B, mod_bstride] */
+    long mod_bstride;
+    const void* dy; long ld_dy;
+    const void* dres;                        /* bf16, row stride ld_y */
+    void* y; long ld_y;
+    float* red1; float* red2; int red_per_batch;
+    const float* rope_cos; const float* rope_sin; int head_dim;
+    int rows, D, rows_per_batch;
+    float eps;
+} ftmi_wan_row_args;
+int ftmi_wan_ln_fwd(const ftmi_wan_row_args* args, ftmi_stream stream);
+int ftmi_wan_ln_bwd(const ftmi_wan_row_args* args, ftmi_stream stream);
+int ftmi_wan_rms_rope_fwd(const ftmi_wan_row_args* args, ftmi_stream stream);
+int ftmi_wan_rms_rope_bwd(const ftmi_wan_row_args* args, ftmi_stream stream);
+int ftmi_wan_gate_res_fwd(const ftmi_wan_row_args* args, ftmi_stream stream);
+int ftmi_wan_gate_res_bwd(const ftmi_wan_row_args* args, ftmi_stream stream);
+int ftmi_wan_colsum(const ftmi_wan_row_args* args, ftmi_stream stream);
+
+/* Sum of squares of a flat fp32 gradient (shard): scratch[0] <- sum g^2 (order-fixed; scratch >= FTMI_CLIP_SCRATCH_FLOATS floats).  Sharded training
+ * all-reduces scratch[0] over the ranks before the optimiser call below (the reference's clip_grad_norm_ over DTensor shards, utils/torch.py:99-161). */
+int ftmi_grad_sumsq(const float* grads, long n, float* scratch, ftmi_stream stream);
+/* torch.optim.AdamW on bf16 parameters with bf16 moments (the reference's bf16 full fine-tune, optimizer.py:17-46): every torch op of the update is one
+ * fp32 computation rounded to bf16.  grads: fp32 (the reduce-scattered shard), multiplied by min(1, max_norm / (sqrt(*sumsq) + 1e-6)) and rounded to
+ * bf16 first (sumsq NULL: no clip).  grad_norm_out (may be NULL) receives sqrt(*sumsq). */
+int ftmi_adamw_bf16_step(void* params, const float* grads, void* exp_avg, void* exp_avg_sq, long n, const float* sumsq, float max_norm, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int step, float* grad_norm_out, ftmi_stream stream);
+
 /* fp32 flat LoRA params (A region [L,8,r,D] then B region [L,8,D,r]) -> the bf16 (hi, lo) working copies of ftmi_ltx_weights */
 int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
                       void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream);
