@@ -124,6 +124,8 @@ class _WanBlockFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         blk = ctx.blk
+        if blk._pre_backward is not None:
+            blk._pre_backward(blk)  # sharded training: gather this block's parameters (prefetch the previous block's), take a gradient buffer
         B, S, T, D = ctx.dims
         x, enc, mod = ctx.saved_tensors
         n1, qkv, qn, kn, o1, lse1, a1, x1, n2, q2, kv2, q2n, k2n, o2, lse2, x2, n3, act, pre, f = ctx.acts
@@ -194,7 +196,9 @@ class MI355XWanBlock(nn.Module):
         self.grad_flat: Optional[torch.Tensor] = None  # fp32, allocated by ``zero_grad_flat`` (the sharded trainer hands in its own buffer)
         self._transposed: Optional[Dict[str, torch.Tensor]] = None
         self._transposed_version = None
-        self._grad_hook = None
+        self._grad_hook = None     # callable(block) at the end of the block's backward (its gradients are final)
+        self._pre_forward = None   # callable(block) before the block's forward / backward: sharded training gathers the parameters there
+        self._pre_backward = None
         self._param_src: Optional[torch.Tensor] = None  # sharded training: the all-gathered parameters to compute with instead of ``flat``
 
     # -- parameter / gradient views -----------------------------------------------------------------------------------------------------------
@@ -253,4 +257,6 @@ class MI355XWanBlock(nn.Module):
         return self.layout.named_views(self.flat.data)
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor, rotary) -> torch.Tensor:
+        if self._pre_forward is not None:
+            self._pre_forward(self)
         return _WanBlockFunction.apply(self, hidden_states.contiguous(), encoder_hidden_states.contiguous(), temb.contiguous(), rotary[0], rotary[1])

@@ -1,0 +1,115 @@
+"""One Wan-T2V FULL fine-tune optimisation step (BASELINE config 4; reference loop: finetrainers/trainer/sft_trainer/trainer.py:430-503 with
+``--training_type full-finetune`` and FSDP-2, :171-181): posterior sample + flow-match noising -> DiT forward -> MSE -> backward producing every parameter
+gradient -> fp32 reduce-scatter of each unit's gradient to its owners -> global-norm clip over the shards -> AdamW on the bf16 shards.
+
+Parameters are sharded over the data-parallel ranks unit by unit (wan/fsdp.py): the blocks gather their parameters right before they compute, the next
+block's all-gather and the previous block's reduce-scatter run on RCCL's stream meanwhile.  On one GPU the same code runs with whole "shards" and no
+collectives."""
+
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from .fsdp import ParameterSharder
+from .model import MI355XWanTransformer3DModel
+from .specification import MI355XWanSpecOps
+
+bf16 = torch.bfloat16
+
+
+class MI355XWanFullFinetuneStep:
+    def __init__(self, transformer: MI355XWanTransformer3DModel, spec: Optional[MI355XWanSpecOps] = None, lr: float = 1e-5, betas=(0.9, 0.95),
+                 eps: float = 1e-8, weight_decay: float = 1e-4, max_grad_norm: float = 1.0, parallel=None, generator: Optional[torch.Generator] = None,
+                 lr_scheduler=None):
+        self.transformer, self.spec = transformer, spec or MI355XWanSpecOps()
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.parallel, self.generator, self.lr_scheduler = parallel, generator, lr_scheduler
+        active = parallel is not None and parallel.active
+        world, rank = (parallel.world_size, parallel.rank) if active else (1, 0)
+        backend = parallel.backend if active else "none"
+        tr = transformer
+        if active:  # replicas start from rank 0's weights (the reference loads the same checkpoint on every rank)
+            parallel.broadcast_(tr.root.data, src=0)
+            for blk in tr.blocks:
+                parallel.broadcast_(blk.flat.data, src=0)
+        names = ["root"] + [f"blocks.{i}" for i in range(len(tr.blocks))]
+        self.sharder = ParameterSharder([tr.root.data] + [b.flat.data for b in tr.blocks], names, world, rank, backend)
+        # from here on each rank keeps only its shards: the modules' parameters ARE the shards (what an optimiser / checkpoint writer of this rank sees)
+        tr.root.data = self.sharder.units[0].shard
+        for i, blk in enumerate(tr.blocks):
+            blk.flat.data = self.sharder.units[i + 1].shard
+            blk._pre_forward = self._pre_forward
+            blk._pre_backward = self._pre_backward
+            blk._grad_hook = self._post_backward
+        self._index = {id(b): i + 1 for i, b in enumerate(tr.blocks)}
+        self.exp_avg = [torch.zeros_like(u.shard) for u in self.sharder.units]
+        self.exp_avg_sq = [torch.zeros_like(u.shard) for u in self.sharder.units]
+        dev = tr.device
+        self._scratch = torch.zeros(ops.CLIP_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
+        self._total = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+    # ---- hooks driven by the blocks -----------------------------------------------------------------------------------------------------------
+    def _pre_forward(self, blk) -> None:
+        i = self._index[id(blk)]
+        blk._param_src = self.sharder.acquire(i)
+        self.sharder.prefetch(i + 1)
+
+    def _pre_backward(self, blk) -> None:
+        i = self._index[id(blk)]
+        blk._param_src = self.sharder.acquire(i)
+        if i > 1:
+            self.sharder.prefetch(i - 1)
+        blk.grad_flat = self.sharder.grad_buffer(i)
+        blk.mark_updated()  # the gathered copy is new: rebuild the transposed weights of the input-gradient GEMMs
+
+    def _post_backward(self, blk) -> None:
+        self.sharder.scatter_grad(self._index[id(blk)])
+        blk.grad_flat = None
+
+    # ---- the step -----------------------------------------------------------------------------------------------------------------------------
+    def step(self, moments: torch.Tensor, encoder_hidden_states: torch.Tensor, latents_mean: torch.Tensor, latents_std: torch.Tensor,
+             sigmas: torch.Tensor, posterior_noise: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        tr, sh = self.transformer, self.sharder
+        tr._root_src = sh.acquire(0)
+        tr.root_grad = sh.grad_buffer(0)
+        pred, target, _ = self.spec.forward(tr, moments, encoder_hidden_states, sigmas, latents_mean, latents_std, posterior_noise=posterior_noise, noise=noise,
+                                            generator=self.generator)
+        loss = self.spec.loss_backward(pred, target)
+        sh.scatter_grad(0)
+        tr.root_grad = None
+        sh.finish_gradients()
+        # global gradient norm over all shards of all ranks (utils/torch.py:99-161 on DTensor shards): per-unit sums of squares, one all-reduce
+        self._total.zero_()
+        for u in sh.units:
+            self._total += ops.grad_sumsq(u.shard_grad, self._scratch)
+        if sh.world > 1:
+            dist.all_reduce(self._total, op=dist.ReduceOp.SUM)
+        self.step_count += 1
+        lr = self.lr if self.lr_scheduler is None else self.lr_scheduler.current_lr()
+        gn = torch.empty(1, dtype=torch.float32, device=tr.device)
+        for u, m, v in zip(sh.units, self.exp_avg, self.exp_avg_sq):
+            ops.adamw_bf16_step(u.shard, u.shard_grad, m, v, self.step_count, lr, self.betas, self.eps, self.weight_decay, sumsq=self._total,
+                                max_norm=self.max_grad_norm, grad_norm_out=gn)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        sh.release_all()
+        sh.zero_shard_grads()
+        tr._root_src = None
+        for blk in tr.blocks:
+            blk._param_src = None
+        return {"loss": loss.detach(), "grad_norm": gn}
+
+    @torch.no_grad()
+    def gathered_parameters(self) -> Dict[str, torch.Tensor]:
+        """{unit name: full bf16 parameters} assembled from all ranks (checkpointing, tests)."""
+        out = {}
+        sh = self.sharder
+        for i, u in enumerate(sh.units):
+            out[u.name] = sh.acquire(i).clone()
+            sh.release_all()
+        return out
