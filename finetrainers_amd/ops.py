@@ -416,7 +416,7 @@ def _wan_call(name: str, x, y, rows_per_batch, eps=1e-6, w=None, b=None, shift=N
     a.w, a.b = ptr(w), ptr(b)
     a.shift, a.scale = ptr(shift), ptr(scale)
     a.mod_bstride = scale.stride(0) if scale is not None else 0
-    if shift is not None and scale is not None and shift.stride(0) != scale.stride(0):
+    if shift is not None and scale is not None and shift.stride(0) != scale.stride(0) and rows > rows_per_batch:
         raise ValueError("shift and scale must share their sample stride")
     a.dy, a.ld_dy = ptr(dy), (dy.stride(0) if dy is not None else 0)
     a.dres = ptr(dres)

@@ -153,6 +153,7 @@ class _LnModFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, shift, scale, eps: float):
         B, S, D = x.shape
+        shift, scale = shift.contiguous(), scale.contiguous()
         y = ops.wan_ln(x.view(B * S, D), S, shift=shift, scale=scale, eps=eps)
         ctx.save_for_backward(x, scale)
         ctx.eps = eps
