@@ -1440,6 +1440,8 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 2>), gq, dim3(256), kDq128, st, a);
         int rc128 = check_launch("attn_bwd_dq");
         if (rc128) return rc128;
+        // (one fused dK + dV pass at head_dim 128 needs 256 VGPR + 186 AGPR at one wave per SIMD and measured 11.8 ms against 10.5 ms for the two passes
+        //  at 21 504 tokens x 12 heads -- profiles/r02_attention_experiments.txt)
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<2, 0>), gk, dim3(256), kDkv128, st, a);
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<2, 1>), gk, dim3(256), kDkv128, st, a);
         return check_launch("attn_bwd_dkdv");

@@ -1214,6 +1214,24 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     if (a.P % 64 || a.Q % 64) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: P and Q must be multiples of 64");
     if ((a.ldu % 8) || (a.ldv % 8)) return set_error(FTMI_ERR_INVALID, "gemm_tn: leading dimensions must keep 16-byte row alignment");
     const int nsteps = (a.M + 63) / 64;
+    // full-size weight gradients (Wan full fine-tune: dW [N, K] += dY^T X with N, K in the thousands): 256 x 128 tiles -- 8 MFMAs per 6 fragment
+    // reads and wave instead of 2 per 3 -- when both extents are large, nothing is folded / grouped and the token count is whole 64-row steps
+    static const int tn_big = env_int("FTMI_TN_BIG", 1);
+    if (tn_big && !a.u_fold && !a.v_fold && a.u_grp_p == 0 && a.v_grp_p == 0 && a.batch <= 1 && a.M % 64 == 0 && a.M >= 2048 && a.P >= 512 && a.Q >= 512 &&
+        ((a.P % 256 == 0 && a.Q % 128 == 0) || (a.Q % 256 == 0 && a.P % 128 == 0))) {
+        if ((a.ldu % 8) || (a.ldv % 8)) return set_error(FTMI_ERR_INVALID, "gemm_tn: leading dimensions must keep 16-byte row alignment");
+        const bool tallP = (a.P % 256 == 0 && a.Q % 128 == 0) && (a.P >= a.Q || !(a.Q % 256 == 0 && a.P % 128 == 0));
+        const int bp = tallP ? 256 : 128, bq = tallP ? 128 : 256;
+        const int tiles = (a.P / bp) * (a.Q / bq);
+        int want = (256 + tiles - 1) / tiles;  // fill the 256 CUs: split the token loop when there are fewer tiles
+        int per = (nsteps + want - 1) / want;
+        if (per < 8) per = nsteps < 8 ? nsteps : 8;
+        a.msteps_per_split = per;
+        const dim3 grid(tiles * ((nsteps + per - 1) / per), 1);
+        ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q, st);
+        const int rc = tallP ? launch_tn2f<256, 128, 1, 1>(a, grid, st) : launch_tn2f<128, 256, 1, 1>(a, grid, st);
+        return rc ? rc : check_launch("gemm_tn");
+    }
     const bool wideP = (a.P % 128 == 0) && (a.P >= a.Q);
     const bool wideQ = !wideP && (a.Q % 128 == 0);
     const int bp = wideP ? 128 : 64, bq = wideP ? 64 : (wideQ ? 128 : 64);

@@ -415,3 +415,60 @@ def test_wan_sharded_step_two_ranks_on_one_gpu():
     # per step: root + 2 blocks gathered for the forward, both blocks still resident for the backward; + the 3 gathers of gathered_parameters()
     assert ag == 2 * 3 + 3 and rs == 2 * 3
 
+
+
+def test_wan_specification_mirror_loads_a_diffusers_directory_and_saves_the_model(tmp_path):
+    """B1 for Wan: the spec built with the reference's constructor keywords loads ``<root>/transformer`` (config.json + safetensors, Conv3d-shaped patch
+    embedding), refuses a path that does not resolve, runs ``forward`` with the reference's dict arguments (stored moments + latents_mean / latents_std
+    passing through the collation uncollated), and ``_save_model`` writes a diffusers directory that loads back bit-identically."""
+    import json
+
+    from safetensors.torch import load_file, save_file
+
+    from finetrainers_amd.wan import MI355XWanModelSpecification
+    from oracle import wan
+
+    dev = _dev()
+    kw = dict(num_attention_heads=2, attention_head_dim=128, ffn_dim=512, num_layers=1, text_dim=64)
+    omodel = wan.build_model(wan.WanConfig(**kw), seed=0)
+    sd = {k.replace("ffn.proj_in.", "ffn.net.0.proj.").replace("ffn.proj_out.", "ffn.net.2."): v.contiguous() for k, v in omodel.state_dict().items()}
+    tdir = tmp_path / "snap" / "transformer"
+    tdir.mkdir(parents=True)
+    save_file(sd, str(tdir / "diffusion_pytorch_model.safetensors"))
+    (tdir / "config.json").write_text(json.dumps(dict(kw, _class_name="WanTransformer3DModel", patch_size=[1, 2, 2], in_channels=16, out_channels=16,
+                                                      freq_dim=256, qk_norm="rms_norm_across_heads", cross_attn_norm=True, eps=1e-6, image_dim=None)))
+    with pytest.raises(FileNotFoundError):
+        MI355XWanModelSpecification(pretrained_model_name_or_path=str(tmp_path / "nope")).load_diffusion_models(device=dev)
+    spec = MI355XWanModelSpecification(pretrained_model_name_or_path=str(tmp_path / "snap"), transformer_dtype=bf16)
+    comps = spec.load_diffusion_models(device=dev)
+    model = comps["transformer"]
+    assert model.config.num_layers == 1 and spec._resolution_dim_keys == {"latents": (2, 3, 4)}
+    b = _wan_batch(B=1)
+    items = [{"latents": b["moments"].to(dev), "latents_mean": b["mean"].to(dev), "latents_std": b["std"].to(dev)}]
+    lat = spec.collate_latents(items)
+    assert lat["latents_mean"].shape == (16,) and lat["latents"].shape[0] == 1
+    cond = spec.collate_conditions([{"encoder_hidden_states": b["text"].to(dev)}])
+    with torch.no_grad():
+        pred, target, _ = spec.forward(model, cond, lat, b["sigmas"][:1].to(dev), scheduler=comps["scheduler"], compute_posterior=True,
+                                       posterior_noise=b["eps"].to(dev), noise=b["noise"].to(dev))
+    p_ref, t_ref, _ = wan.spec_forward(omodel, b["moments"], b["mean"], b["std"], b["text"], b["sigmas"][:1].view(-1, 1, 1, 1, 1), b["eps"], b["noise"])
+    assert torch.equal(target.cpu(), t_ref) and _rel(pred, p_ref.detach()) < 5e-3
+    spec._save_model(str(tmp_path / "out"), model, None, comps["scheduler"])
+    back = load_file(str(tmp_path / "out" / "transformer" / "diffusion_pytorch_model.safetensors"))
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    assert json.loads((tmp_path / "out" / "transformer" / "config.json").read_text())["_class_name"] == "WanTransformer3DModel"
+
+
+@pytest.mark.parametrize("M,P,Q", [(2112, 768, 640), (2112, 640, 768), (4096, 1536, 1536)])
+def test_gemm_tn_full_size_weight_gradient_tiles(M, P, Q):
+    """dW += dY^T X at full-fine-tune sizes takes the 256 x 128 (or 128 x 256) tile path of ftmi_gemm_tn; against an fp32 matmul, with += semantics."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + P)
+    u = torch.randn(M, P, generator=g).to(bf16)
+    v = torch.randn(M, Q, generator=g).to(bf16)
+    out = torch.ones(P, Q, dtype=torch.float32, device=dev)
+    ops.gemm_tn(u.to(dev), v.to(dev), out=out)
+    ref = 1.0 + u.float().t() @ v.float()
+    assert _rel(out, ref) < 1e-5

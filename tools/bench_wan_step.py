@@ -2,7 +2,7 @@
 tokens of width 1536, 512 text tokens), 30 blocks, random-init weights of the architecture, synthetic posterior moments / text embeddings, bf16
 parameters and moments, fp32 gradients, nothing recomputed.  The config's FSDP-2 sharding needs 8 GPUs (the driver's scaling run); on one GPU the same
 step object runs with whole shards and no collectives.  Not the bench.py line (that is BASELINE's metric on configs[1]).
-    python tools/bench_wan_step.py [steps] [layers]"""
+    python tools/bench_wan_step.py [steps] [layers] [--cpu-baseline]"""
 import json
 import os
 import sys
@@ -56,10 +56,37 @@ flop = L * (3.0 * lin + 3.5 * att)                                            # 
 print(f"Wan2.1-T2V-1.3B full fine-tune step, 81x512x512 ({S} video + {T} text tokens), {L} blocks, batch 1: {ms:.1f} ms/step = {1e3 / ms:.3f} samples/s; "
       f"{flop / ms / 1e9:.0f} TF/s algorithmic = {flop / ms / 1e9 / 2500:.3f} of the dense bf16 peak; loss {out['loss'].item():.4f} grad_norm {out['grad_norm'].item():.4e}; "
       f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
-print(json.dumps({"metric": "train samples/sec (+ step ms) Wan-T2V-1.3B full fine-tune 81x512x512 (BASELINE configs[3], one GPU, unsharded)", "value": 1e3 / ms,
+line = ({"metric": "train samples/sec (+ step ms) Wan-T2V-1.3B full fine-tune 81x512x512 (BASELINE configs[3], one GPU, unsharded)", "value": 1e3 / ms,
                   "unit": "samples/s", "n_gpus": 1, "steps": steps, "warmup": 2, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                   "dtype": "bf16", "data": "synthetic posterior moments [1,32,21,64,64] + random text embeds [1,512,4096], random-init weights of the Wan2.1-T2V-1.3B DiT",
                   "config": {"workload": f"Wan-T2V-1.3B full fine-tune bf16 step, 81x512x512 clip ({S} video + {T} text tokens), batch 1, {L} blocks",
                              "global_batch": 1, "seq_len": S, "parallelism": "dp1 (whole shards)", "activation_checkpointing": False},
                   "step_tflop_algorithmic": flop / 1e12, "mfma_utilisation_step": flop / ms / 1e9 / 2500, "final_loss": out["loss"].item(),
-                  "peak_memory_gib": torch.cuda.max_memory_allocated() / 2**30}))
+                  "peak_memory_gib": torch.cuda.max_memory_allocated() / 2**30})
+if "--cpu-baseline" in sys.argv:
+    # the oracle (CPU restatement of the reference step, kind "port") on the box's host threads on a bounded sample of the same workload: ONE block forward +
+    # backward (all parameter gradients) at the full 21 504 + 512 tokens, 1 warm-up + 1 timed, scaled by the block count.  tools/ may import oracle/ for
+    # exactly this (it is the checker and the baseline, never the product).
+    from oracle import wan  # noqa: E402
+
+    oblk = wan.WanTransformerBlock(wan.WanConfig(num_layers=1)).to(bf16)
+    gcpu = torch.Generator().manual_seed(0)
+    xv = torch.randn(1, S, D, generator=gcpu).to(bf16)
+    ev = torch.randn(1, T, D, generator=gcpu).to(bf16)
+    tv = torch.randn(1, 6, D, generator=gcpu).to(bf16)
+    ang = torch.rand(S, 64, generator=gcpu, dtype=torch.float64) * 6.283
+    freqs = torch.polar(torch.ones_like(ang), ang).view(1, 1, S, 64)
+    times = []
+    for it in range(2):
+        for p_ in oblk.parameters():
+            p_.grad = None
+        xr = xv.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        oblk(xr, ev, tv, freqs).backward(torch.ones_like(xv))
+        times.append(time.perf_counter() - t0)
+    per_block = times[-1]
+    print(f"cpu_baseline (kind port, {torch.get_num_threads()} threads): oracle block forward + backward at {S} + {T} tokens {per_block:.1f} s (warm-up {times[0]:.1f} s) "
+          f"-> x{L} blocks = {per_block * L:.0f} s per sample-step = {1.0 / (per_block * L):.5f} samples/s; GPU / CPU = {per_block * L * 1e3 / ms:.0f}x")
+    line["cpu_baseline"] = {"value": 1.0 / (per_block * L), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                            "sample": f"oracle WanTransformerBlock forward + backward at the full {S} + {T} tokens, 1 warm-up + 1 timed = {per_block:.1f} s, scaled x{L} blocks"}
+print(json.dumps(line))
