@@ -472,3 +472,48 @@ def test_gemm_tn_full_size_weight_gradient_tiles(M, P, Q):
     ops.gemm_tn(u.to(dev), v.to(dev), out=out)
     ref = 1.0 + u.float().t() @ v.float()
     assert _rel(out, ref) < 1e-5
+
+
+def test_wan_model_full_depth_parity_config4_architecture():
+    """BASELINE config 4's architecture at its full size -- Wan2.1-T2V-1.3B: width 1536 = 12 heads x 128, feed-forward 8960, 30 blocks, 4096-wide text
+    embeddings, 1.42 B parameters -- on a small clip (48 video + 16 text tokens): loss, prediction and the gradient of every one of the 825 parameter
+    tensors against the bf16 CPU oracle.  (The 2-block test above carries the fp32 yardstick; at this size only the bf16 oracle is run.)"""
+    from finetrainers_amd.wan import MI355XWanSpecOps, MI355XWanTransformer3DModel, WanTransformerConfig
+    from oracle import ltx, wan
+
+    dev = _dev()
+    torch.manual_seed(0)
+    omodel = wan.WanTransformer3DModel(wan.WanConfig()).to(bf16)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(7)
+        for n, p in omodel.named_parameters():
+            if "norm" in n and n.endswith("weight"):
+                p.copy_((1 + 0.1 * torch.randn(p.shape, generator=g)).to(bf16))
+    sd = {k.replace("ffn.proj_in.", "ffn.net.0.proj.").replace("ffn.proj_out.", "ffn.net.2."): v for k, v in omodel.state_dict().items()}
+    gmodel = MI355XWanTransformer3DModel(WanTransformerConfig(), device=dev)
+    gmodel.load_diffusers_state_dict(sd)
+    del sd
+    b = _wan_batch(B=1)
+    gt = torch.Generator().manual_seed(5)
+    text = torch.randn(1, 16, 4096, generator=gt).to(bf16)
+    pred_ref, target, _ = wan.spec_forward(omodel, b["moments"], b["mean"], b["std"], text, b["sigmas"][:1].view(-1, 1, 1, 1, 1), b["eps"], b["noise"])
+    loss_ref = wan.sft_loss(pred_ref, target, b["sigmas"][:1])
+    loss_ref.backward()
+    g_ref = {n.replace("ffn.proj_in.", "ffn.net.0.proj.").replace("ffn.proj_out.", "ffn.net.2."): p.grad for n, p in omodel.named_parameters()}
+
+    spec = MI355XWanSpecOps()
+    gmodel.zero_grad_flat()
+    pred, tgt, _ = spec.forward(gmodel, b["moments"].to(dev), text.to(dev), b["sigmas"][:1].to(dev), b["mean"].to(dev), b["std"].to(dev),
+                                posterior_noise=b["eps"].to(dev), noise=b["noise"].to(dev))
+    loss = spec.loss_backward(pred, tgt)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().reshape(g_ref[k].shape) for k, v in gmodel.named_grads().items()}
+    assert set(got) == set(g_ref) and len(got) == 30 * 27 + 15
+    glob, worst = ltx.grads_rel_l2(got, g_ref)
+    per_block = [ltx.grads_rel_l2({k: v for k, v in got.items() if k.startswith(f"blocks.{i}.")}, {k: v for k, v in g_ref.items() if k.startswith(f"blocks.{i}.")})[0]
+                 for i in (0, 14, 29)]
+    e_pred, e_loss = _rel(pred, pred_ref.detach()), abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    print(f"[wan-model 1.3B, 30 blocks] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref.item():.6f} (rel {e_loss:.2e}) | all 825 parameter gradients {glob:.2e} "
+          f"(worst tensor {worst:.2e}); blocks 0 / 14 / 29: {per_block[0]:.2e} / {per_block[1]:.2e} / {per_block[2]:.2e}")
+    assert e_pred < 2e-2 and e_loss < 3e-3
+    assert glob < 1.5e-2 and worst < 0.15
