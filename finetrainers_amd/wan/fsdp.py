@@ -48,8 +48,10 @@ class ShardedUnit:
 class ParameterSharder:
     """Schedules all-gathers / reduce-scatters of ``units`` (root first, then the blocks in forward order)."""
 
-    def __init__(self, unit_params: List[torch.Tensor], names: List[str], world: int, rank: int, backend: str, n_block_buffers: int = 2):
+    def __init__(self, unit_params: List[torch.Tensor], names: List[str], world: int, rank: int, backend: str, n_block_buffers: int = 2,
+                 force_collectives: bool = False):
         self.world, self.rank, self.backend = world, rank, backend
+        self._local = world == 1 and not force_collectives  # force_collectives: run the gathers / scatters even on a one-rank communicator (RCCL smoke)
         self.units = [ShardedUnit(n, p, world, rank) for n, p in zip(names, unit_params)]
         dev = unit_params[0].device
         dtype = unit_params[0].dtype
@@ -69,7 +71,7 @@ class ParameterSharder:
     # ---- collectives ------------------------------------------------------------------------------------------------------------------------
     def _all_gather(self, full: torch.Tensor, shard: torch.Tensor):
         self.gathers_issued += 1
-        if self.world == 1:
+        if self._local:
             full[: shard.numel()].copy_(shard)
             return None
         if self.backend == "nccl":
@@ -81,7 +83,7 @@ class ParameterSharder:
 
     def _reduce_scatter_mean(self, out: torch.Tensor, full: torch.Tensor):
         self.scatters_issued += 1
-        if self.world == 1:
+        if self._local:
             out.copy_(full[: out.numel()])
             return None
         if self.backend == "nccl":
@@ -118,7 +120,7 @@ class ParameterSharder:
         u = self.units[i]
         if u.full is not None:
             return
-        if self.world == 1:  # nothing to gather: compute straight out of the (whole) shard
+        if self._local:  # nothing to gather: compute straight out of the (whole) shard
             u.full = u.shard
             return
         buf = self._buffer_for(u)

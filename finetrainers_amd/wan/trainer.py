@@ -37,7 +37,8 @@ class MI355XWanFullFinetuneStep:
             for blk in tr.blocks:
                 parallel.broadcast_(blk.flat.data, src=0)
         names = ["root"] + [f"blocks.{i}" for i in range(len(tr.blocks))]
-        self.sharder = ParameterSharder([tr.root.data] + [b.flat.data for b in tr.blocks], names, world, rank, backend)
+        self.sharder = ParameterSharder([tr.root.data] + [b.flat.data for b in tr.blocks], names, world, rank, backend, force_collectives=active and world == 1)
+        self._reduce_norm = active
         # from here on each rank keeps only its shards: the modules' parameters ARE the shards (what an optimiser / checkpoint writer of this rank sees)
         tr.root.data = self.sharder.units[0].shard
         for i, blk in enumerate(tr.blocks):
@@ -87,7 +88,7 @@ class MI355XWanFullFinetuneStep:
         self._total.zero_()
         for u in sh.units:
             self._total += ops.grad_sumsq(u.shard_grad, self._scratch)
-        if sh.world > 1:
+        if self._reduce_norm:
             dist.all_reduce(self._total, op=dist.ReduceOp.SUM)
         self.step_count += 1
         lr = self.lr if self.lr_scheduler is None else self.lr_scheduler.current_lr()

@@ -517,3 +517,35 @@ def test_wan_model_full_depth_parity_config4_architecture():
           f"(worst tensor {worst:.2e}); blocks 0 / 14 / 29: {per_block[0]:.2e} / {per_block[1]:.2e} / {per_block[2]:.2e}")
     assert e_pred < 2e-2 and e_loss < 3e-3
     assert glob < 1.5e-2 and worst < 0.15
+
+
+def test_wan_sharded_step_on_rccl_single_rank():
+    """The sharded step's collectives on RCCL with a one-rank communicator (the pool has one GPU per box): bf16 all-gathers into the rotating buffers,
+    fp32 ReduceOp.AVG reduce-scatters issued from inside the backward on RCCL's stream, the norm all-reduce.  Must reproduce the local step."""
+    import os
+
+    from finetrainers_amd.parallel import DataParallelBackend
+    from finetrainers_amd.wan import MI355XWanFullFinetuneStep
+
+    os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 90))
+    dev = _dev()
+    b = _wan_batch()
+    par = DataParallelBackend(backend="nccl", exercise_collectives=True)
+    try:
+        res = []
+        for use_par in (False, True):
+            _, gmodel = _wan_model_pair(seed=0)
+            step = MI355XWanFullFinetuneStep(gmodel, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-2, max_grad_norm=1.0, parallel=par if use_par else None)
+            for _ in range(2):
+                out = step.step(b["moments"].to(dev), b["text"].to(dev), b["mean"].to(dev), b["std"].to(dev), b["sigmas"].to(dev), posterior_noise=b["eps"].to(dev),
+                                noise=b["noise"].to(dev))
+            torch.cuda.synchronize()
+            res.append((out["loss"].item(), out["grad_norm"].item(), torch.cat([u.shard[: u.numel] for u in step.sharder.units]).clone(), step.sharder))
+        (l0, g0, p0, s0), (l1, g1, p1, s1) = res
+        same = (p0 == p1).float().mean().item()
+        print(f"[wan-fsdp rccl 1 rank] loss {l0:.6f} / {l1:.6f} grad_norm {g0:.5e} / {g1:.5e}; identical parameters {same:.4f}; all-gathers {s1.gathers_issued}, "
+              f"reduce-scatters {s1.scatters_issued}")
+        assert s0.gathers_issued == 0 and s1.gathers_issued == 2 * 3 and s1.scatters_issued == 2 * 3
+        assert abs(l0 - l1) < 1e-4 * abs(l0) and abs(g0 - g1) < 1e-3 * g0 and same > 0.97
+    finally:
+        par.destroy()
