@@ -1,6 +1,7 @@
 """CPU-side tests (no GPU): the C-ABI library loads and exports every symbol the header declares, host logic of the
 ModelSpecification / attention-provider / step mirrors, and the product path's refusal to run without the GPU."""
 
+import math
 import os
 import re
 import subprocess
@@ -533,3 +534,44 @@ def test_cogvideox_host_tables_match_oracle():
     ts = torch.tensor([3, 500, 998])
     assert torch.equal(tab.loss_weights(ts), 1 / (1 - osch.alphas_cumprod[ts]))
     assert dict(cfg.__dict__, use_rotary_positional_embeddings=False, patch_size_t=None, ofs_embed_dim=None) == ocfg.__dict__  # the 2b defaults agree
+
+
+def test_wan_host_tables_layouts_and_spec_ops_match_oracle():
+    """Wan host-side pieces (no kernels): the rotary tables against the oracle's complex table, the flat parameter layouts (diffusers names, fused q|k|v
+    and cross k|v views contiguous, 16-byte aligned slices, the 1.3B parameter count), the config loader, and the spec-level torch arithmetic
+    (moment normalisation, flow-match mix, target) on the CPU against oracle/wan.py -- the posterior draw is the library's and is tested on the GPU."""
+    from finetrainers_amd.wan.block import WanBlockLayout
+    from finetrainers_amd.wan.model import RootLayout, WanTransformerConfig, rotary_tables
+    from finetrainers_amd.wan.specification import MI355XWanSpecOps
+    from oracle import wan
+
+    cfg, ocfg = WanTransformerConfig(), wan.WanConfig()
+    for (f, h, w) in ((21, 64, 64), (3, 8, 12)):
+        cos, sin = rotary_tables(cfg, f, h, w)
+        freqs = wan.WanRotaryPosEmbed(ocfg)(torch.zeros(1, 16, f, h, w))[0, 0]  # complex128 [S, 64]
+        assert cos.shape == (f * (h // 2) * (w // 2), 64) and torch.equal(cos, freqs.real.float()) and torch.equal(sin, freqs.imag.float())
+    lay = WanBlockLayout(cfg.inner_dim, cfg.ffn_dim)
+    oblk = wan.WanTransformerBlock(ocfg)
+    names = {n.replace("ffn.proj_in.", "ffn.net.0.proj.").replace("ffn.proj_out.", "ffn.net.2."): tuple(p.shape) for n, p in oblk.named_parameters()}
+    assert {n: s for n, s in lay.entries} == names and lay.total == sum(p.numel() for p in oblk.parameters())
+    assert all(off % 8 == 0 for off, _ in lay.offsets.values())
+    flat = torch.arange(lay.total, dtype=torch.float32)
+    D = cfg.inner_dim
+    qkv = lay.view(flat, "w_qkv1")
+    assert qkv.shape == (3 * D, D) and torch.equal(qkv[D:2 * D], lay.view(flat, "attn1.to_k.weight")) and torch.equal(qkv[2 * D:], lay.view(flat, "attn1.to_v.weight"))
+    kv = lay.view(flat, "w_kv2")
+    assert torch.equal(kv[:D], lay.view(flat, "attn2.to_k.weight")) and torch.equal(lay.view(flat, "b_kv2")[D:], lay.view(flat, "attn2.to_v.bias"))
+    root = RootLayout(cfg)
+    omodel_names = {k: tuple(v.shape) for k, v in wan.WanTransformer3DModel(wan.WanConfig(num_layers=0)).state_dict().items()}
+    omodel_names["patch_embedding.weight"] = (D, 64)  # the Conv3d weight in its GEMM shape
+    assert {n: s for n, s in root.entries} == omodel_names
+    assert 30 * lay.total + sum(math.prod(s) for _, s in root.entries) == 1_418_996_800  # Wan2.1-T2V-1.3B
+    assert WanTransformerConfig.from_dict({"patch_size": [1, 2, 2], "num_layers": 2, "_class_name": "WanTransformer3DModel"}).num_layers == 2
+
+    # spec ops around the posterior draw
+    g = torch.Generator().manual_seed(0)
+    mom = torch.randn(2, 32, 3, 8, 12, generator=g).bfloat16()
+    mean, std = 0.1 * torch.randn(16, generator=g), 1 + 0.2 * torch.rand(16, generator=g)
+    spec = MI355XWanSpecOps()
+    assert spec._resolution_dim_keys == {"latents": (2, 3, 4)}
+    assert torch.equal(spec.normalize_latents(mom[:, :16], mean, std), wan.normalize_latents(mom[:, :16], mean, std))
