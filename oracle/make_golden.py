@@ -329,6 +329,37 @@ def main() -> None:
         temb_w, tproj_w, text_w, _ = ref_embed(wmodel.condition_embedder, torch.tensor([310, 840]), wtext)
     tensors["wan.embed.temb"], tensors["wan.embed.timestep_proj"], tensors["wan.embed.text"] = temb_w, tproj_w, text_w
 
+    # ---- HunyuanVideo: the reference's spec forward executed around a recording stub transformer -----------------------------
+    # (the DiT itself is [upstream]; what is pinned here is everything the reference does around the call: posterior draw, VAE scaling factor,
+    #  flow-match mix, integer timesteps, guidance * 1000, the keyword set handed to the transformer, the target)
+    hy_ns = dict(TYPING_NS, FF=FF, DiagonalGaussianDistribution=MU.DiagonalGaussianDistribution, HunyuanVideoTransformer3DModel=object)
+    hy_fwd = extract("finetrainers/models/hunyuan_video/base_specification.py", "forward", hy_ns, cls="HunyuanVideoModelSpecification")
+    gh = torch.Generator().manual_seed(31)
+    Bh, Ch, Fh, Hh, Wh = 2, 4, 3, 6, 8
+    hy_mom = torch.randn(Bh, 2 * Ch, Fh, Hh, Wh, generator=gh)
+    hy_mom[:, Ch:] = hy_mom[:, Ch:] * 0.3 - 2.0
+    hy_mom = hy_mom.bfloat16()
+    hy_cond = {"encoder_hidden_states": torch.randn(Bh, 5, 16, generator=gh).bfloat16(), "encoder_attention_mask": torch.tensor([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]]),
+               "pooled_projections": torch.randn(Bh, 8, generator=gh).bfloat16()}
+    hy_sig = torch.tensor([0.27, 0.66]).view(Bh, 1, 1, 1, 1)
+    seen = {}
+
+    def hy_stub(**kw):  # records what the reference hands over and returns a deterministic function of it
+        seen.update({k_: (v_.clone() if torch.is_tensor(v_) else v_) for k_, v_ in kw.items()})
+        return ((kw["hidden_states"].float() * 0.5 + kw["guidance"].view(-1, 1, 1, 1, 1).float() * 1e-4 + kw["timestep"].view(-1, 1, 1, 1, 1).float() * 1e-3).to(kw["hidden_states"].dtype),)
+
+    hy_self = types.SimpleNamespace(vae_config=types.SimpleNamespace(scaling_factor=0.476986))
+    for tag, cp in (("hunyuan.spec_moments", False), ("hunyuan.spec_latents", True)):
+        lat_in = hy_mom.clone() if not cp else hy_mom[:, :Ch].clone()
+        with torch.no_grad():
+            pred_h, target_h, _ = hy_fwd(hy_self, hy_stub, dict(hy_cond), {"latents": lat_in}, hy_sig, guidance=6.0, generator=torch.Generator().manual_seed(91),
+                                         compute_posterior=cp)
+        assert set(seen) == {"hidden_states", "guidance", "encoder_hidden_states", "encoder_attention_mask", "pooled_projections", "timestep", "return_dict"}
+        for k_, v_ in (("latents_in", lat_in), ("pred", pred_h), ("target", target_h), ("noisy", seen["hidden_states"]), ("guidance", seen["guidance"]),
+                       ("timestep", seen["timestep"])):
+            tensors[f"{tag}.{k_}"] = v_
+    tensors["hunyuan.spec.sigmas"] = hy_sig.flatten()
+
     tensors = {k: v.detach().clone().contiguous() for k, v in tensors.items()}
     path = os.path.join(OUT, "reference_fixtures.safetensors")
     save_file(tensors, path, metadata={"generator": "oracle/make_golden.py", "reference": "a-r-r-o-w/finetrainers @ 2025-08-29"})
