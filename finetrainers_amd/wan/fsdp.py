@@ -13,7 +13,9 @@ The MI355X design keeps that data flow but is built for one process per GPU over
     process group stream waits for the kernels already queued on the compute stream that still read the buffer, so reuse needs no host sync);
   * two full-size fp32 gradient buffers rotate the same way: block i's backward accumulates into one while block i + 1's reduce-scatter drains the other;
   * the root unit (embedders, output projection: 2 % of the parameters) is gathered once per step.
-gloo (tests: CPU, or two ranks on one GPU) runs the same schedule synchronously with host staging."""
+gloo (tests: CPU, or two ranks on one GPU) runs the same schedule synchronously with host staging.
+Status: the schedule is tested at world size 2 over gloo and on a one-rank RCCL communicator; the overlap described above is the intended behaviour of
+asynchronous collectives on the process group's stream and has not been traced on a multi-GPU node yet."""
 
 from __future__ import annotations
 
