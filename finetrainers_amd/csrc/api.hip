@@ -498,6 +498,12 @@ int ftmi_grad_sumsq(const float* grads, long n, float* scratch, ftmi_stream stre
     return sumsq(grads, n, scratch, st);
 }
 
+int ftmi_clip_by_sumsq(float* grads, long n, const float* sumsq, float max_norm, float* grad_norm_out, ftmi_stream stream) {
+    if (!grads || !sumsq || n < 0) return set_error(FTMI_ERR_INVALID, "ftmi_clip_by_sumsq: bad argument");
+    if (n == 0) return 0;
+    return clip_scale(grads, n, sumsq, max_norm, grad_norm_out, (hipStream_t)stream);
+}
+
 int ftmi_adamw_bf16_step(void* params, const float* grads, void* exp_avg, void* exp_avg_sq, long n, const float* sumsq_in, float max_norm, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int step, float* grad_norm_out, ftmi_stream stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return set_error(FTMI_ERR_INVALID, "ftmi_adamw_bf16_step: bad argument");

@@ -519,3 +519,10 @@ def adamw_bf16_step(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, be
     check(_lib.load().ftmi_adamw_bf16_step(ptr(params), ptr(grads), ptr(exp_avg), ptr(exp_avg_sq), params.numel(), ptr(sumsq), float(max_norm), float(lr),
                                             float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), ptr(grad_norm_out), stream_ptr()),
           "ftmi_adamw_bf16_step")
+
+
+def clip_by_sumsq_(grads: torch.Tensor, sumsq: torch.Tensor, max_norm: float, grad_norm_out: Optional[torch.Tensor] = None) -> None:
+    """grads (flat fp32) *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)), in place."""
+    require_gpu_tensor(grads, "grads", torch.float32)
+    require_gpu_tensor(sumsq, "sumsq", torch.float32)
+    check(_lib.load().ftmi_clip_by_sumsq(ptr(grads), grads.numel(), ptr(sumsq), float(max_norm), ptr(grad_norm_out), stream_ptr()), "ftmi_clip_by_sumsq")

@@ -24,7 +24,10 @@ bf16 = torch.bfloat16
 class MI355XWanFullFinetuneStep:
     def __init__(self, transformer: MI355XWanTransformer3DModel, spec: Optional[MI355XWanSpecOps] = None, lr: float = 1e-5, betas=(0.9, 0.95),
                  eps: float = 1e-8, weight_decay: float = 1e-4, max_grad_norm: float = 1.0, parallel=None, generator: Optional[torch.Generator] = None,
-                 lr_scheduler=None):
+                 lr_scheduler=None, gradient_accumulation_steps: int = 1):
+        if gradient_accumulation_steps < 1:
+            raise ValueError("gradient_accumulation_steps must be >= 1")
+        self.gradient_accumulation_steps, self._micro_step = gradient_accumulation_steps, 0
         self.transformer, self.spec = transformer, spec or MI355XWanSpecOps()
         self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
         self.parallel, self.generator, self.lr_scheduler = parallel, generator, lr_scheduler
@@ -80,7 +83,10 @@ class MI355XWanFullFinetuneStep:
         tr.root_grad = sh.grad_buffer(0)
         pred, target, _ = self.spec.forward(tr, moments, encoder_hidden_states, sigmas, latents_mean, latents_std, posterior_noise=posterior_noise, noise=noise,
                                             generator=self.generator)
-        loss = self.spec.loss_backward(pred, target)
+        gas = self.gradient_accumulation_steps
+        self._micro_step += 1
+        sync = self._micro_step % gas == 0  # last micro-step of the window: the optimiser steps (trainer.py:498)
+        loss = self.spec.loss_backward(pred, target, grad_scale=1.0 / gas)
         sh.scatter_grad(0)
         tr.root_grad = None
         sh.finish_gradients()
@@ -90,20 +96,38 @@ class MI355XWanFullFinetuneStep:
             self._total += ops.grad_sumsq(u.shard_grad, self._scratch)
         if self._reduce_norm:
             dist.all_reduce(self._total, op=dist.ReduceOp.SUM)
-        self.step_count += 1
-        lr = self.lr if self.lr_scheduler is None else self.lr_scheduler.current_lr()
         gn = torch.empty(1, dtype=torch.float32, device=tr.device)
-        for u, m, v in zip(sh.units, self.exp_avg, self.exp_avg_sq):
-            ops.adamw_bf16_step(u.shard, u.shard_grad, m, v, self.step_count, lr, self.betas, self.eps, self.weight_decay, sumsq=self._total,
-                                max_norm=self.max_grad_norm, grad_norm_out=gn)
-        if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+        if sync:
+            self.step_count += 1
+            lr = self.lr if self.lr_scheduler is None else self.lr_scheduler.current_lr()
+            for u, m, v in zip(sh.units, self.exp_avg, self.exp_avg_sq):
+                ops.adamw_bf16_step(u.shard, u.shard_grad, m, v, self.step_count, lr, self.betas, self.eps, self.weight_decay, sumsq=self._total,
+                                    max_norm=self.max_grad_norm, grad_norm_out=gn)
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step()
+            sh.zero_shard_grads()
+        else:  # the reference clips after every backward, also where no optimiser step follows: the accumulated shard gradients are scaled in place
+            for u in sh.units:
+                ops.clip_by_sumsq_(u.shard_grad, self._total, self.max_grad_norm, grad_norm_out=gn)
         sh.release_all()
-        sh.zero_shard_grads()
         tr._root_src = None
         for blk in tr.blocks:
             blk._param_src = None
         return {"loss": loss.detach(), "grad_norm": gn}
+
+    def state_dict(self) -> Dict[str, object]:
+        """This rank's optimiser state (moments of its shards) and counters; the parameters themselves are the modules' shards."""
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count, "micro_step": self._micro_step,
+                "lr_scheduler": None if self.lr_scheduler is None else self.lr_scheduler.state_dict()}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        for dst, src in zip(self.exp_avg, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            dst.copy_(src)
+        self.step_count, self._micro_step = int(sd["step"]), int(sd.get("micro_step", 0))
+        if self.lr_scheduler is not None and sd.get("lr_scheduler") is not None:
+            self.lr_scheduler.load_state_dict(sd["lr_scheduler"])
 
     @torch.no_grad()
     def gathered_parameters(self) -> Dict[str, torch.Tensor]:

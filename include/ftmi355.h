@@ -357,6 +357,10 @@ int ftmi_wan_colsum(const ftmi_wan_row_args* args, ftmi_stream stream);
 /* Sum of squares of a flat fp32 gradient (shard): scratch[0] <- sum g^2 (order-fixed; scratch >= FTMI_CLIP_SCRATCH_FLOATS floats).  Sharded training
  * all-reduces scratch[0] over the ranks before the optimiser call below (the reference's clip_grad_norm_ over DTensor shards, utils/torch.py:99-161). */
 int ftmi_grad_sumsq(const float* grads, long n, float* scratch, ftmi_stream stream);
+/* In-place clip of a flat fp32 gradient (shard) by a global norm given as a device sum of squares: grads *= min(1, max_norm / (sqrt(*sumsq) + 1e-6)).
+ * The non-stepping micro-steps of a gradient-accumulation window in sharded training (the reference clips after EVERY backward,
+ * trainer/sft_trainer/trainer.py:487-492); the stepping micro-step clips inside ftmi_adamw_bf16_step. */
+int ftmi_clip_by_sumsq(float* grads, long n, const float* sumsq, float max_norm, float* grad_norm_out, ftmi_stream stream);
 /* torch.optim.AdamW on bf16 parameters with bf16 moments (the reference's bf16 full fine-tune, optimizer.py:17-46): every torch op of the update is one
  * fp32 computation rounded to bf16.  grads: fp32 (the reduce-scattered shard), multiplied by min(1, max_norm / (sqrt(*sumsq) + 1e-6)) and rounded to
  * bf16 first (sumsq NULL: no clip).  grad_norm_out (may be NULL) receives sqrt(*sumsq). */

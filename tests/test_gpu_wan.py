@@ -549,3 +549,42 @@ def test_wan_sharded_step_on_rccl_single_rank():
         assert abs(l0 - l1) < 1e-4 * abs(l0) and abs(g0 - g1) < 1e-3 * g0 and same > 0.97
     finally:
         par.destroy()
+
+
+def test_wan_step_gradient_accumulation_and_state_dict():
+    """Two micro-steps on the same batch with 1 / gas loss scaling accumulate to the single-step gradient (no clip active), so the optimiser lands on the
+    same parameters; with a tight bound the non-stepping micro-step clips the accumulated shard gradients in place like the reference loop; the step
+    object's state round-trips."""
+    from finetrainers_amd.wan import MI355XWanFullFinetuneStep
+
+    dev = _dev()
+    b = _wan_batch()
+    args = lambda: (b["moments"].to(dev), b["text"].to(dev), b["mean"].to(dev), b["std"].to(dev), b["sigmas"].to(dev))
+    kw = dict(posterior_noise=b["eps"].to(dev), noise=b["noise"].to(dev))
+    res = []
+    for gas in (1, 2):
+        _, gmodel = _wan_model_pair(seed=0)
+        step = MI355XWanFullFinetuneStep(gmodel, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-2, max_grad_norm=1e9, gradient_accumulation_steps=gas)
+        before = torch.cat([u.shard[: u.numel] for u in step.sharder.units]).clone()
+        for micro in range(gas):
+            out = step.step(*args(), **kw)
+            if micro < gas - 1:
+                assert step.step_count == 0 and torch.equal(torch.cat([u.shard[: u.numel] for u in step.sharder.units]), before)  # nothing moves before the window closes
+                assert float(step.sharder.units[1].shard_grad.abs().max()) > 0  # ... but the gradients are kept
+        torch.cuda.synchronize()
+        assert step.step_count == 1 and float(step.sharder.units[1].shard_grad.abs().max()) == 0.0
+        res.append((out["grad_norm"].item(), torch.cat([u.shard[: u.numel] for u in step.sharder.units]).clone(), step))
+    (g1, p1, s1), (g2, p2, s2) = res
+    same = (p1 == p2).float().mean().item()
+    print(f"[wan-gas] grad_norm {g1:.5e} (1 step) / {g2:.5e} (2 micro-steps); identical parameters {same:.4f}")
+    assert abs(g1 - g2) < 1e-4 * g1 and same > 0.97
+    # tight bound: after the first micro-step the kept gradients have norm max_norm
+    _, gmodel = _wan_model_pair(seed=0)
+    step = MI355XWanFullFinetuneStep(gmodel, lr=1e-3, max_grad_norm=0.05, gradient_accumulation_steps=2)
+    out = step.step(*args(), **kw)
+    kept = math.sqrt(sum(float(u.shard_grad.double().pow(2).sum()) for u in step.sharder.units))
+    assert out["grad_norm"].item() > 0.2 and abs(kept - 0.05) < 1e-3 * 0.05
+    sd = step.state_dict()
+    assert sd["micro_step"] == 1 and sd["step"] == 0 and len(sd["exp_avg"]) == len(step.sharder.units)
+    s2.load_state_dict(s1.state_dict())
+    assert s2.step_count == 1 and torch.equal(s2.exp_avg[1], s1.exp_avg[1])
