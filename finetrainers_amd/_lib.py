@@ -138,6 +138,9 @@ _SIGS = {
     **{f"ftmi_wan_{n}": (c_int, [POINTER(WanRowArgs), c_void_p]) for n in ("ln_fwd", "ln_bwd", "rms_rope_fwd", "rms_rope_bwd", "gate_res_fwd",
                                                                            "gate_res_bwd", "colsum")},
     "ftmi_grad_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
+    "ftmi_head_rms_rope_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ftmi_head_rms_rope_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p]),
     "ftmi_clip_by_sumsq": (c_int, [c_void_p, c_long, c_void_p, c_float, c_void_p, c_void_p]),
     "ftmi_adamw_bf16_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_int,
                                      c_void_p, c_void_p]),

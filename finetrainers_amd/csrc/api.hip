@@ -430,6 +430,29 @@ int ftmi_cog_head_ln_bwd(const void* x, long ld, const void* w, const void* dy, 
     return cog_head_ln_bwd(a, (hipStream_t)stream);
 }
 
+int ftmi_head_rms_rope_fwd(const void* x, long ld, const void* w, void* y, long ld_y, int rows, int D, int head_dim, float eps, const float* rope_cos,
+                           const float* rope_sin, int rows_per_batch, int rope_from, ftmi_stream stream) {
+    if (!x || !w || !y || ld < D || (ld % 8) || (ld_y % 8) || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_head_rms_rope_fwd: bad argument");
+    CogLnArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.y = (bf16_t*)y; a.rows = rows; a.D = D; a.ld = ld; a.ld_out = ld_y; a.eps = eps; a.head_dim = head_dim; a.rms = 1;
+    a.cos = rope_cos; a.sin = rope_sin; a.seg0 = rope_cos ? rope_from : 0;
+    a.rows_per_batch = rope_cos ? rows_per_batch : (rows > 0 ? rows : 1);
+    return cog_head_ln_fwd(a, (hipStream_t)stream);
+}
+
+int ftmi_head_rms_rope_bwd(const void* x, long ld, const void* w, const void* dy, long ld_dy, void* dx, long ld_dx, int rows, int D, int head_dim, float eps,
+                           const float* rope_cos, const float* rope_sin, int rows_per_batch, int rope_from, ftmi_stream stream) {
+    if (!x || !w || !dy || !dx || ld < D || (ld % 8) || (ld_dy % 8) || (ld_dx % 8) || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_head_rms_rope_bwd: bad argument");
+    CogLnArgs a;
+    a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.dy = (const bf16_t*)dy; a.dx = (bf16_t*)dx; a.rows = rows; a.D = D; a.ld = ld; a.ld_dy = ld_dy; a.ld_out = ld_dx;
+    a.eps = eps; a.head_dim = head_dim; a.rms = 1;
+    a.cos = rope_cos; a.sin = rope_sin; a.seg0 = rope_cos ? rope_from : 0;
+    a.rows_per_batch = rope_cos ? rows_per_batch : (rows > 0 ? rows : 1);
+    return cog_head_ln_bwd(a, (hipStream_t)stream);
+}
+
 int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, void* out, int rows, int D, int rows_per_batch, int text_len,
                            ftmi_stream stream) {
     if (!y || !gate || !out) return set_error(FTMI_ERR_INVALID, "ftmi_cog_gate_residual: null argument");

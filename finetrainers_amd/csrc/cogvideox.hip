@@ -30,6 +30,12 @@ FTMI_DEVICE float gsum8(float v) {  // sum over an aligned group of 8 lanes (= o
     v += __shfl_xor(v, 4, 64);
     return v;
 }
+template <int LANES>
+FTMI_DEVICE float gsum(float v) {  // sum over an aligned group of 8 (head_dim 64) or 16 (head_dim 128) lanes = one head
+    v = gsum8(v);
+    if constexpr (LANES == 16) v += __shfl_xor(v, 8, 64);
+    return v;
+}
 FTMI_DEVICE void up8(const bf16_t* p, float (&f)[8]) {
     const s16x8 r = *reinterpret_cast<const s16x8*>(p);
 #pragma unroll
@@ -168,16 +174,20 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(CogLnArgs a) {
 // CogVideoXAttnProcessor2_0: q, k <- norm_q / norm_k (LayerNorm per head), then -- rotary checkpoints (CogVideoX-5b) -- apply_rotary_emb on the video
 // tokens only: channel pairs (2i, 2i+1) of a head rotate by the angle of (position, i); cos / sin are fp32 [S, 64] with every frequency repeated
 // twice (embeddings.apply_rotary_emb(use_real=True, use_real_unbind_dim=-1)):  out = bf(n * cos + rot(n) * sin),  rot(n) = (-n[2i+1], n[2i]).
-template <int NC, bool BWD>
+// HD = head width (64: CogVideoX, 128: HunyuanVideo); RMS: RMSNorm per head (no mean, no bias; the reference's patched F.rms_norm: one bf16 rounding)
+// instead of LayerNorm.  The rotary tables are fp32 [S, HD] (every frequency repeated for its channel pair).
+template <int NC, bool BWD, int HD = 64, bool RMS = false>
 __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
+    constexpr int HM = HD / 8 - 1;  // chunk-in-head mask
+    constexpr float kInv = 1.0f / HD;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const int nchunk = a.D / 8;
     const long ro = (long)row * a.ld, rdy = (long)row * (a.ld_dy ? a.ld_dy : a.ld), rout = (long)row * (a.ld_out ? a.ld_out : a.ld);
     const int pos = row % a.rows_per_batch;
     const bool rope = a.cos != nullptr && pos >= a.seg0;
-    const float* cp = rope ? a.cos + (long)(pos - a.seg0) * 64 : nullptr;
-    const float* sp = rope ? a.sin + (long)(pos - a.seg0) * 64 : nullptr;
+    const float* cp = rope ? a.cos + (long)(pos - a.seg0) * HD : nullptr;
+    const float* sp = rope ? a.sin + (long)(pos - a.seg0) * HD : nullptr;
 #pragma unroll
     for (int it = 0; it < NC; ++it) {
         const int c = lane + 64 * it;  // chunk c covers channels 8 (c % 8) .. +7 of head c / 8; the 8 lanes of a head are adjacent
@@ -185,11 +195,11 @@ __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
         float xv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wv[8], bv[8], cv[8], sv[8];
         if (on) {
             up8(a.x + ro + c * 8, xv);
-            up8(a.w + (c & 7) * 8, wv);
-            if (!BWD) up8(a.b + (c & 7) * 8, bv);
+            up8(a.w + (c & HM) * 8, wv);
+            if (!BWD && !RMS) up8(a.b + (c & HM) * 8, bv);
             if (rope) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp + (c & 7) * 8), c1 = *reinterpret_cast<const f32x4*>(cp + (c & 7) * 8 + 4);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + (c & 7) * 8), s1 = *reinterpret_cast<const f32x4*>(sp + (c & 7) * 8 + 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp + (c & HM) * 8), c1 = *reinterpret_cast<const f32x4*>(cp + (c & HM) * 8 + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp + (c & HM) * 8), s1 = *reinterpret_cast<const f32x4*>(sp + (c & HM) * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     cv[e] = c0[e]; cv[4 + e] = c1[e];
@@ -200,15 +210,15 @@ __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += xv[e];
-        const float mean = gsum8(s) * (1.0f / 64);
+        const float mean = RMS ? 0.f : gsum<HD / 8>(s) * kInv;
         float v = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v += (xv[e] - mean) * (xv[e] - mean);
-        const float rstd = rsqrtf(gsum8(v) * (1.0f / 64) + a.eps);
+        const float rstd = rsqrtf(gsum<HD / 8>(v) * kInv + a.eps);
         float o[8];
         if constexpr (!BWD) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = on ? (xv[e] - mean) * rstd * wv[e] + bv[e] : 0.f;
+            for (int e = 0; e < 8; ++e) o[e] = on ? (RMS ? xv[e] * rstd * wv[e] : (xv[e] - mean) * rstd * wv[e] + bv[e]) : 0.f;
             if (rope && on) {
                 float n[8];
 #pragma unroll
@@ -243,8 +253,8 @@ __global__ __launch_bounds__(256) void head_ln_kernel(CogLnArgs a) {
                 c1 += gv[e];
                 c2 += gv[e] * ((xv[e] - mean) * rstd);
             }
-            c1 = gsum8(c1) * (1.0f / 64);
-            c2 = gsum8(c2) * (1.0f / 64);
+            c1 = RMS ? 0.f : gsum<HD / 8>(c1) * kInv;
+            c2 = gsum<HD / 8>(c2) * kInv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = rstd * (gv[e] - c1 - (xv[e] - mean) * rstd * c2);
             if (on) st8(a.dx + rout + c * 8, o);
@@ -367,7 +377,14 @@ int cog_head_ln_fwd(const CogLnArgs& a, hipStream_t st) {
     if (a.rows <= 0) return 0;
     const dim3 grid((a.rows + 3) / 4);
 #define COMMA_FALSE , false
-    FTMI_COG_DISPATCH(head_ln_kernel, COMMA_FALSE)
+#define COMMA_FALSE_RMS128 , false, 128, true
+    if (a.head_dim == 128 && a.rms) {
+        FTMI_COG_DISPATCH(head_ln_kernel, COMMA_FALSE_RMS128)
+    } else if (a.head_dim == 64 && !a.rms) {
+        FTMI_COG_DISPATCH(head_ln_kernel, COMMA_FALSE)
+    } else {
+        return set_error(FTMI_ERR_UNSUPPORTED, "head norm: LayerNorm over 64-channel heads or RMSNorm over 128-channel heads");
+    }
     return check_launch("cog_head_ln_fwd");
 }
 int cog_head_ln_bwd(const CogLnArgs& a, hipStream_t st) {
@@ -375,7 +392,14 @@ int cog_head_ln_bwd(const CogLnArgs& a, hipStream_t st) {
     if (a.rows <= 0) return 0;
     const dim3 grid((a.rows + 3) / 4);
 #define COMMA_TRUE , true
-    FTMI_COG_DISPATCH(head_ln_kernel, COMMA_TRUE)
+#define COMMA_TRUE_RMS128 , true, 128, true
+    if (a.head_dim == 128 && a.rms) {
+        FTMI_COG_DISPATCH(head_ln_kernel, COMMA_TRUE_RMS128)
+    } else if (a.head_dim == 64 && !a.rms) {
+        FTMI_COG_DISPATCH(head_ln_kernel, COMMA_TRUE)
+    } else {
+        return set_error(FTMI_ERR_UNSUPPORTED, "head norm: LayerNorm over 64-channel heads or RMSNorm over 128-channel heads");
+    }
     return check_launch("cog_head_ln_bwd");
 }
 int cog_gate_residual(const CogLnArgs& a, hipStream_t st) {

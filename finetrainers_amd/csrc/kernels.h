@@ -229,6 +229,8 @@ struct CogLnArgs {
     long ld = 0;                 // head_ln: row stride of x
     long ld_dy = 0, ld_out = 0;  // head_ln: row strides of dy and of the output (y / dx); 0 = ld
     float eps = 1e-5f;
+    int head_dim = 64;           // head_ln: 64 (LayerNorm per head, CogVideoX) or 128 with rms (RMSNorm per head, HunyuanVideo); rotary tables [S, head_dim]
+    int rms = 0;
 };
 int cog_ln_mod_fwd(const CogLnArgs& a, hipStream_t st);    // y = bf(bf(LN(x; w, b)) * onep) + shift
 int cog_ln_mod_bwd(const CogLnArgs& a, hipStream_t st);    // dx = [dres +] LN'(x)[bf(dy * onep) * w]

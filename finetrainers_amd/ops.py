@@ -92,7 +92,12 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         out = torch.empty((M, N), dtype=bf16, device=x.device)
     elif out.shape != (M, N) or out.dtype != bf16 or out.stride(1) != 1:
         raise ValueError("gemm_nt: out must be an [M, N] bf16 view with contiguous columns")
-    out2 = torch.empty((M, N), dtype=bf16, device=x.device) if want_out2 else None
+    ldo = out.stride(0)
+    # the C entry point moves out2 / resid / aux with out's row stride (include/ftmi355.h): give the pre-activation the same stride, refuse the others
+    out2 = (torch.empty((M, N), dtype=bf16, device=x.device) if ldo == N else torch.empty((M, ldo), dtype=bf16, device=x.device)[:, :N]) if want_out2 else None
+    for name, t in (("aux", aux), ("resid", resid)):
+        if t is not None and (t.shape != (M, N) or t.stride(1) != 1 or t.stride(0) != ldo):
+            raise ValueError(f"gemm_nt: {name} must be an [M, N] bf16 view with the row stride of out ({ldo})")
     check(_lib.load().ftmi_gemm_nt(M, N, K, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), float(alpha), ptr(out), out.stride(0), epilogue,
                                     ptr(out2), ptr(resid), ptr(gate), rows_per_batch, ptr(aux), variant, stream_ptr()), "ftmi_gemm_nt")
     return (out, out2) if want_out2 else out
@@ -526,3 +531,29 @@ def clip_by_sumsq_(grads: torch.Tensor, sumsq: torch.Tensor, max_norm: float, gr
     require_gpu_tensor(grads, "grads", torch.float32)
     require_gpu_tensor(sumsq, "sumsq", torch.float32)
     check(_lib.load().ftmi_clip_by_sumsq(ptr(grads), grads.numel(), ptr(sumsq), float(max_norm), ptr(grad_norm_out), stream_ptr()), "ftmi_clip_by_sumsq")
+
+
+# ---- HunyuanVideo (include/ftmi355.h: ftmi_head_rms_rope_*) ----------------------------------------------------------------------------------
+def head_rms_rope(x2d, w, head_dim: int = 128, eps: float = 1e-6, rope=None, rows_per_batch: int = 0, rope_from: int = 0, out=None):
+    """Per-head RMSNorm of x2d [rows, D] (a bf16 view, any row stride % 8) + real-form rotary embedding on the rows at position >= rope_from of each sample."""
+    x2d = _rows2d(x2d, "x")
+    rows, D = x2d.shape
+    out = torch.empty((rows, D), dtype=bf16, device=x2d.device) if out is None else _rows2d(out, "out")
+    cos, sin = (None, None) if rope is None else rope
+    if rope is not None:
+        n = (rows_per_batch or rows) - rope_from
+        _f32(cos, "rope cos", (n, head_dim))
+        _f32(sin, "rope sin", (n, head_dim))
+    check(_lib.load().ftmi_head_rms_rope_fwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(out), out.stride(0), rows, D, int(head_dim), float(eps), ptr(cos), ptr(sin),
+                                             int(rows_per_batch or rows), int(rope_from), stream_ptr()), "ftmi_head_rms_rope_fwd")
+    return out
+
+
+def head_rms_rope_bwd(x2d, w, dy2d, head_dim: int = 128, eps: float = 1e-6, rope=None, rows_per_batch: int = 0, rope_from: int = 0, out=None):
+    x2d, dy2d = _rows2d(x2d, "x"), _rows2d(dy2d, "dy")
+    rows, D = x2d.shape
+    out = torch.empty((rows, D), dtype=bf16, device=x2d.device) if out is None else _rows2d(out, "out")
+    cos, sin = (None, None) if rope is None else rope
+    check(_lib.load().ftmi_head_rms_rope_bwd(ptr(x2d), x2d.stride(0), ptr(w), ptr(dy2d), dy2d.stride(0), ptr(out), out.stride(0), rows, D, int(head_dim), float(eps),
+                                             ptr(cos), ptr(sin), int(rows_per_batch or rows), int(rope_from), stream_ptr()), "ftmi_head_rms_rope_bwd")
+    return out

@@ -105,7 +105,8 @@ int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const voi
 
 /* Generic building blocks (exposed for tests / incremental adoption) */
 /* out[M,N] = bf16(alpha * x[M,K] w[N,K]^T + bias) ; epilogue: 0 store, 1 gelu-tanh (out2 <- pre-activation),
- * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux).  variant: 8 = automatic tile / K-loop choice (use this);
+ * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux).  out2, resid and aux are [M, N] views with out's row stride ldo.
+ * variant: 8 = automatic tile / K-loop choice (use this);
  * other ids pin one kernel (bit-identical A/B partners, see gemm.hip) */
 int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha,
                  void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
@@ -318,6 +319,16 @@ int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, floa
  * accumulation window where no optimiser step follows; ftmi_clip_adamw_step covers the stepping micro-step, this call the others.
  * scratch: >= FTMI_CLIP_SCRATCH_FLOATS floats; grad_norm_out (may be NULL) receives the pre-clip norm; order-fixed reduction. */
 int ftmi_clip_grad_norm(float* grads, long n, float max_norm, float* scratch, float* grad_norm_out, ftmi_stream stream);
+
+/* HunyuanVideo ([upstream] diffusers Attention(qk_norm = "rms_norm") + HunyuanVideoAttnProcessor2_0, restated in oracle/hunyuan.py): q / k
+ * RMSNorm over each head's head_dim channels (128; weight [head_dim] bf16, eps 1e-6, the reference's patched F.rms_norm: one bf16 rounding), then -- on
+ * the rows at position >= rope_from of a sample of rows_per_batch tokens (the video tokens of a joint [text | video] sequence) -- the rotary embedding
+ * in its real form: rope_cos / rope_sin fp32 [rows_per_batch - rope_from, head_dim], every frequency repeated for its channel pair; NULL: none.
+ * x / y / dy / dx: [rows, D] bf16 views with their own row strides (multiples of 8).  Only the input gradient is produced (LoRA training). */
+int ftmi_head_rms_rope_fwd(const void* x, long ld, const void* w, void* y, long ld_y, int rows, int D, int head_dim, float eps, const float* rope_cos,
+                           const float* rope_sin, int rows_per_batch, int rope_from, ftmi_stream stream);
+int ftmi_head_rms_rope_bwd(const void* x, long ld, const void* w, const void* dy, long ld_dy, void* dx, long ld_dx, int rows, int D, int head_dim, float eps,
+                           const float* rope_cos, const float* rope_sin, int rows_per_batch, int rope_from, ftmi_stream stream);
 
 /* ---- Wan-T2V full fine-tune (BASELINE config 4; finetrainers/models/wan/base_specification.py:433-493 driving [upstream]
  * diffusers transformer_wan.py; restated in oracle/wan.py).  Every parameter trains, so the backward kernels also produce the column sums the

@@ -1,0 +1,137 @@
+"""HunyuanVideo (BASELINE config 5) on the GPU against oracle/hunyuan.py: the per-head RMSNorm + rotary kernel and the single-stream block
+(40 of the model's 60 blocks) with LoRA on to_q / to_k / to_v, forward and backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _rope(S, hd=128, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ang = torch.rand(S, hd // 2, generator=g) * 6.283
+    return ang.cos().repeat_interleave(2, dim=1).float().contiguous(), ang.sin().repeat_interleave(2, dim=1).float().contiguous()
+
+
+def test_head_rms_rope_kernel_matches_the_oracle():
+    """Per-head RMSNorm (128 channels, the reference's patched F.rms_norm) + real-form rotary embedding on the video rows of a [text | video] sequence,
+    on strided views, forward and input gradient."""
+    from finetrainers_amd import ops
+    from oracle import cogvideox as cvx
+    from oracle import ltx
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(0)
+    B, T, S, H, hd = 2, 5, 43, 3, 128
+    N, D = T + S, H * hd
+    x = torch.randn(B, N, 2 * D, generator=g).to(bf16)  # the kernel reads the second half of each row (a strided view)
+    dy = torch.randn(B, N, D, generator=g).to(bf16)
+    w = (1 + 0.1 * torch.randn(hd, generator=g)).to(bf16)
+    cos, sin = _rope(S)
+    rms = ltx.RMSNorm(hd, 1e-6, elementwise_affine=True).to(bf16)
+    with torch.no_grad():
+        rms.weight.copy_(w)
+    xr = x[..., D:].clone().requires_grad_(True)
+    heads = rms(xr.unflatten(2, (H, hd)).transpose(1, 2))  # [B, H, N, hd]
+    y_ref = torch.cat([heads[:, :, :T], cvx.apply_rotary_emb(heads[:, :, T:], (cos, sin))], dim=2)
+    y_ref.backward(dy.unflatten(2, (H, hd)).transpose(1, 2))
+    xg = x.to(dev).view(B * N, 2 * D)[:, D:]
+    rope = (cos.to(dev), sin.to(dev))
+    y = ops.head_rms_rope(xg, w.to(dev), hd, 1e-6, rope=rope, rows_per_batch=N, rope_from=T)
+    assert _rel(y.view(B, N, D), y_ref.detach().transpose(1, 2).flatten(2)) < 2e-3
+    dx = ops.head_rms_rope_bwd(xg, w.to(dev), dy.to(dev).view(B * N, D), hd, 1e-6, rope=rope, rows_per_batch=N, rope_from=T)
+    assert _rel(dx.view(B, N, D), xr.grad) < 4e-3
+    y0 = ops.head_rms_rope(xg, w.to(dev), hd, 1e-6)  # no rotary embedding
+    assert _rel(y0.view(B, N, D), heads.detach().transpose(1, 2).flatten(2)) < 2e-3
+
+
+@pytest.mark.parametrize("B,T,S,masked", [(2, 8, 40, True), (1, 16, 150, False)])
+def test_single_stream_block_forward_backward_parity(B, T, S, masked):
+    """One single-stream block (heads of 128, LoRA r = 64 on to_q / to_k / to_v): outputs and input gradients of both token streams and the 6 LoRA
+    gradients against the oracle block on the CPU (which takes [video | text]; the MI355X block keeps [text | video] -- same function of the tokens);
+    padded text keys masked like the reference's attention mask."""
+    from finetrainers_amd.hunyuan_video import MI355XHunyuanSingleBlock
+    from oracle import hunyuan as hy
+    from oracle import ltx
+
+    dev = _dev()
+    cfg = hy.HunyuanVideoConfig(num_attention_heads=2, attention_head_dim=128, num_layers=0, num_single_layers=1, num_refiner_layers=1, text_embed_dim=64,
+                                pooled_projection_dim=32)
+    D = cfg.inner_dim
+    torch.manual_seed(0)
+    oblk = hy.SingleStreamBlock(cfg)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(7)
+        oblk.attn.norm_q.weight.copy_(1 + 0.1 * torch.randn(128, generator=g))
+        oblk.attn.norm_k.weight.copy_(1 + 0.1 * torch.randn(128, generator=g))
+    oblk = oblk.to(bf16)
+    for p in oblk.parameters():
+        p.requires_grad_(False)
+    for t in ("to_q", "to_k", "to_v"):
+        lin = ltx.LoraLinear(getattr(oblk.attn, t), 64, 64.0)
+        with torch.no_grad():
+            lin.lora_B["default"].weight.normal_(0, 0.02, generator=g)
+        setattr(oblk.attn, t, lin)
+    sd = {k: v for k, v in oblk.state_dict().items()}
+    gblk = MI355XHunyuanSingleBlock(dim=D, heads=2, device=dev)
+    gblk.load_diffusers_state_dict({k: v for k, v in sd.items() if "lora_" not in k})
+    gblk.add_adapter(r=64, lora_alpha=64.0)
+    with torch.no_grad():
+        for i, t in enumerate(("to_q", "to_k", "to_v")):
+            gblk.lora_A[i].copy_(sd[f"attn.{t}.lora_A.default.weight"])
+            gblk.lora_B[i].copy_(sd[f"attn.{t}.lora_B.default.weight"])
+
+    g = torch.Generator().manual_seed(B * 100 + S)
+    video = torch.randn(B, S, D, generator=g).to(bf16)
+    text = torch.randn(B, T, D, generator=g).to(bf16)
+    temb = torch.randn(B, D, generator=g).to(bf16)
+    dvid = torch.randn(B, S, D, generator=g).to(bf16)
+    dtxt = torch.randn(B, T, D, generator=g).to(bf16)
+    cos, sin = _rope(S, seed=3)
+    tmask = torch.ones(B, T, dtype=torch.long)
+    if masked:
+        tmask[0, T - 3:] = 0
+    amask = torch.cat([torch.ones(B, S, dtype=torch.bool), tmask.bool()], dim=1).view(B, 1, 1, S + T)
+
+    def run_oracle():
+        for p in oblk.parameters():
+            p.grad = None
+        vr, tr = video.clone().requires_grad_(True), text.clone().requires_grad_(True)
+        hv, ht = oblk(vr, tr, temb, amask if masked else None, (cos, sin))
+        torch.autograd.backward([hv, ht], [dvid, dtxt])
+        grads = {n: p.grad.detach().clone() for n, p in oblk.named_parameters() if p.grad is not None}
+        return hv.detach(), ht.detach(), vr.grad, tr.grad, grads
+
+    hv_ref, ht_ref, dv_ref, dt_ref, g_ref = run_oracle()
+    with ltx.accumulation_order_variant(128):
+        _, _, _, _, g_alt = run_oracle()
+    floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
+
+    tokens = torch.cat([text, video], 1).to(dev).requires_grad_(True)
+    out = gblk(tokens, temb.to(dev), T, (cos.to(dev), sin.to(dev)), text_mask=tmask if masked else None)
+    out.backward(torch.cat([dtxt, dvid], 1).to(dev))
+    torch.cuda.synchronize()
+    got = {}
+    for i, t in enumerate(("to_q", "to_k", "to_v")):
+        got[f"attn.{t}.lora_A.default.weight"] = gblk.lora_A.grad[i].cpu()
+        got[f"attn.{t}.lora_B.default.weight"] = gblk.lora_B.grad[i].cpu()
+    assert set(got) == set(g_ref)
+    glob, worst = ltx.grads_rel_l2(got, g_ref)
+    e_hv, e_ht = _rel(out[:, T:], hv_ref), _rel(out[:, :T], ht_ref)
+    e_dv, e_dt = _rel(tokens.grad[:, T:], dv_ref), _rel(tokens.grad[:, :T], dt_ref)
+    print(f"[hunyuan-single B={B} T={T} S={S} masked={masked}] out video {e_hv:.2e} text {e_ht:.2e} | dx video {e_dv:.2e} text {e_dt:.2e} | LoRA grads {glob:.2e} "
+          f"(worst {worst:.2e}); summation-order floor {floor:.2e} / {floor_worst:.2e}")
+    assert e_hv < 5e-3 and e_ht < 5e-3 and e_dv < 1e-2 and e_dt < 1e-2
+    # at this width (K = 256) the chunked-summation variant of the oracle barely reorders anything, so its floor (1e-4) is no yardstick: the residual is the
+    # attention's bf16 P / dS and tile order, as for CogVideoX -- bounds = the residuals measured on an MI355X (2.2e-3 / 5.0e-3) x 1.5 and the CogVideoX block's
+    assert glob < 4.8e-3 and worst < 8e-3
