@@ -1,1 +1,1 @@
-from .block import MI355XHunyuanSingleBlock  # noqa: F401
+from .block import MI355XHunyuanDualBlock, MI355XHunyuanSingleBlock  # noqa: F401

@@ -158,3 +158,190 @@ class MI355XHunyuanSingleBlock(nn.Module):
         temb_silu = torch.nn.functional.silu(temb.to(bf16)).contiguous()
         cos, sin = image_rotary_emb
         return _SingleBlockFunction.apply(self, tokens.contiguous(), temb_silu, key_bias, cos.contiguous(), sin.contiguous(), int(text_len), self.lora_A, self.lora_B)
+
+
+class _DualBlockFunction(torch.autograd.Function):
+    """One sample (the modulation, the attention and its mask are per sample anyway; the module loops over the batch).  The two streams stay in their own
+    buffers [T, D] / [S, D] as in the reference; only q, k, v are laid out as one joint [T + S] sequence (text first) for the attention."""
+
+    @staticmethod
+    def forward(ctx, blk: "MI355XHunyuanDualBlock", x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b):
+        S, D = x_v.shape
+        T = x_t.shape[0]
+        N, H, hd, s = T + S, blk.heads, 128, blk.lora_scale
+        A = lambda i: None if lora_a is None else lora_a[i]
+        Bm = lambda i: None if lora_b is None else lora_b[i]
+        rope = (rope_cos, rope_sin)
+
+        def modulation(w, b):  # AdaLayerNormZero: (shift, scale, gate) of the attention, then of the feed-forward, each [1, D]
+            m = ops.gemm_nt(temb_silu, w, b).view(1, 6, D)
+            return [m[:, i].contiguous() for i in (0, 2, 3, 5)] + [(1 + m[:, 1]).contiguous(), (1 + m[:, 4]).contiguous()]
+
+        sh_v, g_v, shm_v, gm_v, op_v, opm_v = modulation(blk.norm1_lin_w, blk.norm1_lin_b)
+        sh_t, g_t, shm_t, gm_t, op_t, opm_t = modulation(blk.norm1c_lin_w, blk.norm1c_lin_b)
+        n_v = ops.cog_ln_mod(x_v[None], blk.ones, blk.zeros, sh_v, op_v, 0, 1e-6)[0]
+        n_t = ops.cog_ln_mod(x_t[None], blk.ones, blk.zeros, sh_t, op_t, 0, 1e-6)[0]
+        qj, kj, vj = (torch.empty((N, D), dtype=bf16, device=x_v.device) for _ in range(3))
+        q_v, xa_q = ops.linear_lora_fwd(n_v, blk.wq, blk.bq, A(0), Bm(0), s)
+        k_v, xa_k = ops.linear_lora_fwd(n_v, blk.wk, blk.bk, A(1), Bm(1), s)
+        v_v, xa_v = ops.linear_lora_fwd(n_v, blk.wv, blk.bv, A(2), Bm(2), s)
+        ops.head_rms_rope(q_v, blk.norm_q_w, hd, 1e-6, rope=rope, rows_per_batch=S, rope_from=0, out=qj[T:])
+        ops.head_rms_rope(k_v, blk.norm_k_w, hd, 1e-6, rope=rope, rows_per_batch=S, rope_from=0, out=kj[T:])
+        vj[T:].copy_(v_v)
+        q_t = ops.gemm_nt(n_t, blk.add_q_w, blk.add_q_b)
+        k_t = ops.gemm_nt(n_t, blk.add_k_w, blk.add_k_b)
+        ops.gemm_nt(n_t, blk.add_v_w, blk.add_v_b, out=vj[:T])
+        ops.head_rms_rope(q_t, blk.norm_added_q_w, hd, 1e-6, out=qj[:T])
+        ops.head_rms_rope(k_t, blk.norm_added_k_w, hd, 1e-6, out=kj[:T])
+        heads = lambda t: t.view(1, N, H, hd).permute(0, 2, 1, 3)
+        o, lse = ops.attn_fwd(heads(qj), heads(kj), heads(vj), key_bias)
+        o2d = o.permute(0, 2, 1, 3).reshape(N, D)
+        a_v, xa_o = ops.linear_lora_fwd(o2d[T:], blk.wo, blk.bo, A(3), Bm(3), s)
+        a_t = ops.gemm_nt(o2d[:T], blk.add_out_w, blk.add_out_b)
+        h_v = ops.cog_gate_residual(x_v[None], a_v[None], g_v, 0)[0]
+        h_t = ops.cog_gate_residual(x_t[None], a_t[None], g_t, 0)[0]
+        n2_v = ops.cog_ln_mod(h_v[None], blk.ones, blk.zeros, shm_v, opm_v, 0, 1e-6)[0]
+        n2_t = ops.cog_ln_mod(h_t[None], blk.ones, blk.zeros, shm_t, opm_t, 0, 1e-6)[0]
+        act_v, pre_v = ops.gemm_nt(n2_v, blk.ff1_w, blk.ff1_b, epilogue=1, want_out2=True)
+        act_t, pre_t = ops.gemm_nt(n2_t, blk.ffc1_w, blk.ffc1_b, epilogue=1, want_out2=True)
+        out_v = ops.cog_gate_residual(h_v[None], ops.gemm_nt(act_v, blk.ff2_w, blk.ff2_b)[None], gm_v, 0)[0]
+        out_t = ops.cog_gate_residual(h_t[None], ops.gemm_nt(act_t, blk.ffc2_w, blk.ffc2_b)[None], gm_t, 0)[0]
+        ctx.blk, ctx.rope, ctx.key_bias, ctx.has_lora = blk, rope, key_bias, lora_a is not None
+        ctx.save_for_backward(x_v, x_t, n_v, n_t, q_v, k_v, q_t, k_t, qj, kj, vj, o, lse, h_v, h_t, n2_v, n2_t, pre_v, pre_t, g_v, g_t, gm_v, gm_t, op_v, op_t, opm_v,
+                              opm_t, xa_q, xa_k, xa_v, xa_o, lora_a if lora_a is not None else x_v.new_empty(0), lora_b if lora_b is not None else x_v.new_empty(0))
+        return out_v, out_t
+
+    @staticmethod
+    def backward(ctx, dout_v, dout_t):
+        blk, rope = ctx.blk, ctx.rope
+        (x_v, x_t, n_v, n_t, q_v, k_v, q_t, k_t, qj, kj, vj, o, lse, h_v, h_t, n2_v, n2_t, pre_v, pre_t, g_v, g_t, gm_v, gm_t, op_v, op_t, opm_v, opm_t,
+         xa_q, xa_k, xa_v, xa_o, lora_a, lora_b) = ctx.saved_tensors
+        if not ctx.has_lora:
+            lora_a = lora_b = None
+        S, D = x_v.shape
+        T = x_t.shape[0]
+        N, H, hd, s = T + S, blk.heads, 128, blk.lora_scale
+        A = lambda i: None if lora_a is None else lora_a[i]
+        Bm = lambda i: None if lora_b is None else lora_b[i]
+        ga = torch.zeros_like(lora_a) if lora_a is not None else None
+        gb = torch.zeros_like(lora_b) if lora_b is not None else None
+        GA = lambda i: None if ga is None else ga[i]
+        GB = lambda i: None if gb is None else gb[i]
+        dout_v, dout_t = dout_v.contiguous(), dout_t.contiguous()
+        ones = blk.ones_rows(1, x_v.device)
+        add = lambda a, b: ops.cog_gate_residual(a[None], b[None], ones, 0)[0]  # bf16 accumulation of two gradient tensors
+
+        def ff_bwd(dout, gm, pre, w2_t, w1_t, h, opm):  # out = h + gate * FF(LN(h) * (1 + scale) + shift)
+            df = ops.cog_gate_residual(None, dout[None], gm, 0)[0]
+            dn2 = ops.gemm_nt(ops.gemm_nt(df, w2_t, None, epilogue=3, aux=pre), w1_t, None)
+            return ops.cog_ln_mod_bwd(h[None], blk.ones, opm, dn2[None], 0, 1e-6, dres=dout[None])[0]
+
+        dh_v = ff_bwd(dout_v, gm_v, pre_v, blk.ff2_w_t, blk.ff1_w_t, h_v, opm_v)
+        dh_t = ff_bwd(dout_t, gm_t, pre_t, blk.ffc2_w_t, blk.ffc1_w_t, h_t, opm_t)
+        # attention outputs: h = x + gate_msa * (o W_o^T + b)
+        o2d = o.permute(0, 2, 1, 3).reshape(N, D)
+        doj = torch.empty((N, D), dtype=bf16, device=x_v.device)
+        da_v = ops.cog_gate_residual(None, dh_v[None], g_v, 0)[0]
+        do_v, _, _ = ops.linear_lora_bwd(o2d[T:], da_v, xa_o, blk.wo_t, A(3), Bm(3), s, GA(3), GB(3))
+        doj[T:].copy_(do_v)
+        ops.gemm_nt(ops.cog_gate_residual(None, dh_t[None], g_t, 0)[0], blk.add_out_w_t, None, out=doj[:T])
+        heads = lambda t: t.view(1, N, H, hd).permute(0, 2, 1, 3)
+        flat = lambda t: t.permute(0, 2, 1, 3).reshape(N, D)
+        dqj, dkj, dvj = (flat(t) for t in ops.attn_bwd(heads(qj), heads(kj), heads(vj), o, lse, heads(doj), ctx.key_bias))
+        # video stream: RMSNorm + rotary backward, the three LoRA projections
+        dq_v = ops.head_rms_rope_bwd(q_v, blk.norm_q_w, dqj[T:], hd, 1e-6, rope=rope, rows_per_batch=S, rope_from=0)
+        dk_v = ops.head_rms_rope_bwd(k_v, blk.norm_k_w, dkj[T:], hd, 1e-6, rope=rope, rows_per_batch=S, rope_from=0)
+        dn_q, _, _ = ops.linear_lora_bwd(n_v, dq_v, xa_q, blk.wq_t, A(0), Bm(0), s, GA(0), GB(0))
+        dn_k, _, _ = ops.linear_lora_bwd(n_v, dk_v, xa_k, blk.wk_t, A(1), Bm(1), s, GA(1), GB(1))
+        dn_vv, _, _ = ops.linear_lora_bwd(n_v, dvj[T:], xa_v, blk.wv_t, A(2), Bm(2), s, GA(2), GB(2))
+        dn_v = add(add(dn_vv, dn_k), dn_q)
+        dx_v = ops.cog_ln_mod_bwd(x_v[None], blk.ones, op_v, dn_v[None], 0, 1e-6, dres=dh_v[None])[0]
+        # text stream
+        dq_t = ops.head_rms_rope_bwd(q_t, blk.norm_added_q_w, dqj[:T], hd, 1e-6)
+        dk_t = ops.head_rms_rope_bwd(k_t, blk.norm_added_k_w, dkj[:T], hd, 1e-6)
+        dn_t = add(add(ops.gemm_nt(dvj[:T], blk.add_v_w_t, None), ops.gemm_nt(dk_t, blk.add_k_w_t, None)), ops.gemm_nt(dq_t, blk.add_q_w_t, None))
+        dx_t = ops.cog_ln_mod_bwd(x_t[None], blk.ones, op_t, dn_t[None], 0, 1e-6, dres=dh_t[None])[0]
+        return None, dx_v, dx_t, None, None, None, None, ga, gb
+
+
+class MI355XHunyuanDualBlock(nn.Module):
+    """HunyuanVideo dual-stream block (20 of the 60 blocks; [upstream] ``HunyuanVideoTransformerBlock``, oracle/hunyuan.py ``DualStreamBlock``): the video and
+    the text tokens have their own modulation, projections, q / k norms and feed-forward and meet in ONE joint attention.  LoRA on the video stream's to_q /
+    to_k / to_v / to_out.0 (what the default target regex matches; the text stream's ``add_*_proj`` / ``to_add_out`` stay frozen)."""
+
+    _KEYS = {
+        "norm1.linear.weight": "norm1_lin_w", "norm1.linear.bias": "norm1_lin_b", "norm1_context.linear.weight": "norm1c_lin_w", "norm1_context.linear.bias": "norm1c_lin_b",
+        "attn.to_q.weight": "wq", "attn.to_q.bias": "bq", "attn.to_k.weight": "wk", "attn.to_k.bias": "bk", "attn.to_v.weight": "wv", "attn.to_v.bias": "bv",
+        "attn.to_out.0.weight": "wo", "attn.to_out.0.bias": "bo", "attn.norm_q.weight": "norm_q_w", "attn.norm_k.weight": "norm_k_w",
+        "attn.add_q_proj.weight": "add_q_w", "attn.add_q_proj.bias": "add_q_b", "attn.add_k_proj.weight": "add_k_w", "attn.add_k_proj.bias": "add_k_b",
+        "attn.add_v_proj.weight": "add_v_w", "attn.add_v_proj.bias": "add_v_b", "attn.to_add_out.weight": "add_out_w", "attn.to_add_out.bias": "add_out_b",
+        "attn.norm_added_q.weight": "norm_added_q_w", "attn.norm_added_k.weight": "norm_added_k_w",
+        "ff.net.0.proj.weight": "ff1_w", "ff.net.0.proj.bias": "ff1_b", "ff.net.2.weight": "ff2_w", "ff.net.2.bias": "ff2_b",
+        "ff_context.net.0.proj.weight": "ffc1_w", "ff_context.net.0.proj.bias": "ffc1_b", "ff_context.net.2.weight": "ffc2_w", "ff_context.net.2.bias": "ffc2_b",
+    }
+    _TRANSPOSED = ("wq", "wk", "wv", "wo", "add_q_w", "add_k_w", "add_v_w", "add_out_w", "ff1_w", "ff2_w", "ffc1_w", "ffc2_w")
+
+    def __init__(self, dim: int = 3072, heads: int = 24, mlp_ratio: float = 4.0, device: Optional[torch.device] = None):
+        super().__init__()
+        if dim != heads * 128:
+            raise ValueError("HunyuanVideo blocks have heads of 128 channels")
+        self.dim, self.heads = dim, heads
+        mlp = int(dim * mlp_ratio)
+        dev = device or torch.device("cuda", 0)
+        shapes = {"norm1_lin_w": (6 * dim, dim), "norm1_lin_b": (6 * dim,), "norm1c_lin_w": (6 * dim, dim), "norm1c_lin_b": (6 * dim,),
+                  "ff1_w": (mlp, dim), "ff1_b": (mlp,), "ff2_w": (dim, mlp), "ff2_b": (dim,), "ffc1_w": (mlp, dim), "ffc1_b": (mlp,), "ffc2_w": (dim, mlp), "ffc2_b": (dim,)}
+        for name in self._KEYS.values():
+            is_weight = name in ("wq", "wk", "wv", "wo") or name.endswith("_w")
+            shape = shapes.get(name) or ((128,) if name.startswith("norm_") else ((dim, dim) if is_weight else (dim,)))
+            self.register_buffer(name, torch.zeros(shape, dtype=bf16, device=dev))
+        for name in self._TRANSPOSED:
+            self.register_buffer(name + "_t", None, persistent=False)
+        self.register_buffer("ones", torch.ones(dim, dtype=bf16, device=dev), persistent=False)
+        self.register_buffer("zeros", torch.zeros(dim, dtype=bf16, device=dev), persistent=False)
+        self.lora_A: Optional[nn.Parameter] = None  # [4, r, D]: to_q, to_k, to_v, to_out.0
+        self.lora_B: Optional[nn.Parameter] = None  # [4, D, r]
+        self.lora_scale = 0.0
+        self._ones_rows: Dict[int, torch.Tensor] = {}
+
+    ones_rows = MI355XHunyuanSingleBlock.ones_rows
+
+    @torch.no_grad()
+    def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        sd = {k.replace(".base_layer.", "."): v for k, v in sd.items()}
+        missing = [k for k in self._KEYS if k not in sd]
+        if missing:
+            raise KeyError(f"HunyuanVideo dual-stream block state dict lacks {missing[:4]}")
+        for k, name in self._KEYS.items():
+            getattr(self, name).copy_(sd[k].to(bf16))
+        for name in self._TRANSPOSED:
+            setattr(self, name + "_t", ops.transpose_bf16(getattr(self, name)))
+
+    def add_adapter(self, r: int = 64, lora_alpha: float = 64.0) -> None:
+        if r % 64 != 0:
+            raise ValueError("ranks that are multiples of 64 (the LTX model shows the zero-padding route for the others)")
+        dev, D = self.wq.device, self.dim
+        a = torch.empty(4, r, D, dtype=torch.float32, device=dev).uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)
+        self.lora_A, self.lora_B = nn.Parameter(a), nn.Parameter(torch.zeros(4, D, r, dtype=torch.float32, device=dev))
+        self.lora_scale = float(lora_alpha) / r
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor, image_rotary_emb,
+                text_mask: Optional[torch.Tensor] = None):
+        """``hidden_states`` [B, S, D] (video), ``encoder_hidden_states`` [B, T, D] (text), ``temb`` [B, D], ``image_rotary_emb`` = (cos, sin) fp32 [S, 128],
+        ``text_mask`` [B, T] (1 = real token) -> (video, text) like the reference block."""
+        if self.wq_t is None:
+            raise RuntimeError("load_diffusers_state_dict first (it also builds the transposed weights the input-gradient GEMMs use)")
+        B, S, _ = hidden_states.shape
+        T = encoder_hidden_states.shape[1]
+        cos, sin = (t.contiguous() for t in image_rotary_emb)
+        temb_silu = torch.nn.functional.silu(temb.to(bf16)).contiguous()
+        outs_v, outs_t = [], []
+        for b in range(B):
+            key_bias = None
+            if text_mask is not None:
+                key_bias = torch.zeros((1, T + S), dtype=torch.float32, device=hidden_states.device)
+                key_bias[0, :T].masked_fill_(~text_mask[b].to(hidden_states.device).bool(), float("-inf"))
+            ov, ot = _DualBlockFunction.apply(self, hidden_states[b].contiguous(), encoder_hidden_states[b].contiguous(), temb_silu[b:b + 1], key_bias, cos, sin,
+                                              self.lora_A, self.lora_B)
+            outs_v.append(ov)
+            outs_t.append(ot)
+        return torch.stack(outs_v), torch.stack(outs_t)

@@ -135,3 +135,75 @@ def test_single_stream_block_forward_backward_parity(B, T, S, masked):
     # at this width (K = 256) the chunked-summation variant of the oracle barely reorders anything, so its floor (1e-4) is no yardstick: the residual is the
     # attention's bf16 P / dS and tile order, as for CogVideoX -- bounds = the residuals measured on an MI355X (2.2e-3 / 5.0e-3) x 1.5 and the CogVideoX block's
     assert glob < 4.8e-3 and worst < 8e-3
+
+
+@pytest.mark.parametrize("B,T,S,masked", [(2, 8, 40, True), (1, 16, 150, False)])
+def test_dual_stream_block_forward_backward_parity(B, T, S, masked):
+    """One dual-stream block (heads of 128; LoRA r = 64 on the video stream's to_q / to_k / to_v / to_out.0, the text stream's add_*_proj frozen): both
+    output streams, both input gradients and the 8 LoRA gradients against the oracle block."""
+    from finetrainers_amd.hunyuan_video import MI355XHunyuanDualBlock
+    from oracle import hunyuan as hy
+    from oracle import ltx
+
+    dev = _dev()
+    cfg = hy.HunyuanVideoConfig(num_attention_heads=2, attention_head_dim=128, num_layers=1, num_single_layers=0, num_refiner_layers=1, text_embed_dim=64,
+                                pooled_projection_dim=32)
+    D = cfg.inner_dim
+    torch.manual_seed(0)
+    oblk = hy.DualStreamBlock(cfg)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            getattr(oblk.attn, n).weight.copy_(1 + 0.1 * torch.randn(128, generator=g))
+    oblk = oblk.to(bf16)
+    for p in oblk.parameters():
+        p.requires_grad_(False)
+    targets = ("to_q", "to_k", "to_v", "to_out.0")
+    for t in targets[:3]:
+        setattr(oblk.attn, t, ltx.LoraLinear(getattr(oblk.attn, t), 64, 64.0))
+    oblk.attn.to_out[0] = ltx.LoraLinear(oblk.attn.to_out[0], 64, 64.0)
+    with torch.no_grad():
+        for n, p in oblk.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0, 0.02, generator=g)
+    sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2.").replace("ff_context.proj_in.", "ff_context.net.0.proj.")
+          .replace("ff_context.proj_out.", "ff_context.net.2."): v for k, v in oblk.state_dict().items()}
+    gblk = MI355XHunyuanDualBlock(dim=D, heads=2, device=dev)
+    gblk.load_diffusers_state_dict({k: v for k, v in sd.items() if "lora_" not in k})
+    gblk.add_adapter(r=64, lora_alpha=64.0)
+    with torch.no_grad():
+        for i, t in enumerate(targets):
+            gblk.lora_A[i].copy_(sd[f"attn.{t}.lora_A.default.weight"])
+            gblk.lora_B[i].copy_(sd[f"attn.{t}.lora_B.default.weight"])
+
+    g = torch.Generator().manual_seed(B * 100 + S + 1)
+    video = torch.randn(B, S, D, generator=g).to(bf16)
+    text = torch.randn(B, T, D, generator=g).to(bf16)
+    temb = torch.randn(B, D, generator=g).to(bf16)
+    dvid = torch.randn(B, S, D, generator=g).to(bf16)
+    dtxt = torch.randn(B, T, D, generator=g).to(bf16)
+    cos, sin = _rope(S, seed=5)
+    tmask = torch.ones(B, T, dtype=torch.long)
+    if masked:
+        tmask[0, T - 3:] = 0
+    amask = torch.cat([torch.ones(B, S, dtype=torch.bool), tmask.bool()], dim=1).view(B, 1, 1, S + T)
+    vr, tr = video.clone().requires_grad_(True), text.clone().requires_grad_(True)
+    hv_ref, ht_ref = oblk(vr, tr, temb, amask if masked else None, (cos, sin))
+    torch.autograd.backward([hv_ref, ht_ref], [dvid, dtxt])
+    g_ref = {n: p.grad.detach().clone() for n, p in oblk.named_parameters() if p.grad is not None}
+
+    vg, tg = video.to(dev).requires_grad_(True), text.to(dev).requires_grad_(True)
+    ov, ot = gblk(vg, tg, temb.to(dev), (cos.to(dev), sin.to(dev)), text_mask=tmask if masked else None)
+    torch.autograd.backward([ov, ot], [dvid.to(dev), dtxt.to(dev)])
+    torch.cuda.synchronize()
+    got = {}
+    for i, t in enumerate(targets):
+        got[f"attn.{t}.lora_A.default.weight"] = gblk.lora_A.grad[i].cpu()
+        got[f"attn.{t}.lora_B.default.weight"] = gblk.lora_B.grad[i].cpu()
+    assert set(got) == set(g_ref)
+    glob, worst = ltx.grads_rel_l2(got, g_ref)
+    e_hv, e_ht, e_dv, e_dt = _rel(ov, hv_ref.detach()), _rel(ot, ht_ref.detach()), _rel(vg.grad, vr.grad), _rel(tg.grad, tr.grad)
+    print(f"[hunyuan-dual B={B} T={T} S={S} masked={masked}] out video {e_hv:.2e} text {e_ht:.2e} | dx video {e_dv:.2e} text {e_dt:.2e} | LoRA grads {glob:.2e} "
+          f"(worst {worst:.2e})")
+    assert e_hv < 5e-3 and e_ht < 5e-3 and e_dv < 1e-2 and e_dt < 1e-2
+    assert glob < 4.8e-3 and worst < 8e-3  # the CogVideoX block's bounds (same kernels, same noise sources)
