@@ -207,3 +207,104 @@ def test_dual_stream_block_forward_backward_parity(B, T, S, masked):
           f"(worst {worst:.2e})")
     assert e_hv < 5e-3 and e_ht < 5e-3 and e_dv < 1e-2 and e_dt < 1e-2
     assert glob < 4.8e-3 and worst < 8e-3  # the CogVideoX block's bounds (same kernels, same noise sources)
+
+
+def _to_diffusers_key(k):
+    """oracle/hunyuan.py module names -> diffusers HunyuanVideoTransformer3DModel parameter names."""
+    k = k.replace("context_embedder.refiner_blocks.", "context_embedder.token_refiner.refiner_blocks.").replace(".norm_out_linear.", ".norm_out.linear.")
+    if k.startswith("norm_out_linear."):
+        k = "norm_out.linear." + k[len("norm_out_linear."):]
+    if k.startswith("x_embedder."):
+        k = "x_embedder.proj." + k[len("x_embedder."):]
+    for a in ("ff_context", "ff"):
+        k = k.replace(f"{a}.proj_in.", f"{a}.net.0.proj.").replace(f"{a}.proj_out.", f"{a}.net.2.")
+    return k
+
+
+def test_model_and_step_parity_small():
+    """The whole HunyuanVideo LoRA SFT forward + backward at 2 dual-stream + 2 single-stream blocks (heads of 128): spec ops (posterior draw, scaling factor,
+    flow-match mix, guidance), patch embedding, condition embedding, masked token refiner, blocks, output norm + projection, un-patchify, loss, and the
+    gradient of every one of the 28 LoRA tensors against oracle/hunyuan.py; then the fused step (grad-norm against the oracle, parameters move)."""
+    import math
+
+    from finetrainers_amd.hunyuan_video import HunyuanVideoTransformerConfig, MI355XHunyuanVideoSFTStep, MI355XHunyuanVideoSpecOps, MI355XHunyuanVideoTransformer3DModel
+    from oracle import hunyuan as hy
+    from oracle import ltx
+
+    dev = _dev()
+    kw = dict(num_attention_heads=2, attention_head_dim=128, num_layers=2, num_single_layers=2, num_refiner_layers=1, text_embed_dim=64, pooled_projection_dim=64)
+    omodel = hy.build_model(hy.HunyuanVideoConfig(**kw), seed=0, dtype=torch.float32)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, p in omodel.named_parameters():
+            if "norm" in n and n.endswith("weight") and p.dim() == 1:
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+    omodel = omodel.to(bf16)
+    for p in omodel.parameters():
+        p.requires_grad_(False)
+    for blk in omodel.transformer_blocks:
+        for t in ("to_q", "to_k", "to_v"):
+            setattr(blk.attn, t, ltx.LoraLinear(getattr(blk.attn, t), 64, 64.0))
+        blk.attn.to_out[0] = ltx.LoraLinear(blk.attn.to_out[0], 64, 64.0)
+    for blk in omodel.single_transformer_blocks:
+        for t in ("to_q", "to_k", "to_v"):
+            setattr(blk.attn, t, ltx.LoraLinear(getattr(blk.attn, t), 64, 64.0))
+    with torch.no_grad():
+        for n, p in omodel.named_parameters():
+            if "lora_B" in n:
+                p.normal_(0, 0.02, generator=g)
+    sd = {_to_diffusers_key(k): v for k, v in omodel.state_dict().items()}
+    gmodel = MI355XHunyuanVideoTransformer3DModel(HunyuanVideoTransformerConfig(**kw), device=dev)
+    gmodel.load_diffusers_state_dict(sd)
+    gmodel.add_adapter(r=64, lora_alpha=64.0)
+    gmodel.load_lora_state_dict({k: v for k, v in sd.items() if "lora_" in k})
+
+    g = torch.Generator().manual_seed(11)
+    B, C, F_, H, W, T = 2, 16, 2, 8, 12, 8
+    moments = torch.randn(B, 2 * C, F_, H, W, generator=g).to(bf16)
+    moments[:, C:] = (moments[:, C:].float() * 0.3 - 2.0).to(bf16)
+    eps = torch.randn(B, C, F_, H, W, generator=g).to(bf16)
+    noise = torch.randn(B, C, F_, H, W, generator=g).to(bf16)
+    cond = {"encoder_hidden_states": torch.randn(B, T, 64, generator=g).to(bf16), "encoder_attention_mask": torch.tensor([[1, 1, 1, 1, 1, 0, 0, 0], [1] * 8]),
+            "pooled_projections": torch.randn(B, 64, generator=g).to(bf16)}
+    sig = torch.tensor([0.23, 0.81])
+    pred_ref, target_ref, _ = hy.spec_forward(omodel, moments, cond, sig.view(-1, 1, 1, 1, 1), noise, guidance=6.0, compute_posterior=False, posterior_noise=eps)
+    lref = (pred_ref.float() - target_ref.float()).pow(2)
+    loss_ref = lref.mean(list(range(1, lref.ndim))).mean()
+    loss_ref.backward()
+    g_ref = {_to_diffusers_key(n).replace(".default.", "."): p.grad.detach().clone() for n, p in omodel.named_parameters() if p.grad is not None}
+    gn_ref = math.sqrt(sum(float(v.double().pow(2).sum()) for v in g_ref.values()))
+    for p_ in omodel.parameters():
+        p_.grad = None
+    with ltx.accumulation_order_variant(128):  # the oracle's own summation-order floor on the same inputs (frozen Linears summed in 128-wide partials)
+        pa, ta, _ = hy.spec_forward(omodel, moments, cond, sig.view(-1, 1, 1, 1, 1), noise, guidance=6.0, compute_posterior=False, posterior_noise=eps)
+        la = (pa.float() - ta.float()).pow(2)
+        la.mean(list(range(1, la.ndim))).mean().backward()
+    g_alt = {_to_diffusers_key(n).replace(".default.", "."): p.grad.detach().clone() for n, p in omodel.named_parameters() if p.grad is not None}
+    floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
+
+    spec = MI355XHunyuanVideoSpecOps()
+    gcond = {k: v.to(dev) for k, v in cond.items()}
+    pred, target, _ = spec.forward(gmodel, moments.to(dev), dict(gcond), sig.to(dev), guidance=6.0, compute_posterior=False, posterior_noise=eps.to(dev), noise=noise.to(dev))
+    loss = spec.loss_backward(pred, target)
+    torch.cuda.synchronize()
+    got = {k: v.cpu() for k, v in gmodel.lora_grad_state_dict().items()}
+    assert set(got) == set(g_ref) and len(got) == 2 * (2 * 4 + 2 * 3)
+    glob, worst = ltx.grads_rel_l2(got, g_ref)
+    e_pred, e_loss = _rel(pred, pred_ref.detach()), abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    print(f"[hunyuan-model 2+2 blocks] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref.item():.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
+          f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
+    assert torch.equal(target.cpu(), target_ref) and e_pred < 1e-2 and e_loss < 1e-3
+    assert glob < max(2.5 * floor, 9e-3) and worst < max(2.5 * floor_worst, 1.3e-2)  # measured on an MI355X: 6.2e-3 / 8.7e-3
+
+    for p in gmodel.lora_parameters():
+        p.grad = None
+    step = MI355XHunyuanVideoSFTStep(gmodel, spec, lr=1e-3, betas=(0.9, 0.99), guidance=6.0)
+    before = step.flat.clone()
+    out = step.step(moments.to(dev), gcond, sig.to(dev), compute_posterior=False, posterior_noise=eps.to(dev), noise=noise.to(dev))
+    torch.cuda.synchronize()
+    print(f"[hunyuan-step] loss {out['loss'].item():.6f} grad_norm {out['grad_norm'].item():.5e} vs oracle {gn_ref:.5e}")
+    assert abs(out["loss"].item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item()) and abs(out["grad_norm"].item() - gn_ref) < 5e-3 * gn_ref
+    assert not torch.equal(step.flat, before) and gmodel.transformer_blocks[0].lora_A.grad is None
+    assert gmodel.single_transformer_blocks[1].lora_B.data_ptr() >= step.flat.data_ptr()  # the adapters live in the step's flat buffer
+    assert gmodel.apply_layerwise_casting() == 2 * 24 + 2 * 10  # Linear weights + biases of the blocks (norm / modulation layers skipped)
