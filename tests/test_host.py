@@ -575,3 +575,36 @@ def test_wan_host_tables_layouts_and_spec_ops_match_oracle():
     spec = MI355XWanSpecOps()
     assert spec._resolution_dim_keys == {"latents": (2, 3, 4)}
     assert torch.equal(spec.normalize_latents(mom[:, :16], mean, std), wan.normalize_latents(mom[:, :16], mean, std))
+
+
+def test_hunyuan_host_tables_and_key_maps_match_oracle():
+    """HunyuanVideo host-side pieces (no kernels): the 3-axis rotary table bit-identical to the oracle's, and the frozen-front / block parameter names and
+    shapes equal to the oracle model's (translated to the diffusers names) -- what ``load_diffusers_state_dict`` will ask a checkpoint for."""
+    from finetrainers_amd.hunyuan_video.block import MI355XHunyuanDualBlock, MI355XHunyuanSingleBlock
+    from finetrainers_amd.hunyuan_video.model import HunyuanVideoTransformerConfig, _front_keys, rotary_tables
+    from oracle import hunyuan as hy
+
+    cfg, ocfg = HunyuanVideoTransformerConfig(), hy.HunyuanVideoConfig()
+    for (f, h, w) in ((16, 68, 120), (3, 8, 12)):
+        a, b = rotary_tables(cfg, f, h, w), hy.rotary_tables(ocfg, f, h, w)
+        assert a[0].shape == (f * (h // 2) * (w // 2), 128) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    def to_diffusers(k):
+        k = k.replace("context_embedder.refiner_blocks.", "context_embedder.token_refiner.refiner_blocks.").replace(".norm_out_linear.", ".norm_out.linear.")
+        if k.startswith("norm_out_linear."):
+            k = "norm_out.linear." + k[len("norm_out_linear."):]
+        if k.startswith("x_embedder."):
+            k = "x_embedder.proj." + k[len("x_embedder."):]
+        for a_ in ("ff_context", "ff"):
+            k = k.replace(f"{a_}.proj_in.", f"{a_}.net.0.proj.").replace(f"{a_}.proj_out.", f"{a_}.net.2.")
+        return k
+
+    kw = dict(num_attention_heads=2, attention_head_dim=128, num_layers=1, num_single_layers=1, num_refiner_layers=2, text_embed_dim=64, pooled_projection_dim=64)
+    sd = {to_diffusers(k): tuple(v.shape) for k, v in hy.HunyuanVideoTransformer3DModel(hy.HunyuanVideoConfig(**kw)).state_dict().items()}
+    front = {k: v for k, v in sd.items() if not k.startswith(("transformer_blocks", "single_transformer_blocks"))}
+    front["x_embedder.proj.weight"] = (256, 64)  # the Conv3d weight in its GEMM shape
+    assert front == dict(_front_keys(HunyuanVideoTransformerConfig(**kw)))
+    dev = torch.device("cpu")
+    for prefix, blk in (("transformer_blocks.0.", MI355XHunyuanDualBlock(256, 2, device=dev)), ("single_transformer_blocks.0.", MI355XHunyuanSingleBlock(256, 2, device=dev))):
+        want = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        assert want == {k: tuple(getattr(blk, n).shape) for k, n in blk._KEYS.items()}
