@@ -13,7 +13,6 @@ their outputs are not part of the prediction), so neither the loss nor any gradi
 
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 

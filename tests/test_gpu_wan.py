@@ -352,7 +352,6 @@ def _wan_two_rank_worker(rank, port, q):
     import os
 
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import numpy as np
     import torch
 
     from finetrainers_amd.parallel import DataParallelBackend
