@@ -225,7 +225,7 @@ int ftmi_attn_bwd(const ftmi_attn_desc* desc, const void* q, const void* k, cons
 }
 
 int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha, void* out, long ldo,
-                 int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch, const void* aux, int variant,
+                 int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch, const void* aux, long ld_side, int variant,
                  ftmi_stream stream) {
     if (!x || !w || !out) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_nt: null tensor");
     if (epilogue < 0 || epilogue > 3) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_nt: bad epilogue");
@@ -234,9 +234,11 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
     GemmNtArgs a;
     a.X = (const bf16_t*)x; a.ldx = ldx; a.W = (const bf16_t*)w; a.ldw = ldw; a.M = M; a.N = N; a.K = K;
     a.bias = (const bf16_t*)bias; a.alpha = alpha; a.out = (bf16_t*)out; a.ldo = ldo; a.epi = epilogue;
-    a.out2 = (bf16_t*)out2; a.ldo2 = ldo; a.resid = (const bf16_t*)resid; a.ldr = ldo;
+    if (ld_side < 0 || (ld_side % 8) || (ld_side > 0 && ld_side < N)) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_nt: bad side stride");
+    const long lds = ld_side > 0 ? ld_side : ldo;  // row stride of out2 / resid / aux
+    a.out2 = (bf16_t*)out2; a.ldo2 = lds; a.resid = (const bf16_t*)resid; a.ldr = lds;
     a.gate = (const bf16_t*)gate; a.gate_bstride = N; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
-    a.aux = (const bf16_t*)aux; a.ldaux = ldo; a.variant = variant;
+    a.aux = (const bf16_t*)aux; a.ldaux = lds; a.variant = variant;
     return gemm_nt(a, (hipStream_t)stream);
 }
 

@@ -71,8 +71,7 @@ class _SingleBlockFunction(torch.autograd.Function):
         dy = ops.cog_gate_residual(None, dout, gate, 0).view(M, D)  # d proj_out output = gate * d out
         wt = blk.proj_out_w_t  # [D + mlp, D]
         do = ops.gemm_nt(dy, wt[:D], None)                             # gradient of the attention features
-        dpre = torch.empty_like(cat)[:, D:]                             # same row stride as pre (a view like the forward's MLP features)
-        ops.gemm_nt(dy, wt[D:], None, epilogue=3, aux=pre, out=dpre)   # (gradient of the MLP features) * gelu'(pre)
+        dpre = ops.gemm_nt(dy, wt[D:], None, epilogue=3, aux=pre)      # (gradient of the MLP features) * gelu'(pre)
         dn_mlp = ops.gemm_nt(dpre, blk.proj_mlp_w_t, None)
         heads = lambda t: t.view(B, N, H, hd).permute(0, 2, 1, 3)
         flat = lambda t: t.permute(0, 2, 1, 3).reshape(M, D)

@@ -92,14 +92,15 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         out = torch.empty((M, N), dtype=bf16, device=x.device)
     elif out.shape != (M, N) or out.dtype != bf16 or out.stride(1) != 1:
         raise ValueError("gemm_nt: out must be an [M, N] bf16 view with contiguous columns")
-    ldo = out.stride(0)
-    # the C entry point moves out2 / resid / aux with out's row stride (include/ftmi355.h): give the pre-activation the same stride, refuse the others
-    out2 = (torch.empty((M, N), dtype=bf16, device=x.device) if ldo == N else torch.empty((M, ldo), dtype=bf16, device=x.device)[:, :N]) if want_out2 else None
-    for name, t in (("aux", aux), ("resid", resid)):
-        if t is not None and (t.shape != (M, N) or t.stride(1) != 1 or t.stride(0) != ldo):
-            raise ValueError(f"gemm_nt: {name} must be an [M, N] bf16 view with the row stride of out ({ldo})")
+    # out2 (allocated here, contiguous) / resid / aux share ONE row stride, which need not be out's (include/ftmi355.h: ld_side)
+    out2 = torch.empty((M, N), dtype=bf16, device=x.device) if want_out2 else None
+    side = [t for t in (out2, resid, aux) if t is not None]
+    for t in side:
+        if t.shape != (M, N) or t.stride(1) != 1 or t.stride(0) != side[0].stride(0):
+            raise ValueError("gemm_nt: out2 / resid / aux must be [M, N] bf16 views with contiguous columns and one common row stride")
+    ld_side = side[0].stride(0) if side else 0
     check(_lib.load().ftmi_gemm_nt(M, N, K, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), float(alpha), ptr(out), out.stride(0), epilogue,
-                                    ptr(out2), ptr(resid), ptr(gate), rows_per_batch, ptr(aux), variant, stream_ptr()), "ftmi_gemm_nt")
+                                    ptr(out2), ptr(resid), ptr(gate), rows_per_batch, ptr(aux), ld_side, variant, stream_ptr()), "ftmi_gemm_nt")
     return (out, out2) if want_out2 else out
 
 

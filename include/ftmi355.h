@@ -105,12 +105,12 @@ int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const voi
 
 /* Generic building blocks (exposed for tests / incremental adoption) */
 /* out[M,N] = bf16(alpha * x[M,K] w[N,K]^T + bias) ; epilogue: 0 store, 1 gelu-tanh (out2 <- pre-activation),
- * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux).  out2, resid and aux are [M, N] views with out's row stride ldo.
+ * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux).  out2, resid and aux are [M, N] views with row stride ld_side (0: out's ldo).
  * variant: 8 = automatic tile / K-loop choice (use this);
  * other ids pin one kernel (bit-identical A/B partners, see gemm.hip) */
 int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha,
                  void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
-                 const void* aux, int variant, ftmi_stream stream);
+                 const void* aux, long ld_side, int variant, ftmi_stream stream);
 /* c[P,Q] (fp32) += scale * u[M,P]^T v[M,Q] */
 int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, long ldv, float* c, long ldc, float scale,
                  ftmi_stream stream);

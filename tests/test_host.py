@@ -54,7 +54,7 @@ def test_c_abi_error_reporting(lib):
     with pytest.raises(ValueError):
         _lib.check(rc, "ftmi_ltx_workspace_offset")
     # NULL tensors are rejected before any launch
-    rc = lib.ftmi_gemm_nt(128, 128, 64, None, 64, None, 64, None, 1.0, None, 128, 0, None, None, None, 0, None, 0, None)
+    rc = lib.ftmi_gemm_nt(128, 128, 64, None, 64, None, 64, None, 1.0, None, 128, 0, None, None, None, 0, None, 0, 0, None)
     assert rc == _lib.FTMI_ERR_INVALID
     desc = _lib.AttnDesc(B=1, H=1, Sq=64, Sk=64, d=32, scale=0.1)
     rc = lib.ftmi_attn_fwd(ctypes.byref(desc), None, None, None, None, None, None, None)
