@@ -52,3 +52,93 @@ class MI355XHunyuanVideoSpecOps:
         loss, dpred = ops.mse_loss(pred.detach().contiguous(), target.contiguous(), None, want_grad=True, grad_scale=grad_scale)
         pred.backward(dpred)
         return loss.reshape(()) * grad_scale
+
+
+class MI355XHunyuanVideoModelSpecification(MI355XHunyuanVideoSpecOps):
+    """Mirror of ``HunyuanVideoModelSpecification`` (finetrainers/models/hunyuan_video/base_specification.py:100-420) for the SFT hot path: same constructor
+    keywords, ``_resolution_dim_keys``, ``load_diffusion_models``, ``collate_*``, ``forward`` with the reference's signature, ``_save_lora_weights``.
+    Text encoders (Llama + CLIP), VAE, pipeline and validation stay with the reference."""
+
+    def __init__(self, pretrained_model_name_or_path: Optional[str] = "hunyuanvideo-community/HunyuanVideo", tokenizer_id: Optional[str] = None,
+                 text_encoder_id: Optional[str] = None, transformer_id: Optional[str] = None, vae_id: Optional[str] = None,
+                 text_encoder_dtype: torch.dtype = torch.bfloat16, transformer_dtype: torch.dtype = torch.bfloat16, vae_dtype: torch.dtype = torch.bfloat16,
+                 revision: Optional[str] = None, cache_dir: Optional[str] = None, condition_model_processors: Optional[list] = None,
+                 latent_model_processors: Optional[list] = None, transformer_config=None, vae_scaling_factor: float = 0.476986, **kwargs) -> None:
+        if transformer_dtype != torch.bfloat16:
+            raise ValueError("the MI355X backend computes in bf16 (fp32 accumulation); transformer_dtype must be torch.bfloat16 "
+                             "(fp8 storage = --layerwise_upcasting_modules transformer -> transformer.apply_layerwise_casting())")
+        super().__init__(scaling_factor=vae_scaling_factor)
+        self.pretrained_model_name_or_path = pretrained_model_name_or_path
+        self.tokenizer_id, self.text_encoder_id, self.transformer_id, self.vae_id = tokenizer_id, text_encoder_id, transformer_id, vae_id
+        self.text_encoder_dtype, self.transformer_dtype, self.vae_dtype = text_encoder_dtype, transformer_dtype, vae_dtype
+        self.revision, self.cache_dir = revision, cache_dir
+        self.condition_model_processors = condition_model_processors or []
+        self.latent_model_processors = latent_model_processors or []
+        self.transformer_config = transformer_config
+
+    def load_diffusion_models(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, device: Optional[torch.device] = None) -> Dict[str, object]:
+        """-> {"transformer", "scheduler"} (base_specification.py:191-210).  With no ``state_dict`` the frozen weights come from ``transformer_id`` or
+        ``<pretrained_model_name_or_path>/transformer`` (a local diffusers directory); a path that does not resolve RAISES -- never random weights."""
+        from .. import wire
+        from ..ltx_video.specification import FlowMatchSigmas
+        from .model import HunyuanVideoTransformerConfig, MI355XHunyuanVideoTransformer3DModel
+
+        cfg = self.transformer_config
+        if state_dict is None:
+            directory = wire.resolve_transformer_dir(self.pretrained_model_name_or_path, self.transformer_id)
+            disk = wire.load_transformer_config(directory)
+            if disk:
+                cfg = HunyuanVideoTransformerConfig.from_dict(disk)
+            state_dict = wire.load_transformer_state_dict(directory)
+        cfg = cfg or HunyuanVideoTransformerConfig()
+        self.transformer_config = cfg
+        transformer = MI355XHunyuanVideoTransformer3DModel(cfg, device=device)
+        transformer.load_diffusers_state_dict(state_dict)
+        return {"transformer": transformer, "scheduler": FlowMatchSigmas()}
+
+    @staticmethod
+    def _collate(data):
+        out = {}
+        for k in data[0]:
+            vals = [d[k] for d in data]
+            out[k] = torch.cat(vals) if torch.is_tensor(vals[0]) else vals[0]
+        return out
+
+    def collate_conditions(self, data):
+        return self._collate(data)
+
+    def collate_latents(self, data):
+        return self._collate(data)
+
+    def forward(self, transformer, condition_model_conditions: Dict[str, torch.Tensor], latent_model_conditions: Dict[str, torch.Tensor],
+                sigmas: torch.Tensor, guidance: float = 1.0, scheduler=None, generator: Optional[torch.Generator] = None, compute_posterior: bool = True,
+                noise: Optional[torch.Tensor] = None, posterior_noise: Optional[torch.Tensor] = None, **kwargs):
+        """base_specification.py:294-330 -> (pred, target, sigmas); ``compute_posterior = False``: "latents" are the stored VAE moments [B, 2C, F, H, W]."""
+        latents = latent_model_conditions.pop("latents")
+        cond = {k: condition_model_conditions[k] for k in ("encoder_hidden_states", "encoder_attention_mask", "pooled_projections")}
+        return MI355XHunyuanVideoSpecOps.forward(self, transformer, latents, cond, sigmas, guidance=guidance, compute_posterior=compute_posterior,
+                                                 posterior_noise=posterior_noise, noise=noise, generator=generator)
+
+    def _save_lora_weights(self, directory: str, transformer_state_dict: Optional[Dict[str, torch.Tensor]] = None, scheduler=None,
+                           metadata: Optional[Dict[str, str]] = None, *args, **kwargs) -> None:
+        """base_specification.py:383-399: ``pytorch_lora_weights.safetensors`` (``transformer.``-prefixed peft keys + metadata) and the scheduler config."""
+        import json
+        import os
+
+        from .. import wire
+
+        if transformer_state_dict is not None:
+            wire.save_lora_weights(directory, transformer_state_dict, metadata)
+        if scheduler is not None:
+            os.makedirs(os.path.join(directory, "scheduler"), exist_ok=True)
+            with open(os.path.join(directory, "scheduler", "scheduler_config.json"), "w") as f:
+                json.dump({"_class_name": "FlowMatchEulerDiscreteScheduler", "num_train_timesteps": 1000, "shift": 1.0}, f, indent=2)
+
+    def load_condition_models(self):
+        raise NotImplementedError("text encoders are outside the MI355X hot path; use the reference specification")
+
+    def load_latent_models(self):
+        raise NotImplementedError("the VAE is outside the MI355X hot path; use the reference specification")
+
+    def validation(self, *a, **k):
+        raise NotImplementedError("inference / validation is outside the MI355X hot path; use the reference specification")

@@ -308,3 +308,47 @@ def test_model_and_step_parity_small():
     assert not torch.equal(step.flat, before) and gmodel.transformer_blocks[0].lora_A.grad is None
     assert gmodel.single_transformer_blocks[1].lora_B.data_ptr() >= step.flat.data_ptr()  # the adapters live in the step's flat buffer
     assert gmodel.apply_layerwise_casting() == 2 * 24 + 2 * 10  # Linear weights + biases of the blocks (norm / modulation layers skipped)
+
+
+def test_hunyuan_specification_mirror_loads_a_diffusers_directory_and_saves_lora(tmp_path):
+    """B1 for HunyuanVideo: the spec built with the reference's constructor keywords loads ``<root>/transformer`` (config.json + safetensors, Conv3d-shaped
+    patch embedding), refuses a path that does not resolve, runs ``forward`` with the reference's dict arguments and writes the LoRA file."""
+    import json
+
+    from safetensors.torch import save_file
+
+    from finetrainers_amd import wire
+    from finetrainers_amd.hunyuan_video import MI355XHunyuanVideoModelSpecification
+    from oracle import hunyuan as hy
+
+    dev = _dev()
+    kw = dict(num_attention_heads=2, attention_head_dim=128, num_layers=1, num_single_layers=1, num_refiner_layers=1, text_embed_dim=64, pooled_projection_dim=64)
+    omodel = hy.build_model(hy.HunyuanVideoConfig(**kw), seed=0)
+    sd = {_to_diffusers_key(k): v.contiguous() for k, v in omodel.state_dict().items()}
+    tdir = tmp_path / "snap" / "transformer"
+    tdir.mkdir(parents=True)
+    save_file(sd, str(tdir / "diffusion_pytorch_model.safetensors"))
+    (tdir / "config.json").write_text(json.dumps(dict(kw, _class_name="HunyuanVideoTransformer3DModel", in_channels=16, out_channels=16, patch_size=2, patch_size_t=1,
+                                                      qk_norm="rms_norm", guidance_embeds=True, rope_axes_dim=[16, 56, 56], rope_theta=256.0, mlp_ratio=4.0)))
+    with pytest.raises(FileNotFoundError):
+        MI355XHunyuanVideoModelSpecification(pretrained_model_name_or_path=str(tmp_path / "nope")).load_diffusion_models(device=dev)
+    spec = MI355XHunyuanVideoModelSpecification(pretrained_model_name_or_path=str(tmp_path / "snap"), transformer_dtype=bf16)
+    comps = spec.load_diffusion_models(device=dev)
+    model = comps["transformer"]
+    assert model.config.num_single_layers == 1 and spec._resolution_dim_keys == {"latents": (2, 3, 4)}
+    model.add_adapter(r=64, lora_alpha=64.0)
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(1, 16, 2, 8, 12, generator=g).to(bf16)
+    noise = torch.randn(1, 16, 2, 8, 12, generator=g).to(bf16)
+    cond = spec.collate_conditions([{"encoder_hidden_states": torch.randn(1, 8, 64, generator=g).to(bf16).to(dev), "encoder_attention_mask": torch.ones(1, 8, dtype=torch.long),
+                                     "pooled_projections": torch.randn(1, 64, generator=g).to(bf16).to(dev)}])
+    sig = torch.tensor([0.4])
+    with torch.no_grad():
+        pred, target, _ = spec.forward(model, dict(cond), spec.collate_latents([{"latents": lat.to(dev)}]), sig.to(dev), guidance=6.0, scheduler=comps["scheduler"], noise=noise.to(dev))
+    ocond = {k: v.cpu() for k, v in cond.items()}
+    p_ref, t_ref, _ = hy.spec_forward(omodel, lat, ocond, sig.view(-1, 1, 1, 1, 1), noise, guidance=6.0)
+    assert torch.equal(target.cpu(), t_ref) and _rel(pred, p_ref.detach()) < 5e-3
+    out = tmp_path / "ckpt"
+    spec._save_lora_weights(str(out), model.lora_state_dict(), comps["scheduler"], wire.lora_config_metadata(64, 64.0, ["to_q", "to_k", "to_v", "to_out.0"]))
+    tensors, _ = wire.load_lora_weights(str(out))
+    assert len(tensors) == 2 * (4 + 3) and (out / "scheduler" / "scheduler_config.json").exists()
