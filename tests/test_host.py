@@ -608,3 +608,27 @@ def test_hunyuan_host_tables_and_key_maps_match_oracle():
     for prefix, blk in (("transformer_blocks.0.", MI355XHunyuanDualBlock(256, 2, device=dev)), ("single_transformer_blocks.0.", MI355XHunyuanSingleBlock(256, 2, device=dev))):
         want = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
         assert want == {k: tuple(getattr(blk, n).shape) for k, n in blk._KEYS.items()}
+
+
+def test_wan_and_hunyuan_specification_collation_and_guards():
+    """Spec mirrors, host-only parts: ``latents_mean`` / ``latents_std`` pass through the Wan collation uncollated (modeling_utils.py:22), tensors are
+    concatenated on dim 0, non-bf16 transformer dtypes are refused, encoders / VAE / validation stay with the reference."""
+    from finetrainers_amd.hunyuan_video.specification import MI355XHunyuanVideoModelSpecification
+    from finetrainers_amd.wan.specification import IGNORE_KEYS_FOR_COLLATION, MI355XWanModelSpecification
+
+    wspec = MI355XWanModelSpecification(pretrained_model_name_or_path=None)
+    items = [{"latents": torch.zeros(1, 32, 2, 4, 4), "latents_mean": torch.arange(16.0), "latents_std": torch.ones(16)} for _ in range(3)]
+    out = wspec.collate_latents(items)
+    assert out["latents"].shape == (3, 32, 2, 4, 4) and out["latents_mean"].shape == (16,) and {"latents_mean", "latents_std"} <= IGNORE_KEYS_FOR_COLLATION
+    hspec = MI355XHunyuanVideoModelSpecification(pretrained_model_name_or_path=None)
+    cond = hspec.collate_conditions([{"encoder_hidden_states": torch.zeros(1, 5, 8), "encoder_attention_mask": torch.ones(1, 5, dtype=torch.long), "pooled_projections": torch.zeros(1, 4)}] * 2)
+    assert cond["encoder_hidden_states"].shape == (2, 5, 8) and cond["encoder_attention_mask"].shape == (2, 5) and hspec.scaling_factor == 0.476986
+    for cls in (MI355XWanModelSpecification, MI355XHunyuanVideoModelSpecification):
+        with pytest.raises(ValueError):
+            cls(transformer_dtype=torch.float16)
+        spec = cls(pretrained_model_name_or_path=None)
+        for fn in (spec.load_condition_models, spec.load_latent_models, spec.validation):
+            with pytest.raises(NotImplementedError):
+                fn()
+        with pytest.raises(FileNotFoundError):
+            spec.load_diffusion_models()  # nothing to load from: never random weights
