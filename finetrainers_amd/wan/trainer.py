@@ -130,6 +130,18 @@ class MI355XWanFullFinetuneStep:
             self.lr_scheduler.load_state_dict(sd["lr_scheduler"])
 
     @torch.no_grad()
+    def gathered_state_dict(self) -> Dict[str, torch.Tensor]:
+        """{diffusers parameter name: full bf16 tensor} assembled from all ranks (every rank must call it: it all-gathers unit by unit) -- what
+        ``MI355XWanModelSpecification._save_model(directory, transformer, transformer_state_dict = ...)`` writes (trainer.py:293-305 gathers the FSDP state
+        dict the same way before saving).  After sharding, the modules' own parameters are only this rank's slices."""
+        full = self.gathered_parameters()
+        tr = self.transformer
+        out = dict(tr.root_layout.named_views(full["root"]))
+        for i, blk in enumerate(tr.blocks):
+            out.update({f"blocks.{i}.{k}": v for k, v in blk.layout.named_views(full[f"blocks.{i}"]).items()})
+        return out
+
+    @torch.no_grad()
     def gathered_parameters(self) -> Dict[str, torch.Tensor]:
         """{unit name: full bf16 parameters} assembled from all ranks (checkpointing, tests)."""
         out = {}

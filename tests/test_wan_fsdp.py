@@ -85,3 +85,45 @@ def test_parameter_sharder_single_rank_needs_no_copies():
     sh.finish_gradients()
     assert torch.equal(sh.units[1].shard_grad, torch.full((1280,), 2.0))
     _ = np  # (numpy is only here so that the workers never send torch storages through the queue)
+
+
+def _ckpt_worker(rank, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from finetrainers_amd.parallel import DataParallelBackend
+    from finetrainers_amd.wan import MI355XWanFullFinetuneStep, MI355XWanTransformer3DModel, WanTransformerConfig
+    from oracle import wan
+
+    par = DataParallelBackend(backend="gloo", device=torch.device("cpu"))
+    try:
+        kw = dict(num_attention_heads=2, attention_head_dim=128, ffn_dim=512, num_layers=2, text_dim=64)
+        sd = {k.replace("ffn.proj_in.", "ffn.net.0.proj.").replace("ffn.proj_out.", "ffn.net.2."): v for k, v in wan.build_model(wan.WanConfig(**kw), seed=0).state_dict().items()}
+        model = MI355XWanTransformer3DModel(WanTransformerConfig(**kw), device=torch.device("cpu"))
+        model.load_diffusers_state_dict(sd)
+        if rank == 1:  # replicas start from rank 0's weights: a different local copy must not survive
+            model.blocks[0].flat.data.zero_()
+        step = MI355XWanFullFinetuneStep(model, parallel=par)
+        total = model.blocks[0].layout.total
+        ok = model.blocks[0].flat.numel() * 2 >= total and model.blocks[0].flat.numel() < total  # the module now holds half of the block
+        got = step.gathered_state_dict()
+        ok &= set(got) == set(sd)
+        for k, v in got.items():
+            ok &= bool(torch.equal(v.reshape(sd[k].shape), sd[k]))
+        q.put((rank, bool(ok)))
+    finally:
+        par.destroy()
+
+
+def test_sharded_wan_model_gathers_its_checkpoint_world2_gloo():
+    """After ``MI355XWanFullFinetuneStep`` shards the parameters each module holds half of its unit; ``gathered_state_dict`` reassembles the diffusers-named
+    tensors bit for bit on every rank (CPU tensors over gloo: the sharding / naming logic has no kernels in it)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 97
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
