@@ -254,6 +254,8 @@ class MI355XWanBlock(nn.Module):
         self.mark_updated()
 
     def state_dict_views(self) -> Dict[str, torch.Tensor]:
+        if self.flat.numel() < self.layout.total:
+            raise RuntimeError("this block's parameters are sharded over the ranks: use the step object's gathered_state_dict()")
         return self.layout.named_views(self.flat.data)
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor, rotary) -> torch.Tensor:

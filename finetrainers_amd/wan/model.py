@@ -216,6 +216,8 @@ class MI355XWanTransformer3DModel(nn.Module):
 
     def state_dict_views(self) -> Dict[str, torch.Tensor]:
         """{diffusers parameter name: view of the flat buffers} (the patch embedding in its GEMM shape [D, C pt ph pw])."""
+        if self.root.numel() < self.root_layout.total:
+            raise RuntimeError("the parameters are sharded over the ranks: use the step object's gathered_state_dict()")
         out = dict(self.root_layout.named_views(self.root.data))
         for i, blk in enumerate(self.blocks):
             out.update({f"blocks.{i}.{k}": v for k, v in blk.state_dict_views().items()})

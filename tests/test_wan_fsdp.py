@@ -104,6 +104,11 @@ def _ckpt_worker(rank, port, q):
         step = MI355XWanFullFinetuneStep(model, parallel=par)
         total = model.blocks[0].layout.total
         ok = model.blocks[0].flat.numel() * 2 >= total and model.blocks[0].flat.numel() < total  # the module now holds half of the block
+        try:
+            model.state_dict_views()
+            ok = False  # must refuse: the local tensors are slices
+        except RuntimeError:
+            pass
         got = step.gathered_state_dict()
         ok &= set(got) == set(sd)
         for k, v in got.items():
