@@ -632,3 +632,29 @@ def test_wan_and_hunyuan_specification_collation_and_guards():
                 fn()
         with pytest.raises(FileNotFoundError):
             spec.load_diffusion_models()  # nothing to load from: never random weights
+
+
+def test_hunyuan_step_rehomes_adapters_into_one_flat_buffer_and_saves_peft_keys(tmp_path):
+    """Host-only parts of the HunyuanVideo step: the 200 (here 7) adapters' Parameters become views of ONE flat fp32 buffer (what the fused clip + AdamW
+    launch updates), and ``lora_state_dict`` carries the peft names the reference's ``_save_lora_weights`` writes."""
+    from finetrainers_amd import wire
+    from finetrainers_amd.hunyuan_video import HunyuanVideoTransformerConfig, MI355XHunyuanVideoSFTStep, MI355XHunyuanVideoTransformer3DModel
+
+    cfg = HunyuanVideoTransformerConfig(num_attention_heads=2, num_layers=1, num_single_layers=1, num_refiner_layers=1, text_embed_dim=64, pooled_projection_dim=64)
+    model = MI355XHunyuanVideoTransformer3DModel(cfg, device=torch.device("cpu"))
+    model.add_adapter(r=64, lora_alpha=32.0)
+    with torch.no_grad():
+        model.single_transformer_blocks[0].lora_B.normal_()
+    before = model.single_transformer_blocks[0].lora_B.detach().clone()
+    step = MI355XHunyuanVideoSFTStep(model)
+    n = sum(p.numel() for p in model.lora_parameters())
+    assert step.flat.numel() == n == (4 + 3) * 2 * 64 * 256
+    lo, hi = step.flat.data_ptr(), step.flat.data_ptr() + 4 * n
+    assert all(lo <= p.data_ptr() < hi for p in model.lora_parameters()) and torch.equal(model.single_transformer_blocks[0].lora_B, before)
+    step.flat.zero_()
+    assert float(model.transformer_blocks[0].lora_A.detach().abs().max()) == 0.0 and model.transformer_blocks[0].lora_scale == 0.5
+    sd = model.lora_state_dict()
+    assert len(sd) == 14 and "transformer_blocks.0.attn.to_out.0.lora_B.weight" in sd and "single_transformer_blocks.0.attn.to_v.lora_A.weight" in sd
+    wire.save_lora_weights(str(tmp_path), sd, wire.lora_config_metadata(64, 32.0, ["to_q", "to_k", "to_v", "to_out.0"]))
+    tensors, _ = wire.load_lora_weights(str(tmp_path))
+    assert len(tensors) == 14
