@@ -17,6 +17,9 @@ import torch
 from .. import ops
 
 
+from ..ltx_video.specification import IGNORE_KEYS_FOR_COLLATION  # modeling_utils.py: keys passed through from the first sample
+
+
 class CogVideoXDDIMTables:
     """The two things the step needs from ``CogVideoXDDIMScheduler``: ``alphas_cumprod`` (fp32 [1000], built exactly as the scheduler's
     constructor does: scaled-linear betas, SNR shift, optional zero-terminal-SNR rescale) and ``config.num_train_timesteps``."""
@@ -161,8 +164,11 @@ class MI355XCogVideoXModelSpecification(MI355XCogVideoXSpecOps):
     def _collate(data):
         out = {}
         for k in data[0]:
+            if k in IGNORE_KEYS_FOR_COLLATION:
+                out[k] = data[0][k]
+                continue
             vals = [d[k] for d in data]
-            out[k] = torch.cat([v if v.dim() > 0 else v[None] for v in vals], dim=0) if torch.is_tensor(vals[0]) else vals[0]
+            out[k] = torch.cat([v if v.dim() > 0 else v[None] for v in vals], dim=0) if torch.is_tensor(vals[0]) else vals  # non-tensors: the list
         return out
 
     def collate_conditions(self, data):

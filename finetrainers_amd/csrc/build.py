@@ -2,6 +2,7 @@
 
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -38,11 +39,25 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra: str = "") -> str:
+    """Content hash of the inputs of one build product.  File times are not used: a snapshot copied to another machine (gpurun) keeps
+    contents, not necessarily times, and a shipped object newer than its edited source must not pass for fresh."""
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def _stale(target: str, digest: str) -> bool:
+    stamp = target + ".sha256"
+    return not (os.path.exists(target) and os.path.exists(stamp) and open(stamp).read() == digest)
+
+
+def _stamp(target: str, digest: str) -> None:
+    with open(target + ".sha256", "w") as f:
+        f.write(digest)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -54,28 +69,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def compile_one(src: str) -> str:
         s = os.path.join(HERE, src)
         o = os.path.join(objdir, src + ".o")
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+        flags = FLAGS + EXTRA_FLAGS.get(src, [])
+        dg = _digest([s] + hdrs, " ".join(flags))  # a change of flags (e.g. FTMI_EXPERIMENTAL on / off) invalidates the object
+        if force or _stale(o, dg):
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+            _stamp(o, dg)
         return o
 
-    # a change of flags (e.g. FTMI_EXPERIMENTAL on / off) invalidates every object
-    sig = " ".join(FLAGS) + " | " + repr(sorted(EXTRA_FLAGS.items()))
-    sig_path = os.path.join(objdir, "flags.txt")
-    if not os.path.exists(sig_path) or open(sig_path).read() != sig:
-        force = True
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    with open(sig_path, "w") as f:
-        f.write(sig)
     lib = os.path.abspath(LIB)
-    if force or _stale(lib, objs):
+    dg = _digest(objs)
+    if force or _stale(lib, dg):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        _stamp(lib, dg)
     return lib
 
 

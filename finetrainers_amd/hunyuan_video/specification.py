@@ -15,6 +15,9 @@ from .. import ops
 bf16 = torch.bfloat16
 
 
+from ..ltx_video.specification import IGNORE_KEYS_FOR_COLLATION  # modeling_utils.py: keys passed through from the first sample
+
+
 class MI355XHunyuanVideoSpecOps:
     def __init__(self, scaling_factor: float = 0.476986):
         self.scaling_factor = scaling_factor  # AutoencoderKLHunyuanVideo config [upstream]
@@ -100,8 +103,11 @@ class MI355XHunyuanVideoModelSpecification(MI355XHunyuanVideoSpecOps):
     def _collate(data):
         out = {}
         for k in data[0]:
+            if k in IGNORE_KEYS_FOR_COLLATION:
+                out[k] = data[0][k]
+                continue
             vals = [d[k] for d in data]
-            out[k] = torch.cat(vals) if torch.is_tensor(vals[0]) else vals[0]
+            out[k] = torch.cat(vals) if torch.is_tensor(vals[0]) else vals  # per-sample non-tensor fields stay a list (modeling_utils.py collate_*)
         return out
 
     def collate_conditions(self, data):

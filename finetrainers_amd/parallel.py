@@ -4,11 +4,12 @@ Restates the slice of finetrainers/parallel the DP path uses (``BaseParallelBack
 PTD backend parallel/ptd.py:41-279: ``init_process_group("nccl")``, ``replicate(bucket_cap_mb=100)`` DDP,
 ``split_dataset_by_node``; scalar reductions parallel/utils.py:6-19) -- retargeted, not translated:
 
-  * the trainable state is ONE flat fp32 LoRA-gradient buffer (234.9 MB at r=64), so the gradient exchange is a
-    single ``all_reduce`` issued right after backward instead of the c10d reducer's 100 MB buckets.  Step compute
-    is tens of ms while 235 MB over a 7-link xGMI mesh is well under 3 ms even with a ring, so
-    one large collective (fewer, larger messages -- what xGMI likes) beats bucket/overlap machinery for this
-    workload; averaging is folded into the collective (``ReduceOp.AVG`` on RCCL, SUM + scale on gloo);
+  * the trainable state is ONE flat fp32 LoRA-gradient buffer (234.9 MB at r=64) laid out [A | B] with the layer axis leading, so
+    the gradients of a contiguous block range are two contiguous slices.  The DiT backward runs in block ranges
+    (``ftmi_ltx_backward_range``) and ``GradBucketReducer`` all-reduces (AVG) the two slices of each finished range right away,
+    asynchronously on RCCL's stream, while the earlier blocks still compute -- the role of the c10d reducer's 100 MB buckets
+    without parameter hooks (default 7 blocks per bucket: 4 buckets of 2 x 29.4 MB; only the last one is exposed).  Averaging is
+    folded into the collective (``ReduceOp.AVG`` on RCCL, SUM + scale on gloo);
   * the three logging scalars (grad-norm mean, loss mean, loss max: trainer.py:512-518) are reduced in ONE small
     collective and stay on the device -- no ``.item()`` on the critical path;
   * ``NCCL_P2P_DISABLE`` from the reference's example scripts is never set: it would force RCCL off xGMI.
@@ -160,4 +161,14 @@ class GradBucketReducer:
             work.wait()
             if div is not None:
                 div.div_(self.backend.world_size)
+        self._pending.clear()
+
+    def abort(self) -> None:
+        """A backward that raised after issuing some buckets: wait for the collectives already in flight (every rank issued them, so they
+        complete) and forget them -- the next step must neither wait on stale handles nor re-divide their tensors."""
+        for work, _ in self._pending:
+            try:
+                work.wait()
+            except Exception:
+                pass
         self._pending.clear()

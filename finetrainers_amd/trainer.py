@@ -143,6 +143,10 @@ class MI355XSFTStep:
         tr._grad_bucket_hook = self.reducer.bucket_ready if exchange else None
         try:
             pred.backward(dpred)  # DP: buckets of finished blocks are all-reduced (AVG) on RCCL's stream while this still runs
+        except BaseException:
+            if exchange:
+                self.reducer.abort()  # buckets issued before the failure: drained and dropped, never carried into the next step
+            raise
         finally:
             tr._grad_bucket_hook = None
         if not sync:

@@ -86,7 +86,9 @@ class LRSchedule:
 
     @classmethod
     def from_args(cls, base_lr: float, name: str, **kwargs) -> "LRSchedule":
-        return cls(base_lr, lr_multiplier(name, lr_init=base_lr, **kwargs))
+        # lr_init / lr_end of the polynomial schedule keep the reference's defaults (1e-3, 1e-7: optimizer.py:200-201) unless the caller passes
+        # them -- the reference trainer never does (sft_trainer/trainer.py:221-228), so its multiplier decays to 1e-4 whatever the base lr
+        return cls(base_lr, lr_multiplier(name, **kwargs))
 
     def current_lr(self) -> float:
         return self.base_lr * self.multiplier(self.last_epoch)

@@ -74,6 +74,9 @@ class MI355XWanFullFinetuneStep:
     def _post_backward(self, blk) -> None:
         self.sharder.scatter_grad(self._index[id(blk)])
         blk.grad_flat = None
+        # the transposed weights of this block's input-gradient GEMMs are a full-size copy of its parameters: kept alive they would add
+        # up to one unsharded bf16 model per rank, which is what the sharding exists to avoid
+        blk._transposed = None
 
     # ---- the step -----------------------------------------------------------------------------------------------------------------------------
     def step(self, moments: torch.Tensor, encoder_hidden_states: torch.Tensor, latents_mean: torch.Tensor, latents_std: torch.Tensor,

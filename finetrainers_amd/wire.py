@@ -140,7 +140,16 @@ class PrecomputedSampleFeeder:
             raise RuntimeError("precomputed-sample feeder failed") from self._err
         cb, lb, ev = item
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)  # device-side wait only: the copy was issued batches ago
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)  # device-side wait only: the copy was issued batches ago
+            # The tensors were allocated on the worker's side stream.  The step that consumes them is asynchronous on the host, so the
+            # caller may drop the dicts while forward / backward kernels that read them (the text states up to the end of the backward) are
+            # still queued; without this the caching allocator would hand the blocks back to the side stream's pool at once and the
+            # worker's next prefetch copy could overwrite them under those kernels.
+            for d in (cb, lb):
+                for v in d.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
         return cb, lb
 
     def close(self) -> None:
