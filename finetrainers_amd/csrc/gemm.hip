@@ -554,7 +554,8 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
         }
     }
     const size_t smem = (size_t)kl_lds_stages(LOOP) * T::STAGE;
-    ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * (double)(a.K + a.K2), st);
+    // algorithmic FLOPs: the extension's K2 carries the (hi, lo, hi) bf16 planes of an fp32 operand -- three executed K-steps per algorithmic one
+    ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * ((double)a.K + (double)a.K2 / 3.0), st);
     if (smem > 65536) {
         static const bool attr_ok =  // once per instantiation, thread-safe
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, LOOP>),
@@ -830,6 +831,19 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (a.N % 64 != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: N must be a multiple of 64");
     if ((a.ldx % 8) || (a.ldw % 8) || (a.ldo % 8) || (a.K2 > 0 && ((a.ldx2 % 8) || (a.ldw2 % 8))))
         return set_error(FTMI_ERR_INVALID, "gemm_nt: leading dimensions must keep 16-byte row alignment");
+    // the persistent 256 x 256 stream-K kernel (gemm_sk.hip): 60 pins it; 61 = the automatic choice among the one-tile-per-workgroup kernels
+    // below.  8 (auto) takes it only with FTMI_SK=1: measured on the step's shapes (profiles/r03_gemm_streamk.txt) it is correct but 5-25 %
+    // SLOWER than the one-tile kernels -- a persistent workgroup waits for its own 128 KB of output stores (vmcnt counts stores in order with
+    // the next tile's loads: ~7 us per tile at the ~11 B/clk a CU stores), which a one-tile workgroup leaves draining behind its s_endpgm
+    // while its successor on the CU already computes; the fp32 fix-up of a 256 x 256 partial costs another ~6 us per hand-off.
+    if (a.variant == 60) {
+        if (!gemm_nt_sk_eligible(a)) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: the stream-K kernel needs N % 256 == 0, M >= 1024, K >= 256 and 256-wide groups");
+        return gemm_nt_sk(a, st);
+    }
+    if (a.variant == 8) {
+        static const int use_sk = env_int("FTMI_SK", 0);
+        if (use_sk && gemm_nt_sk_eligible(a)) return gemm_nt_sk(a, st);
+    }
     if (a.split_r > 0) {  // fp32-equivalent LoRA down-projection: always the LDS-ring skinny kernel (any M, any N, grouped W allowed)
         if (a.K2 != 0 || a.epi != EPI_STORE || a.bias || a.K < 256 || a.split_r % 64 != 0 || (a.N / 2) % a.split_r != 0)
             return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: split (hi/lo) mode needs a plain store, K >= 256 and whole groups of split_r outputs");
@@ -864,7 +878,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     if (!wide && ((a.xk_grp_n > 0 && a.xk_grp_n % 64 != 0) || (a.x2_grp_n > 0 && a.x2_grp_n % 64 != 0)))
         return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
     if (wide) {
-        int variant = a.variant;
+        int variant = a.variant == 61 ? 8 : a.variant;
         if (variant == 8) {
             // auto: pick the tile by the measured cost model of DESIGN.md section 6 -- a K-tile costs its SIMD 32 cycles per MFMA
             // plus ~85 issue cycles per 1-KiB direct-to-LDS load, tiles run in rounds of (256 CUs x workgroups per CU):

@@ -85,6 +85,12 @@ struct GemmNtArgs {
     int map_gm = 1, map_gn = 8, map_rm = 0, map_rn = 0;
 };
 int gemm_nt(const GemmNtArgs& a, hipStream_t st);
+// persistent 256 x 256 stream-K form of the same contract (gemm_sk.hip); gemm_nt() routes eligible launches to it
+bool gemm_nt_sk_eligible(const GemmNtArgs& a);
+int gemm_nt_sk(const GemmNtArgs& a, hipStream_t st);
+int gemm_nt_sk_status();
+int gemm_nt_sk_trace(unsigned long long* out, int cap);
+bool sk_build_work(int ntiles, int G, int nk, int ov, int minp, int pc, int ac, int* work);
 
 struct GemmTnArgs {
     const bf16_t* U = nullptr;  // [M, ldu], P columns used

@@ -106,11 +106,27 @@ int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const voi
 /* Generic building blocks (exposed for tests / incremental adoption) */
 /* out[M,N] = bf16(alpha * x[M,K] w[N,K]^T + bias) ; epilogue: 0 store, 1 gelu-tanh (out2 <- pre-activation),
  * 2 out = resid + (gate ? gate[b] * y : y), 3 out = y * gelu'(aux).  out2, resid and aux are [M, N] views with row stride ld_side (0: out's ldo).
- * variant: 8 = automatic tile / K-loop choice (use this);
+ * variant: 8 = automatic kernel / tile choice (use this); 60 = the persistent 256 x 256 stream-K kernel (FTMI_ERR_UNSUPPORTED where it does
+ * not apply), 61 = automatic choice among the one-tile-per-workgroup kernels only;
  * other ids pin one kernel (bit-identical A/B partners, see gemm.hip) */
 int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha,
                  void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
                  const void* aux, long ld_side, int variant, ftmi_stream stream);
+/* The stream-K split of the persistent GEMM as a pure host function (no device needed; tests): the last `ntiles mod n_workgroups` tiles of
+ * a launch form a cost line of (nk + owner_cost) units per tile -- nk K iterations, owner_cost = what finishing the tile (LoRA extension +
+ * epilogue) costs in K-iteration units -- cut into n_workgroups shares of equal cost; a cut inside a tile charges partial_cost to the workgroup
+ * after it (it stores a partial) and add_cost to the tile's owner; cuts closer than min_piece iterations to a tile edge snap to it.
+ * work[w] = {t0, k0, t1, k1, kinds, n_whole, contributor_mask, 0}: the share of workgroup w starts at K iteration k0 of stream-K tile t0 and
+ * ends before iteration k1 of tile t1; kinds bit 0 = it opens with a partial piece (published to its owner), bit 1 = it closes with the owner
+ * piece [0, k1) of tile t1; n_whole whole tiles in between; contributor_mask bit i = workgroup w + 1 + i holds a partial of that tile. */
+int ftmi_gemm_sk_plan(int ntiles, int n_workgroups, int nk, int owner_cost, int min_piece, int partial_cost, int add_cost,
+                      int* work /* [n_workgroups][8] */);
+/* 0 = every stream-K hand-off so far completed; 1 = a bounded wait for a partial gave up (results of that launch are wrong); < 0 = error.
+ * Synchronises the device (tests and debugging only). */
+int ftmi_gemm_sk_status(void);
+/* Debugging aid (FTMI_SK_TRACE=1): shader-clock stamps of the last stream-K launch, out[n_workgroups][16] (start, end of each K phase,
+ * hand-off waits, segment ends; 0 = unused); returns n_workgroups, 0 if nothing was traced.  Synchronises the device. */
+int ftmi_gemm_sk_trace(unsigned long long* out, int capacity);
 /* c[P,Q] (fp32) += scale * u[M,P]^T v[M,Q] */
 int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, long ldv, float* c, long ldc, float scale,
                  ftmi_stream stream);
