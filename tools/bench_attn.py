@@ -30,7 +30,7 @@ if cross:
     bias[0, 32:] = -10000.0
     bias[1, 96:] = -10000.0
 flops = 4.0 * B * H * S * Sk * D * (2.5 if bwd else 1.0)
-KEYS = ("FTMI_ATTN_GEN", "FTMI_ATTN_FWD_GEN", "FTMI_ATTN_DQ_GEN", "FTMI_ATTN_DKV_GEN", "FTMI_ATTN_FWD")
+KEYS = ("FTMI_ATTN_GEN", "FTMI_ATTN_FWD_GEN", "FTMI_ATTN_DQ_GEN", "FTMI_ATTN_DKV_GEN", "FTMI_ATTN_FWD", "FTMI_ATTN_FWD8", "FTMI_ATTN_BWD8")
 
 
 def setenv(spec):
@@ -41,7 +41,7 @@ def setenv(spec):
         os.environ[a] = b
 
 
-setenv("FTMI_ATTN_GEN=1")
+setenv("FTMI_ATTN_FWD8=0,FTMI_ATTN_BWD8=0")
 out0, lse0 = ops.attn_fwd(q, k, v, bias)
 ref = ops.attn_bwd(q, k, v, out0, lse0, dout, bias) if bwd else (out0,)
 torch.cuda.synchronize()
