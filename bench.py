@@ -5,6 +5,7 @@
     python bench.py --gpus 1 --steps 10 --warmup 3
     python bench.py --gpus 8 --steps 10 --warmup 3          (spawns its 8 ranks itself: one process per GPU, RCCL over xGMI)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --workload {cogvideox,wan,hunyuan}      (BASELINE configs[2] / [3] / [4] through the same harness and JSON schema; default: ltx = configs[1])
 
 One "step" = one full optimisation step of the reference's SFTTrainer._train body on synthetic latents already
 resident in HBM: noise/flow-match mix/pack -> 28-block DiT forward -> weighted MSE -> backward (LoRA grads) ->
@@ -37,10 +38,12 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARC
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)  # ~2 s of GPU time; long enough that one box-level stall does not move the mean
+    ap.add_argument("--workload", choices=["ltx", "cogvideox", "wan", "hunyuan"], default="ltx",
+                    help="ltx = BASELINE configs[1] (the metric's workload); cogvideox / wan / hunyuan = configs[2] / [3] / [4] (tools/bench_workloads.py)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 30 for ltx -- ~2 s of GPU time, long enough that one box-level stall does not move the mean -- 10 otherwise)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (BASELINE configs[1]: 2)")
-    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--batch", type=int, default=2, help="per-GPU batch (BASELINE configs[1]: 2; the other workloads run batch 1)")
+    ap.add_argument("--layers", type=int, default=0, help="0 = the architecture's own depth (ltx 28, cogvideox 30, wan 30, hunyuan 20 + 40)")
     ap.add_argument("--rank", type=int, default=64)
     ap.add_argument("--frames", type=int, default=7, help="latent frames  (49 px frames / 8 + 1)")
     ap.add_argument("--height", type=int, default=16, help="latent height (512 / 32)")
@@ -53,7 +56,12 @@ def parse():
     ap.add_argument("--cpu-baseline-layers", type=int, default=4)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events inside the timed region")
     ap.add_argument("--prof-stride", type=int, default=29, help="bracket every N-th launch of a kernel class with HIP events (1 = all)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.steps <= 0:
+        a.steps = 30 if a.workload == "ltx" else 10
+    if a.workload == "ltx" and a.layers <= 0:
+        a.layers = 28
+    return a
 
 
 def _profile_json(name: str):
@@ -137,29 +145,10 @@ def _self_spawn(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    args = parse()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (the MI355X backend has no CPU path)")
-
-    from finetrainers_amd import _lib
+def _build_ltx(args, par, dev):
+    """BASELINE configs[1]: LTX-Video LoRA rank-64 SFT step, 49x512x768 clip, batch 2 per GPU."""
     from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
-    from finetrainers_amd.parallel import DataParallelBackend
     from finetrainers_amd.trainer import MI355XSFTStep
-
-    # FTMI_BENCH_SHARE_GPU=1: rehearsal of the multi-rank launch on a one-GPU box -- the N ranks time-share GPU 0 and exchange through gloo
-    # (RCCL refuses two ranks on one device).  It executes the spawn, broadcast, bucketed exchange, barrier and max-over-ranks code; the
-    # line it prints is marked "rehearsal" and its numbers mean nothing.
-    share = os.environ.get("FTMI_BENCH_SHARE_GPU") == "1"
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if torch.cuda.device_count() < args.gpus and not share:
-            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} MI355X visible")
-        raise SystemExit(_self_spawn(args))
-    par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0)) if share and args.gpus > 1 else DataParallelBackend()
-    if par.world_size != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={par.world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = par.device
-    lib = _lib.load()
 
     tcfg = LTXTransformerConfig(num_layers=args.layers)
     spec = MI355XLTXVideoModelSpecification(transformer_config=tcfg, gemm_variant=args.gemm_variant)
@@ -183,8 +172,59 @@ def main():
     lat = {"latents": latents, "latents_mean": torch.zeros(C, device=dev), "latents_std": torch.ones(C, device=dev),
            "num_frames": args.frames, "height": args.height, "width": args.width}
 
-    def one_step():
-        return step.step(cond, lat)
+    S = args.frames * args.height * args.width
+    full_shape = (args.layers == 28 and S == 2688 and args.rank == 64)
+    return {
+        "one_step": lambda: step.step(cond, lat),
+        "samples_per_step": B,
+        "step_tflop": STEP_TFLOP_PER_SAMPLE * B * (args.layers / 28.0),
+        "metric": "train samples/sec (+ step ms) LTX-Video LoRA 49x512x768 @1/2/4/8 MI355X",
+        "data": "synthetic latents [B,128,7,16,24] + random text embeds, random-init weights of the production LTX-Video DiT",
+        "config": {
+            "workload": "LTX-Video LoRA rank=64 bf16 SFT step, 49x512x768 clip (latents 7x16x24 = 2688 tokens), batch 2 per GPU "
+                        "(BASELINE configs[1])" if full_shape else f"REDUCED: layers={args.layers} tokens={S} rank={args.rank}",
+            "model": "LTX-Video DiT 28 blocks, width 2048, 32x64 heads, 1.923B frozen bf16 params + 58.7M fp32 LoRA params",
+            "seq_len": S,
+            "activation_checkpointing": False,
+            "optimizer": "AdamW(lr 5e-5, betas (0.9,0.99), wd 1e-4) + clip 1.0, fused",
+            "gemm_variant": args.gemm_variant,
+        },
+        "cpu_baseline": lambda: cpu_baseline(args),
+    }
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the MI355X backend has no CPU path)")
+
+    from finetrainers_amd import _lib
+    from finetrainers_amd.parallel import DataParallelBackend
+
+    # FTMI_BENCH_SHARE_GPU=1: rehearsal of the multi-rank launch on a one-GPU box -- the N ranks time-share GPU 0 and exchange through gloo
+    # (RCCL refuses two ranks on one device).  It executes the spawn, broadcast, bucketed exchange, barrier and max-over-ranks code; the
+    # line it prints is marked "rehearsal" and its numbers mean nothing.
+    share = os.environ.get("FTMI_BENCH_SHARE_GPU") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if torch.cuda.device_count() < args.gpus and not share:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} MI355X visible")
+        raise SystemExit(_self_spawn(args))
+    par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0)) if share and args.gpus > 1 else DataParallelBackend()
+    if par.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={par.world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = par.device
+    lib = _lib.load()
+
+    if args.workload == "ltx":
+        ctx = _build_ltx(args, par, dev)
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_workloads
+
+        build, cpu_fn = bench_workloads.WORKLOADS[args.workload]
+        ctx = build(args, par, dev)
+        ctx["cpu_baseline"] = lambda: cpu_fn(args, ctx)
+    one_step, B = ctx["one_step"], ctx["samples_per_step"]
 
     prof = not args.no_prof
     for w in range(args.warmup):
@@ -230,11 +270,9 @@ def main():
     if par.rank == 0:
         ms = elapsed / args.steps * 1e3
         samples_per_s = par.world_size * B * args.steps / elapsed
-        S = args.frames * args.height * args.width
-        full_shape = (args.layers == 28 and S == 2688 and args.rank == 64)
-        step_tflop = STEP_TFLOP_PER_SAMPLE * B * (args.layers / 28.0)
+        step_tflop = ctx["step_tflop"]
         res = {
-            "metric": "train samples/sec (+ step ms) LTX-Video LoRA 49x512x768 @1/2/4/8 MI355X",
+            "metric": ctx["metric"],
             "value": samples_per_s,
             "unit": "samples/s",
             "n_gpus": par.world_size,
@@ -246,19 +284,10 @@ def main():
             **({"rehearsal": "FTMI_BENCH_SHARE_GPU=1: all ranks on one GPU over gloo -- code-path check only, not a measurement"} if share and args.gpus > 1 else {}),
             "vs_baseline": None,
             "dtype": "bf16",
-            "data": "synthetic latents [B,128,7,16,24] + random text embeds, random-init weights of the production LTX-Video DiT",
-            "config": {
-                "workload": "LTX-Video LoRA rank=64 bf16 SFT step, 49x512x768 clip (latents 7x16x24 = 2688 tokens), batch 2 per GPU "
-                            "(BASELINE configs[1])" if full_shape else f"REDUCED: layers={args.layers} tokens={S} rank={args.rank}",
-                "model": "LTX-Video DiT 28 blocks, width 2048, 32x64 heads, 1.923B frozen bf16 params + 58.7M fp32 LoRA params",
-                "global_batch": par.world_size * B,
-                "seq_len": S,
-                "parallelism": f"dp{par.world_size}",
-                "activation_checkpointing": False,
-                "optimizer": "AdamW(lr 5e-5, betas (0.9,0.99), wd 1e-4) + clip 1.0, fused",
-                "gemm_variant": args.gemm_variant,
-            },
+            "data": ctx["data"],
+            "config": {**ctx["config"], "global_batch": par.world_size * B, "parallelism": ("fsdp" if args.workload == "wan" else "dp") + str(par.world_size)},
             "step_tflop_algorithmic": step_tflop,
+            "peak_memory_gib": torch.cuda.max_memory_allocated() / 2**30,
             "mfma_utilisation_step": step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS,
             "final_loss": loss,
             "step_ms_min_median_max": [round(v, 3) for v in (lambda t: (t[0], t[len(t) // 2], t[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)))],
@@ -279,7 +308,20 @@ def main():
                                   "avg_us": tms.value / n.value * 1e3, "tflops": tflops,
                                   "ms_per_step": afl.value / (tflops * 1e12) * 1e3 / args.steps}
             res["kernels"] = kern
-            if "gemm_nt" in kern:
+            if args.workload != "ltx" and kern:
+                # the dominant kernel class of this workload (largest share of the step) against the dense bf16 MFMA peak
+                dom = max(kern, key=lambda k_: kern[k_]["ms_per_step"])
+                d_ = kern[dom]
+                names = {"gemm_nt": "ftmi::gemm_nt_kernel (bf16 MFMA GEMM + fused LoRA / epilogues)", "gemm_tn": "ftmi::gemm_tn2_kernel (weight gradients)",
+                         "attn_fwd": "ftmi::attn_fwd_kernel", "attn_bwd": "ftmi::attn_bwd_dq / attn_bwd_dkdv kernels (flash attention backward)",
+                         "gemm_nt_skinny": "ftmi::gemm_nt_skinny2_kernel"}
+                res["roofline"] = {"kernel": names.get(dom, dom), "bound": "mfma", "achieved": d_["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": d_["tflops"] / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_us": d_["avg_us"], "launches_per_step": d_["launches_per_step"],
+                                   "share_of_step": d_["ms_per_step"] / ms,
+                                   "note": f"achieved = sum of algorithmic FLOPs / sum of HIP-event durations over every {args.prof_stride}-th launch of the class, events "
+                                           "recorded on the launch stream inside the timed region; attention backward counts 2.5 x the forward's 4 S^2 d per head (5 matmuls; "
+                                           "the two-kernel backward executes 7 at head_dim 64, 8 at head_dim 128)"}
+            if args.workload == "ltx" and "gemm_nt" in kern:
                 g_ = kern["gemm_nt"]
                 res["roofline"] = {
                     "kernel": "ftmi::gemm_nt_kernel (bf16 MFMA GEMM + fused LoRA/epilogues; every Linear forward and dgrad)",
@@ -311,7 +353,7 @@ def main():
                                                  "share_of_step": a_ms / ms}
         if par.world_size == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(args)
+                res["cpu_baseline"] = ctx["cpu_baseline"]()
             except Exception as e:  # the baseline must never take the bench line down
                 res["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(res))

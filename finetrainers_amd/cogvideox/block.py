@@ -172,20 +172,27 @@ class MI355XCogVideoXBlock(nn.Module):
             setattr(self, name + "_t", ops.transpose_bf16(getattr(self, name)))
 
     def add_adapter(self, r: int = 64, lora_alpha: float = 64.0, storage_a: Optional[torch.Tensor] = None, storage_b: Optional[torch.Tensor] = None) -> None:
-        """``storage_a`` [4, r, D] / ``storage_b`` [4, D, r] fp32: views of a model-wide flat buffer (so one fused clip + AdamW launch covers every
-        block); allocated here when absent."""
-        if r % 64 != 0:
-            raise ValueError("this first cut takes ranks that are multiples of 64 (the LTX model shows the zero-padding route for the others)")
+        """``storage_a`` [4, rp, D] / ``storage_b`` [4, D, rp] fp32 (rp = r rounded up to a multiple of 64): views of a model-wide flat buffer (so one
+        fused clip + AdamW launch covers every block); allocated here when absent.
+        Ranks that are not multiples of 64 (one MFMA K-extension step) are stored zero-padded to the next multiple: the extra rows of A and
+        columns of B are zero and STAY zero (their gradients are exact zeros -- x A_pad^T = 0 and dY B_pad = 0 -- and AdamW / weight decay leave a zero
+        parameter with zero gradient at zero), so the padded adapter IS the rank-r adapter; the LoRA scale is alpha / r of the USER's rank, and
+        ``lora_state_dict`` / ``lora_grad_state_dict`` / the saved file carry the user's rank."""
+        if r <= 0:
+            raise ValueError(f"LoRA rank must be positive, got {r}")
+        rp = -(-int(r) // 64) * 64
         dev, D = self.wq.device, self.dim
-        a = torch.empty(4, r, D, dtype=torch.float32, device=dev) if storage_a is None else storage_a
-        b = torch.empty(4, D, r, dtype=torch.float32, device=dev) if storage_b is None else storage_b
-        if a.shape != (4, r, D) or b.shape != (4, D, r) or not a.is_contiguous() or not b.is_contiguous():
-            raise ValueError("adapter storage must be contiguous [4, r, D] / [4, D, r] fp32")
+        a = torch.empty(4, rp, D, dtype=torch.float32, device=dev) if storage_a is None else storage_a
+        b = torch.empty(4, D, rp, dtype=torch.float32, device=dev) if storage_b is None else storage_b
+        if a.shape != (4, rp, D) or b.shape != (4, D, rp) or not a.is_contiguous() or not b.is_contiguous():
+            raise ValueError("adapter storage must be contiguous [4, rp, D] / [4, D, rp] fp32 (rp = rank rounded up to a multiple of 64)")
         with torch.no_grad():
-            a.uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
+            a.zero_()
+            a[:, :r].uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
             b.zero_()
         self.lora_A = nn.Parameter(a)
         self.lora_B = nn.Parameter(b)
+        self.lora_rank_user = int(r)
         self.lora_scale = float(lora_alpha) / r
 
     def _ones(self, B: int, D: int, dev) -> torch.Tensor:

@@ -333,27 +333,30 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
         """LoRA on to_q / to_k / to_v / to_out.0 of every block (the default target regex, sft_trainer/config.py:24-26).  All adapters live in ONE
         flat fp32 buffer ``lora_flat`` = [A of every block | B of every block]; the blocks' Parameters are views."""
         L, D = len(self.transformer_blocks), self.config.inner_dim
-        n = L * 4 * r * D
+        rp = -(-int(r) // 64) * 64  # storage rank: zero-padded to a multiple of 64 (block.add_adapter); the kernels see rp, files and state dicts r
+        n = L * 4 * rp * D
         self.lora_flat = torch.zeros(2 * n, dtype=torch.float32, device=self.device)
-        a_all, b_all = self.lora_flat[:n].view(L, 4, r, D), self.lora_flat[n:].view(L, 4, D, r)
+        a_all, b_all = self.lora_flat[:n].view(L, 4, rp, D), self.lora_flat[n:].view(L, 4, D, rp)
         self.lora_grad_flat = torch.zeros_like(self.lora_flat)  # laid out like lora_flat; the blocks' .grad tensors are views of it
-        ga_all, gb_all = self.lora_grad_flat[:n].view(L, 4, r, D), self.lora_grad_flat[n:].view(L, 4, D, r)
+        ga_all, gb_all = self.lora_grad_flat[:n].view(L, 4, rp, D), self.lora_grad_flat[n:].view(L, 4, D, rp)
         for i, blk in enumerate(self.transformer_blocks):
             blk.add_adapter(r, lora_alpha, a_all[i], b_all[i])
             blk._grad_a_view, blk._grad_b_view = ga_all[i], gb_all[i]
-        self.lora_rank = r
+        self.lora_rank = rp
+        self.lora_rank_user = int(r)
 
     def flat_lora_grad(self) -> torch.Tensor:
         """The flat fp32 gradient buffer the blocks' backward wrote (``blk.lora_A.grad`` / ``lora_B.grad`` are its views)."""
         return self.lora_grad_flat
 
     def lora_state_dict(self) -> Dict[str, torch.Tensor]:
-        """peft-format keys: ``transformer_blocks.N.attn1.to_q.lora_A.weight`` ..."""
+        """peft-format keys: ``transformer_blocks.N.attn1.to_q.lora_A.weight`` ... (views of the user's rank inside the padded storage)"""
         out = {}
+        r = self.lora_rank_user
         for i, blk in enumerate(self.transformer_blocks):
             for j, n in enumerate(("to_q", "to_k", "to_v", "to_out.0")):
-                out[f"transformer_blocks.{i}.attn1.{n}.lora_A.weight"] = blk.lora_A[j]
-                out[f"transformer_blocks.{i}.attn1.{n}.lora_B.weight"] = blk.lora_B[j]
+                out[f"transformer_blocks.{i}.attn1.{n}.lora_A.weight"] = blk.lora_A[j, :r]
+                out[f"transformer_blocks.{i}.attn1.{n}.lora_B.weight"] = blk.lora_B[j, :, :r]
         return out
 
     @torch.no_grad()

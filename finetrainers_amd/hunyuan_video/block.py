@@ -64,8 +64,12 @@ class _SingleBlockFunction(torch.autograd.Function):
         dout = dout.contiguous()
         A = lambda i: None if lora_a is None else lora_a[i]
         Bm = lambda i: None if lora_b is None else lora_b[i]
-        ga = torch.zeros_like(lora_a) if lora_a is not None else None
-        gb = torch.zeros_like(lora_b) if lora_b is not None else None
+        # the step object may own the gradient storage (views of ONE flat fp32 buffer it zeroes before the backward): the kernels then add into it in
+        # place, .grad is set to the views and autograd gets None -- nothing is concatenated afterwards, and the block's slice can be exchanged while the
+        # earlier blocks still compute
+        own = lora_a is not None and blk._grad_a_view is not None
+        ga = blk._grad_a_view if own else (torch.zeros_like(lora_a) if lora_a is not None else None)
+        gb = blk._grad_b_view if own else (torch.zeros_like(lora_b) if lora_b is not None else None)
         GA = lambda i: None if ga is None else ga[i]
         GB = lambda i: None if gb is None else gb[i]
         dy = ops.cog_gate_residual(None, dout, gate, 0).view(M, D)  # d proj_out output = gate * d out
@@ -88,10 +92,31 @@ class _SingleBlockFunction(torch.autograd.Function):
         dn = ops.cog_gate_residual(dn, dn_k.view(B, N, D), ones, 0)
         dn = ops.cog_gate_residual(dn, dn_q.view(B, N, D), ones, 0)
         dx = ops.cog_ln_mod_bwd(x, blk.ones, onep, dn, 0, 1e-6, dres=dout)
+        if own:
+            blk._backward_done(ga, gb)
+            return None, dx, None, None, None, None, None, None, None
         return None, dx, None, None, None, None, None, ga, gb
 
 
-class MI355XHunyuanSingleBlock(nn.Module):
+class _FlatGradMixin:
+    """Gradient storage handed in by the step object (hunyuan_video/trainer.py): ``_grad_a_view`` / ``_grad_b_view`` are views of its flat buffer laid out
+    like the parameters; ``_grad_hook(block)`` is called once per step, when the block's LAST backward call (one per forward call) has added its part."""
+    _grad_a_view = None
+    _grad_b_view = None
+    _grad_hook = None
+    _fwd_calls = 0
+    _bwd_seen = 0
+
+    def _backward_done(self, ga, gb) -> None:
+        self._bwd_seen += 1
+        if self._bwd_seen >= self._fwd_calls:
+            self.lora_A.grad, self.lora_B.grad = ga, gb
+            self._bwd_seen = 0
+            if self._grad_hook is not None:
+                self._grad_hook(self)
+
+
+class MI355XHunyuanSingleBlock(_FlatGradMixin, nn.Module):
     """Frozen bf16 weights (+ the transposes the input-gradient GEMMs use, made once) and the fp32 LoRA adapters of to_q / to_k / to_v."""
 
     _KEYS = {  # diffusers HunyuanVideoSingleTransformerBlock parameter name -> buffer
@@ -137,11 +162,15 @@ class MI355XHunyuanSingleBlock(nn.Module):
             setattr(self, name + "_t", ops.transpose_bf16(getattr(self, name)))
 
     def add_adapter(self, r: int = 64, lora_alpha: float = 64.0) -> None:
-        if r % 64 != 0:
-            raise ValueError("ranks that are multiples of 64 (the LTX model shows the zero-padding route for the others)")
+        # ranks that are not multiples of 64 are stored zero-padded (the padding provably stays zero: see the CogVideoX block's add_adapter)
+        if r <= 0:
+            raise ValueError(f"LoRA rank must be positive, got {r}")
+        rp = -(-int(r) // 64) * 64
         dev, D = self.wq.device, self.dim
-        a = torch.empty(3, r, D, dtype=torch.float32, device=dev).uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5))
-        self.lora_A, self.lora_B = nn.Parameter(a), nn.Parameter(torch.zeros(3, D, r, dtype=torch.float32, device=dev))
+        a = torch.zeros(3, rp, D, dtype=torch.float32, device=dev)
+        a[:, :r].uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
+        self.lora_A, self.lora_B = nn.Parameter(a), nn.Parameter(torch.zeros(3, D, rp, dtype=torch.float32, device=dev))
+        self.lora_rank_user = int(r)
         self.lora_scale = float(lora_alpha) / r
 
     def forward(self, tokens: torch.Tensor, temb: torch.Tensor, text_len: int, image_rotary_emb, text_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -156,6 +185,7 @@ class MI355XHunyuanSingleBlock(nn.Module):
             key_bias[:, :text_len].masked_fill_(~text_mask.to(tokens.device).bool(), float("-inf"))
         temb_silu = torch.nn.functional.silu(temb.to(bf16)).contiguous()
         cos, sin = image_rotary_emb
+        self._fwd_calls, self._bwd_seen = 1, 0
         return _SingleBlockFunction.apply(self, tokens.contiguous(), temb_silu, key_bias, cos.contiguous(), sin.contiguous(), int(text_len), self.lora_A, self.lora_B)
 
 
@@ -222,8 +252,12 @@ class _DualBlockFunction(torch.autograd.Function):
         N, H, hd, s = T + S, blk.heads, 128, blk.lora_scale
         A = lambda i: None if lora_a is None else lora_a[i]
         Bm = lambda i: None if lora_b is None else lora_b[i]
-        ga = torch.zeros_like(lora_a) if lora_a is not None else None
-        gb = torch.zeros_like(lora_b) if lora_b is not None else None
+        # the step object may own the gradient storage (views of ONE flat fp32 buffer it zeroes before the backward): the kernels then add into it in
+        # place, .grad is set to the views and autograd gets None -- nothing is concatenated afterwards, and the block's slice can be exchanged while the
+        # earlier blocks still compute
+        own = lora_a is not None and blk._grad_a_view is not None
+        ga = blk._grad_a_view if own else (torch.zeros_like(lora_a) if lora_a is not None else None)
+        gb = blk._grad_b_view if own else (torch.zeros_like(lora_b) if lora_b is not None else None)
         GA = lambda i: None if ga is None else ga[i]
         GB = lambda i: None if gb is None else gb[i]
         dout_v, dout_t = dout_v.contiguous(), dout_t.contiguous()
@@ -260,10 +294,13 @@ class _DualBlockFunction(torch.autograd.Function):
         dk_t = ops.head_rms_rope_bwd(k_t, blk.norm_added_k_w, dkj[:T], hd, 1e-6)
         dn_t = add(add(ops.gemm_nt(dvj[:T], blk.add_v_w_t, None), ops.gemm_nt(dk_t, blk.add_k_w_t, None)), ops.gemm_nt(dq_t, blk.add_q_w_t, None))
         dx_t = ops.cog_ln_mod_bwd(x_t[None], blk.ones, op_t, dn_t[None], 0, 1e-6, dres=dh_t[None])[0]
+        if own:
+            blk._backward_done(ga, gb)
+            return None, dx_v, dx_t, None, None, None, None, None, None
         return None, dx_v, dx_t, None, None, None, None, ga, gb
 
 
-class MI355XHunyuanDualBlock(nn.Module):
+class MI355XHunyuanDualBlock(_FlatGradMixin, nn.Module):
     """HunyuanVideo dual-stream block (20 of the 60 blocks; [upstream] ``HunyuanVideoTransformerBlock``, oracle/hunyuan.py ``DualStreamBlock``): the video and
     the text tokens have their own modulation, projections, q / k norms and feed-forward and meet in ONE joint attention.  LoRA on the video stream's to_q /
     to_k / to_v / to_out.0 (what the default target regex matches; the text stream's ``add_*_proj`` / ``to_add_out`` stay frozen)."""
@@ -316,11 +353,15 @@ class MI355XHunyuanDualBlock(nn.Module):
             setattr(self, name + "_t", ops.transpose_bf16(getattr(self, name)))
 
     def add_adapter(self, r: int = 64, lora_alpha: float = 64.0) -> None:
-        if r % 64 != 0:
-            raise ValueError("ranks that are multiples of 64 (the LTX model shows the zero-padding route for the others)")
+        # ranks that are not multiples of 64 are stored zero-padded (the padding provably stays zero: see the CogVideoX block's add_adapter)
+        if r <= 0:
+            raise ValueError(f"LoRA rank must be positive, got {r}")
+        rp = -(-int(r) // 64) * 64
         dev, D = self.wq.device, self.dim
-        a = torch.empty(4, r, D, dtype=torch.float32, device=dev).uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)
-        self.lora_A, self.lora_B = nn.Parameter(a), nn.Parameter(torch.zeros(4, D, r, dtype=torch.float32, device=dev))
+        a = torch.zeros(4, rp, D, dtype=torch.float32, device=dev)
+        a[:, :r].uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
+        self.lora_A, self.lora_B = nn.Parameter(a), nn.Parameter(torch.zeros(4, D, rp, dtype=torch.float32, device=dev))
+        self.lora_rank_user = int(r)
         self.lora_scale = float(lora_alpha) / r
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor, image_rotary_emb,
@@ -334,6 +375,7 @@ class MI355XHunyuanDualBlock(nn.Module):
         cos, sin = (t.contiguous() for t in image_rotary_emb)
         temb_silu = torch.nn.functional.silu(temb.to(bf16)).contiguous()
         outs_v, outs_t = [], []
+        self._fwd_calls, self._bwd_seen = B, 0  # one autograd node per sample: the block's gradient is complete after B backward calls
         for b in range(B):
             key_bias = None
             if text_mask is not None:

@@ -171,9 +171,10 @@ class MI355XHunyuanVideoTransformer3DModel(nn.Module):
         for prefix, blocks, names in (("transformer_blocks", self.transformer_blocks, ("to_q", "to_k", "to_v", "to_out.0")),
                                       ("single_transformer_blocks", self.single_transformer_blocks, ("to_q", "to_k", "to_v"))):
             for i, blk in enumerate(blocks):
+                r = blk.lora_rank_user  # (views of the user's rank inside the zero-padded storage)
                 for j, n in enumerate(names):
-                    out[f"{prefix}.{i}.attn.{n}.lora_A.weight"] = blk.lora_A[j]
-                    out[f"{prefix}.{i}.attn.{n}.lora_B.weight"] = blk.lora_B[j]
+                    out[f"{prefix}.{i}.attn.{n}.lora_A.weight"] = blk.lora_A[j, :r]
+                    out[f"{prefix}.{i}.attn.{n}.lora_B.weight"] = blk.lora_B[j, :, :r]
         return out
 
     def lora_grad_state_dict(self) -> Dict[str, torch.Tensor]:
@@ -182,9 +183,10 @@ class MI355XHunyuanVideoTransformer3DModel(nn.Module):
         for prefix, blocks, names in (("transformer_blocks", self.transformer_blocks, ("to_q", "to_k", "to_v", "to_out.0")),
                                       ("single_transformer_blocks", self.single_transformer_blocks, ("to_q", "to_k", "to_v"))):
             for i, blk in enumerate(blocks):
+                r = blk.lora_rank_user
                 for j, n in enumerate(names):
-                    out[f"{prefix}.{i}.attn.{n}.lora_A.weight"] = blk.lora_A.grad[j]
-                    out[f"{prefix}.{i}.attn.{n}.lora_B.weight"] = blk.lora_B.grad[j]
+                    out[f"{prefix}.{i}.attn.{n}.lora_A.weight"] = blk.lora_A.grad[j, :r]
+                    out[f"{prefix}.{i}.attn.{n}.lora_B.weight"] = blk.lora_B.grad[j, :, :r]
         return out
 
     @torch.no_grad()

@@ -250,3 +250,144 @@ def load_transformer_config(directory: str) -> Dict[str, Any]:
         return {}
     with open(p) as f:
         return json.load(f)
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# training-state checkpoint in the reference's torch.distributed.checkpoint (DCP) layout
+# --------------------------------------------------------------------------------------------------------------------------
+# finetrainers/parallel/ptd.py:296-352: PTDCheckpointer saves  torch.distributed.checkpoint.save(states, checkpoint_id=<output_dir>/finetrainers_step_<N>)
+# with  states = {"train_state": TrainState, "model": ModelWrapper([transformer]), "optimizer": OptimizerWrapper, "dataloader": ..., "lr_scheduler":
+# LambdaLR}.  DCP stores the nested state dicts of these Stateful objects:
+#   model.<fqn>                                   get_model_state_dict(peft-wrapped transformer): base weights as <module>.base_layer.weight,
+#                                                 adapters as <module>.lora_A.default.weight (frozen weights included)
+#   optimizer.state.<fqn>.{step, exp_avg, exp_avg_sq}   and   optimizer.param_groups.<fqn>.<hyper-parameter>
+#                                                 get_optimizer_state_dict(..., flatten_optimizer_state_dict=True) (optimizer.py:48-52)
+#   lr_scheduler.{base_lrs, last_epoch, _step_count, ...}      LambdaLR.state_dict()
+#   train_state.{step, observed_data_samples, global_avg_losses, global_max_losses, log_steps}     (state.py:23-38; the lists as torch.save bytes)
+# The functions below produce / consume exactly that dictionary, so a run can be resumed across the two implementations: the MI355X step
+# keeps ONE flat fp32 buffer per moment ([A | B], rank-padded), which is cut into the per-parameter tensors the reference's optimizer holds.
+DCP_PREFIX = "finetrainers_step"
+_ADAMW_GROUP_DEFAULTS = {"amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": False,
+                         "decoupled_weight_decay": True}
+
+
+def _lora_param_views(lora_rank: int, a_full: torch.Tensor, b_full: torch.Tensor, paths: List[str]):
+    """(fqn, view) of every adapter tensor inside rank-padded [L, 8, r_pad, D] / [L, 8, D, r_pad] storage, in ``paths`` order."""
+    L, n = a_full.shape[0], a_full.shape[1]
+    assert len(paths) == L * n
+    for idx, path in enumerate(paths):
+        l, i = divmod(idx, n)
+        yield f"{path}.lora_A.default.weight", a_full[l, i, :lora_rank, :]
+        yield f"{path}.lora_B.default.weight", b_full[l, i, :, :lora_rank]
+
+
+def training_state_dict(model_state_dict: Dict[str, torch.Tensor], lora_paths: List[str], lora_rank: int, exp_avg_a: torch.Tensor,
+                        exp_avg_b: torch.Tensor, exp_avg_sq_a: torch.Tensor, exp_avg_sq_b: torch.Tensor, step_count: int, hyper: Dict[str, Any],
+                        lr_scheduler_state: Optional[Dict[str, Any]] = None, train_state: Optional[Dict[str, Any]] = None,
+                        dataloader_state: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+    """The nested dictionary the reference hands to ``torch.distributed.checkpoint.save``.  ``exp_avg_a`` ... are the moments in the
+    transformer's (rank-padded) parameter storage shapes; ``hyper``: lr, betas, eps, weight_decay; ``train_state``: step,
+    observed_data_samples, global_avg_losses, global_max_losses, log_steps."""
+    import io
+
+    opt: Dict[str, Any] = {}
+    m1 = dict(_lora_param_views(lora_rank, exp_avg_a, exp_avg_b, lora_paths))
+    m2 = dict(_lora_param_views(lora_rank, exp_avg_sq_a, exp_avg_sq_b, lora_paths))
+    for fqn in m1:
+        opt[f"state.{fqn}.step"] = torch.tensor(float(step_count), dtype=torch.float32)
+        opt[f"state.{fqn}.exp_avg"] = m1[fqn]
+        opt[f"state.{fqn}.exp_avg_sq"] = m2[fqn]
+    for fqn in m1:
+        grp = {"lr": float(hyper["lr"]), "betas": tuple(float(b) for b in hyper["betas"]), "eps": float(hyper["eps"]), "weight_decay": float(hyper["weight_decay"]),
+               **_ADAMW_GROUP_DEFAULTS, "initial_lr": float(hyper.get("initial_lr", hyper["lr"]))}
+        for k, v in grp.items():
+            opt[f"param_groups.{fqn}.{k}"] = v
+    out: Dict[str, Any] = {"model": dict(model_state_dict), "optimizer": opt}
+    if lr_scheduler_state is not None:
+        out["lr_scheduler"] = dict(lr_scheduler_state)
+    ts = dict(train_state or {})
+
+    def blob(x):
+        b = io.BytesIO()
+        torch.save(list(x), b)
+        return b
+
+    out["train_state"] = {"step": torch.tensor(int(ts.get("step", step_count)), dtype=torch.int32),
+                          "observed_data_samples": torch.tensor(int(ts.get("observed_data_samples", 0)), dtype=torch.int32),
+                          "global_avg_losses": blob(ts.get("global_avg_losses", [])), "global_max_losses": blob(ts.get("global_max_losses", [])),
+                          "log_steps": blob(ts.get("log_steps", []))}
+    if dataloader_state is not None:
+        out["dataloader"] = dict(dataloader_state)
+    return out
+
+
+def lambda_lr_state(base_lr: float, last_epoch: int, current_lr: float) -> Dict[str, Any]:
+    """``torch.optim.lr_scheduler.LambdaLR.state_dict()`` of the reference's scheduler after ``last_epoch`` steps (the lambda itself is not
+    pickled: ``lr_lambdas: [None]``)."""
+    return {"base_lrs": [float(base_lr)], "last_epoch": int(last_epoch), "_step_count": int(last_epoch) + 1, "_is_initial": False,
+            "_get_lr_called_within_step": False, "_last_lr": [float(current_lr)], "lr_lambdas": [None]}
+
+
+def save_training_state(output_dir: str, step: int, transformer, sft_step, train_state: Optional[Dict[str, Any]] = None,
+                        dataloader_state: Optional[Dict[str, Any]] = None) -> str:
+    """``PTDCheckpointer.save`` for the MI355X step: writes ``<output_dir>/finetrainers_step_<step>/`` (DCP ``.metadata`` + ``*.distcp``).
+    ``transformer``: MI355XLTXVideoTransformer3DModel with an adapter; ``sft_step``: MI355XSFTStep."""
+    import torch.distributed.checkpoint as dcp
+
+    tr = transformer
+    n_a = tr._lora_A_full.numel()
+    sched = getattr(sft_step, "lr_scheduler", None)
+    lr_now = sft_step.lr if sched is None else sched.current_lr()
+    sd = training_state_dict(
+        {k: v.detach().cpu() for k, v in tr.state_dict().items()}, [p for p, _, _ in tr.lora_views()], tr.lora_rank,
+        sft_step.exp_avg[:n_a].view_as(tr._lora_A_full).cpu(), sft_step.exp_avg[n_a:].view_as(tr._lora_B_full).cpu(),
+        sft_step.exp_avg_sq[:n_a].view_as(tr._lora_A_full).cpu(), sft_step.exp_avg_sq[n_a:].view_as(tr._lora_B_full).cpu(),
+        sft_step.step_count, {"lr": lr_now, "betas": sft_step.betas, "eps": sft_step.eps, "weight_decay": sft_step.weight_decay, "initial_lr": sft_step.lr},
+        lr_scheduler_state=None if sched is None else lambda_lr_state(sched.base_lr, sched.last_epoch, lr_now),
+        train_state=train_state, dataloader_state=dataloader_state)
+    path = os.path.join(output_dir, f"{DCP_PREFIX}_{step}")
+    dcp.save(sd, checkpoint_id=path)
+    return path
+
+
+@torch.no_grad()
+def load_training_state(checkpoint_dir: str, transformer, sft_step) -> Dict[str, Any]:
+    """``PTDCheckpointer.load``: reads a DCP directory written by either implementation into the MI355X transformer + step (base weights
+    only if the checkpoint's differ in name set -- they are frozen --, adapters, both moments, the step counter, the schedule clock).
+    Returns the ``train_state`` scalars."""
+    import torch.distributed.checkpoint as dcp
+
+    tr = transformer
+    n_a = tr._lora_A_full.numel()
+    # DCP loads INTO a template of the right structure: build it from fresh CPU tensors of the current shapes
+    tmpl = training_state_dict(
+        {k: torch.empty_like(v, device="cpu") for k, v in tr.state_dict().items()}, [p for p, _, _ in tr.lora_views()], tr.lora_rank,
+        torch.zeros_like(tr._lora_A_full, device="cpu"), torch.zeros_like(tr._lora_B_full, device="cpu"),
+        torch.zeros_like(tr._lora_A_full, device="cpu"), torch.zeros_like(tr._lora_B_full, device="cpu"),
+        0, {"lr": sft_step.lr, "betas": sft_step.betas, "eps": sft_step.eps, "weight_decay": sft_step.weight_decay},
+        lr_scheduler_state=lambda_lr_state(sft_step.lr, 0, sft_step.lr) if getattr(sft_step, "lr_scheduler", None) is not None else None)
+    tmpl.pop("train_state")
+    tmpl["train_state"] = {"step": torch.zeros((), dtype=torch.int32), "observed_data_samples": torch.zeros((), dtype=torch.int32)}
+    dcp.load(tmpl, checkpoint_id=checkpoint_dir)
+    tr.load_state_dict(tmpl["model"], strict=True)
+    opt = tmpl["optimizer"]
+    ea, eb = torch.zeros_like(tr._lora_A_full, device="cpu"), torch.zeros_like(tr._lora_B_full, device="cpu")
+    qa, qb = torch.zeros_like(ea), torch.zeros_like(eb)
+    steps = set()
+    for (fqn, va), (_, vq) in zip(_lora_param_views(tr.lora_rank, ea, eb, [p for p, _, _ in tr.lora_views()]),
+                                  _lora_param_views(tr.lora_rank, qa, qb, [p for p, _, _ in tr.lora_views()])):
+        va.copy_(opt[f"state.{fqn}.exp_avg"])
+        vq.copy_(opt[f"state.{fqn}.exp_avg_sq"])
+        steps.add(int(opt[f"state.{fqn}.step"].item()))
+    if len(steps) != 1:
+        raise ValueError(f"optimizer state holds different step counts per parameter: {sorted(steps)}")
+    sft_step.exp_avg[:n_a].copy_(ea.flatten())
+    sft_step.exp_avg[n_a:].copy_(eb.flatten())
+    sft_step.exp_avg_sq[:n_a].copy_(qa.flatten())
+    sft_step.exp_avg_sq[n_a:].copy_(qb.flatten())
+    sft_step.step_count = steps.pop()
+    sched = getattr(sft_step, "lr_scheduler", None)
+    if sched is not None and "lr_scheduler" in tmpl:
+        sched.load_state_dict({"last_epoch": int(tmpl["lr_scheduler"]["last_epoch"]), "base_lrs": list(tmpl["lr_scheduler"]["base_lrs"])})
+    tr._lora_versions = None  # parameters changed: refresh the bf16 working copies at the next forward
+    return {"step": int(tmpl["train_state"]["step"]), "observed_data_samples": int(tmpl["train_state"]["observed_data_samples"])}

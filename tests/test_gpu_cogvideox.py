@@ -237,10 +237,12 @@ def _block_pair(rank=64):
     return cfg, oblk, gblk, names
 
 
-@pytest.mark.parametrize("B,T,S", [(2, 8, 40), (1, 16, 150)])
+@pytest.mark.parametrize("B,T,S", [(2, 8, 40), (1, 16, 150), (1, 226, 17550)])
 def test_block_forward_backward_parity(B, T, S):
     """One CogVideoX block at the 2b width, forward and backward (dx for both token streams + the 8 LoRA gradients), against the oracle block
-    on the CPU; the LoRA-gradient bound is the oracle's own summation-order floor on the same inputs x 1.5, as for LTX."""
+    on the CPU; the LoRA-gradient bound is the oracle's own summation-order floor on the same inputs x 1.5, as for LTX.
+    (1, 226, 17550) is BASELINE config 3's real token count (49 x 480 x 720: 226 text + 17 550 video tokens): the oracle block takes ~12 s per
+    forward + backward on the box's host cores, twice for the floor."""
     from oracle import ltx
 
     cfg, oblk, gblk, names = _block_pair()
@@ -285,7 +287,8 @@ def test_block_forward_backward_parity(B, T, S):
     assert e_dv < 1e-2 and e_dt < 1e-2
     # the floor only reorders the frozen Linears; the block's remaining difference is the attention (bf16 P / dS on the MFMA, its own tile
     # order).  Bounds = the residuals measured on an MI355X x 1.5 (3.2e-3 / 5.1e-3 at B=2, S=40), and never more than 2.5 floors.
-    assert glob < BLOCK_GRAD_GLOBAL and worst < BLOCK_GRAD_WORST
+    if S < 1000:
+        assert glob < BLOCK_GRAD_GLOBAL and worst < BLOCK_GRAD_WORST
     assert glob < 2.5 * floor and worst < 2.5 * floor_worst
 
 
@@ -348,18 +351,23 @@ def test_model_step_parity_two_blocks(rotary, layers, native):
     sig = torch.tensor([0.21, 0.77])
     osch = cvx.CogVideoXDDIMScheduler()
 
-    def run_oracle():
-        for p in omodel.parameters():
+    def run_oracle(model=omodel, cast=bf16):
+        for p in model.parameters():
             p.grad = None
-        pred, target, _ = cvx.spec_forward(omodel, osch, lat, text, sig, noise=noise)
+        pred, target, _ = cvx.spec_forward(model, osch, lat.to(cast), text.to(cast), sig, noise=noise.to(cast))
         loss = cvx.sft_loss(pred, target, sig, osch)
         loss.backward()
-        return loss.item(), pred.detach(), {n: p.grad.detach().clone() for n, p in omodel.named_parameters() if p.grad is not None}
+        return loss.item(), pred.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
     loss_ref, pred_ref, g_ref = run_oracle()
     with ltx.accumulation_order_variant(512):
         _, _, g_alt = run_oracle()
     floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
+    # third corner of the triangle: the same graph on the same (bf16-valued) weights and inputs evaluated in fp32
+    import copy
+
+    _, _, g32 = run_oracle(copy.deepcopy(omodel).float(), torch.float32)
+    o32, o32_worst = ltx.grads_rel_l2(g_ref, g32)
 
     spec = MI355XCogVideoXSpecOps()
     pred, target, _ = spec.forward(gmodel, lat.to(dev), text.to(dev), sig.to(dev), noise=noise.to(dev))
@@ -377,6 +385,11 @@ def test_model_step_parity_two_blocks(rotary, layers, native):
           f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
     assert e_pred < 1e-2 * max(1.0, layers / 8) and e_loss < 1e-3
     assert glob < 2.5 * floor + 1e-3 and worst < 2.5 * floor_worst + 2e-3
+    k32, k32_worst = ltx.grads_rel_l2(got, g32)
+    print(f"[cog-model L={layers} rotary={rotary} native={native}] vs the fp32 evaluation of the graph: kernel {k32:.2e} / {k32_worst:.2e}, bf16 oracle {o32:.2e} / {o32_worst:.2e}")
+    # against exact arithmetic the kernels may not be further away than the reference's own bf16 path (+ 15 %: the two bf16 evaluations
+    # differ from each other by the floor)
+    assert k32 < 1.15 * o32 + 3e-4 and k32_worst < 1.3 * o32_worst + 1e-3
 
     # the fused step on top: sigma table, DDIM noising, forward, loss, backward, flat gradient, clip + AdamW over the model-wide LoRA buffer
     from finetrainers_amd.cogvideox import MI355XCogVideoXSFTStep
@@ -507,17 +520,18 @@ def test_specification_mirror_loads_a_diffusers_directory_and_saves_lora(tmp_pat
     assert (out / "scheduler" / "scheduler_config.json").exists()
 
 
-def _cog_two_rank_worker(rank, port, q):
+def _cog_two_rank_worker(rank, port, q, backend="gloo"):
     import os
 
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0" if backend == "gloo" else str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
 
     from finetrainers_amd.cogvideox import CogVideoXTransformerConfig, MI355XCogVideoXSFTStep, MI355XCogVideoXTransformer3DModel
     from finetrainers_amd.parallel import DataParallelBackend
     from oracle import cogvideox as cvx
 
-    par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0))
+    par = DataParallelBackend(backend=backend, device=torch.device("cuda", 0) if backend == "gloo" else None)
     try:
         kw = dict(num_layers=3, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
         omodel = cvx.build_model(cvx.CogVideoXConfig(**kw), seed=0, rank=0)
@@ -541,7 +555,14 @@ def _cog_two_rank_worker(rank, port, q):
         par.destroy()
 
 
-def test_cogvideox_dp_step_two_ranks_on_one_gpu():
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the round-end driver's multi-GPU node); single-GPU boxes run the gloo variant")
+def test_cogvideox_dp_step_two_ranks_rccl():
+    """The same world-size-2 step over RCCL on two GPUs: bucketed all-reduce (AVG) issued from inside the backward; both replicas end the step with a
+    bit-identical gradient norm (hence clip coefficient) and bit-identical parameters."""
+    test_cogvideox_dp_step_two_ranks_on_one_gpu(backend="nccl")
+
+
+def test_cogvideox_dp_step_two_ranks_on_one_gpu(backend="gloo"):
     """World size 2 over gloo on one GPU: rank 0's adapter is broadcast, the flat LoRA gradient is averaged, both replicas end the step bit-identical."""
     import os
 
@@ -549,8 +570,8 @@ def test_cogvideox_dp_step_two_ranks_on_one_gpu():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29900 + os.getpid() % 90
-    procs = [ctx.Process(target=_cog_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    port = 29900 + os.getpid() % 90 + (95 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_cog_two_rank_worker, args=(r, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
@@ -559,3 +580,52 @@ def test_cogvideox_dp_step_two_ranks_on_one_gpu():
         assert p.exitcode == 0
     (_, g0, p0), (_, g1, p1) = res
     assert g0 == g1 and (p0 == p1).all() and g0 > 0
+
+
+def test_rank32_runs_on_zero_padded_storage():
+    """--rank 32 (the reference examples' other common rank): parameters are stored at rank 64 with zero padding, the LoRA scale is alpha / 32, the
+    gradients of the 32 real rows / columns match the rank-32 oracle, the padding's gradients are exact zeros and the padding is still zero after
+    optimiser steps with weight decay; state dict and saved tensors carry rank 32."""
+    from finetrainers_amd.cogvideox import CogVideoXTransformerConfig, MI355XCogVideoXSFTStep, MI355XCogVideoXSpecOps, MI355XCogVideoXTransformer3DModel
+    from oracle import cogvideox as cvx
+    from oracle import ltx
+
+    dev = _dev()
+    kw = dict(num_layers=2, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16)
+    omodel = cvx.build_model(cvx.CogVideoXConfig(**kw), seed=0, rank=32, alpha=16.0, lora_b_std=0.02)
+    sd = {k.replace("ff.proj_in.", "ff.net.0.proj.").replace("ff.proj_out.", "ff.net.2."): v for k, v in omodel.state_dict().items()}
+    gmodel = MI355XCogVideoXTransformer3DModel(CogVideoXTransformerConfig(**kw), device=dev)
+    gmodel.load_diffusers_state_dict(sd)
+    gmodel.add_adapter(r=32, lora_alpha=16.0)
+    gmodel.load_lora_state_dict({k: v for k, v in sd.items() if "lora_" in k})
+    assert gmodel.lora_rank == 64 and gmodel.lora_rank_user == 32 and all(v.shape[0 if "lora_A" in k else 1] == 32 for k, v in gmodel.lora_state_dict().items())
+    g = torch.Generator().manual_seed(11)
+    lat, noise = torch.randn(2, 3, 16, 8, 12, generator=g).to(bf16), torch.randn(2, 3, 16, 8, 12, generator=g).to(bf16)
+    text, sig = torch.randn(2, 16, 4096, generator=g).to(bf16), torch.tensor([0.21, 0.77])
+    osch = cvx.CogVideoXDDIMScheduler()
+    pred_ref, target_ref, _ = cvx.spec_forward(omodel, osch, lat, text, sig, noise=noise)
+    loss_ref = cvx.sft_loss(pred_ref, target_ref, sig, osch)
+    loss_ref.backward()
+    g_ref = {n.replace(".default", ""): p.grad for n, p in omodel.named_parameters() if p.grad is not None}
+    spec = MI355XCogVideoXSpecOps()
+    pred, target, _ = spec.forward(gmodel, lat.to(dev), text.to(dev), sig.to(dev), noise=noise.to(dev))
+    loss = spec.loss_backward(pred, target, sig.to(dev))
+    torch.cuda.synchronize()
+    got = {}
+    for i, blk in enumerate(gmodel.transformer_blocks):
+        assert float(blk.lora_A.grad[:, 32:].abs().max()) == 0.0 and float(blk.lora_B.grad[:, :, 32:].abs().max()) == 0.0
+        for j, n in enumerate(("to_q", "to_k", "to_v", "to_out.0")):
+            got[f"transformer_blocks.{i}.attn1.{n}.lora_A.weight"] = blk.lora_A.grad[j, :32].cpu()
+            got[f"transformer_blocks.{i}.attn1.{n}.lora_B.weight"] = blk.lora_B.grad[j, :, :32].cpu()
+    assert set(got) == set(g_ref)
+    glob, worst = ltx.grads_rel_l2(got, g_ref)
+    print(f"[cog-rank32] loss {loss.item():.6f} vs {loss_ref.item():.6f}; LoRA grads {glob:.2e} (worst {worst:.2e})")
+    assert abs(loss.item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item()) and glob < 8e-3 and worst < 2e-2
+    for blk in gmodel.transformer_blocks:
+        blk.lora_A.grad = blk.lora_B.grad = None
+    step = MI355XCogVideoXSFTStep(gmodel, spec, lr=1e-3, betas=(0.9, 0.99), weight_decay=1e-2)
+    for _ in range(3):
+        step.step(lat.to(dev), text.to(dev), sigmas=sig.to(dev), noise=noise.to(dev))
+    torch.cuda.synchronize()
+    for blk in gmodel.transformer_blocks:
+        assert float(blk.lora_A[:, 32:].abs().max()) == 0.0 and float(blk.lora_B[:, :, 32:].abs().max()) == 0.0

@@ -55,19 +55,22 @@ def test_head_rms_rope_kernel_matches_the_oracle():
     assert _rel(y0.view(B, N, D), heads.detach().transpose(1, 2).flatten(2)) < 2e-3
 
 
-@pytest.mark.parametrize("B,T,S,masked", [(2, 8, 40, True), (1, 16, 150, False)])
-def test_single_stream_block_forward_backward_parity(B, T, S, masked):
+@pytest.mark.parametrize("B,T,S,masked,heads", [(2, 8, 40, True, 2), (1, 16, 150, False, 2), (1, 256, 32640, True, 24)])
+def test_single_stream_block_forward_backward_parity(B, T, S, masked, heads):
     """One single-stream block (heads of 128, LoRA r = 64 on to_q / to_k / to_v): outputs and input gradients of both token streams and the 6 LoRA
     gradients against the oracle block on the CPU (which takes [video | text]; the MI355X block keeps [text | video] -- same function of the tokens);
-    padded text keys masked like the reference's attention mask."""
+    padded text keys masked like the reference's attention mask.  The last case is BASELINE config 5's single-stream block AT ITS REAL SIZE: width
+    3072 = 24 x 128, 61 x 544 x 960 -> 32 640 video + 256 text tokens (one oracle pass of ~70 TFLOP on the box's host cores; the summation-order
+    floor is not re-run there)."""
     from finetrainers_amd.hunyuan_video import MI355XHunyuanSingleBlock
     from oracle import hunyuan as hy
     from oracle import ltx
 
     dev = _dev()
-    cfg = hy.HunyuanVideoConfig(num_attention_heads=2, attention_head_dim=128, num_layers=0, num_single_layers=1, num_refiner_layers=1, text_embed_dim=64,
+    cfg = hy.HunyuanVideoConfig(num_attention_heads=heads, attention_head_dim=128, num_layers=0, num_single_layers=1, num_refiner_layers=1, text_embed_dim=64,
                                 pooled_projection_dim=32)
     D = cfg.inner_dim
+    big = S > 10000
     torch.manual_seed(0)
     oblk = hy.SingleStreamBlock(cfg)
     with torch.no_grad():
@@ -83,7 +86,7 @@ def test_single_stream_block_forward_backward_parity(B, T, S, masked):
             lin.lora_B["default"].weight.normal_(0, 0.02, generator=g)
         setattr(oblk.attn, t, lin)
     sd = {k: v for k, v in oblk.state_dict().items()}
-    gblk = MI355XHunyuanSingleBlock(dim=D, heads=2, device=dev)
+    gblk = MI355XHunyuanSingleBlock(dim=D, heads=heads, device=dev)
     gblk.load_diffusers_state_dict({k: v for k, v in sd.items() if "lora_" not in k})
     gblk.add_adapter(r=64, lora_alpha=64.0)
     with torch.no_grad():
@@ -113,9 +116,11 @@ def test_single_stream_block_forward_backward_parity(B, T, S, masked):
         return hv.detach(), ht.detach(), vr.grad, tr.grad, grads
 
     hv_ref, ht_ref, dv_ref, dt_ref, g_ref = run_oracle()
-    with ltx.accumulation_order_variant(128):
-        _, _, _, _, g_alt = run_oracle()
-    floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
+    floor = floor_worst = float("nan")
+    if not big:
+        with ltx.accumulation_order_variant(128):
+            _, _, _, _, g_alt = run_oracle()
+        floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
 
     tokens = torch.cat([text, video], 1).to(dev).requires_grad_(True)
     out = gblk(tokens, temb.to(dev), T, (cos.to(dev), sin.to(dev)), text_mask=tmask if masked else None)
@@ -221,8 +226,10 @@ def _to_diffusers_key(k):
     return k
 
 
-def test_model_and_step_parity_small():
-    """The whole HunyuanVideo LoRA SFT forward + backward at 2 dual-stream + 2 single-stream blocks (heads of 128): spec ops (posterior draw, scaling factor,
+@pytest.mark.parametrize("nl,ns", [(2, 2), (20, 40)])
+def test_model_and_step_parity_small(nl, ns):
+    """(nl, ns) = (20, 40): BASELINE config 5's FULL DEPTH -- 20 dual-stream + 40 single-stream blocks -- at a small width and clip.)
+    The whole HunyuanVideo LoRA SFT forward + backward at 2 dual-stream + 2 single-stream blocks (heads of 128): spec ops (posterior draw, scaling factor,
     flow-match mix, guidance), patch embedding, condition embedding, masked token refiner, blocks, output norm + projection, un-patchify, loss, and the
     gradient of every one of the 28 LoRA tensors against oracle/hunyuan.py; then the fused step (grad-norm against the oracle, parameters move)."""
     import math
@@ -232,7 +239,7 @@ def test_model_and_step_parity_small():
     from oracle import ltx
 
     dev = _dev()
-    kw = dict(num_attention_heads=2, attention_head_dim=128, num_layers=2, num_single_layers=2, num_refiner_layers=1, text_embed_dim=64, pooled_projection_dim=64)
+    kw = dict(num_attention_heads=2, attention_head_dim=128, num_layers=nl, num_single_layers=ns, num_refiner_layers=1, text_embed_dim=64, pooled_projection_dim=64)
     omodel = hy.build_model(hy.HunyuanVideoConfig(**kw), seed=0, dtype=torch.float32)
     g = torch.Generator().manual_seed(7)
     with torch.no_grad():
@@ -282,6 +289,19 @@ def test_model_and_step_parity_small():
         la.mean(list(range(1, la.ndim))).mean().backward()
     g_alt = {_to_diffusers_key(n).replace(".default.", "."): p.grad.detach().clone() for n, p in omodel.named_parameters() if p.grad is not None}
     floor, floor_worst = ltx.grads_rel_l2(g_alt, g_ref)
+    # third corner of the triangle: the same graph on the same (bf16-valued) weights and inputs evaluated in fp32
+    import copy
+
+    m32 = copy.deepcopy(omodel).float()
+    for p_ in m32.parameters():
+        p_.grad = None
+    cond32 = {k: (v.float() if v.is_floating_point() else v) for k, v in cond.items()}
+    p32, t32, _ = hy.spec_forward(m32, moments.float(), cond32, sig.view(-1, 1, 1, 1, 1), noise.float(), guidance=6.0, compute_posterior=False, posterior_noise=eps.float())
+    l32 = (p32.float() - t32.float()).pow(2)
+    l32.mean(list(range(1, l32.ndim))).mean().backward()
+    g32 = {_to_diffusers_key(n).replace(".default.", "."): p.grad.detach().clone() for n, p in m32.named_parameters() if p.grad is not None}
+    o32, o32_worst = ltx.grads_rel_l2(g_ref, g32)
+    del m32
 
     spec = MI355XHunyuanVideoSpecOps()
     gcond = {k: v.to(dev) for k, v in cond.items()}
@@ -289,13 +309,16 @@ def test_model_and_step_parity_small():
     loss = spec.loss_backward(pred, target)
     torch.cuda.synchronize()
     got = {k: v.cpu() for k, v in gmodel.lora_grad_state_dict().items()}
-    assert set(got) == set(g_ref) and len(got) == 2 * (2 * 4 + 2 * 3)
+    assert set(got) == set(g_ref) and len(got) == 2 * (nl * 4 + ns * 3)
     glob, worst = ltx.grads_rel_l2(got, g_ref)
     e_pred, e_loss = _rel(pred, pred_ref.detach()), abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
-    print(f"[hunyuan-model 2+2 blocks] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref.item():.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
+    print(f"[hunyuan-model {nl}+{ns} blocks] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref.item():.6f} (rel {e_loss:.2e}) | LoRA grads {glob:.2e} (worst {worst:.2e}); "
           f"summation-order floor {floor:.2e} / {floor_worst:.2e}")
-    assert torch.equal(target.cpu(), target_ref) and e_pred < 1e-2 and e_loss < 1e-3
-    assert glob < max(2.5 * floor, 9e-3) and worst < max(2.5 * floor_worst, 1.3e-2)  # measured on an MI355X: 6.2e-3 / 8.7e-3
+    assert torch.equal(target.cpu(), target_ref) and e_pred < 1e-2 * max(1.0, (nl + ns) / 8) and e_loss < 1e-3
+    assert glob < max(2.5 * floor, 9e-3) and worst < max(2.5 * floor_worst, 1.3e-2)  # measured on an MI355X (2 + 2 blocks): 6.2e-3 / 8.7e-3
+    k32, k32_worst = ltx.grads_rel_l2(got, g32)
+    print(f"[hunyuan-model {nl}+{ns} blocks] vs the fp32 evaluation of the graph: kernel {k32:.2e} / {k32_worst:.2e}, bf16 oracle {o32:.2e} / {o32_worst:.2e}")
+    assert k32 < 1.15 * o32 + 3e-4 and k32_worst < 1.3 * o32_worst + 1e-3  # not further from exact arithmetic than the reference's own bf16 path
 
     for p in gmodel.lora_parameters():
         p.grad = None
@@ -307,7 +330,7 @@ def test_model_and_step_parity_small():
     assert abs(out["loss"].item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item()) and abs(out["grad_norm"].item() - gn_ref) < 5e-3 * gn_ref
     assert not torch.equal(step.flat, before) and gmodel.transformer_blocks[0].lora_A.grad is None
     assert gmodel.single_transformer_blocks[1].lora_B.data_ptr() >= step.flat.data_ptr()  # the adapters live in the step's flat buffer
-    assert gmodel.apply_layerwise_casting() == 2 * 24 + 2 * 10  # Linear weights + biases of the blocks (norm / modulation layers skipped)
+    assert gmodel.apply_layerwise_casting() == nl * 24 + ns * 10  # Linear weights + biases of the blocks (norm / modulation layers skipped)
 
 
 def test_hunyuan_specification_mirror_loads_a_diffusers_directory_and_saves_lora(tmp_path):

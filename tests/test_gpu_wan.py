@@ -172,15 +172,17 @@ def _wan_block_pair(D=256, heads=2, ffn=512, seed=0):
     return cfg, oblk, gblk
 
 
-@pytest.mark.parametrize("B,S,T", [(2, 48, 16), (1, 200, 64)])
-def test_wan_block_full_finetune_parity(B, S, T):
+@pytest.mark.parametrize("B,S,T,geom", [(2, 48, 16, (256, 2, 512)), (1, 200, 64, (256, 2, 512)), (1, 21504, 512, (1536, 12, 8960))])
+def test_wan_block_full_finetune_parity(B, S, T, geom):
     """One Wan block (heads of 128 like Wan2.1), forward + backward: output, gradients of the video tokens, the text tokens and the time projection,
     and the gradient of EVERY parameter (26 tensors + the modulation table) against the bf16 CPU oracle.  The yardstick printed next to each error is
-    the bf16 oracle's own distance from the same block evaluated in fp32."""
+    the bf16 oracle's own distance from the same block evaluated in fp32.  The last case is BASELINE config 4's block AT ITS REAL SIZE: Wan2.1-T2V-1.3B
+    geometry (width 1536 = 12 x 128, ffn 8960) at 81 x 512 x 512 -> 21 504 video + 512 text tokens (the oracle block takes ~15 s per forward + backward
+    on the box's host cores, twice: bf16 and fp32)."""
     from oracle import ltx, wan
 
-    cfg, oblk, gblk = _wan_block_pair()
-    dev, D, hd = _dev(), 256, 128
+    cfg, oblk, gblk = _wan_block_pair(*geom)
+    dev, D, hd = _dev(), geom[0], 128
     g = torch.Generator().manual_seed(B * 1000 + S)
     x = torch.randn(B, S, D, generator=g).to(bf16)
     enc = torch.randn(B, T, D, generator=g).to(bf16)
@@ -348,16 +350,17 @@ def test_wan_full_finetune_step_single_gpu():
     assert step.sharder.units[1].shard.data_ptr() == gmodel.blocks[0].flat.data_ptr() and gmodel.blocks[0]._param_src is None
 
 
-def _wan_two_rank_worker(rank, port, q):
+def _wan_two_rank_worker(rank, port, q, backend="gloo"):
     import os
 
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0" if backend == "gloo" else str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch
 
     from finetrainers_amd.parallel import DataParallelBackend
     from finetrainers_amd.wan import MI355XWanFullFinetuneStep
 
-    par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0))
+    par = DataParallelBackend(backend=backend, device=torch.device("cuda", 0) if backend == "gloo" else None)
     try:
         _, gmodel = _wan_model_pair(seed=rank)  # different weights per rank: the step object broadcasts rank 0's
         b = _wan_batch()
@@ -376,7 +379,14 @@ def _wan_two_rank_worker(rank, port, q):
         par.destroy()
 
 
-def test_wan_sharded_step_two_ranks_on_one_gpu():
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X (the round-end driver's multi-GPU node); single-GPU boxes run the gloo variant")
+def test_wan_sharded_step_two_ranks_rccl():
+    """The sharded step over RCCL on two GPUs: bf16 all-gather / fp32 reduce-scatter per unit across xGMI, issued asynchronously around the blocks;
+    losses, gradient norms (hence clip coefficients) and gathered parameters bit-identical on both ranks, and equal to the single-GPU step."""
+    test_wan_sharded_step_two_ranks_on_one_gpu(backend="nccl")
+
+
+def test_wan_sharded_step_two_ranks_on_one_gpu(backend="gloo"):
     """World size 2 over gloo on one GPU, both ranks on the same batch: each rank owns half of every unit, gathers before use, reduce-scatters the
     gradients; two steps end with the same parameters as the single-GPU step object (mean of two identical gradients = the gradient)."""
     import os
@@ -387,8 +397,8 @@ def test_wan_sharded_step_two_ranks_on_one_gpu():
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + os.getpid() % 90
-    procs = [ctx.Process(target=_wan_two_rank_worker, args=(r, port, q)) for r in range(2)]
+    port = 29800 + os.getpid() % 90 + (95 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_wan_two_rank_worker, args=(r, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
@@ -515,7 +525,14 @@ def test_wan_model_full_depth_parity_config4_architecture():
     print(f"[wan-model 1.3B, 30 blocks] pred {e_pred:.2e} loss {loss.item():.6f} vs {loss_ref.item():.6f} (rel {e_loss:.2e}) | all 825 parameter gradients {glob:.2e} "
           f"(worst tensor {worst:.2e}); blocks 0 / 14 / 29: {per_block[0]:.2e} / {per_block[1]:.2e} / {per_block[2]:.2e}")
     assert e_pred < 2e-2 and e_loss < 3e-3
-    assert glob < 1.5e-2 and worst < 0.15
+    # per tensor: the weight matrices (the bulk of the 1.42 B parameters) and the 1-D tensors (biases, norm weights, modulation rows: sums over
+    # tokens of bf16-rounded rows, a few of them tiny against the bf16 noise they collect) are bounded separately
+    mats = {k: v for k, v in g_ref.items() if v.dim() >= 2 and min(v.shape) > 8}
+    vecs = {k: v for k, v in g_ref.items() if k not in mats}
+    w_mat = ltx.grads_rel_l2({k: got[k] for k in mats}, mats)[1]
+    w_vec = ltx.grads_rel_l2({k: got[k] for k in vecs}, vecs)[1]
+    print(f"[wan-model 1.3B, 30 blocks] worst weight matrix {w_mat:.2e} ({len(mats)} tensors), worst 1-D tensor {w_vec:.2e} ({len(vecs)} tensors)")
+    assert glob < 1.5e-2 and w_mat < 4e-2 and w_vec < 0.15
 
 
 def test_wan_sharded_step_on_rccl_single_rank():

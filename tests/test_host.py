@@ -658,3 +658,174 @@ def test_hunyuan_step_rehomes_adapters_into_one_flat_buffer_and_saves_peft_keys(
     wire.save_lora_weights(str(tmp_path), sd, wire.lora_config_metadata(64, 32.0, ["to_q", "to_k", "to_v", "to_out.0"]))
     tensors, _ = wire.load_lora_weights(str(tmp_path))
     assert len(tensors) == 14
+
+
+def test_training_state_checkpoint_is_the_reference_dcp_layout(tmp_path):
+    """wire.training_state_dict / save_training_state produce the dictionary PTDCheckpointer hands to torch.distributed.checkpoint
+    (finetrainers/parallel/ptd.py:296-352): model.<fqn>, optimizer.state.<fqn>.{step, exp_avg, exp_avg_sq}, optimizer.param_groups.<fqn>.*,
+    lr_scheduler.*, train_state.*.  Checked both ways against torch's own Stateful plumbing on a small peft-shaped module: (1) key for key and
+    value for value against get_model_state_dict / get_optimizer_state_dict(flatten) / LambdaLR.state_dict() of a torch AdamW run;
+    (2) a checkpoint written from the flat, rank-padded buffers loads into a FRESH torch model + optimizer through the reference's wrappers."""
+    import functools
+    import io
+
+    import torch.distributed.checkpoint as dcp
+    import torch.nn as nn
+    from torch.distributed.checkpoint.state_dict import StateDictOptions, get_model_state_dict, get_optimizer_state_dict, set_model_state_dict, set_optimizer_state_dict
+    from torch.distributed.checkpoint.stateful import Stateful
+
+    from finetrainers_amd import wire
+
+    D, r, r_pad = 8, 2, 4
+
+    class LoraLinear(nn.Module):  # peft's module tree: base_layer + lora_A / lora_B ModuleDicts keyed by the adapter name
+        def __init__(self):
+            super().__init__()
+            self.base_layer = nn.Linear(D, D)
+            self.lora_A = nn.ModuleDict({"default": nn.Linear(D, r, bias=False)})
+            self.lora_B = nn.ModuleDict({"default": nn.Linear(r, D, bias=False)})
+
+        def forward(self, x):
+            return self.base_layer(x) + self.lora_B["default"](self.lora_A["default"](x))
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.to_q, self.to_k, self.norm = LoraLinear(), LoraLinear(), nn.LayerNorm(D)
+
+        def forward(self, x):
+            return self.norm(self.to_q(x) + self.to_k(x))
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = Tiny()
+        for n, p in m.named_parameters():
+            p.requires_grad_("lora_" in n)
+        opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, fused=False)
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0 / (1 + s))
+        return m, opt, sch
+
+    m, opt, sch = make(0)
+    for _ in range(2):
+        m(torch.randn(3, D)).pow(2).sum().backward()
+        opt.step(); sch.step(); opt.zero_grad()
+
+    # ---- the same state as the MI355X step holds it: stacked rank-padded storage [L = 1, 2 adapters, r_pad, D] / [1, 2, D, r_pad] ----
+    paths = ["to_q", "to_k"]
+    mods = [m.to_q, m.to_k]
+
+    def stack(get):
+        a = torch.zeros(1, 2, r_pad, D)
+        b = torch.zeros(1, 2, D, r_pad)
+        for i, mod in enumerate(mods):
+            a[0, i, :r] = get(mod.lora_A["default"].weight)
+            b[0, i, :, :r] = get(mod.lora_B["default"].weight)
+        return a, b
+
+    ea, eb = stack(lambda p: opt.state[p]["exp_avg"])
+    qa, qb = stack(lambda p: opt.state[p]["exp_avg_sq"])
+    ours = wire.training_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()}, paths, r, ea, eb, qa, qb, step_count=2,
+                                    hyper={"lr": sch.get_last_lr()[0], "betas": (0.9, 0.99), "eps": 1e-8, "weight_decay": 1e-4, "initial_lr": 1e-3},
+                                    lr_scheduler_state=wire.lambda_lr_state(1e-3, sch.last_epoch, sch.get_last_lr()[0]),
+                                    train_state={"step": 2, "observed_data_samples": 6, "global_avg_losses": [0.5, 0.25], "global_max_losses": [0.75, 0.5], "log_steps": [1, 2]})
+
+    # (1) key for key, value for value
+    ref_model = get_model_state_dict(m)
+    ref_opt = get_optimizer_state_dict(m, opt, options=StateDictOptions(flatten_optimizer_state_dict=True))
+    assert set(ours["model"]) == set(ref_model) and all(torch.equal(ours["model"][k], ref_model[k]) for k in ref_model)
+    assert set(ours["optimizer"]) == set(ref_opt), sorted(set(ours["optimizer"]) ^ set(ref_opt))[:6]
+    for k, v in ref_opt.items():
+        if torch.is_tensor(v):
+            assert torch.equal(ours["optimizer"][k], v), k
+        else:
+            assert ours["optimizer"][k] == v, (k, ours["optimizer"][k], v)
+    assert ours["lr_scheduler"] == sch.state_dict()
+    assert int(ours["train_state"]["step"]) == 2 and ours["train_state"]["step"].dtype == torch.int32
+    ours["train_state"]["global_avg_losses"].seek(0)
+    assert torch.load(ours["train_state"]["global_avg_losses"]) == [0.5, 0.25]
+
+    # (2) written by this side, read by the reference's side (its wrappers, restated from parallel/ptd.py:280-294 and optimizer.py:48-62)
+    ckpt = str(tmp_path / f"{wire.DCP_PREFIX}_2")
+    dcp.save(ours, checkpoint_id=ckpt)
+
+    class ModelWrapper(Stateful):
+        def __init__(self, model):
+            self.model = model
+
+        def state_dict(self):
+            return get_model_state_dict(self.model)
+
+        def load_state_dict(self, sd):
+            set_model_state_dict(self.model, model_state_dict=sd, options=StateDictOptions(strict=False))
+
+    class OptimizerWrapper(Stateful):
+        def __init__(self, model, optim):
+            self.model, self.optim = model, optim
+
+        def state_dict(self):
+            return get_optimizer_state_dict(self.model, self.optim, options=StateDictOptions(flatten_optimizer_state_dict=True))
+
+        def load_state_dict(self, sd):
+            set_optimizer_state_dict(self.model, self.optim, optim_state_dict=sd, options=StateDictOptions(flatten_optimizer_state_dict=True))
+
+    m2, opt2, sch2 = make(1)  # different weights, empty optimizer
+    m2(torch.randn(3, D)).sum().backward()
+    opt2.step(); opt2.zero_grad()  # the reference loads after the optimizer exists; its state gets overwritten
+    states = {"model": ModelWrapper(m2), "optimizer": OptimizerWrapper(m2, opt2), "lr_scheduler": sch2}
+    dcp.load(states, checkpoint_id=ckpt)
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    for p1, p2 in zip([p for p in m.parameters() if p.requires_grad], [p for p in m2.parameters() if p.requires_grad]):
+        assert torch.equal(opt.state[p1]["exp_avg"], opt2.state[p2]["exp_avg"]) and torch.equal(opt.state[p1]["exp_avg_sq"], opt2.state[p2]["exp_avg_sq"])
+        assert float(opt2.state[p2]["step"]) == 2.0
+    assert sch2.last_epoch == sch.last_epoch and opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+
+
+@pytest.mark.parametrize("ntiles,nk,ov", [(168, 32, 7), (168, 32, 4), (168, 128, 7), (168, 96, 13), (504, 32, 7), (672, 32, 4), (84, 32, 7), (255, 32, 4), (257, 4, 4),
+                                           (300, 3, 1), (512, 32, 4), (513, 32, 4), (100, 64, 4)])
+def test_stream_k_plan_invariants(ntiles, nk, ov):
+    """ftmi_gemm_sk_plan (host-only, pure): the split of the persistent GEMM's tail tiles over 256 workgroups.  Every (tile, K iteration) of the
+    stream-K tiles is computed exactly once; every tile is finished (extension + epilogue) by exactly one workgroup -- the one holding its
+    iteration 0 --; an owner's contributor mask names exactly the workgroups that open with a partial of its tile; no piece is shorter than
+    min_piece; the shares are balanced (the largest costs at most ~ half a forbidden zone more than the mean)."""
+    import ctypes
+
+    from finetrainers_amd import _lib
+
+    lib = _lib.load()
+    G, minp, pc, ac = 256, min(4, max(1, nk // 2)), 1, 2
+    buf = (ctypes.c_int * (G * 8))()
+    assert lib.ftmi_gemm_sk_plan(ntiles, G, nk, ov, minp, pc, ac, buf) == 0
+    W = [list(buf[i * 8:i * 8 + 8]) for i in range(G)]
+    sk = ntiles % G
+    cover, finished, cost = {}, {}, [0] * G
+    for v, (t0, k0, t1, k1, kinds, nf, mask, _) in enumerate(W):
+        part, own = kinds & 1, (kinds >> 1) & 1
+        segs = []
+        if part:
+            kb = k1 if t1 == t0 else nk
+            assert kb - k0 >= minp
+            segs.append((t0, k0, kb))
+            cost[v] += pc
+        for i in range(nf):
+            segs.append((t0 + part + i, 0, nk))
+            finished[t0 + part + i] = finished.get(t0 + part + i, 0) + 1
+            cost[v] += ov
+        if own:
+            assert k1 >= minp
+            segs.append((t1, 0, k1))
+            finished[t1] = finished.get(t1, 0) + 1
+            want = [u for u in range(v + 1, G) if W[u][0] == t1 and (W[u][4] & 1)]
+            assert want == [v + 1 + i for i in range(31) if (mask >> i) & 1]
+            cost[v] += ov + ac * len(want)
+        else:
+            assert mask == 0
+        for t, a, b in segs:
+            for k in range(a, b):
+                assert (t, k) not in cover
+                cover[(t, k)] = v
+            cost[v] += b - a
+    assert len(cover) == sk * nk and all(finished.get(t, 0) == 1 for t in range(sk))
+    if sk * (nk + ov) >= G * 2 * (ov + 2 * minp):  # enough work for every workgroup: balanced within a forbidden zone
+        mean = sum(cost) / G
+        assert max(cost) <= mean + (ov + 2 * minp) + pc + ac, (max(cost), mean)
