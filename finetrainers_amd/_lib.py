@@ -109,6 +109,7 @@ _SIGS = {
     "ftmi_gemm_sk_status": (c_int, []),
     "ftmi_gemm_sk_trace": (c_int, [POINTER(ctypes.c_ulonglong), c_int]),
     "ftmi_gemm_tn": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_float, c_void_p]),
+    "ftmi_fp8_upcast": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ftmi_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ftmi_norm_modulate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ftmi_norm_modulate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),

@@ -260,6 +260,11 @@ int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, lo
     return gemm_tn(a, (hipStream_t)stream);
 }
 
+int ftmi_fp8_upcast(const void* src, void* dst, int rows, int cols, int transpose, ftmi_stream stream) {
+    if (!src || !dst) return set_error(FTMI_ERR_INVALID, "ftmi_fp8_upcast: null tensor");
+    return fp8_upcast((const uint8_t*)src, (bf16_t*)dst, rows, cols, transpose, (hipStream_t)stream);
+}
+
 int ftmi_transpose_bf16(const void* in, void* out, int rows, int cols, ftmi_stream stream) {
     if (!in || !out) return set_error(FTMI_ERR_INVALID, "ftmi_transpose_bf16: null tensor");
     return transpose_bf16((const bf16_t*)in, (bf16_t*)out, rows, cols, (hipStream_t)stream);

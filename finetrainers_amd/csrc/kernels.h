@@ -114,6 +114,8 @@ struct GemmTnArgs {
     long u_bstride = 0, v_bstride = 0, c_bstride = 0;
 };
 int gemm_tn(const GemmTnArgs& a, hipStream_t st);
+// fp8 (e4m3fn) weight storage: exact up-cast to bf16, plain [rows, cols] or transposed [cols, rows] (cast.hip)
+int fp8_upcast(const uint8_t* src, bf16_t* dst, int rows, int cols, int transpose, hipStream_t st);
 
 // ---- attention -----------------------------------------------------------------------------------
 struct AttnArgs {

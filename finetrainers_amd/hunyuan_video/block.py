@@ -56,6 +56,8 @@ class _SingleBlockFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         blk, T, rope = ctx.blk, ctx.T, ctx.rope
+        if blk._bwd_seen == 0:
+            blk._materialize_bwd()  # fp8 storage: the transposed bf16 weights of THIS block into the shared arena (no-op otherwise)
         x, n, q, k, qn, kn, v, o, lse, pre, cat, onep, gate, xa_q, xa_k, xa_v, lora_a, lora_b = ctx.saved_tensors
         if not ctx.has_lora:
             lora_a = lora_b = None
@@ -116,7 +118,60 @@ class _FlatGradMixin:
                 self._grad_hook(self)
 
 
-class MI355XHunyuanSingleBlock(_FlatGradMixin, nn.Module):
+class _Fp8StorageMixin:
+    """Real fp8 weight storage (the reference's layerwise up-casting, trainer/sft_trainer/trainer.py:111-118: storage float8_e4m3fn, compute bf16).
+    ``store_weights_fp8`` moves every 2-D frozen weight of the block into e4m3fn bytes and drops its bf16 buffer and its transposed bf16 copy;
+    ``_materialize_fwd`` / ``_materialize_bwd`` cast the block's weights up into a bf16 arena the model shares between ALL blocks (forward layout /
+    transposed layout for the input-gradient GEMMs) right before the block's forward / backward kernels are queued -- same stream, so the arena is
+    reused safely block after block.  1 byte per frozen parameter in HBM instead of 4 (bf16 + transposed bf16)."""
+    _w8 = None          # name -> float8_e4m3fn tensor
+    _arena_fwd = None   # bf16 scratch shared by all blocks (set by the model)
+    _arena_bwd = None
+
+    def _weight_names_2d(self):
+        # (the reference's skip patterns keep every module whose name contains "norm" in bf16 -- args.py:395 --: the AdaLN Linear layers stay as they are)
+        return [n for n, b in self.named_buffers() if b is not None and b.dim() == 2 and not n.endswith("_t") and not n.startswith("norm")]
+
+    def _transposed_names(self):
+        return list(getattr(self, "_TRANSPOSED", ("wq", "wk", "wv", "proj_mlp_w", "proj_out_w")))
+
+    def fp8_elements(self):
+        """(elements of all 2-D weights, elements of the transposed subset): what the two arenas must hold."""
+        src = self._w8 if self._w8 is not None else {n: getattr(self, n) for n in self._weight_names_2d()}
+        return sum(v.numel() for v in src.values()), sum(src[n].numel() for n in self._transposed_names())
+
+    @torch.no_grad()
+    def store_weights_fp8(self) -> int:
+        names = self._weight_names_2d()
+        self._w8 = {n: getattr(self, n).to(torch.float8_e4m3fn).contiguous() for n in names}
+        self._shapes = {n: tuple(getattr(self, n).shape) for n in names}
+        for n in names:
+            setattr(self, n, None)
+        for n in self._transposed_names():
+            setattr(self, n + "_t", None)
+        return len(names)
+
+    def _materialize_fwd(self) -> None:
+        if self._w8 is None:
+            return
+        off = 0
+        for n, w8 in self._w8.items():
+            k = w8.numel()
+            setattr(self, n, ops.fp8_upcast(w8, out=self._arena_fwd[off:off + k]))
+            off += k
+
+    def _materialize_bwd(self) -> None:
+        if self._w8 is None:
+            return
+        off = 0
+        for n in self._transposed_names():
+            w8 = self._w8[n]
+            k = w8.numel()
+            setattr(self, n + "_t", ops.fp8_upcast(w8, out=self._arena_bwd[off:off + k], transpose=True))
+            off += k
+
+
+class MI355XHunyuanSingleBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
     """Frozen bf16 weights (+ the transposes the input-gradient GEMMs use, made once) and the fp32 LoRA adapters of to_q / to_k / to_v."""
 
     _KEYS = {  # diffusers HunyuanVideoSingleTransformerBlock parameter name -> buffer
@@ -152,6 +207,8 @@ class MI355XHunyuanSingleBlock(_FlatGradMixin, nn.Module):
 
     @torch.no_grad()
     def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        if self._w8 is not None:
+            raise RuntimeError("the block's weights are stored in fp8: load the bf16 weights first, cast afterwards")
         sd = {k.replace(".base_layer.", "."): v for k, v in sd.items()}
         missing = [k for k in self._KEYS if k not in sd]
         if missing:
@@ -166,7 +223,7 @@ class MI355XHunyuanSingleBlock(_FlatGradMixin, nn.Module):
         if r <= 0:
             raise ValueError(f"LoRA rank must be positive, got {r}")
         rp = -(-int(r) // 64) * 64
-        dev, D = self.wq.device, self.dim
+        dev, D = self.ones.device, self.dim  # (self.wq is gone once the weights are stored in fp8)
         a = torch.zeros(3, rp, D, dtype=torch.float32, device=dev)
         a[:, :r].uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
         self.lora_A, self.lora_B = nn.Parameter(a), nn.Parameter(torch.zeros(3, D, rp, dtype=torch.float32, device=dev))
@@ -176,8 +233,9 @@ class MI355XHunyuanSingleBlock(_FlatGradMixin, nn.Module):
     def forward(self, tokens: torch.Tensor, temb: torch.Tensor, text_len: int, image_rotary_emb, text_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``tokens`` [B, T + S, D] bf16 (text first), ``temb`` [B, D] the conditioning vector, ``image_rotary_emb`` = (cos, sin) fp32 [S, 128],
         ``text_mask`` [B, T] (1 = real token; None: all real) -> the block's output tokens in the same layout."""
-        if self.wq_t is None:
+        if self.wq_t is None and self._w8 is None:
             raise RuntimeError("load_diffusers_state_dict first (it also builds the transposed weights the input-gradient GEMMs use)")
+        self._materialize_fwd()
         B, N, _ = tokens.shape
         key_bias = None
         if text_mask is not None:  # padded text tokens are never attended to (the reference masks every key beyond a sample's real text length)
@@ -243,6 +301,8 @@ class _DualBlockFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout_v, dout_t):
         blk, rope = ctx.blk, ctx.rope
+        if blk._bwd_seen == 0:
+            blk._materialize_bwd()  # fp8 storage: the transposed bf16 weights of THIS block into the shared arena (no-op otherwise)
         (x_v, x_t, n_v, n_t, q_v, k_v, q_t, k_t, qj, kj, vj, o, lse, h_v, h_t, n2_v, n2_t, pre_v, pre_t, g_v, g_t, gm_v, gm_t, op_v, op_t, opm_v, opm_t,
          xa_q, xa_k, xa_v, xa_o, lora_a, lora_b) = ctx.saved_tensors
         if not ctx.has_lora:
@@ -300,7 +360,7 @@ class _DualBlockFunction(torch.autograd.Function):
         return None, dx_v, dx_t, None, None, None, None, ga, gb
 
 
-class MI355XHunyuanDualBlock(_FlatGradMixin, nn.Module):
+class MI355XHunyuanDualBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
     """HunyuanVideo dual-stream block (20 of the 60 blocks; [upstream] ``HunyuanVideoTransformerBlock``, oracle/hunyuan.py ``DualStreamBlock``): the video and
     the text tokens have their own modulation, projections, q / k norms and feed-forward and meet in ONE joint attention.  LoRA on the video stream's to_q /
     to_k / to_v / to_out.0 (what the default target regex matches; the text stream's ``add_*_proj`` / ``to_add_out`` stay frozen)."""
@@ -343,6 +403,8 @@ class MI355XHunyuanDualBlock(_FlatGradMixin, nn.Module):
 
     @torch.no_grad()
     def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        if self._w8 is not None:
+            raise RuntimeError("the block's weights are stored in fp8: load the bf16 weights first, cast afterwards")
         sd = {k.replace(".base_layer.", "."): v for k, v in sd.items()}
         missing = [k for k in self._KEYS if k not in sd]
         if missing:
@@ -357,7 +419,7 @@ class MI355XHunyuanDualBlock(_FlatGradMixin, nn.Module):
         if r <= 0:
             raise ValueError(f"LoRA rank must be positive, got {r}")
         rp = -(-int(r) // 64) * 64
-        dev, D = self.wq.device, self.dim
+        dev, D = self.ones.device, self.dim  # (self.wq is gone once the weights are stored in fp8)
         a = torch.zeros(4, rp, D, dtype=torch.float32, device=dev)
         a[:, :r].uniform_(-(1.0 / D) ** 0.5, (1.0 / D) ** 0.5)  # kaiming_uniform_(a = sqrt(5)) on [r, D]
         self.lora_A, self.lora_B = nn.Parameter(a), nn.Parameter(torch.zeros(4, D, rp, dtype=torch.float32, device=dev))
@@ -368,8 +430,9 @@ class MI355XHunyuanDualBlock(_FlatGradMixin, nn.Module):
                 text_mask: Optional[torch.Tensor] = None):
         """``hidden_states`` [B, S, D] (video), ``encoder_hidden_states`` [B, T, D] (text), ``temb`` [B, D], ``image_rotary_emb`` = (cos, sin) fp32 [S, 128],
         ``text_mask`` [B, T] (1 = real token) -> (video, text) like the reference block."""
-        if self.wq_t is None:
+        if self.wq_t is None and self._w8 is None:
             raise RuntimeError("load_diffusers_state_dict first (it also builds the transposed weights the input-gradient GEMMs use)")
+        self._materialize_fwd()
         B, S, _ = hidden_states.shape
         T = encoder_hidden_states.shape[1]
         cos, sin = (t.contiguous() for t in image_rotary_emb)

@@ -196,20 +196,36 @@ class MI355XHunyuanVideoTransformer3DModel(nn.Module):
             v.copy_(sd[k].to(v))
 
     @torch.no_grad()
-    def apply_layerwise_casting(self, storage_dtype: torch.dtype = torch.float8_e4m3fn) -> int:
-        """Config 5's "fake-fp8 weight cast" (trainer/sft_trainer/trainer.py:111-118 -> diffusers ``apply_layerwise_casting``): Linear weights and biases are
-        STORED in fp8 and cast up for every forward; the up-cast is exact, so the arithmetic is that of bf16 weights holding fp8-representable values --
-        the frozen weights are rounded once here and kept in bf16 (288 GB make the storage saving irrelevant).  Norm layers, embeddings and the output
+    def apply_layerwise_casting(self, storage_dtype: torch.dtype = torch.float8_e4m3fn, real_storage: bool = True) -> int:
+        """Config 5's "fake-fp8 weight cast" (trainer/sft_trainer/trainer.py:111-118 -> diffusers ``apply_layerwise_casting``): Linear weights and biases of
+        the blocks are STORED in fp8 and cast up to bf16 for every forward; the up-cast is exact, so the arithmetic is that of bf16 weights holding
+        fp8-representable values.  ``real_storage`` (default): the 2-D weights really live as e4m3fn bytes -- 1 byte per frozen parameter instead of the 4 of
+        a bf16 copy plus its transposed twin -- and every block casts its weights up into a bf16 arena shared by all blocks right before it runs
+        (``ftmi_fp8_upcast``; forward layout / transposed layout for the input-gradient GEMMs).  ``real_storage=False``: the weights are rounded to
+        fp8-representable values and kept in bf16 (same numbers, no saving).  Norm layers (the AdaLN Linears included), embeddings and the output
         projection are skipped like the reference's default pattern (args.py:395).  Returns the number of tensors cast."""
+        if storage_dtype != torch.float8_e4m3fn and real_storage:
+            raise ValueError("real fp8 storage is e4m3fn (the reference's --layerwise_upcasting_storage_dtype default); other dtypes: real_storage=False")
         n = 0
-        for blk in list(self.transformer_blocks) + list(self.single_transformer_blocks):
+        blocks = list(self.transformer_blocks) + list(self.single_transformer_blocks)
+        for blk in blocks:
             for name, buf in blk.named_buffers():
                 if buf is None or name.endswith("_t") or name in ("ones", "zeros") or name.startswith("norm"):
                     continue
                 buf.copy_(buf.to(storage_dtype).to(bf16))
                 n += 1
-            for name in getattr(blk, "_TRANSPOSED", ("wq", "wk", "wv", "proj_mlp_w", "proj_out_w")):
-                setattr(blk, name + "_t", ops.transpose_bf16(getattr(blk, name)))
+            if real_storage:
+                blk.store_weights_fp8()
+            else:
+                for name in getattr(blk, "_TRANSPOSED", ("wq", "wk", "wv", "proj_mlp_w", "proj_out_w")):
+                    setattr(blk, name + "_t", ops.transpose_bf16(getattr(blk, name)))
+        if real_storage and blocks:
+            n_fwd = max(blk.fp8_elements()[0] for blk in blocks)
+            n_bwd = max(blk.fp8_elements()[1] for blk in blocks)
+            self._weight_arena_fwd = torch.empty(n_fwd, dtype=bf16, device=self.device)
+            self._weight_arena_bwd = torch.empty(n_bwd, dtype=bf16, device=self.device)
+            for blk in blocks:
+                blk._arena_fwd, blk._arena_bwd = self._weight_arena_fwd, self._weight_arena_bwd
         return n
 
     # -- frozen front: forward only -----------------------------------------------------------------------------------------------------------------

@@ -115,6 +115,21 @@ def gemm_tn(u: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def fp8_upcast(w8: torch.Tensor, out: Optional[torch.Tensor] = None, transpose: bool = False) -> torch.Tensor:
+    """bf16 copy of a [rows, cols] ``torch.float8_e4m3fn`` weight (exact), optionally transposed to [cols, rows]; ``out``: a contiguous bf16 tensor of the
+    result's size (e.g. a slice of a per-model weight arena)."""
+    if w8.dtype != torch.float8_e4m3fn or w8.dim() != 2 or not w8.is_contiguous() or not w8.is_cuda:
+        raise ValueError("fp8_upcast: a contiguous 2-D float8_e4m3fn tensor on the GPU is required")
+    rows, cols = w8.shape
+    shape = (cols, rows) if transpose else (rows, cols)
+    if out is None:
+        out = torch.empty(shape, dtype=bf16, device=w8.device)
+    elif out.numel() != rows * cols or out.dtype != bf16 or not out.is_contiguous():
+        raise ValueError("fp8_upcast: out must be a contiguous bf16 tensor with rows * cols elements")
+    check(_lib.load().ftmi_fp8_upcast(ptr(w8), ptr(out), rows, cols, int(transpose), stream_ptr()), "ftmi_fp8_upcast")
+    return out.view(shape)
+
+
 def transpose_bf16(x: torch.Tensor) -> torch.Tensor:
     rows, cols = x.shape
     out = torch.empty((cols, rows), dtype=bf16, device=x.device)

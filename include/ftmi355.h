@@ -130,6 +130,10 @@ int ftmi_gemm_sk_trace(unsigned long long* out, int capacity);
 /* c[P,Q] (fp32) += scale * u[M,P]^T v[M,Q] */
 int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, long ldv, float* c, long ldc, float scale,
                  ftmi_stream stream);
+/* fp8 weight storage of the layerwise up-casting recipe (finetrainers/trainer/sft_trainer/trainer.py:111-118: storage float8_e4m3fn, compute bf16):
+ * dst (bf16) = exact up-cast of src [rows, cols] (OCP e4m3fn bytes); transpose != 0: dst is [cols, rows] = src^T (rows, cols multiples of 64) -- the layout
+ * the input-gradient GEMMs read.  Called per block right before it runs; 1 byte read + 2 bytes written per weight. */
+int ftmi_fp8_upcast(const void* src, void* dst, int rows, int cols, int transpose, ftmi_stream stream);
 /* out[cols,rows] = in[rows,cols]^T (bf16); used once at load time for the dgrad copies of frozen weights */
 int ftmi_transpose_bf16(const void* in, void* out, int rows, int cols, ftmi_stream stream);
 

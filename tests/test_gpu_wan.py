@@ -218,7 +218,8 @@ def test_wan_block_full_finetune_parity(B, S, T, geom):
     print(f"[wan-block B={B} S={S} T={T}] out {e_o:.2e} (oracle bf16 vs fp32 {_rel(o_ref, o32):.2e}) | dx {e_dx:.2e} ({_rel(dx_ref, dx32):.2e}) "
           f"d text {e_de:.2e} ({_rel(de_ref, de32):.2e}) d temb {e_dt:.2e} ({_rel(dt_ref, dt32):.2e}) | parameter grads vs bf16 oracle {glob:.2e} (worst {worst:.2e}), "
           f"vs fp32 oracle {glob32:.2e} (worst {worst32:.2e}); bf16 oracle vs fp32 oracle {floor:.2e} (worst {floor_worst:.2e})")
-    assert e_o < 5e-3 and e_dx < 1e-2 and e_de < 1e-2 and e_dt < 1e-2
+    # (the text-token gradient at the real size sums 21 504 queries' bf16 contributions per text row: the bf16 oracle itself is 1.3e-2 from fp32 there)
+    assert e_o < 5e-3 and e_dx < 1e-2 and e_de < max(1e-2, 1.1 * _rel(de_ref, de32)) and e_dt < 1e-2
     assert glob < 2.0 * floor + 2e-3 and worst < 2.0 * floor_worst + 5e-3  # both sides carry bf16 noise of the size of the floor
     # against the fp32 evaluation of the same block the kernels must not be further away than the reference's own bf16 path (x 1.5)
     assert glob32 < 1.5 * floor + 1e-3 and worst32 < 1.5 * floor_worst + 2e-3
@@ -532,7 +533,9 @@ def test_wan_model_full_depth_parity_config4_architecture():
     w_mat = ltx.grads_rel_l2({k: got[k] for k in mats}, mats)[1]
     w_vec = ltx.grads_rel_l2({k: got[k] for k in vecs}, vecs)[1]
     print(f"[wan-model 1.3B, 30 blocks] worst weight matrix {w_mat:.2e} ({len(mats)} tensors), worst 1-D tensor {w_vec:.2e} ({len(vecs)} tensors)")
-    assert glob < 1.5e-2 and w_mat < 4e-2 and w_vec < 0.15
+    # yardstick (block test above, same architecture): the bf16 oracle's OWN worst tensors against fp32 are 3.4e-2 ... 3.9e-2 (small clips) and 0.19 (a 1-D tensor
+    # at the real token count)
+    assert glob < 1.5e-2 and w_mat < 3e-2 and w_vec < 0.15
 
 
 def test_wan_sharded_step_on_rccl_single_rank():
