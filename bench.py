@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--height", type=int, default=16, help="latent height (512 / 32)")
     ap.add_argument("--width", type=int, default=24, help="latent width  (768 / 32)")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("FTMI_GEMM_VARIANT", "8")))
+    ap.add_argument("--gradient-checkpointing", action="store_true",
+                    help="hunyuan only: every block keeps its input and recomputes its forward inside the backward (the reference's --gradient_checkpointing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["full", "quick"], default="full",
                     help="full: SURVEY 8d protocol (1 warm-up + 3 timed steps; cfg 2 on --cpu-baseline-layers blocks in bf16 and fp32, cfg 1 at full depth); "
@@ -61,6 +63,8 @@ def parse():
         a.steps = 30 if a.workload == "ltx" else 10
     if a.workload == "ltx" and a.layers <= 0:
         a.layers = 28
+    if a.gradient_checkpointing and a.workload != "hunyuan":
+        ap.error("--gradient-checkpointing: only the hunyuan workload recomputes (the other three keep their activations: 10 / 63 / 74 GiB of 288)")
     return a
 
 

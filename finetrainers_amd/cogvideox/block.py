@@ -62,14 +62,14 @@ class _BlockFunction(torch.autograd.Function):
 
         ctx.blk, ctx.T, ctx.rope = blk, T, rope
         ctx.has_lora = lora_a is not None
-        ctx.save_for_backward(x, n1, q, k, qn, kn, v, o, lse, h1, n2, pre, onep1, gate1, onep2, gate2, xa_q, xa_k, xa_v, xa_o,
+        ctx.save_for_backward(x, n1, q, k, qn, kn, v, o, lse, h1, pre, onep1, gate1, onep2, gate2, xa_q, xa_k, xa_v, xa_o,
                               lora_a if lora_a is not None else x.new_empty(0), lora_b if lora_b is not None else x.new_empty(0))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         blk, T = ctx.blk, ctx.T
-        x, n1, q, k, qn, kn, v, o, lse, h1, n2, pre, onep1, gate1, onep2, gate2, xa_q, xa_k, xa_v, xa_o, lora_a, lora_b = ctx.saved_tensors
+        x, n1, q, k, qn, kn, v, o, lse, h1, pre, onep1, gate1, onep2, gate2, xa_q, xa_k, xa_v, xa_o, lora_a, lora_b = ctx.saved_tensors
         if not ctx.has_lora:
             lora_a = lora_b = None
         B, N, D = x.shape

@@ -29,6 +29,7 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # tools/ab_variants.sh).  Never set for the product library.
 if os.environ.get("FTMI_EXPERIMENTAL", "0") not in ("", "0"):
     FLAGS.append("-DFTMI_EXPERIMENTAL")
+    SOURCES.insert(2, "gemm_skinny.hip")  # the 64 x 128-tile LoRA down-projection kernel (measured slower than the shipped one: profiles/r03_skinny_experiments.txt)
     HEADERS.append(os.path.join("..", "..", "tools", "gemm_experimental.hip.h"))
 
 

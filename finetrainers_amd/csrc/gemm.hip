@@ -848,6 +848,12 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         if (a.K2 != 0 || a.epi != EPI_STORE || a.bias || a.K < 256 || a.split_r % 64 != 0 || (a.N / 2) % a.split_r != 0)
             return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: split (hi/lo) mode needs a plain store, K >= 256 and whole groups of split_r outputs");
         if ((a.w_grp_n > 0 && a.w_grp_n % 64) || (a.xk_grp_n > 0 && a.xk_grp_n % 64)) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
+#ifdef FTMI_EXPERIMENTAL
+        // third-generation kernel (gemm_skinny.hip: 64 x 128 tiles, optional K cut across workgroups): correct, and 3-30 % SLOWER in the step than
+        // the kernel below on every setting tried (profiles/r03_skinny_experiments.txt) -- research build only
+        static const int use_sk3 = env_int("FTMI_SKINNY3", 0);
+        if (use_sk3 && gemm_nt_skinny3_eligible(a)) return gemm_nt_skinny3(a, st);
+#endif
         ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
         constexpr int kSmem = 4 * 3 * 12288;
         static const bool attr_ok =

@@ -516,6 +516,7 @@ struct SkScratch {
     unsigned* flags = nullptr;  // [G] flags, then the error word
     unsigned epoch = 0;
     int G = 0;
+    hipEvent_t done = nullptr;  // recorded after this stream's latest launch
 };
 struct SkTables {
     int* work = nullptr;        // device
@@ -526,6 +527,13 @@ std::mutex g_sk_mu;
 unsigned long long* g_sk_trace = nullptr;
 int g_sk_trace_G = 0;
 std::unordered_map<uint64_t, SkScratch> g_sk_scratch;  // one per (device, stream): launches on one stream are ordered, so one set of slots suffices
+// A persistent launch polls flags of workgroups with HIGHER ids, so it makes progress only if all of its G workgroups become resident.  Two such
+// launches racing on two streams can each hold half of the CUs and wait for the other half for ever (found by the concurrent-stream test in a busy
+// process: the polls gave up after their ~1 s bound and said so in the status word).  So stream-K launches of one device are chained: a launch on
+// another stream than the previous one first waits (device side, hipStreamWaitEvent) for that one's completion event.  Kernels of OTHER kinds on
+// other streams only delay a persistent launch: they finish without waiting for anybody.
+uint64_t g_sk_last_key[64] = {0};
+bool g_sk_last_valid[64] = {false};
 std::unordered_map<std::string, SkTables> g_sk_tables;  // one per (device, tile grid, K iterations, cost constants)
 
 int sk_cus(int dev) {
@@ -660,6 +668,7 @@ int gemm_nt_sk_status() {
     for (auto& kv : g_sk_scratch) {
         unsigned e = 0;
         if (hipMemcpy(&e, kv.second.flags + kv.second.G, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (e != 0 && hipMemset(kv.second.flags + kv.second.G, 0, sizeof(e)) != hipSuccess) return -1;  // read and clear: the next call reports later launches only
         worst |= e;
     }
     return (int)worst;
@@ -749,15 +758,38 @@ int gemm_nt_sk(const GemmNtArgs& a, hipStream_t st) {
         g_sk_trace = tbuf;
         g_sk_trace_G = s.G;
     }
-    // algorithmic FLOPs: the extension's K2 carries the (hi, lo, hi) bf16 planes of an fp32 operand -- three executed K-steps per algorithmic one
-    ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * ((double)a.K + (double)a.K2 / 3.0), st);
-    const bool ext = a.K2 > 0;
-    switch (a.epi) {
-        case EPI_STORE: return ext ? launch_sk<EPI_STORE, true>(a, s, st) : launch_sk<EPI_STORE, false>(a, s, st);
-        case EPI_GELU: return ext ? launch_sk<EPI_GELU, true>(a, s, st) : launch_sk<EPI_GELU, false>(a, s, st);
-        case EPI_RESID: return ext ? launch_sk<EPI_RESID, true>(a, s, st) : launch_sk<EPI_RESID, false>(a, s, st);
-        default: return ext ? launch_sk<EPI_DGELU, true>(a, s, st) : launch_sk<EPI_DGELU, false>(a, s, st);
+    const uint64_t my_key = ((uint64_t)(uintptr_t)st) * 64 + (uint64_t)dev;
+    {   // never two persistent launches side by side on one device (see g_sk_last_key)
+        std::lock_guard<std::mutex> lk(g_sk_mu);
+        const int d = dev & 63;
+        if (g_sk_last_valid[d] && g_sk_last_key[d] != my_key) {
+            auto it = g_sk_scratch.find(g_sk_last_key[d]);
+            if (it != g_sk_scratch.end() && it->second.done != nullptr && hipStreamWaitEvent(st, it->second.done, 0) != hipSuccess)
+                return set_error(FTMI_ERR_LAUNCH, "gemm_nt_sk: cannot chain to the previous persistent launch");
+        }
     }
+    int rc;
+    {
+        // algorithmic FLOPs: the extension's K2 carries the (hi, lo, hi) bf16 planes of an fp32 operand -- three executed K-steps per algorithmic one
+        ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * ((double)a.K + (double)a.K2 / 3.0), st);
+        const bool ext = a.K2 > 0;
+        switch (a.epi) {
+            case EPI_STORE: rc = ext ? launch_sk<EPI_STORE, true>(a, s, st) : launch_sk<EPI_STORE, false>(a, s, st); break;
+            case EPI_GELU: rc = ext ? launch_sk<EPI_GELU, true>(a, s, st) : launch_sk<EPI_GELU, false>(a, s, st); break;
+            case EPI_RESID: rc = ext ? launch_sk<EPI_RESID, true>(a, s, st) : launch_sk<EPI_RESID, false>(a, s, st); break;
+            default: rc = ext ? launch_sk<EPI_DGELU, true>(a, s, st) : launch_sk<EPI_DGELU, false>(a, s, st); break;
+        }
+    }
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_sk_mu);
+        SkScratch& sc = g_sk_scratch[my_key];
+        if (sc.done == nullptr && hipEventCreateWithFlags(&sc.done, hipEventDisableTiming) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "gemm_nt_sk: cannot create the completion event");
+        if (hipEventRecord(sc.done, st) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "gemm_nt_sk: cannot record the completion event");
+        g_sk_last_key[dev & 63] = my_key;
+        g_sk_last_valid[dev & 63] = true;
+    }
+    return 0;
 }
 
 }  // namespace ftmi

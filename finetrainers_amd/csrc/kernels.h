@@ -90,6 +90,11 @@ bool gemm_nt_sk_eligible(const GemmNtArgs& a);
 int gemm_nt_sk(const GemmNtArgs& a, hipStream_t st);
 int gemm_nt_sk_status();
 int gemm_nt_sk_trace(unsigned long long* out, int cap);
+// LoRA down-projection (split hi/lo mode), third generation (gemm_skinny.hip, FTMI_EXPERIMENTAL builds only): 64 x 128 tiles, K cut across
+// workgroups when the tiles alone would leave most CUs idle.  Measured slower than gemm_nt_skinny2_kernel; selected with FTMI_SKINNY3=1.
+bool gemm_nt_skinny3_eligible(const GemmNtArgs& a);
+int gemm_nt_skinny3_slices(int M, int N, int K);
+int gemm_nt_skinny3(const GemmNtArgs& a, hipStream_t st);
 bool sk_build_work(int ntiles, int G, int nk, int ov, int minp, int pc, int ac, int* work);
 
 struct GemmTnArgs {

@@ -26,7 +26,9 @@ bf16 = torch.bfloat16
 
 class _SingleBlockFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, blk: "MI355XHunyuanSingleBlock", x, temb_silu, key_bias, rope_cos, rope_sin, text_len, lora_a, lora_b):
+    def _run(blk: "MI355XHunyuanSingleBlock", x, temb_silu, key_bias, rope_cos, rope_sin, text_len, lora_a, lora_b, need_out: bool = True):
+        """The block's forward kernels: (output, the tensors its backward reads).  Called by ``forward`` and, under gradient checkpointing, a second time
+        by ``backward`` -- the kernels are deterministic, so the recomputed activations are bit-identical to the ones that were dropped."""
         B, N, D = x.shape
         M, H, hd, T, s = B * N, blk.heads, 128, int(text_len), blk.lora_scale
         mod = ops.gemm_nt(temb_silu, blk.norm_lin_w, blk.norm_lin_b).view(B, 3, D)  # shift, scale, gate
@@ -45,22 +47,44 @@ class _SingleBlockFunction(torch.autograd.Function):
         kn = ops.head_rms_rope(k, blk.norm_k_w, hd, 1e-6, rope=rope, rows_per_batch=N, rope_from=T)
         heads = lambda t: t.view(B, N, H, hd).permute(0, 2, 1, 3)
         o, lse = ops.attn_fwd(heads(qn), heads(kn), heads(v), key_bias)
-        cat[:, :D].copy_(o.permute(0, 2, 1, 3).reshape(M, D))
-        y = ops.gemm_nt(cat, blk.proj_out_w, blk.proj_out_b)
-        out = ops.cog_gate_residual(x, y.view(B, N, D), gate, 0)
-        ctx.blk, ctx.T, ctx.rope, ctx.key_bias, ctx.has_lora = blk, T, rope, key_bias, lora_a is not None
-        ctx.save_for_backward(x, n, q, k, qn, kn, v, o, lse, pre, cat, onep, gate, xa_q, xa_k, xa_v,
-                              lora_a if lora_a is not None else x.new_empty(0), lora_b if lora_b is not None else x.new_empty(0))
+        out = None
+        if need_out:  # (the recomputation inside the backward stops here: nothing downstream of the attention is read again)
+            cat[:, :D].copy_(o.permute(0, 2, 1, 3).reshape(M, D))
+            y = ops.gemm_nt(cat, blk.proj_out_w, blk.proj_out_b)
+            out = ops.cog_gate_residual(x, y.view(B, N, D), gate, 0)
+        # proj_out and the MLP carry no adapter: their input (``cat``, 5 x the token width) is not needed again and is NOT kept -- 40 GB over the 40 blocks
+        # at 32 896 tokens
+        return out, (n, q, k, qn, kn, v, o, lse, pre, onep, gate, xa_q, xa_k, xa_v)
+
+    @staticmethod
+    def forward(ctx, blk: "MI355XHunyuanSingleBlock", x, temb_silu, key_bias, rope_cos, rope_sin, text_len, lora_a, lora_b):
+        out, acts = _SingleBlockFunction._run(blk, x, temb_silu, key_bias, rope_cos, rope_sin, text_len, lora_a, lora_b)
+        ctx.blk, ctx.T, ctx.rope, ctx.key_bias, ctx.has_lora = blk, int(text_len), (rope_cos, rope_sin), key_bias, lora_a is not None
+        ctx.recompute = bool(blk.gradient_checkpointing)
+        la, lb = (lora_a, lora_b) if lora_a is not None else (x.new_empty(0), x.new_empty(0))
+        if ctx.recompute:  # --gradient_checkpointing: keep the block's INPUT only (1 token-width tensor instead of 12)
+            ctx.save_for_backward(x, temb_silu, la, lb)
+        else:
+            ctx.save_for_backward(x, *acts, la, lb)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         blk, T, rope = ctx.blk, ctx.T, ctx.rope
+        if ctx.recompute:
+            x, temb_silu, lora_a, lora_b = ctx.saved_tensors
+            if not ctx.has_lora:
+                lora_a = lora_b = None
+            if blk._bwd_seen == 0:
+                blk._materialize_fwd()  # fp8 storage: the arena holds another block's weights by now
+            _, acts = _SingleBlockFunction._run(blk, x, temb_silu, ctx.key_bias, rope[0], rope[1], T, lora_a, lora_b, need_out=False)
+            n, q, k, qn, kn, v, o, lse, pre, onep, gate, xa_q, xa_k, xa_v = acts
+        else:
+            x, n, q, k, qn, kn, v, o, lse, pre, onep, gate, xa_q, xa_k, xa_v, lora_a, lora_b = ctx.saved_tensors
+            if not ctx.has_lora:
+                lora_a = lora_b = None
         if blk._bwd_seen == 0:
             blk._materialize_bwd()  # fp8 storage: the transposed bf16 weights of THIS block into the shared arena (no-op otherwise)
-        x, n, q, k, qn, kn, v, o, lse, pre, cat, onep, gate, xa_q, xa_k, xa_v, lora_a, lora_b = ctx.saved_tensors
-        if not ctx.has_lora:
-            lora_a = lora_b = None
         B, N, D = x.shape
         M, H, hd, s = B * N, blk.heads, 128, blk.lora_scale
         dout = dout.contiguous()
@@ -106,6 +130,7 @@ class _FlatGradMixin:
     _grad_a_view = None
     _grad_b_view = None
     _grad_hook = None
+    gradient_checkpointing = False  # True: the block keeps only its input and runs its forward kernels again inside the backward
     _fwd_calls = 0
     _bwd_seen = 0
 
@@ -252,7 +277,8 @@ class _DualBlockFunction(torch.autograd.Function):
     buffers [T, D] / [S, D] as in the reference; only q, k, v are laid out as one joint [T + S] sequence (text first) for the attention."""
 
     @staticmethod
-    def forward(ctx, blk: "MI355XHunyuanDualBlock", x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b):
+    def _run(blk: "MI355XHunyuanDualBlock", x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b, need_out: bool = True):
+        """Forward kernels of one sample: ((video out, text out), the tensors the backward reads); run again by ``backward`` under gradient checkpointing."""
         S, D = x_v.shape
         T = x_t.shape[0]
         N, H, hd, s = T + S, blk.heads, 128, blk.lora_scale
@@ -291,22 +317,43 @@ class _DualBlockFunction(torch.autograd.Function):
         n2_t = ops.cog_ln_mod(h_t[None], blk.ones, blk.zeros, shm_t, opm_t, 0, 1e-6)[0]
         act_v, pre_v = ops.gemm_nt(n2_v, blk.ff1_w, blk.ff1_b, epilogue=1, want_out2=True)
         act_t, pre_t = ops.gemm_nt(n2_t, blk.ffc1_w, blk.ffc1_b, epilogue=1, want_out2=True)
-        out_v = ops.cog_gate_residual(h_v[None], ops.gemm_nt(act_v, blk.ff2_w, blk.ff2_b)[None], gm_v, 0)[0]
-        out_t = ops.cog_gate_residual(h_t[None], ops.gemm_nt(act_t, blk.ffc2_w, blk.ffc2_b)[None], gm_t, 0)[0]
-        ctx.blk, ctx.rope, ctx.key_bias, ctx.has_lora = blk, rope, key_bias, lora_a is not None
-        ctx.save_for_backward(x_v, x_t, n_v, n_t, q_v, k_v, q_t, k_t, qj, kj, vj, o, lse, h_v, h_t, n2_v, n2_t, pre_v, pre_t, g_v, g_t, gm_v, gm_t, op_v, op_t, opm_v,
-                              opm_t, xa_q, xa_k, xa_v, xa_o, lora_a if lora_a is not None else x_v.new_empty(0), lora_b if lora_b is not None else x_v.new_empty(0))
+        out_v = out_t = None
+        if need_out:  # (the recomputation inside the backward stops before the second feed-forward GEMMs)
+            out_v = ops.cog_gate_residual(h_v[None], ops.gemm_nt(act_v, blk.ff2_w, blk.ff2_b)[None], gm_v, 0)[0]
+            out_t = ops.cog_gate_residual(h_t[None], ops.gemm_nt(act_t, blk.ffc2_w, blk.ffc2_b)[None], gm_t, 0)[0]
+        return (out_v, out_t), (n_v, n_t, q_v, k_v, q_t, k_t, qj, kj, vj, o, lse, h_v, h_t, pre_v, pre_t, g_v, g_t, gm_v, gm_t, op_v, op_t, opm_v, opm_t,
+                                xa_q, xa_k, xa_v, xa_o)
+
+    @staticmethod
+    def forward(ctx, blk: "MI355XHunyuanDualBlock", x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b):
+        (out_v, out_t), acts = _DualBlockFunction._run(blk, x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b)
+        ctx.blk, ctx.rope, ctx.key_bias, ctx.has_lora = blk, (rope_cos, rope_sin), key_bias, lora_a is not None
+        ctx.recompute = bool(blk.gradient_checkpointing)
+        la, lb = (lora_a, lora_b) if lora_a is not None else (x_v.new_empty(0), x_v.new_empty(0))
+        if ctx.recompute:  # --gradient_checkpointing: keep the two input streams only
+            ctx.save_for_backward(x_v, x_t, temb_silu, la, lb)
+        else:
+            ctx.save_for_backward(x_v, x_t, *acts, la, lb)
         return out_v, out_t
 
     @staticmethod
     def backward(ctx, dout_v, dout_t):
         blk, rope = ctx.blk, ctx.rope
+        if ctx.recompute:
+            x_v, x_t, temb_silu, lora_a, lora_b = ctx.saved_tensors
+            if not ctx.has_lora:
+                lora_a = lora_b = None
+            if blk._bwd_seen == 0:
+                blk._materialize_fwd()  # fp8 storage: the arena holds another block's weights by now
+            _, acts = _DualBlockFunction._run(blk, x_v, x_t, temb_silu, ctx.key_bias, rope[0], rope[1], lora_a, lora_b, need_out=False)
+        else:
+            x_v, x_t, *acts, lora_a, lora_b = ctx.saved_tensors
+            if not ctx.has_lora:
+                lora_a = lora_b = None
+        (n_v, n_t, q_v, k_v, q_t, k_t, qj, kj, vj, o, lse, h_v, h_t, pre_v, pre_t, g_v, g_t, gm_v, gm_t, op_v, op_t, opm_v, opm_t,
+         xa_q, xa_k, xa_v, xa_o) = acts
         if blk._bwd_seen == 0:
             blk._materialize_bwd()  # fp8 storage: the transposed bf16 weights of THIS block into the shared arena (no-op otherwise)
-        (x_v, x_t, n_v, n_t, q_v, k_v, q_t, k_t, qj, kj, vj, o, lse, h_v, h_t, n2_v, n2_t, pre_v, pre_t, g_v, g_t, gm_v, gm_t, op_v, op_t, opm_v, opm_t,
-         xa_q, xa_k, xa_v, xa_o, lora_a, lora_b) = ctx.saved_tensors
-        if not ctx.has_lora:
-            lora_a = lora_b = None
         S, D = x_v.shape
         T = x_t.shape[0]
         N, H, hd, s = T + S, blk.heads, 128, blk.lora_scale

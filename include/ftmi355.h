@@ -121,8 +121,10 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
  * piece [0, k1) of tile t1; n_whole whole tiles in between; contributor_mask bit i = workgroup w + 1 + i holds a partial of that tile. */
 int ftmi_gemm_sk_plan(int ntiles, int n_workgroups, int nk, int owner_cost, int min_piece, int partial_cost, int add_cost,
                       int* work /* [n_workgroups][8] */);
-/* 0 = every stream-K hand-off so far completed; 1 = a bounded wait for a partial gave up (results of that launch are wrong); < 0 = error.
- * Synchronises the device (tests and debugging only). */
+/* 0 = every stream-K hand-off since the previous call completed; 1 = a bounded wait for a partial gave up (results of that launch are wrong);
+ * < 0 = error.  Reads and clears the word; call it after synchronising the streams that ran stream-K launches (tests and debugging only).
+ * Persistent launches of one device are chained across streams (a launch waits, device side, for the previous one's completion event): two of
+ * them side by side could each hold half of the CUs and poll the other half's flags for ever. */
 int ftmi_gemm_sk_status(void);
 /* Debugging aid (FTMI_SK_TRACE=1): shader-clock stamps of the last stream-K launch, out[n_workgroups][16] (start, end of each K phase,
  * hand-off waits, segment ends; 0 = unused); returns n_workgroups, 0 if nothing was traced.  Synchronises the device. */

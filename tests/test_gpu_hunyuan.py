@@ -466,3 +466,57 @@ def test_real_fp8_weight_storage_is_bit_identical_and_smaller():
         assert torch.allclose(g0[k], g1[k], rtol=0, atol=0) or ((g0[k] - g1[k]).norm() / g0[k].norm()) < 1e-6, k  # (fp32 atomics in the weight-gradient GEMMs)
     print(f"[hunyuan-fp8-storage] HBM freed by the cast: rounded-in-bf16 {s0 / 2**20:.1f} MiB, real fp8 storage {s1 / 2**20:.1f} MiB")
     assert s1 > s0 + 1  # the bf16 weights and their transposed copies went away
+
+
+def test_gradient_checkpointing_gives_the_same_gradients_from_less_memory():
+    """--gradient_checkpointing (reference: trainer/sft_trainer/trainer.py:155-157 -> utils/activation_checkpoint.py:24-49, every block wrapped): the blocks
+    keep only their inputs and run their forward kernels again inside the backward.  Prediction bit-identical, LoRA gradients identical up to the fp32
+    atomics of the weight-gradient GEMMs, with bf16 weights and with real fp8 storage (the shared weight arena is refilled for the recomputation),
+    "full" and "block_skip"; the activations alive at the end of the forward shrink."""
+    from finetrainers_amd.hunyuan_video import HunyuanVideoTransformerConfig, MI355XHunyuanVideoSpecOps, MI355XHunyuanVideoTransformer3DModel
+    from oracle import hunyuan as hy
+
+    dev = _dev()
+    kw = dict(num_attention_heads=2, attention_head_dim=128, num_layers=2, num_single_layers=3, num_refiner_layers=1, text_embed_dim=64, pooled_projection_dim=64)
+    omodel = hy.build_model(hy.HunyuanVideoConfig(**kw), seed=0, dtype=torch.float32).to(bf16)
+    sd = {_to_diffusers_key(k): v for k, v in omodel.state_dict().items()}
+    g = torch.Generator().manual_seed(12)
+    B, C, F_, H, W, T = 2, 16, 4, 16, 24, 8
+    lat = torch.randn(B, C, F_, H, W, generator=g).to(bf16).to(dev)
+    noise = torch.randn(B, C, F_, H, W, generator=g).to(bf16).to(dev)
+    cond = {"encoder_hidden_states": torch.randn(B, T, 64, generator=g).to(bf16).to(dev), "encoder_attention_mask": torch.tensor([[1, 1, 1, 1, 1, 0, 0, 0], [1] * 8]).to(dev),
+            "pooled_projections": torch.randn(B, 64, generator=g).to(bf16).to(dev)}
+    sig = torch.tensor([0.25, 0.75], device=dev)
+    runs = {}
+    for name, fp8, ckpt in (("plain", False, None), ("full", False, ("full", 1)), ("fp8+full", True, ("full", 1)), ("fp8+skip2", True, ("block_skip", 2))):
+        torch.manual_seed(3)  # (add_adapter draws A from the global generator)
+        m = MI355XHunyuanVideoTransformer3DModel(HunyuanVideoTransformerConfig(**kw), device=dev)
+        m.load_diffusers_state_dict(sd)
+        m.apply_layerwise_casting(real_storage=fp8)
+        m.add_adapter(r=64, lora_alpha=64.0)
+        with torch.no_grad():
+            gg = torch.Generator(device=dev).manual_seed(5)
+            for p in m.lora_parameters()[1::2]:
+                p.copy_(torch.randn(p.shape, generator=gg, device=dev) * 0.02)
+        if ckpt is not None:
+            assert m.apply_activation_checkpointing(*ckpt) is m and m.is_gradient_checkpointing
+        spec = MI355XHunyuanVideoSpecOps()
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        pred, target, _ = spec.forward(m, lat, dict(cond), sig, guidance=4.0, noise=noise)
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated() - base  # activations kept for the backward
+        spec.loss_backward(pred, target)
+        torch.cuda.synchronize()
+        runs[name] = (pred.detach().clone(), {k: v.clone() for k, v in m.lora_grad_state_dict().items()}, held)
+        del m, pred, target
+    p0, g0, h0 = runs["plain"]
+    for name in ("full", "fp8+full", "fp8+skip2"):
+        p1, g1, h1 = runs[name]
+        assert torch.equal(p0, p1), name
+        for k in g0:
+            assert ((g0[k] - g1[k]).norm() / g0[k].norm()) < 1e-6, (name, k)
+    print("[hunyuan-checkpointing] activations held after the forward: " + ", ".join(f"{n} {runs[n][2] / 2**20:.1f} MiB" for n in runs))
+    assert runs["full"][2] < 0.35 * h0 and runs["fp8+full"][2] < 0.35 * h0 and runs["fp8+full"][2] < runs["fp8+skip2"][2] < h0
+    with pytest.raises(ValueError):
+        MI355XHunyuanVideoTransformer3DModel(HunyuanVideoTransformerConfig(**kw), device=dev).apply_activation_checkpointing("ops")

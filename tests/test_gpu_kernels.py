@@ -118,6 +118,11 @@ def test_linear_lora_fwd(M, variant):
     err = ((hi.double() + lo.double()) - xa64).norm() / xa64.norm()
     print(f"[parity] lora xa (hi+lo) vs fp64   M={M}: rel_l2={err:.3e}")
     assert err < 2e-5, "x A^T must carry fp32-equivalent precision (bf16 operands would give ~3e-3)"
+    # the down-projection may cut K across workgroups (gemm_skinny.hip: the last slice to arrive adds the partial tiles in slice order): the bits
+    # must not depend on the arrival order
+    for _ in range(3):
+        y2, xa2 = ops.linear_lora_fwd(x.to(dev), w.to(dev), b.to(dev), A.to(dev), Bm.to(dev), s, variant=variant)
+        assert torch.equal(xa2.cpu(), xa.to(bf16)) and torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("M", [96, 700, 5376])

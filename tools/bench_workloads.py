@@ -204,6 +204,9 @@ def build_hunyuan(args, par, dev) -> Dict[str, Any]:
                 setattr(blk, name + "_t", ops.transpose_bf16(getattr(blk, name)))
     model.apply_layerwise_casting()
     model.add_adapter(r=args.rank, lora_alpha=float(args.rank))
+    ckpt = bool(getattr(args, "gradient_checkpointing", False))
+    if ckpt:
+        model.apply_activation_checkpointing("full")
     with torch.no_grad():
         for p in model.lora_parameters()[1::2]:
             p.normal_(0, 0.01, generator=g)  # B != 0 so every gradient path carries data
@@ -234,7 +237,8 @@ def build_hunyuan(args, par, dev) -> Dict[str, Any]:
         "config": {"workload": f"HunyuanVideo LoRA rank={args.rank} SFT step, fp8 weight storage / bf16 compute, 61x544x960 clip ({S} video + {T} text tokens), batch 1 per GPU, "
                                f"{nd} dual-stream + {ns} single-stream blocks (BASELINE configs[4])" + ("" if full else " -- REDUCED depth"),
                    "model": "HunyuanVideo DiT: 20 dual + 40 single blocks, width 3072, 24 x 128 heads, 12.8 B frozen parameters", "seq_len": N,
-                   "activation_checkpointing": False, "orchestration": "python, per block over the C ABI"},
+                   "activation_checkpointing": ckpt, "weight_storage": "float8_e4m3fn bytes in HBM, per-block up-cast into a shared bf16 arena",
+                   "orchestration": "python, per block over the C ABI"},
         "layers": nd + ns,
         "dual_single": (nd, ns, dual, single),
     }
