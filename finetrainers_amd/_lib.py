@@ -82,6 +82,23 @@ class CogWeights(Structure):
     _fields_ = [(n, c_void_p) for n in COG_WEIGHT_FIELDS]
 
 
+class HySingleConfig(Structure):
+    """include/ftmi355.h: ftmi_hy_single_config."""
+
+    _fields_ = [("B", c_int), ("T", c_int), ("S", c_int), ("D", c_int), ("H", c_int), ("mlp", c_int), ("r", c_int), ("lora_scale", c_float), ("eps", c_float),
+                ("gemm_variant", c_int)]
+
+
+HY_SINGLE_WEIGHT_FIELDS = [
+    "norm_lin_w", "norm_lin_b", "proj_mlp_w", "proj_mlp_b", "wq", "bq", "wk", "bk", "wv", "bv", "norm_q_w", "norm_k_w", "proj_out_w", "proj_out_b",
+    "wq_t", "wk_t", "wv_t", "proj_mlp_w_t", "proj_out_w_t", "lora_a", "lora_b", "ones", "zeros",
+]
+
+
+class HySingleWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in HY_SINGLE_WEIGHT_FIELDS]
+
+
 class WanRowArgs(Structure):
     """include/ftmi355.h: ftmi_wan_row_args."""
 
@@ -154,6 +171,12 @@ _SIGS = {
     "ftmi_cog_blocks_backward": (c_int, [POINTER(CogConfig), POINTER(CogWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                          c_int, c_int, c_int, c_void_p]),
     "ftmi_lora_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ftmi_hy_single_saved_bytes": (c_size_t, [POINTER(HySingleConfig)]),
+    "ftmi_hy_single_scratch_bytes": (c_size_t, [POINTER(HySingleConfig)]),
+    "ftmi_hy_single_forward": (c_int, [POINTER(HySingleConfig), POINTER(HySingleWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "ftmi_hy_single_backward": (c_int, [POINTER(HySingleConfig), POINTER(HySingleWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

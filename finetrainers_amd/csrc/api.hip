@@ -480,6 +480,25 @@ int ftmi_cog_gate_residual(const void* res, const void* y, const void* gate, voi
     return cog_gate_residual(a, (hipStream_t)stream);
 }
 
+size_t ftmi_hy_single_saved_bytes(const ftmi_hy_single_config* cfg) { return cfg ? hy_single_saved_bytes(*cfg) : 0; }
+size_t ftmi_hy_single_scratch_bytes(const ftmi_hy_single_config* cfg) { return cfg ? hy_single_scratch_bytes(*cfg) : 0; }
+int ftmi_hy_single_forward(const ftmi_hy_single_config* cfg, const ftmi_hy_single_weights* w, const void* x, const void* temb_silu, const float* key_bias,
+                           const float* rope_cos, const float* rope_sin, void* out, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                           ftmi_stream stream) {
+    if (!cfg || !w || !x || !temb_silu || !saved || !scratch || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_hy_single_forward: bad argument");
+    return hy_single_forward(*cfg, *w, (const bf16_t*)x, (const bf16_t*)temb_silu, key_bias, rope_cos, rope_sin, (bf16_t*)out, saved, saved_bytes, scratch,
+                             scratch_bytes, (hipStream_t)stream);
+}
+int ftmi_hy_single_backward(const ftmi_hy_single_config* cfg, const ftmi_hy_single_weights* w, const void* x, const void* dout, const float* key_bias,
+                            const float* rope_cos, const float* rope_sin, const void* ones_rows, void* dx, float* grad_a, float* grad_b, void* saved,
+                            size_t saved_bytes, void* scratch, size_t scratch_bytes, ftmi_stream stream) {
+    if (!cfg || !w || !x || !dout || !ones_rows || !dx || !saved || !scratch || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_hy_single_backward: bad argument");
+    return hy_single_backward(*cfg, *w, (const bf16_t*)x, (const bf16_t*)dout, key_bias, rope_cos, rope_sin, (const bf16_t*)ones_rows, (bf16_t*)dx, grad_a,
+                              grad_b, saved, saved_bytes, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
 int ftmi_cog_patchify(const void* latents, void* tokens, int B, int F, int C, int H, int W, int patch, ftmi_stream stream) {
     if (!latents || !tokens) return set_error(FTMI_ERR_INVALID, "ftmi_cog_patchify: null argument");
     return cog_patch_permute((const bf16_t*)latents, (bf16_t*)tokens, B, F, C, H, W, patch, 1, (hipStream_t)stream);

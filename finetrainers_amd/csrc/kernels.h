@@ -289,6 +289,16 @@ int wan_colsum(const WanRowArgs& a, hipStream_t st);
 int adamw_bf16_step(bf16_t* p, const float* g, bf16_t* m, bf16_t* v, long n, const float* sumsq_in, float max_norm, float lr, float beta1, float beta2,
                     float eps, float wd, int step, float* grad_norm_out, hipStream_t st);
 
+// HunyuanVideo single-stream block orchestrator (hy_dit.hip)
+size_t hy_single_saved_bytes(const ftmi_hy_single_config& c);
+size_t hy_single_scratch_bytes(const ftmi_hy_single_config& c);
+int hy_single_forward(const ftmi_hy_single_config& c, const ftmi_hy_single_weights& w, const bf16_t* x, const bf16_t* temb_silu, const float* key_bias,
+                      const float* rope_cos, const float* rope_sin, bf16_t* out, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                      hipStream_t st);
+int hy_single_backward(const ftmi_hy_single_config& c, const ftmi_hy_single_weights& w, const bf16_t* x, const bf16_t* dout, const float* key_bias,
+                       const float* rope_cos, const float* rope_sin, const bf16_t* ones_rows, bf16_t* dx, float* grad_a, float* grad_b, void* saved,
+                       size_t saved_bytes, void* scratch, size_t scratch_bytes, hipStream_t st);
+
 int cog_patch_permute(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W, int p, int to_tokens, hipStream_t st);  // latents <-> patch tokens
 
 }  // namespace ftmi

@@ -19,9 +19,24 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
-from .. import ops
+import ctypes
+
+from .. import _lib, ops
+from .._lib import HySingleConfig, HySingleWeights, check, ptr, stream_ptr
 
 bf16 = torch.bfloat16
+_NATIVE_SCRATCH: Dict[int, torch.Tensor] = {}  # device index -> byte buffer shared by every natively run block on that device (one stream at a time)
+
+
+def _native_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _NATIVE_SCRATCH.get(idx)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _NATIVE_SCRATCH.pop(idx, None)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _NATIVE_SCRATCH[idx] = buf
+    return buf
 
 
 class _SingleBlockFunction(torch.autograd.Function):
@@ -124,6 +139,90 @@ class _SingleBlockFunction(torch.autograd.Function):
         return None, dx, None, None, None, None, None, ga, gb
 
 
+class _SingleBlockNativeFunction(torch.autograd.Function):
+    """The same block as ``_SingleBlockFunction`` with ONE C call per direction (``ftmi_hy_single_forward / _backward``, csrc/hy_dit.hip: the identical
+    kernel sequence, issued from C out of a planned ``saved`` buffer per block and a ``scratch`` buffer shared by all blocks).  Gradient checkpointing
+    keeps the block's input only and rebuilds ``saved`` inside the backward (the forward call with ``out = NULL``)."""
+
+    @staticmethod
+    def _args(blk: "MI355XHunyuanSingleBlock", B: int, N: int, T: int, lora_a, lora_b, backward: bool):
+        D = blk.dim
+        cfg = HySingleConfig(B=B, T=T, S=N - T, D=D, H=blk.heads, mlp=blk.mlp_dim, r=0 if lora_a is None else int(lora_a.shape[1]),
+                             lora_scale=float(blk.lora_scale), eps=1e-6, gemm_variant=8)
+        w = HySingleWeights()
+        names = ["norm_lin_w", "norm_lin_b", "proj_mlp_w", "proj_mlp_b", "wq", "bq", "wk", "bk", "wv", "bv", "norm_q_w", "norm_k_w", "proj_out_w", "proj_out_b", "ones", "zeros"]
+        if backward:
+            names += ["wq_t", "wk_t", "wv_t", "proj_mlp_w_t", "proj_out_w_t"]
+        keep = []
+        for n in names:
+            t = getattr(blk, n)
+            if t is None or not t.is_contiguous():
+                raise RuntimeError(f"HunyuanVideo single-stream block: weight '{n}' is not materialised")
+            keep.append(t)
+            setattr(w, n, ptr(t))
+        if lora_a is not None:
+            la, lb = lora_a.contiguous(), lora_b.contiguous()
+            keep += [la, lb]
+            w.lora_a, w.lora_b = ptr(la), ptr(lb)
+        return cfg, w, keep
+
+    @staticmethod
+    def _forward_call(blk, x, temb_silu, key_bias, rope_cos, rope_sin, T, lora_a, lora_b, out):
+        B, N, _ = x.shape
+        cfg, w, keep = _SingleBlockNativeFunction._args(blk, B, N, T, lora_a, lora_b, backward=False)
+        lib = _lib.load()
+        saved = torch.empty(lib.ftmi_hy_single_saved_bytes(ctypes.byref(cfg)), dtype=torch.uint8, device=x.device)
+        scratch = _native_scratch(x.device, lib.ftmi_hy_single_scratch_bytes(ctypes.byref(cfg)))
+        check(lib.ftmi_hy_single_forward(ctypes.byref(cfg), ctypes.byref(w), ptr(x), ptr(temb_silu), ptr(key_bias), ptr(rope_cos), ptr(rope_sin), ptr(out),
+                                         ptr(saved), saved.numel(), ptr(scratch), scratch.numel(), stream_ptr()), "ftmi_hy_single_forward")
+        return saved
+
+    @staticmethod
+    def forward(ctx, blk: "MI355XHunyuanSingleBlock", x, temb_silu, key_bias, rope_cos, rope_sin, text_len, lora_a, lora_b):
+        out = torch.empty_like(x)
+        saved = _SingleBlockNativeFunction._forward_call(blk, x, temb_silu, key_bias, rope_cos, rope_sin, int(text_len), lora_a, lora_b, out)
+        ctx.blk, ctx.T, ctx.rope, ctx.key_bias, ctx.has_lora = blk, int(text_len), (rope_cos, rope_sin), key_bias, lora_a is not None
+        ctx.recompute = bool(blk.gradient_checkpointing)
+        la, lb = (lora_a, lora_b) if lora_a is not None else (x.new_empty(0), x.new_empty(0))
+        if ctx.recompute:
+            ctx.save_for_backward(x, temb_silu, la, lb)
+        else:
+            ctx.save_for_backward(x, temb_silu, la, lb, saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk, T, rope = ctx.blk, ctx.T, ctx.rope
+        if ctx.recompute:
+            x, temb_silu, lora_a, lora_b = ctx.saved_tensors
+        else:
+            x, temb_silu, lora_a, lora_b, saved = ctx.saved_tensors
+        if not ctx.has_lora:
+            lora_a = lora_b = None
+        if ctx.recompute:
+            if blk._bwd_seen == 0:
+                blk._materialize_fwd()  # fp8 storage: the arena holds another block's weights by now
+            saved = _SingleBlockNativeFunction._forward_call(blk, x, temb_silu, ctx.key_bias, rope[0], rope[1], T, lora_a, lora_b, None)
+        if blk._bwd_seen == 0:
+            blk._materialize_bwd()
+        B, N, _ = x.shape
+        dout = dout.contiguous()
+        own = lora_a is not None and blk._grad_a_view is not None
+        ga = blk._grad_a_view if own else (torch.zeros_like(lora_a) if lora_a is not None else None)
+        gb = blk._grad_b_view if own else (torch.zeros_like(lora_b) if lora_b is not None else None)
+        cfg, w, keep = _SingleBlockNativeFunction._args(blk, B, N, T, lora_a, lora_b, backward=True)
+        lib = _lib.load()
+        scratch = _native_scratch(x.device, lib.ftmi_hy_single_scratch_bytes(ctypes.byref(cfg)))
+        dx = torch.empty_like(x)
+        check(lib.ftmi_hy_single_backward(ctypes.byref(cfg), ctypes.byref(w), ptr(x), ptr(dout), ptr(ctx.key_bias), ptr(rope[0]), ptr(rope[1]),
+                                          ptr(blk.ones_rows(B, x.device)), ptr(dx), ptr(ga), ptr(gb), ptr(saved), saved.numel(), ptr(scratch), scratch.numel(),
+                                          stream_ptr()), "ftmi_hy_single_backward")
+        if own:
+            blk._backward_done(ga, gb)
+            return None, dx, None, None, None, None, None, None, None
+        return None, dx, None, None, None, None, None, ga, gb
+
+
 class _FlatGradMixin:
     """Gradient storage handed in by the step object (hunyuan_video/trainer.py): ``_grad_a_view`` / ``_grad_b_view`` are views of its flat buffer laid out
     like the parameters; ``_grad_hook(block)`` is called once per step, when the block's LAST backward call (one per forward call) has added its part."""
@@ -199,6 +298,8 @@ class _Fp8StorageMixin:
 class MI355XHunyuanSingleBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
     """Frozen bf16 weights (+ the transposes the input-gradient GEMMs use, made once) and the fp32 LoRA adapters of to_q / to_k / to_v."""
 
+    native = True  # one C call per direction (csrc/hy_dit.hip); False: the per-kernel composition from Python (the tests compare the two)
+
     _KEYS = {  # diffusers HunyuanVideoSingleTransformerBlock parameter name -> buffer
         "norm.linear.weight": "norm_lin_w", "norm.linear.bias": "norm_lin_b", "proj_mlp.weight": "proj_mlp_w", "proj_mlp.bias": "proj_mlp_b",
         "attn.to_q.weight": "wq", "attn.to_q.bias": "bq", "attn.to_k.weight": "wk", "attn.to_k.bias": "bk", "attn.to_v.weight": "wv", "attn.to_v.bias": "bv",
@@ -269,7 +370,8 @@ class MI355XHunyuanSingleBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
         temb_silu = torch.nn.functional.silu(temb.to(bf16)).contiguous()
         cos, sin = image_rotary_emb
         self._fwd_calls, self._bwd_seen = 1, 0
-        return _SingleBlockFunction.apply(self, tokens.contiguous(), temb_silu, key_bias, cos.contiguous(), sin.contiguous(), int(text_len), self.lora_A, self.lora_B)
+        fn = _SingleBlockNativeFunction if self.native else _SingleBlockFunction
+        return fn.apply(self, tokens.contiguous(), temb_silu, key_bias, cos.contiguous(), sin.contiguous(), int(text_len), self.lora_A, self.lora_B)
 
 
 class _DualBlockFunction(torch.autograd.Function):

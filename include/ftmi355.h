@@ -352,6 +352,43 @@ int ftmi_head_rms_rope_fwd(const void* x, long ld, const void* w, void* y, long 
 int ftmi_head_rms_rope_bwd(const void* x, long ld, const void* w, const void* dy, long ld_dy, void* dx, long ld_dx, int rows, int D, int head_dim, float eps,
                            const float* rope_cos, const float* rope_sin, int rows_per_batch, int rope_from, ftmi_stream stream);
 
+/* HunyuanVideo single-stream block (40 of the 60 blocks of the DiT; [upstream] diffusers HunyuanVideoSingleTransformerBlock as driven by
+ * finetrainers/models/hunyuan_video/base_specification.py:294-330, restated in oracle/hunyuan.py SingleStreamBlock) as ONE call per direction:
+ *   tokens x [B, T + S, D] bf16 (text first), temb_silu [B, D] = silu(conditioning vector), key_bias fp32 [B, T + S] (-inf on padded text keys) or NULL,
+ *   rope_cos / rope_sin fp32 [S, 128] (video rows), LoRA (fp32, rank r, scale alpha / r) on to_q / to_k / to_v.
+ * Buffers are the caller's: `saved` (ftmi_hy_single_saved_bytes: what the backward reads again -- keep it from the forward to the backward of THIS block,
+ * or rebuild it inside the backward by calling the forward with out = NULL, which is gradient checkpointing: utils/activation_checkpoint.py:24-49) and
+ * `scratch` (ftmi_hy_single_scratch_bytes: transients, may be shared by all blocks on a stream).  The weights may be views into an arena that is
+ * refilled per block (fp8 storage: ftmi_fp8_upcast).  The backward ADDS to grad_a [3, r, D] / grad_b [3, D, r] (fp32) and writes dx. */
+typedef struct {
+    int B, T, S;      /* batch, text tokens, video tokens */
+    int D, H, mlp;    /* width = H x 128, MLP width (4 D) */
+    int r;            /* LoRA rank: 0 or a multiple of 64 (smaller ranks zero-padded by the caller) */
+    float lora_scale; /* alpha / (the user's) r */
+    float eps;        /* 1e-6: LayerNorm and q / k RMSNorm */
+    int gemm_variant; /* 8 */
+} ftmi_hy_single_config;
+typedef struct {
+    const void *norm_lin_w, *norm_lin_b;                       /* [3D, D], [3D]   norm.linear */
+    const void *proj_mlp_w, *proj_mlp_b;                       /* [mlp, D], [mlp] */
+    const void *wq, *bq, *wk, *bk, *wv, *bv;                   /* [D, D], [D]     attn.to_q / to_k / to_v */
+    const void *norm_q_w, *norm_k_w;                           /* [128]           attn.norm_q / norm_k */
+    const void *proj_out_w, *proj_out_b;                       /* [D, D + mlp], [D] */
+    const void *wq_t, *wk_t, *wv_t, *proj_mlp_w_t, *proj_out_w_t; /* transposed copies [D, D] x3, [D, mlp], [D + mlp, D]: backward only */
+    const float *lora_a, *lora_b;                              /* fp32 [3, r, D], [3, D, r]; NULL when r == 0 */
+    const void *ones, *zeros;                                  /* bf16 [D]: the affine-free LayerNorm's weight and bias */
+} ftmi_hy_single_weights;
+size_t ftmi_hy_single_saved_bytes(const ftmi_hy_single_config* cfg);
+size_t ftmi_hy_single_scratch_bytes(const ftmi_hy_single_config* cfg);
+/* out [B, T + S, D]; out == NULL: recomputation pass (fills `saved`, stops after the attention) */
+int ftmi_hy_single_forward(const ftmi_hy_single_config* cfg, const ftmi_hy_single_weights* w, const void* x, const void* temb_silu, const float* key_bias,
+                           const float* rope_cos, const float* rope_sin, void* out, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                           ftmi_stream stream);
+/* ones_rows: bf16 [B, D] of 1.0 (the bf16 accumulation of the four gradients of the normalised tokens runs through the gate-residual kernel) */
+int ftmi_hy_single_backward(const ftmi_hy_single_config* cfg, const ftmi_hy_single_weights* w, const void* x, const void* dout, const float* key_bias,
+                            const float* rope_cos, const float* rope_sin, const void* ones_rows, void* dx, float* grad_a, float* grad_b, void* saved,
+                            size_t saved_bytes, void* scratch, size_t scratch_bytes, ftmi_stream stream);
+
 /* ---- Wan-T2V full fine-tune (BASELINE config 4; finetrainers/models/wan/base_specification.py:433-493 driving [upstream]
  * diffusers transformer_wan.py; restated in oracle/wan.py).  Every parameter trains, so the backward kernels also produce the column sums the
  * parameter gradients need; they ADD to red1 / red2 (fp32, zeroed or kept by the caller; atomics: the summation order is not fixed).

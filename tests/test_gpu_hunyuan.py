@@ -162,6 +162,68 @@ def test_single_stream_block_forward_backward_parity(B, T, S, masked, heads):
         assert glob < 4.8e-3 and worst < 8e-3
 
 
+@pytest.mark.parametrize("B,T,S,masked,rank,ckpt", [(2, 8, 40, True, 64, False), (1, 16, 150, False, 32, False), (2, 24, 200, True, 128, True)])
+def test_single_stream_block_c_call_matches_the_python_composition(B, T, S, masked, rank, ckpt):
+    """``ftmi_hy_single_forward / _backward`` (csrc/hy_dit.hip: the whole block as one C call per direction out of a planned ``saved`` buffer and a shared
+    scratch buffer) against the per-kernel composition issued from Python (``native = False``): the same kernels in the same order, so output and input
+    gradient are bit-identical and the LoRA gradients agree up to the fp32 atomics of the weight-gradient GEMMs; also with a zero-padded rank and with
+    gradient checkpointing (the C forward called a second time with out = NULL)."""
+    from finetrainers_amd.hunyuan_video import MI355XHunyuanSingleBlock
+
+    dev = _dev()
+    heads = 2
+    D = heads * 128
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + S)
+    blk = MI355XHunyuanSingleBlock(dim=D, heads=heads, device=dev)
+    with torch.no_grad():
+        for name, buf in blk.named_buffers():
+            if buf is None or name.endswith("_t") or name in ("ones", "zeros"):
+                continue
+            if name.startswith("norm_") and buf.dim() == 1 and buf.numel() == 128:
+                buf.copy_((1 + 0.1 * torch.randn(buf.shape, generator=g, device=dev)).to(bf16))
+            elif buf.dim() == 2:
+                buf.copy_((torch.randn(buf.shape, generator=g, device=dev) / buf.shape[1] ** 0.5).to(bf16))
+            else:
+                buf.copy_((0.02 * torch.randn(buf.shape, generator=g, device=dev)).to(bf16))
+        for name in ("wq", "wk", "wv", "proj_mlp_w", "proj_out_w"):
+            setattr(blk, name + "_t", ops_transpose(getattr(blk, name)))
+    torch.manual_seed(1)
+    blk.add_adapter(r=rank, lora_alpha=float(rank))
+    with torch.no_grad():
+        blk.lora_B[:, :, :rank].normal_(0, 0.02, generator=g)
+    blk.gradient_checkpointing = ckpt
+    tokens0 = torch.randn((B, T + S, D), generator=g, device=dev).to(bf16)
+    temb = torch.randn((B, D), generator=g, device=dev).to(bf16)
+    dout = torch.randn((B, T + S, D), generator=g, device=dev).to(bf16)
+    cos, sin = _rope(S, seed=5)
+    tmask = torch.ones(B, T, dtype=torch.long)
+    if masked:
+        tmask[0, T - 3:] = 0
+    res = []
+    for native in (False, True):
+        blk.native = native
+        blk.lora_A.grad = blk.lora_B.grad = None
+        tokens = tokens0.clone().requires_grad_(True)
+        out = blk(tokens, temb, T, (cos.to(dev), sin.to(dev)), text_mask=tmask if masked else None)
+        out.backward(dout)
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), tokens.grad.clone(), blk.lora_A.grad.clone(), blk.lora_B.grad.clone()))
+    (o0, dx0, ga0, gb0), (o1, dx1, ga1, gb1) = res
+    assert torch.equal(o0, o1), f"outputs differ: {_rel(o1, o0):.2e}"
+    assert torch.equal(dx0, dx1), f"input gradients differ: {_rel(dx1, dx0):.2e}"
+    for a, b_, n in ((ga0, ga1, "A"), (gb0, gb1, "B")):
+        assert float((a - b_).norm() / a.norm()) < 1e-6, n
+    rp = blk.lora_A.shape[1]
+    if rp != rank:  # the zero padding never receives a gradient
+        assert float(ga1[:, rank:].abs().max()) == 0.0 and float(gb1[:, :, rank:].abs().max()) == 0.0
+
+
+def ops_transpose(t):
+    from finetrainers_amd import ops
+
+    return ops.transpose_bf16(t)
+
+
 @pytest.mark.parametrize("B,T,S,masked", [(2, 8, 40, True), (1, 16, 150, False)])
 def test_dual_stream_block_forward_backward_parity(B, T, S, masked):
     """One dual-stream block (heads of 128; LoRA r = 64 on the video stream's to_q / to_k / to_v / to_out.0, the text stream's add_*_proj frozen): both
