@@ -99,6 +99,25 @@ class HySingleWeights(Structure):
     _fields_ = [(n, c_void_p) for n in HY_SINGLE_WEIGHT_FIELDS]
 
 
+class HyDualConfig(Structure):
+    """include/ftmi355.h: ftmi_hy_dual_config."""
+
+    _fields_ = [("T", c_int), ("S", c_int), ("D", c_int), ("H", c_int), ("mlp", c_int), ("r", c_int), ("lora_scale", c_float), ("eps", c_float), ("gemm_variant", c_int)]
+
+
+HY_DUAL_WEIGHT_FIELDS = [
+    "norm1_lin_w", "norm1_lin_b", "norm1c_lin_w", "norm1c_lin_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo",
+    "add_q_w", "add_q_b", "add_k_w", "add_k_b", "add_v_w", "add_v_b", "add_out_w", "add_out_b", "norm_q_w", "norm_k_w", "norm_added_q_w", "norm_added_k_w",
+    "ff1_w", "ff1_b", "ff2_w", "ff2_b", "ffc1_w", "ffc1_b", "ffc2_w", "ffc2_b",
+    "wq_t", "wk_t", "wv_t", "wo_t", "add_q_w_t", "add_k_w_t", "add_v_w_t", "add_out_w_t", "ff1_w_t", "ff2_w_t", "ffc1_w_t", "ffc2_w_t",
+    "lora_a", "lora_b", "ones", "zeros",
+]
+
+
+class HyDualWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in HY_DUAL_WEIGHT_FIELDS]
+
+
 class WanRowArgs(Structure):
     """include/ftmi355.h: ftmi_wan_row_args."""
 
@@ -175,6 +194,12 @@ _SIGS = {
     "ftmi_hy_single_scratch_bytes": (c_size_t, [POINTER(HySingleConfig)]),
     "ftmi_hy_single_forward": (c_int, [POINTER(HySingleConfig), POINTER(HySingleWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "ftmi_hy_dual_saved_bytes": (c_size_t, [POINTER(HyDualConfig)]),
+    "ftmi_hy_dual_scratch_bytes": (c_size_t, [POINTER(HyDualConfig)]),
+    "ftmi_hy_dual_forward": (c_int, [POINTER(HyDualConfig), POINTER(HyDualWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "ftmi_hy_dual_backward": (c_int, [POINTER(HyDualConfig), POINTER(HyDualWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "ftmi_hy_single_backward": (c_int, [POINTER(HySingleConfig), POINTER(HySingleWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
 }

@@ -499,6 +499,25 @@ int ftmi_hy_single_backward(const ftmi_hy_single_config* cfg, const ftmi_hy_sing
                               grad_b, saved, saved_bytes, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+size_t ftmi_hy_dual_saved_bytes(const ftmi_hy_dual_config* cfg) { return cfg ? hy_dual_saved_bytes(*cfg) : 0; }
+size_t ftmi_hy_dual_scratch_bytes(const ftmi_hy_dual_config* cfg) { return cfg ? hy_dual_scratch_bytes(*cfg) : 0; }
+int ftmi_hy_dual_forward(const ftmi_hy_dual_config* cfg, const ftmi_hy_dual_weights* w, const void* x_v, const void* x_t, const void* temb_silu,
+                         const float* key_bias, const float* rope_cos, const float* rope_sin, void* out_v, void* out_t, void* saved, size_t saved_bytes,
+                         void* scratch, size_t scratch_bytes, ftmi_stream stream) {
+    if (!cfg || !w || !x_v || !x_t || !temb_silu || !saved || !scratch || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_hy_dual_forward: bad argument");
+    return hy_dual_forward(*cfg, *w, (const bf16_t*)x_v, (const bf16_t*)x_t, (const bf16_t*)temb_silu, key_bias, rope_cos, rope_sin, (bf16_t*)out_v, (bf16_t*)out_t,
+                           saved, saved_bytes, scratch, scratch_bytes, (hipStream_t)stream);
+}
+int ftmi_hy_dual_backward(const ftmi_hy_dual_config* cfg, const ftmi_hy_dual_weights* w, const void* x_v, const void* x_t, const void* dout_v, const void* dout_t,
+                          const float* key_bias, const float* rope_cos, const float* rope_sin, const void* ones_row, void* dx_v, void* dx_t, float* grad_a,
+                          float* grad_b, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, ftmi_stream stream) {
+    if (!cfg || !w || !x_v || !x_t || !dout_v || !dout_t || !ones_row || !dx_v || !dx_t || !saved || !scratch || (rope_cos == nullptr) != (rope_sin == nullptr))
+        return set_error(FTMI_ERR_INVALID, "ftmi_hy_dual_backward: bad argument");
+    return hy_dual_backward(*cfg, *w, (const bf16_t*)x_v, (const bf16_t*)x_t, (const bf16_t*)dout_v, (const bf16_t*)dout_t, key_bias, rope_cos, rope_sin,
+                            (const bf16_t*)ones_row, (bf16_t*)dx_v, (bf16_t*)dx_t, grad_a, grad_b, saved, saved_bytes, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
 int ftmi_cog_patchify(const void* latents, void* tokens, int B, int F, int C, int H, int W, int patch, ftmi_stream stream) {
     if (!latents || !tokens) return set_error(FTMI_ERR_INVALID, "ftmi_cog_patchify: null argument");
     return cog_patch_permute((const bf16_t*)latents, (bf16_t*)tokens, B, F, C, H, W, patch, 1, (hipStream_t)stream);

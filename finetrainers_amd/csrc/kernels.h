@@ -299,6 +299,15 @@ int hy_single_backward(const ftmi_hy_single_config& c, const ftmi_hy_single_weig
                        const float* rope_cos, const float* rope_sin, const bf16_t* ones_rows, bf16_t* dx, float* grad_a, float* grad_b, void* saved,
                        size_t saved_bytes, void* scratch, size_t scratch_bytes, hipStream_t st);
 
+size_t hy_dual_saved_bytes(const ftmi_hy_dual_config& c);
+size_t hy_dual_scratch_bytes(const ftmi_hy_dual_config& c);
+int hy_dual_forward(const ftmi_hy_dual_config& c, const ftmi_hy_dual_weights& w, const bf16_t* x_v, const bf16_t* x_t, const bf16_t* temb_silu, const float* key_bias,
+                    const float* rope_cos, const float* rope_sin, bf16_t* out_v, bf16_t* out_t, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                    hipStream_t st);
+int hy_dual_backward(const ftmi_hy_dual_config& c, const ftmi_hy_dual_weights& w, const bf16_t* x_v, const bf16_t* x_t, const bf16_t* dout_v, const bf16_t* dout_t,
+                     const float* key_bias, const float* rope_cos, const float* rope_sin, const bf16_t* ones_row, bf16_t* dx_v, bf16_t* dx_t, float* grad_a,
+                     float* grad_b, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, hipStream_t st);
+
 int cog_patch_permute(const bf16_t* src, bf16_t* dst, int B, int F, int C, int H, int W, int p, int to_tokens, hipStream_t st);  // latents <-> patch tokens
 
 }  // namespace ftmi

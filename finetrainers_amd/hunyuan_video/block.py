@@ -22,7 +22,7 @@ import torch.nn as nn
 import ctypes
 
 from .. import _lib, ops
-from .._lib import HySingleConfig, HySingleWeights, check, ptr, stream_ptr
+from .._lib import HY_DUAL_WEIGHT_FIELDS, HyDualConfig, HyDualWeights, HySingleConfig, HySingleWeights, check, ptr, stream_ptr
 
 bf16 = torch.bfloat16
 _NATIVE_SCRATCH: Dict[int, torch.Tensor] = {}  # device index -> byte buffer shared by every natively run block on that device (one stream at a time)
@@ -509,6 +509,84 @@ class _DualBlockFunction(torch.autograd.Function):
         return None, dx_v, dx_t, None, None, None, None, ga, gb
 
 
+class _DualBlockNativeFunction(torch.autograd.Function):
+    """``_DualBlockFunction`` with ONE C call per sample and direction (``ftmi_hy_dual_forward / _backward``, csrc/hy_dit.hip)."""
+
+    @staticmethod
+    def _args(blk: "MI355XHunyuanDualBlock", S: int, T: int, lora_a, lora_b, backward: bool):
+        cfg = HyDualConfig(T=T, S=S, D=blk.dim, H=blk.heads, mlp=int(blk.ff1_w.shape[0]), r=0 if lora_a is None else int(lora_a.shape[1]),
+                           lora_scale=float(blk.lora_scale), eps=1e-6, gemm_variant=8)
+        w = HyDualWeights()
+        keep = []
+        for n in HY_DUAL_WEIGHT_FIELDS:
+            if n in ("lora_a", "lora_b") or (n.endswith("_t") and not backward):
+                continue
+            t = getattr(blk, n)
+            if t is None or not t.is_contiguous():
+                raise RuntimeError(f"HunyuanVideo dual-stream block: weight '{n}' is not materialised")
+            keep.append(t)
+            setattr(w, n, ptr(t))
+        if lora_a is not None:
+            la, lb = lora_a.contiguous(), lora_b.contiguous()
+            keep += [la, lb]
+            w.lora_a, w.lora_b = ptr(la), ptr(lb)
+        return cfg, w, keep
+
+    @staticmethod
+    def _forward_call(blk, x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b, out_v, out_t):
+        cfg, w, keep = _DualBlockNativeFunction._args(blk, x_v.shape[0], x_t.shape[0], lora_a, lora_b, backward=False)
+        lib = _lib.load()
+        saved = torch.empty(lib.ftmi_hy_dual_saved_bytes(ctypes.byref(cfg)), dtype=torch.uint8, device=x_v.device)
+        scratch = _native_scratch(x_v.device, lib.ftmi_hy_dual_scratch_bytes(ctypes.byref(cfg)))
+        check(lib.ftmi_hy_dual_forward(ctypes.byref(cfg), ctypes.byref(w), ptr(x_v), ptr(x_t), ptr(temb_silu), ptr(key_bias), ptr(rope_cos), ptr(rope_sin), ptr(out_v),
+                                       ptr(out_t), ptr(saved), saved.numel(), ptr(scratch), scratch.numel(), stream_ptr()), "ftmi_hy_dual_forward")
+        return saved
+
+    @staticmethod
+    def forward(ctx, blk: "MI355XHunyuanDualBlock", x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b):
+        out_v, out_t = torch.empty_like(x_v), torch.empty_like(x_t)
+        saved = _DualBlockNativeFunction._forward_call(blk, x_v, x_t, temb_silu, key_bias, rope_cos, rope_sin, lora_a, lora_b, out_v, out_t)
+        ctx.blk, ctx.rope, ctx.key_bias, ctx.has_lora = blk, (rope_cos, rope_sin), key_bias, lora_a is not None
+        ctx.recompute = bool(blk.gradient_checkpointing)
+        la, lb = (lora_a, lora_b) if lora_a is not None else (x_v.new_empty(0), x_v.new_empty(0))
+        if ctx.recompute:
+            ctx.save_for_backward(x_v, x_t, temb_silu, la, lb)
+        else:
+            ctx.save_for_backward(x_v, x_t, temb_silu, la, lb, saved)
+        return out_v, out_t
+
+    @staticmethod
+    def backward(ctx, dout_v, dout_t):
+        blk, rope = ctx.blk, ctx.rope
+        if ctx.recompute:
+            x_v, x_t, temb_silu, lora_a, lora_b = ctx.saved_tensors
+        else:
+            x_v, x_t, temb_silu, lora_a, lora_b, saved = ctx.saved_tensors
+        if not ctx.has_lora:
+            lora_a = lora_b = None
+        if ctx.recompute:
+            if blk._bwd_seen == 0:
+                blk._materialize_fwd()  # fp8 storage: the arena holds another block's weights by now
+            saved = _DualBlockNativeFunction._forward_call(blk, x_v, x_t, temb_silu, ctx.key_bias, rope[0], rope[1], lora_a, lora_b, None, None)
+        if blk._bwd_seen == 0:
+            blk._materialize_bwd()
+        dout_v, dout_t = dout_v.contiguous(), dout_t.contiguous()
+        own = lora_a is not None and blk._grad_a_view is not None
+        ga = blk._grad_a_view if own else (torch.zeros_like(lora_a) if lora_a is not None else None)
+        gb = blk._grad_b_view if own else (torch.zeros_like(lora_b) if lora_b is not None else None)
+        cfg, w, keep = _DualBlockNativeFunction._args(blk, x_v.shape[0], x_t.shape[0], lora_a, lora_b, backward=True)
+        lib = _lib.load()
+        scratch = _native_scratch(x_v.device, lib.ftmi_hy_dual_scratch_bytes(ctypes.byref(cfg)))
+        dx_v, dx_t = torch.empty_like(x_v), torch.empty_like(x_t)
+        check(lib.ftmi_hy_dual_backward(ctypes.byref(cfg), ctypes.byref(w), ptr(x_v), ptr(x_t), ptr(dout_v), ptr(dout_t), ptr(ctx.key_bias), ptr(rope[0]), ptr(rope[1]),
+                                        ptr(blk.ones_rows(1, x_v.device)), ptr(dx_v), ptr(dx_t), ptr(ga), ptr(gb), ptr(saved), saved.numel(), ptr(scratch),
+                                        scratch.numel(), stream_ptr()), "ftmi_hy_dual_backward")
+        if own:
+            blk._backward_done(ga, gb)
+            return None, dx_v, dx_t, None, None, None, None, None, None
+        return None, dx_v, dx_t, None, None, None, None, ga, gb
+
+
 class MI355XHunyuanDualBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
     """HunyuanVideo dual-stream block (20 of the 60 blocks; [upstream] ``HunyuanVideoTransformerBlock``, oracle/hunyuan.py ``DualStreamBlock``): the video and
     the text tokens have their own modulation, projections, q / k norms and feed-forward and meet in ONE joint attention.  LoRA on the video stream's to_q /
@@ -525,6 +603,7 @@ class MI355XHunyuanDualBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
         "ff_context.net.0.proj.weight": "ffc1_w", "ff_context.net.0.proj.bias": "ffc1_b", "ff_context.net.2.weight": "ffc2_w", "ff_context.net.2.bias": "ffc2_b",
     }
     _TRANSPOSED = ("wq", "wk", "wv", "wo", "add_q_w", "add_k_w", "add_v_w", "add_out_w", "ff1_w", "ff2_w", "ffc1_w", "ffc2_w")
+    native = True  # one C call per sample and direction (csrc/hy_dit.hip); False: the per-kernel composition from Python (the tests compare the two)
 
     def __init__(self, dim: int = 3072, heads: int = 24, mlp_ratio: float = 4.0, device: Optional[torch.device] = None):
         super().__init__()
@@ -593,7 +672,8 @@ class MI355XHunyuanDualBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
             if text_mask is not None:
                 key_bias = torch.zeros((1, T + S), dtype=torch.float32, device=hidden_states.device)
                 key_bias[0, :T].masked_fill_(~text_mask[b].to(hidden_states.device).bool(), float("-inf"))
-            ov, ot = _DualBlockFunction.apply(self, hidden_states[b].contiguous(), encoder_hidden_states[b].contiguous(), temb_silu[b:b + 1], key_bias, cos, sin,
+            fn = _DualBlockNativeFunction if self.native else _DualBlockFunction
+            ov, ot = fn.apply(self, hidden_states[b].contiguous(), encoder_hidden_states[b].contiguous(), temb_silu[b:b + 1], key_bias, cos, sin,
                                               self.lora_A, self.lora_B)
             outs_v.append(ov)
             outs_t.append(ot)

@@ -389,6 +389,37 @@ int ftmi_hy_single_backward(const ftmi_hy_single_config* cfg, const ftmi_hy_sing
                             const float* rope_cos, const float* rope_sin, const void* ones_rows, void* dx, float* grad_a, float* grad_b, void* saved,
                             size_t saved_bytes, void* scratch, size_t scratch_bytes, ftmi_stream stream);
 
+/* HunyuanVideo dual-stream block (the other 20 blocks; [upstream] diffusers HunyuanVideoTransformerBlock, oracle/hunyuan.py DualStreamBlock), ONE SAMPLE per
+ * call: video x_v [S, D] and text x_t [T, D] keep their own modulation (temb_silu [1, D]), projections, q / k norms and feed-forward and meet in one joint
+ * attention over [text | video] (key_bias fp32 [T + S] or NULL; rope_cos / rope_sin fp32 [S, 128] on the video rows); LoRA (adapters 0..3) on the video
+ * stream's to_q / to_k / to_v / to_out.0.  Buffers and gradient semantics as for the single-stream block; out_v == out_t == NULL: recomputation pass. */
+typedef struct {
+    int T, S;         /* text tokens, video tokens of the sample */
+    int D, H, mlp;    /* width = H x 128, feed-forward width */
+    int r;            /* LoRA rank: 0 or a multiple of 64 */
+    float lora_scale, eps;
+    int gemm_variant; /* 8 */
+} ftmi_hy_dual_config;
+typedef struct {
+    const void *norm1_lin_w, *norm1_lin_b, *norm1c_lin_w, *norm1c_lin_b;              /* [6D, D], [6D]: norm1.linear, norm1_context.linear */
+    const void *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo;                                /* video: attn.to_q / to_k / to_v / to_out.0 */
+    const void *add_q_w, *add_q_b, *add_k_w, *add_k_b, *add_v_w, *add_v_b, *add_out_w, *add_out_b; /* text: attn.add_*_proj, attn.to_add_out */
+    const void *norm_q_w, *norm_k_w, *norm_added_q_w, *norm_added_k_w;                /* [128] */
+    const void *ff1_w, *ff1_b, *ff2_w, *ff2_b, *ffc1_w, *ffc1_b, *ffc2_w, *ffc2_b;    /* [mlp, D], [mlp], [D, mlp], [D]: ff, ff_context */
+    const void *wq_t, *wk_t, *wv_t, *wo_t, *add_q_w_t, *add_k_w_t, *add_v_w_t, *add_out_w_t, *ff1_w_t, *ff2_w_t, *ffc1_w_t, *ffc2_w_t; /* transposed: backward only */
+    const float *lora_a, *lora_b;                                                     /* fp32 [4, r, D], [4, D, r]; NULL when r == 0 */
+    const void *ones, *zeros;                                                         /* bf16 [D] */
+} ftmi_hy_dual_weights;
+size_t ftmi_hy_dual_saved_bytes(const ftmi_hy_dual_config* cfg);
+size_t ftmi_hy_dual_scratch_bytes(const ftmi_hy_dual_config* cfg);
+int ftmi_hy_dual_forward(const ftmi_hy_dual_config* cfg, const ftmi_hy_dual_weights* w, const void* x_v, const void* x_t, const void* temb_silu,
+                         const float* key_bias, const float* rope_cos, const float* rope_sin, void* out_v, void* out_t, void* saved, size_t saved_bytes,
+                         void* scratch, size_t scratch_bytes, ftmi_stream stream);
+/* ones_row: bf16 [D] of 1.0; grad_a [4, r, D] / grad_b [4, D, r] fp32 are ADDED to */
+int ftmi_hy_dual_backward(const ftmi_hy_dual_config* cfg, const ftmi_hy_dual_weights* w, const void* x_v, const void* x_t, const void* dout_v, const void* dout_t,
+                          const float* key_bias, const float* rope_cos, const float* rope_sin, const void* ones_row, void* dx_v, void* dx_t, float* grad_a,
+                          float* grad_b, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, ftmi_stream stream);
+
 /* ---- Wan-T2V full fine-tune (BASELINE config 4; finetrainers/models/wan/base_specification.py:433-493 driving [upstream]
  * diffusers transformer_wan.py; restated in oracle/wan.py).  Every parameter trains, so the backward kernels also produce the column sums the
  * parameter gradients need; they ADD to red1 / red2 (fp32, zeroed or kept by the caller; atomics: the summation order is not fixed).
