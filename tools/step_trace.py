@@ -1,6 +1,7 @@
 """Per-step kernel table from a rocprofv3 --kernel-trace CSV of `bench.py`: the trace is cut at the optimiser kernel (one adamw launch per
 step), set-up and warm-up are dropped, and the kernels of the last N steps are summed -- milliseconds per step and launches per step per
-kernel, GPU-busy time and idle gaps.  Usage: python tools/step_trace.py <*_kernel_trace.csv> [n_steps] [out.csv]"""
+kernel, GPU-busy time and idle gaps.  Usage: python tools/step_trace.py <*_kernel_trace.csv> [n_steps] [out.csv] [marker]
+(marker: substring of a kernel launched exactly once per step -- default "adamw_kernel"; "mse_loss_kernel" for the workloads whose optimiser is several launches)"""
 import collections
 import csv
 import re
@@ -13,9 +14,10 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
+marker = sys.argv[4] if len(sys.argv) > 4 else "adamw_kernel"
+marks = [i for i, r in enumerate(rows) if marker in r[2]]
 if len(marks) < nsteps + 1:
-    sys.exit(f"only {len(marks)} optimiser launches in the trace")
+    sys.exit(f"only {len(marks)} '{marker}' launches in the trace")
 lo, hi = marks[-nsteps - 1] + 1, marks[-1] + 1
 sel = rows[lo:hi]
 span = (sel[-1][1] - rows[lo - 1][1]) / nsteps / 1e6
