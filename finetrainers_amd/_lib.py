@@ -118,6 +118,12 @@ class HyDualWeights(Structure):
     _fields_ = [(n, c_void_p) for n in HY_DUAL_WEIGHT_FIELDS]
 
 
+class WanBlockConfig(Structure):
+    """include/ftmi355.h: ftmi_wan_block_config."""
+
+    _fields_ = [("B", c_int), ("S", c_int), ("T", c_int), ("D", c_int), ("H", c_int), ("F", c_int), ("eps", c_float), ("gemm_variant", c_int)]
+
+
 class WanRowArgs(Structure):
     """include/ftmi355.h: ftmi_wan_row_args."""
 
@@ -194,6 +200,12 @@ _SIGS = {
     "ftmi_hy_single_scratch_bytes": (c_size_t, [POINTER(HySingleConfig)]),
     "ftmi_hy_single_forward": (c_int, [POINTER(HySingleConfig), POINTER(HySingleWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "ftmi_wan_block_saved_bytes": (c_size_t, [POINTER(WanBlockConfig)]),
+    "ftmi_wan_block_scratch_bytes": (c_size_t, [POINTER(WanBlockConfig)]),
+    "ftmi_wan_block_param_elements": (c_size_t, [POINTER(WanBlockConfig)]),
+    "ftmi_wan_block_forward": (c_int, [POINTER(WanBlockConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ftmi_wan_block_backward": (c_int, [POINTER(WanBlockConfig), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "ftmi_hy_dual_saved_bytes": (c_size_t, [POINTER(HyDualConfig)]),
     "ftmi_hy_dual_scratch_bytes": (c_size_t, [POINTER(HyDualConfig)]),
     "ftmi_hy_dual_forward": (c_int, [POINTER(HyDualConfig), POINTER(HyDualWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -615,6 +615,24 @@ FTMI_WAN_ENTRY(wan_gate_res_bwd)
 FTMI_WAN_ENTRY(wan_colsum)
 #undef FTMI_WAN_ENTRY
 
+size_t ftmi_wan_block_saved_bytes(const ftmi_wan_block_config* cfg) { return cfg ? wan_block_saved_bytes(*cfg) : 0; }
+size_t ftmi_wan_block_scratch_bytes(const ftmi_wan_block_config* cfg) { return cfg ? wan_block_scratch_bytes(*cfg) : 0; }
+size_t ftmi_wan_block_param_elements(const ftmi_wan_block_config* cfg) { return cfg ? wan_block_param_elements(*cfg) : 0; }
+int ftmi_wan_block_forward(const ftmi_wan_block_config* cfg, const void* params, const void* x, const void* enc, const float* mod, const float* rope_cos,
+                           const float* rope_sin, void* out, void* saved, size_t saved_bytes, ftmi_stream stream) {
+    if (!cfg || !params || !x || !enc || !mod || !rope_cos || !rope_sin || !out || !saved) return set_error(FTMI_ERR_INVALID, "ftmi_wan_block_forward: null argument");
+    return wan_block_forward(*cfg, (const bf16_t*)params, (const bf16_t*)x, (const bf16_t*)enc, mod, rope_cos, rope_sin, (bf16_t*)out, saved, saved_bytes,
+                             (hipStream_t)stream);
+}
+int ftmi_wan_block_backward(const ftmi_wan_block_config* cfg, const void* params, float* grads, const void* x, const void* enc, const float* mod,
+                            const float* rope_cos, const float* rope_sin, const void* dout, void* dx, void* denc, float* dmod, void* saved, size_t saved_bytes,
+                            void* scratch, size_t scratch_bytes, ftmi_stream stream) {
+    if (!cfg || !params || !grads || !x || !enc || !mod || !rope_cos || !rope_sin || !dout || !dx || !denc || !dmod || !saved || !scratch)
+        return set_error(FTMI_ERR_INVALID, "ftmi_wan_block_backward: null argument");
+    return wan_block_backward(*cfg, (const bf16_t*)params, grads, (const bf16_t*)x, (const bf16_t*)enc, mod, rope_cos, rope_sin, (const bf16_t*)dout, (bf16_t*)dx,
+                              (bf16_t*)denc, dmod, saved, saved_bytes, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
 int ftmi_lora_refresh(const float* a_f32, const float* b_f32, void* lora_a_sp, void* lora_bt_sp, void* lora_b_ext, void* lora_at_ext,
                       void* lora_at_qkv_ext, int L, int r, int D, ftmi_stream stream) {
     return ftmi_lora_refresh_n(a_f32, b_f32, lora_a_sp, lora_bt_sp, lora_b_ext, lora_at_ext, lora_at_qkv_ext, L, 8, r, D, stream);

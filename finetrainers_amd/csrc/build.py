@@ -9,7 +9,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "rowwise.hip", "cast.hip", "cogvideox.hip", "ltx_dit.hip", "cog_dit.hip", "hy_dit.hip", "wan.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "rowwise.hip", "cast.hip", "cogvideox.hip", "ltx_dit.hip", "cog_dit.hip", "hy_dit.hip", "wan.hip", "wan_dit.hip", "api.hip"]
 HEADERS = ["common.hip.h", "kernels.h", os.path.join("..", "..", "include", "ftmi355.h")]
 LIB = os.path.join(HERE, "..", "libftmi355.so")
 FLAGS = [

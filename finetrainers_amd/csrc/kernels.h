@@ -286,6 +286,15 @@ int wan_rms_rope_bwd(const WanRowArgs& a, hipStream_t st);
 int wan_gate_res_fwd(const WanRowArgs& a, hipStream_t st);
 int wan_gate_res_bwd(const WanRowArgs& a, hipStream_t st);
 int wan_colsum(const WanRowArgs& a, hipStream_t st);
+// Wan block orchestrator (wan_dit.hip)
+size_t wan_block_saved_bytes(const ftmi_wan_block_config& c);
+size_t wan_block_scratch_bytes(const ftmi_wan_block_config& c);
+size_t wan_block_param_elements(const ftmi_wan_block_config& c);
+int wan_block_forward(const ftmi_wan_block_config& c, const bf16_t* params, const bf16_t* x, const bf16_t* enc, const float* mod, const float* rope_cos,
+                      const float* rope_sin, bf16_t* out, void* saved, size_t saved_bytes, hipStream_t st);
+int wan_block_backward(const ftmi_wan_block_config& c, const bf16_t* params, float* grads, const bf16_t* x, const bf16_t* enc, const float* mod,
+                       const float* rope_cos, const float* rope_sin, const bf16_t* dout, bf16_t* dx, bf16_t* denc, float* dmod, void* saved,
+                       size_t saved_bytes, void* scratch, size_t scratch_bytes, hipStream_t st);
 int adamw_bf16_step(bf16_t* p, const float* g, bf16_t* m, bf16_t* v, long n, const float* sumsq_in, float max_norm, float lr, float beta1, float beta2,
                     float eps, float wd, int step, float* grad_norm_out, hipStream_t st);
 

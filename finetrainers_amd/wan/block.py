@@ -18,9 +18,23 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import ops
+import ctypes
+
+from .. import _lib, ops
+from .._lib import WanBlockConfig, check, ptr, stream_ptr
 
 bf16 = torch.bfloat16
+_NATIVE_SCRATCH: Dict[int, torch.Tensor] = {}  # device index -> byte buffer shared by every natively run block on that device (one stream at a time)
+
+
+def _native_scratch(device: torch.device, nbytes: int) -> torch.Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _NATIVE_SCRATCH.get(idx)
+    if buf is None or buf.numel() < nbytes:
+        _NATIVE_SCRATCH.pop(idx, None)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _NATIVE_SCRATCH[idx] = buf
+    return buf
 
 
 class WanBlockLayout:
@@ -180,9 +194,63 @@ class _WanBlockFunction(torch.autograd.Function):
         return None, dx.view(B, S, D), denc, dmod.to(ctx.temb_dtype), None, None
 
 
+class _WanBlockNativeFunction(torch.autograd.Function):
+    """``_WanBlockFunction`` with ONE C call per direction (``ftmi_wan_block_forward / _backward``, csrc/wan_dit.hip: the same kernels in the same order,
+    activations in one planned buffer per block, transients in a buffer shared by all blocks).  The sharding hooks run around the calls exactly as in the
+    Python composition: parameters are read through ``blk._params()`` (the local or the all-gathered buffer), gradients go to ``blk.grad_flat``."""
+
+    @staticmethod
+    def _cfg(blk: "MI355XWanBlock", B: int, S: int, T: int) -> WanBlockConfig:
+        return WanBlockConfig(B=B, S=S, T=T, D=blk.dim, H=blk.heads, F=blk.ffn_dim, eps=float(blk.eps), gemm_variant=8)
+
+    @staticmethod
+    def forward(ctx, blk: "MI355XWanBlock", x, enc, temb, rope_cos, rope_sin):
+        B, S, D = x.shape
+        T = enc.shape[1]
+        mod = (blk.param("scale_shift_table").float() + temb.float()).contiguous()
+        cfg = _WanBlockNativeFunction._cfg(blk, B, S, T)
+        lib = _lib.load()
+        params = blk._params()
+        if params.numel() != lib.ftmi_wan_block_param_elements(ctypes.byref(cfg)) or not params.is_contiguous():
+            raise RuntimeError("Wan block: the flat parameter buffer does not have the layout the C orchestrator expects")
+        saved = torch.empty(lib.ftmi_wan_block_saved_bytes(ctypes.byref(cfg)), dtype=torch.uint8, device=x.device)
+        out = torch.empty_like(x)
+        check(lib.ftmi_wan_block_forward(ctypes.byref(cfg), ptr(params), ptr(x), ptr(enc), ptr(mod), ptr(rope_cos), ptr(rope_sin), ptr(out), ptr(saved), saved.numel(),
+                                         stream_ptr()), "ftmi_wan_block_forward")
+        ctx.blk, ctx.dims, ctx.rope, ctx.temb_dtype = blk, (B, S, T, D), (rope_cos, rope_sin), temb.dtype
+        ctx.save_for_backward(x, enc, mod, saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        if blk._pre_backward is not None:
+            blk._pre_backward(blk)  # sharded training: gather this block's parameters (prefetch the previous block's), take a gradient buffer
+        B, S, T, D = ctx.dims
+        x, enc, mod, saved = ctx.saved_tensors
+        dout = dout.contiguous()
+        dmod = torch.zeros((6, B, D), dtype=torch.float32, device=x.device)
+        if blk.grad_flat is None:
+            blk.zero_grad_flat()
+        cfg = _WanBlockNativeFunction._cfg(blk, B, S, T)
+        lib = _lib.load()
+        scratch = _native_scratch(x.device, lib.ftmi_wan_block_scratch_bytes(ctypes.byref(cfg)))
+        dx, denc = torch.empty_like(x), torch.empty_like(enc)
+        check(lib.ftmi_wan_block_backward(ctypes.byref(cfg), ptr(blk._params()), ptr(blk.grad_flat), ptr(x), ptr(enc), ptr(mod), ptr(ctx.rope[0]), ptr(ctx.rope[1]),
+                                          ptr(dout), ptr(dx), ptr(denc), ptr(dmod), ptr(saved), saved.numel(), ptr(scratch), scratch.numel(), stream_ptr()),
+              "ftmi_wan_block_backward")
+        dmod = dmod.permute(1, 0, 2)  # [B, 6, D]
+        blk.grad("scale_shift_table").add_(dmod.sum(0, keepdim=True))
+        if blk._grad_hook is not None:
+            blk._grad_hook(blk)  # sharded training: this block's gradients are final -- start their reduce-scatter while the earlier blocks run
+        return None, dx, denc, dmod.to(ctx.temb_dtype), None, None
+
+
 class MI355XWanBlock(nn.Module):
     """Holds the block's flat bf16 parameters and flat fp32 gradients; ``forward(hidden_states, encoder_hidden_states, temb, rotary)`` like the
     reference block, ``temb`` = the [B, 6, D] time projection, ``rotary`` = (cos, sin) fp32 [S, head_dim / 2]."""
+
+    native = True  # one C call per direction (csrc/wan_dit.hip); False: the per-kernel composition from Python (the tests compare the two)
 
     def __init__(self, dim: int = 1536, heads: int = 12, ffn_dim: int = 8960, eps: float = 1e-6, device: Optional[torch.device] = None):
         super().__init__()
@@ -261,4 +329,5 @@ class MI355XWanBlock(nn.Module):
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor, temb: torch.Tensor, rotary) -> torch.Tensor:
         if self._pre_forward is not None:
             self._pre_forward(self)
-        return _WanBlockFunction.apply(self, hidden_states.contiguous(), encoder_hidden_states.contiguous(), temb.contiguous(), rotary[0], rotary[1])
+        fn = _WanBlockNativeFunction if self.native else _WanBlockFunction
+        return fn.apply(self, hidden_states.contiguous(), encoder_hidden_states.contiguous(), temb.contiguous(), rotary[0], rotary[1])

@@ -455,6 +455,28 @@ int ftmi_wan_gate_res_fwd(const ftmi_wan_row_args* args, ftmi_stream stream);
 int ftmi_wan_gate_res_bwd(const ftmi_wan_row_args* args, ftmi_stream stream);
 int ftmi_wan_colsum(const ftmi_wan_row_args* args, ftmi_stream stream);
 
+/* One Wan-T2V DiT block (the unit FSDP-2 shards, finetrainers/parallel/ptd.py:466-499) as ONE call per direction.  params: the block's flat bf16 parameter
+ * buffer in the order of finetrainers_amd/wan/block.py WanBlockLayout (ftmi_wan_block_param_elements elements: attn1 q|k|v weights, their biases, attn1
+ * to_out, attn1 norm_q / norm_k, attn2 to_q, attn2 k|v weights, their biases, attn2 to_out, attn2 norm_q / norm_k, norm2, ffn.net.0.proj, ffn.net.2,
+ * scale_shift_table) -- the local buffer or the all-gathered one; grads: fp32, same layout, ADDED to (every entry except scale_shift_table, whose
+ * gradient the caller forms from dmod).  x [B, S, D], enc [B, T, D] bf16; mod fp32 [B, 6, D] = scale_shift_table + time projection; rope_cos / rope_sin
+ * fp32 [S, 64].  `saved` (ftmi_wan_block_saved_bytes) must live from the forward to the backward of the block; `scratch` (ftmi_wan_block_scratch_bytes,
+ * backward only) may be shared by all blocks of a stream.  dmod fp32 [6, B, D] is ADDED to (per-sample column sums of d shift / d scale / d gate). */
+typedef struct {
+    int B, S, T;      /* batch, video tokens, text tokens */
+    int D, H, F;      /* width = H x 128, feed-forward width */
+    float eps;        /* 1e-6 */
+    int gemm_variant; /* 8 */
+} ftmi_wan_block_config;
+size_t ftmi_wan_block_saved_bytes(const ftmi_wan_block_config* cfg);
+size_t ftmi_wan_block_scratch_bytes(const ftmi_wan_block_config* cfg);
+size_t ftmi_wan_block_param_elements(const ftmi_wan_block_config* cfg);
+int ftmi_wan_block_forward(const ftmi_wan_block_config* cfg, const void* params, const void* x, const void* enc, const float* mod, const float* rope_cos,
+                           const float* rope_sin, void* out, void* saved, size_t saved_bytes, ftmi_stream stream);
+int ftmi_wan_block_backward(const ftmi_wan_block_config* cfg, const void* params, float* grads, const void* x, const void* enc, const float* mod,
+                            const float* rope_cos, const float* rope_sin, const void* dout, void* dx, void* denc, float* dmod, void* saved, size_t saved_bytes,
+                            void* scratch, size_t scratch_bytes, ftmi_stream stream);
+
 /* Sum of squares of a flat fp32 gradient (shard): scratch[0] <- sum g^2 (order-fixed; scratch >= FTMI_CLIP_SCRATCH_FLOATS floats).  Sharded training
  * all-reduces scratch[0] over the ranks before the optimiser call below (the reference's clip_grad_norm_ over DTensor shards, utils/torch.py:99-161). */
 int ftmi_grad_sumsq(const float* grads, long n, float* scratch, ftmi_stream stream);

@@ -172,6 +172,37 @@ def _wan_block_pair(D=256, heads=2, ffn=512, seed=0):
     return cfg, oblk, gblk
 
 
+@pytest.mark.parametrize("B,S,T", [(2, 48, 16), (1, 200, 64), (2, 320, 40)])
+def test_wan_block_c_call_matches_the_python_composition(B, S, T):
+    """``ftmi_wan_block_forward / _backward`` (csrc/wan_dit.hip: the block as one C call per direction, parameters read from the flat bf16 buffer by the
+    layout's offsets, gradients added into the flat fp32 buffer) against the per-kernel composition issued from Python: output, d tokens, d text and d time
+    projection bit-identical, all 27 parameter-gradient tensors equal up to the order of their fp32 atomics."""
+    cfg, oblk, gblk = _wan_block_pair(256, 2, 512)
+    dev, D, hd = _dev(), 256, 128
+    g = torch.Generator().manual_seed(B * 1000 + S + 7)
+    x = torch.randn(B, S, D, generator=g).to(bf16)
+    enc = torch.randn(B, T, D, generator=g).to(bf16)
+    temb = (0.5 * torch.randn(B, 6, D, generator=g)).to(bf16)
+    dout = torch.randn(B, S, D, generator=g).to(bf16)
+    (cos, sin), _ = _rope_tables(S, hd, seed=4)
+    res = []
+    for native in (False, True):
+        gblk.native = native
+        gblk.zero_grad_flat()
+        xg, eg, tg = (t.to(dev).requires_grad_(True) for t in (x, enc, temb))
+        out = gblk(xg, eg, tg, (cos.to(dev), sin.to(dev)))
+        out.backward(dout.to(dev))
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), xg.grad.clone(), eg.grad.clone(), tg.grad.clone(), {k: v.clone() for k, v in gblk.named_grads().items()}))
+    r0, r1 = res
+    for i, n in enumerate(("output", "d tokens", "d text")):
+        assert torch.equal(r0[i], r1[i]), f"{n} differs: {_rel(r1[i], r0[i]):.2e}"
+    assert _rel(r1[3], r0[3]) < 1e-5, "d time projection"  # (column sums: fp32 atomics)
+    for k, v in r0[4].items():
+        d = float((v - r1[4][k]).norm() / v.norm().clamp_min(1e-30))
+        assert d < 2e-6, (k, d)
+
+
 @pytest.mark.parametrize("B,S,T,geom", [(2, 48, 16, (256, 2, 512)), (1, 200, 64, (256, 2, 512)), (1, 21504, 512, (1536, 12, 8960))])
 def test_wan_block_full_finetune_parity(B, S, T, geom):
     """One Wan block (heads of 128 like Wan2.1), forward + backward: output, gradients of the video tokens, the text tokens and the time projection,

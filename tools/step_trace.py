@@ -24,6 +24,7 @@ span = (sel[-1][1] - rows[lo - 1][1]) / nsteps / 1e6
 
 
 def short(n):
+    n = n.replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*$", "", n).replace("void ", "").replace("ftmi::", "")
     return n[:100]
 
