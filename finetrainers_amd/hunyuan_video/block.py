@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 import ctypes
+import os
 
 from .. import _lib, ops
 from .._lib import HY_DUAL_WEIGHT_FIELDS, HyDualConfig, HyDualWeights, HySingleConfig, HySingleWeights, check, ptr, stream_ptr
@@ -298,7 +299,8 @@ class _Fp8StorageMixin:
 class MI355XHunyuanSingleBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
     """Frozen bf16 weights (+ the transposes the input-gradient GEMMs use, made once) and the fp32 LoRA adapters of to_q / to_k / to_v."""
 
-    native = True  # one C call per direction (csrc/hy_dit.hip); False: the per-kernel composition from Python (the tests compare the two)
+    # one C call per direction (csrc/hy_dit.hip); False (or FTMI_NATIVE_BLOCKS=0 in the environment): the per-kernel composition from Python -- the tests compare the two
+    native = os.environ.get("FTMI_NATIVE_BLOCKS", "1") != "0"
 
     _KEYS = {  # diffusers HunyuanVideoSingleTransformerBlock parameter name -> buffer
         "norm.linear.weight": "norm_lin_w", "norm.linear.bias": "norm_lin_b", "proj_mlp.weight": "proj_mlp_w", "proj_mlp.bias": "proj_mlp_b",
@@ -603,7 +605,7 @@ class MI355XHunyuanDualBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):
         "ff_context.net.0.proj.weight": "ffc1_w", "ff_context.net.0.proj.bias": "ffc1_b", "ff_context.net.2.weight": "ffc2_w", "ff_context.net.2.bias": "ffc2_b",
     }
     _TRANSPOSED = ("wq", "wk", "wv", "wo", "add_q_w", "add_k_w", "add_v_w", "add_out_w", "ff1_w", "ff2_w", "ffc1_w", "ffc2_w")
-    native = True  # one C call per sample and direction (csrc/hy_dit.hip); False: the per-kernel composition from Python (the tests compare the two)
+    native = os.environ.get("FTMI_NATIVE_BLOCKS", "1") != "0"  # one C call per sample and direction (csrc/hy_dit.hip); False: the Python composition
 
     def __init__(self, dim: int = 3072, heads: int = 24, mlp_ratio: float = 4.0, device: Optional[torch.device] = None):
         super().__init__()

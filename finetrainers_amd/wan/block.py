@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 import ctypes
+import os
 
 from .. import _lib, ops
 from .._lib import WanBlockConfig, check, ptr, stream_ptr
@@ -250,7 +251,8 @@ class MI355XWanBlock(nn.Module):
     """Holds the block's flat bf16 parameters and flat fp32 gradients; ``forward(hidden_states, encoder_hidden_states, temb, rotary)`` like the
     reference block, ``temb`` = the [B, 6, D] time projection, ``rotary`` = (cos, sin) fp32 [S, head_dim / 2]."""
 
-    native = True  # one C call per direction (csrc/wan_dit.hip); False: the per-kernel composition from Python (the tests compare the two)
+    # one C call per direction (csrc/wan_dit.hip); False (or FTMI_NATIVE_BLOCKS=0 in the environment): the per-kernel composition from Python -- the tests compare the two
+    native = os.environ.get("FTMI_NATIVE_BLOCKS", "1") != "0"
 
     def __init__(self, dim: int = 1536, heads: int = 12, ffn_dim: int = 8960, eps: float = 1e-6, device: Optional[torch.device] = None):
         super().__init__()
