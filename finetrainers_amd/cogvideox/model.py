@@ -3,8 +3,9 @@
 below block 0 needs a gradient).
 
 Reference: [upstream] diffusers ``CogVideoXTransformer3DModel`` as the reference drives it (``finetrainers/models/cogvideox/base_specification.py:
-296-333``), restated in ``oracle/cogvideox.py``.  Both the sincos-table checkpoints (CogVideoX-2b, BASELINE config 3) and the rotary ones (5b: ``use_rotary_positional_embeddings``, RoPE on the
-video rows of q / k) are covered; the 1.5 family (``patch_size_t``, ``ofs``) is not.
+296-333``), restated in ``oracle/cogvideox.py``.  The sincos-table checkpoints (CogVideoX-2b, BASELINE config 3), the rotary ones (5b: ``use_rotary_positional_embeddings``, RoPE on the
+video rows of q / k) and the 1.5 family (``patch_size_t``: patches over two latent frames embedded by a Linear, ``ofs_embed_dim``: an offset embedding added to the
+time embedding, integer-position rotary tables) are covered.
 
 Token layout: ONE buffer ``[B, T + S, D]``, the T = ``max_text_seq_length`` text tokens first.  Orchestration is Python over C-ABI calls (see
 ``block.py``); torch ops touch only per-sample conditioning vectors ([B, 1920] / [B, 512]) and the host-built constant tables.
@@ -50,6 +51,9 @@ class CogVideoXTransformerConfig:
     temporal_interpolation_scale: float = 1.0
     ff_mult: int = 4
     use_rotary_positional_embeddings: bool = False  # 2b: sincos table added in the patch embed; 5b: rotary embedding inside the attention
+    patch_size_t: Optional[int] = None   # CogVideoX 1.5: 2 (patches span patch_size_t latent frames; the patch embedding is a Linear)
+    ofs_embed_dim: Optional[int] = None  # CogVideoX 1.5: 512 (an "offset" embedding added to the time embedding)
+    patch_bias: bool = True              # CogVideoX 1.5: False
 
     @property
     def inner_dim(self) -> int:
@@ -78,19 +82,28 @@ def sincos_position_table(cfg: CogVideoXTransformerConfig, height: int, width: i
 
 
 def rotary_tables(cfg: CogVideoXTransformerConfig, height: int, width: int, frames: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """``prepare_rotary_positional_embeddings`` (finetrainers/models/cogvideox/utils.py:8-51, the ``patch_size_t is None`` branch) for LATENT sizes:
+    """``prepare_rotary_positional_embeddings`` (finetrainers/models/cogvideox/utils.py:8-51, both branches) for LATENT sizes:
     (cos, sin) fp32 [frames * gh * gw, 64]; head channels split t : h : w = 16 : 24 : 24, each frequency repeated for its channel pair; spatial positions
     are a linspace over the crop of the base grid (sample_height / sample_width) that matches this clip's aspect ratio."""
     p, d = cfg.patch_size, cfg.attention_head_dim
     gh, gw, bh, bw = height // p, width // p, cfg.sample_height // p, cfg.sample_width // p
-    if gh / gw > bh / bw:  # get_resize_crop_region_for_grid((gh, gw), bw, bh)
-        rh, rw = bh, int(round(bh / gh * gw))
+    if cfg.patch_size_t is not None:
+        # the ``patch_size_t`` branch (utils.py:38-51 -> [upstream] get_3d_rotary_pos_embed(grid_type="slice")): plain integer positions, one per patch row /
+        # column / frame GROUP, cut out of the base grid
+        frames = (frames + cfg.patch_size_t - 1) // cfg.patch_size_t
+        if gh > bh or gw > bw:
+            raise ValueError(f"CogVideoX 1.5 rotary tables: the clip's patch grid {gh} x {gw} exceeds the model's base grid {bh} x {bw}")
+        grid_h, grid_w = torch.arange(gh, dtype=torch.float32), torch.arange(gw, dtype=torch.float32)
+        grid_t = torch.arange(frames, dtype=torch.float32)
     else:
-        rw, rh = bw, int(round(bw / gw * gh))
-    top, left = int(round((bh - rh) / 2.0)), int(round((bw - rw) / 2.0))
-    grid_h = torch.linspace(top, (top + rh) * (gh - 1) / gh, gh, dtype=torch.float32)
-    grid_w = torch.linspace(left, (left + rw) * (gw - 1) / gw, gw, dtype=torch.float32)
-    grid_t = torch.linspace(0, frames * (frames - 1) / frames, frames, dtype=torch.float32)
+        if gh / gw > bh / bw:  # get_resize_crop_region_for_grid((gh, gw), bw, bh)
+            rh, rw = bh, int(round(bh / gh * gw))
+        else:
+            rw, rh = bw, int(round(bw / gw * gh))
+        top, left = int(round((bh - rh) / 2.0)), int(round((bw - rw) / 2.0))
+        grid_h = torch.linspace(top, (top + rh) * (gh - 1) / gh, gh, dtype=torch.float32)
+        grid_w = torch.linspace(left, (left + rw) * (gw - 1) / gw, gw, dtype=torch.float32)
+        grid_t = torch.linspace(0, frames * (frames - 1) / frames, frames, dtype=torch.float32)
 
     def one(dim, pos):
         ang = torch.outer(pos, 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim)))
@@ -111,6 +124,20 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int) -> torch.Tensor:
     freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half)
     ang = timesteps[:, None].float() * freqs[None, :]
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+
+def patches_3d(latents: torch.Tensor, p: int, pt: int) -> torch.Tensor:
+    """CogVideoX 1.5 patch layout ([upstream] CogVideoXPatchEmbed with ``patch_size_t``): latents [B, F, C, H, W] -> [B, (F/pt)(H/p)(W/p), C pt p p], channel
+    order (channel, frame, row, column) -- also the layout ``proj_out`` produces, so the same permutation (inverted) un-patchifies the velocity."""
+    B, F_, C, H, W = latents.shape
+    x = latents.reshape(B, F_ // pt, pt, C, H // p, p, W // p, p).permute(0, 1, 4, 6, 3, 2, 5, 7)
+    return x.reshape(B, (F_ // pt) * (H // p) * (W // p), C * pt * p * p).contiguous()
+
+
+def unpatches_3d(tokens: torch.Tensor, F_: int, C: int, H: int, W: int, p: int, pt: int) -> torch.Tensor:
+    B = tokens.shape[0]
+    x = tokens.reshape(B, F_ // pt, H // p, W // p, C, pt, p, p).permute(0, 1, 5, 4, 2, 6, 3, 7)
+    return x.reshape(B, F_, C, H, W).contiguous()
 
 
 class _BlockStackFunction(torch.autograd.Function):
@@ -172,7 +199,7 @@ class _HeadFunction(torch.autograd.Function):
     def forward(ctx, m: "MI355XCogVideoXTransformer3DModel", tokens, onep_out, shift_out, geom):
         B, N, D = tokens.shape
         F_, H, W = geom
-        T, S, p, C = m.config.max_text_seq_length, N - m.config.max_text_seq_length, m.config.patch_size, m.config.out_channels
+        T, S, p, C, pt = m.config.max_text_seq_length, N - m.config.max_text_seq_length, m.config.patch_size, m.config.out_channels, m.config.patch_size_t
         nf = torch.empty((B, S, D), dtype=bf16, device=tokens.device)
         no = torch.empty_like(nf)
         for b in range(B):  # the video rows of a sample are contiguous, the samples are T rows apart
@@ -181,6 +208,8 @@ class _HeadFunction(torch.autograd.Function):
         y = ops.gemm_nt(no.view(B * S, D), m.proj_out_w, m.proj_out_b)
         ctx.m, ctx.geom = m, geom
         ctx.save_for_backward(tokens, nf, onep_out)
+        if pt is not None:
+            return unpatches_3d(y.view(B, S, C * pt * p * p), F_, C, H, W, p, pt)
         return ops.cog_unpatchify(y.view(B, S, p * p * C), F_, C, H, W, p)
 
     @staticmethod
@@ -189,7 +218,8 @@ class _HeadFunction(torch.autograd.Function):
         tokens, nf, onep_out = ctx.saved_tensors
         B, N, D = tokens.shape
         T, S, p = m.config.max_text_seq_length, N - m.config.max_text_seq_length, m.config.patch_size
-        dy = ops.cog_patchify(dvel.contiguous(), p)  # the un-patchify's transpose is the patchify
+        pt = m.config.patch_size_t
+        dy = ops.cog_patchify(dvel.contiguous(), p) if pt is None else patches_3d(dvel.contiguous(), p, pt)  # the un-patchify's transpose is the patchify
         dno = ops.gemm_nt(dy.view(B * S, -1), m.proj_out_w_t, None)
         dnf = ops.cog_ln_mod_bwd(nf, m.norm_out_w, onep_out, dno.view(B, S, D), 0, m.config.norm_eps)
         dtok = torch.zeros_like(tokens)  # the text stream does not reach the output
@@ -210,12 +240,19 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
             raise ValueError("the gfx950 attention kernels need head_dim 64")
         dev = device or torch.device("cuda", 0)
         D, p = c.inner_dim, c.patch_size
+        pvol = p * p * (c.patch_size_t or 1)  # elements of one patch per channel
         z = lambda *shape: torch.zeros(shape, dtype=bf16, device=dev)
-        for name, shape in (("patch_w", (D, c.in_channels * p * p)), ("patch_b", (D,)), ("text_w", (D, c.text_embed_dim)), ("text_b", (D,)),
+        if c.ofs_embed_dim is not None:
+            if c.ofs_embed_dim != c.time_embed_dim:
+                raise ValueError("the ofs embedding is added to the time embedding: ofs_embed_dim must equal time_embed_dim")
+            E = c.ofs_embed_dim
+            for name, shape in (("ofs1_w", (E, E)), ("ofs1_b", (E,)), ("ofs2_w", (E, E)), ("ofs2_b", (E,))):
+                self.register_buffer(name, z(*shape))
+        for name, shape in (("patch_w", (D, c.in_channels * pvol)), ("patch_b", (D,)), ("text_w", (D, c.text_embed_dim)), ("text_b", (D,)),
                             ("time1_w", (c.time_embed_dim, D)), ("time1_b", (c.time_embed_dim,)), ("time2_w", (c.time_embed_dim, c.time_embed_dim)),
                             ("time2_b", (c.time_embed_dim,)), ("norm_final_w", (D,)), ("norm_final_b", (D,)), ("norm_out_lin_w", (2 * D, c.time_embed_dim)),
-                            ("norm_out_lin_b", (2 * D,)), ("norm_out_w", (D,)), ("norm_out_b", (D,)), ("proj_out_w", (p * p * c.out_channels, D)),
-                            ("proj_out_b", (p * p * c.out_channels,))):
+                            ("norm_out_lin_b", (2 * D,)), ("norm_out_w", (D,)), ("norm_out_b", (D,)), ("proj_out_w", (pvol * c.out_channels, D)),
+                            ("proj_out_b", (pvol * c.out_channels,))):
             self.register_buffer(name, z(*shape))
         self.register_buffer("proj_out_w_t", None, persistent=False)
         self.register_buffer("_ones_row", torch.ones(1, D, dtype=bf16, device=dev), persistent=False)
@@ -249,9 +286,15 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
     def load_diffusers_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         """A diffusers ``CogVideoXTransformer3DModel`` state dict (peft ``.base_layer.`` infix accepted, LoRA tensors ignored here)."""
         sd = {k.replace(".base_layer.", "."): v for k, v in sd.items() if "lora_" not in k}
-        for k, name in self._KEYS.items():
+        keys = dict(self._KEYS)
+        if not self.config.patch_bias:
+            keys.pop("patch_embed.proj.bias")  # CogVideoX 1.5: no bias (the buffer stays zero)
+        if self.config.ofs_embed_dim is not None:
+            keys.update({"ofs_embedding.linear_1.weight": "ofs1_w", "ofs_embedding.linear_1.bias": "ofs1_b", "ofs_embedding.linear_2.weight": "ofs2_w",
+                         "ofs_embedding.linear_2.bias": "ofs2_b"})
+        for k, name in keys.items():
             getattr(self, name).copy_(sd[k].to(bf16))
-        self.patch_w.copy_(sd["patch_embed.proj.weight"].reshape(self.patch_w.shape).to(bf16))  # Conv2d [D, C, p, p] -> [D, C p p]
+        self.patch_w.copy_(sd["patch_embed.proj.weight"].reshape(self.patch_w.shape).to(bf16))  # Conv2d [D, C, p, p] -> [D, C p p]; 1.5: Linear [D, C pt p p]
         self.proj_out_w_t = ops.transpose_bf16(self.proj_out_w)
         for i, blk in enumerate(self.transformer_blocks):
             pre = f"transformer_blocks.{i}."
@@ -378,16 +421,20 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
         return self._pos_cache[key]
 
     @torch.no_grad()
-    def _embed(self, hidden_states, encoder_hidden_states, timestep):
+    def _embed(self, hidden_states, encoder_hidden_states, timestep, ofs=None):
         c = self.config
         B, F_, C, H, W = hidden_states.shape
-        T, D, p = c.max_text_seq_length, c.inner_dim, c.patch_size
+        T, D, p, pt = c.max_text_seq_length, c.inner_dim, c.patch_size, c.patch_size_t
         if encoder_hidden_states.shape[1] != T:
             raise ValueError(f"CogVideoX expects {T} text tokens (max_text_seq_length), got {encoder_hidden_states.shape[1]}")
-        S = F_ * (H // p) * (W // p)
+        if pt is not None and F_ % pt:
+            raise ValueError(f"CogVideoX 1.5: the latent frame count {F_} must be a multiple of patch_size_t = {pt} (the specification pads it: _pad_frames)")
+        S = (F_ // (pt or 1)) * (H // p) * (W // p)
         tokens = torch.empty((B, T + S, D), dtype=bf16, device=self.device)
-        patches = ops.cog_patchify(hidden_states.to(bf16), p)
+        patches = ops.cog_patchify(hidden_states.to(bf16), p) if pt is None else patches_3d(hidden_states.to(bf16), p, pt)
         text = encoder_hidden_states.to(bf16).contiguous()
+        if pt is not None and not c.use_rotary_positional_embeddings:
+            raise ValueError("CogVideoX 1.5 checkpoints use rotary position embeddings")
         pos = None if c.use_rotary_positional_embeddings else self._pos_table(F_, H, W)
         for b in range(B):
             ops.gemm_nt(text[b], self.text_w, self.text_b, out=tokens[b, :T])
@@ -396,20 +443,23 @@ class MI355XCogVideoXTransformer3DModel(nn.Module):
                 ops.cog_gate_residual(pos, tokens[b:b + 1], self._ones_row, 0, out=tokens[b:b + 1])  # + sincos table (text rows: + 0)
         t_emb = timestep_embedding(timestep.to(self.device), D).to(bf16)
         emb = ops.gemm_nt(torch.nn.functional.silu(ops.gemm_nt(t_emb, self.time1_w, self.time1_b)), self.time2_w, self.time2_b)
+        if c.ofs_embed_dim is not None:  # [upstream] emb = emb + ofs_embedding(ofs_proj(ofs))
+            o_emb = timestep_embedding(ofs.to(self.device), c.ofs_embed_dim).to(bf16)
+            emb = emb + ops.gemm_nt(torch.nn.functional.silu(ops.gemm_nt(o_emb, self.ofs1_w, self.ofs1_b)), self.ofs2_w, self.ofs2_b)
         mod = ops.gemm_nt(torch.nn.functional.silu(emb), self.norm_out_lin_w, self.norm_out_lin_b)  # AdaLayerNorm: shift, scale = chunk(2)
         return tokens, emb, (1 + mod[:, D:]).contiguous(), mod[:, :D].contiguous()
 
     def forward(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb=None, ofs=None, return_dict: bool = False, **kwargs):
-        if ofs is not None:
-            raise NotImplementedError("the ofs / patch_size_t variants (CogVideoX 1.5) are not wired yet")
         c = self.config
+        if (ofs is not None) != (c.ofs_embed_dim is not None):
+            raise ValueError("ofs must be given exactly for the checkpoints with an ofs embedding (CogVideoX 1.5: ofs_embed_dim)")
         if c.use_rotary_positional_embeddings != (image_rotary_emb is not None):
             raise ValueError("image_rotary_emb must be given exactly for the rotary checkpoints (use_rotary_positional_embeddings)")
         if image_rotary_emb is not None:
             image_rotary_emb = tuple(t.to(device=self.device, dtype=torch.float32).contiguous() for t in image_rotary_emb)
         if self.proj_out_w_t is None:
             raise RuntimeError("load_diffusers_state_dict first")
-        tokens, emb, onep_out, shift_out = self._embed(hidden_states, encoder_hidden_states, timestep)
+        tokens, emb, onep_out, shift_out = self._embed(hidden_states, encoder_hidden_states, timestep, ofs)
         T = self.config.max_text_seq_length
         if self.native_blocks and self.lora_flat is not None:
             temb_silu = torch.nn.functional.silu(emb.to(bf16)).contiguous()

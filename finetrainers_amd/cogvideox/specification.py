@@ -89,14 +89,19 @@ class MI355XCogVideoXSpecOps:
     def forward(self, transformer: Callable, latents: torch.Tensor, encoder_hidden_states: torch.Tensor, sigmas: torch.Tensor,
                 image_rotary_emb=None, noise: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
         """-> (pred, target, sigmas) like the reference (:258-333)."""
-        noisy, target, timesteps = self.noise_and_target(latents, sigmas, noise, generator)
         tcfg = getattr(transformer, "config", None)
+        pt = getattr(tcfg, "patch_size_t", None)
+        if pt is not None:  # :287-288 / :403-410 _pad_frames, as written there: F % pt == 0 still appends a full group of copies of the last frame
+            extra = pt - latents.shape[1] % pt
+            latents = torch.cat([latents, latents[:, -1:].expand(-1, extra, -1, -1, -1)], dim=1)
+        noisy, target, timesteps = self.noise_and_target(latents, sigmas, noise, generator)
         if image_rotary_emb is None and getattr(tcfg, "use_rotary_positional_embeddings", False):  # base_specification.py:302-317
             from .model import rotary_tables
 
             image_rotary_emb = tuple(t.to(noisy.device) for t in rotary_tables(tcfg, noisy.shape[3], noisy.shape[4], noisy.shape[1]))
+        ofs = None if getattr(tcfg, "ofs_embed_dim", None) is None else torch.full((noisy.shape[0],), 2.0, dtype=noisy.dtype, device=noisy.device)  # :296-300
         velocity = transformer(hidden_states=noisy, encoder_hidden_states=encoder_hidden_states, timestep=timesteps, image_rotary_emb=image_rotary_emb,
-                               ofs=None, return_dict=False)[0]
+                               ofs=ofs, return_dict=False)[0]
         sa, so = self.scheduler.coefficients(timesteps)
         pred = _GetVelocity.apply(velocity.to(torch.bfloat16), noisy, sa, so)  # scheduler.get_velocity(velocity, noisy_latents, timesteps)
         return pred, target, sigmas
@@ -148,8 +153,6 @@ class MI355XCogVideoXModelSpecification(MI355XCogVideoXSpecOps):
         if state_dict is None:
             directory = wire.resolve_transformer_dir(self.pretrained_model_name_or_path, self.transformer_id)
             disk = wire.load_transformer_config(directory)
-            if disk.get("ofs_embed_dim") is not None or disk.get("patch_size_t") is not None:
-                raise NotImplementedError("this checkpoint is a CogVideoX 1.5 variant (patch_size_t / ofs); the MI355X DiT covers the 2b and 5b architectures")
             if disk:
                 fields = CogVideoXTransformerConfig.__dataclass_fields__
                 cfg = CogVideoXTransformerConfig(**{k: disk[k] for k in fields if k in disk})

@@ -56,7 +56,8 @@ class CogVideoXConfig:
     spatial_interpolation_scale: float = 1.875
     temporal_interpolation_scale: float = 1.0
     use_rotary_positional_embeddings: bool = False  # 2b: sincos table added in the patch embed; 5b: rotary
-    ofs_embed_dim: Optional[int] = None
+    ofs_embed_dim: Optional[int] = None      # CogVideoX 1.5: 512 (an extra "offset" embedding added to the time embedding)
+    patch_bias: bool = True                  # CogVideoX 1.5: False
     ff_mult: int = 4
 
     @property
@@ -189,7 +190,10 @@ class CogVideoXPatchEmbed(nn.Module):
         super().__init__()
         self.cfg = cfg
         d = cfg.inner_dim
-        self.proj = nn.Conv2d(cfg.in_channels, d, kernel_size=(cfg.patch_size, cfg.patch_size), stride=cfg.patch_size, bias=True)
+        if cfg.patch_size_t is None:  # CogVideoX 1.0: a 2-D patch convolution per frame
+            self.proj = nn.Conv2d(cfg.in_channels, d, kernel_size=(cfg.patch_size, cfg.patch_size), stride=cfg.patch_size, bias=cfg.patch_bias)
+        else:  # CogVideoX 1.5: patches over (patch_size_t frames) x p x p, a Linear over the flattened patch (channel, frame, row, column order)
+            self.proj = nn.Linear(cfg.in_channels * cfg.patch_size * cfg.patch_size * cfg.patch_size_t, d, bias=cfg.patch_bias)
         self.text_proj = nn.Linear(cfg.text_embed_dim, d)
         self.use_positional_embeddings = not cfg.use_rotary_positional_embeddings
         if self.use_positional_embeddings:
@@ -207,8 +211,15 @@ class CogVideoXPatchEmbed(nn.Module):
     def forward(self, text_embeds: torch.Tensor, image_embeds: torch.Tensor) -> torch.Tensor:
         text_embeds = self.text_proj(text_embeds)
         b, f, ch, h, w = image_embeds.shape
-        x = self.proj(image_embeds.reshape(-1, ch, h, w))
-        x = x.view(b, f, *x.shape[1:]).flatten(3).transpose(2, 3).flatten(1, 2)  # [B, F*h*w, D]
+        if self.cfg.patch_size_t is None:
+            x = self.proj(image_embeds.reshape(-1, ch, h, w))
+            x = x.view(b, f, *x.shape[1:]).flatten(3).transpose(2, 3).flatten(1, 2)  # [B, F*h*w, D]
+        else:
+            p, pt = self.cfg.patch_size, self.cfg.patch_size_t
+            x = image_embeds.permute(0, 1, 3, 4, 2)  # [B, F, H, W, C]
+            x = x.reshape(b, f // pt, pt, h // p, p, w // p, p, ch)
+            x = x.permute(0, 1, 3, 5, 7, 2, 4, 6).flatten(4, 7).flatten(1, 3)  # [B, (F/pt)(H/p)(W/p), C pt p p]
+            x = self.proj(x)
         embeds = torch.cat([text_embeds, x], dim=1).contiguous()
         if self.use_positional_embeddings:
             c = self.cfg
@@ -321,7 +332,9 @@ class CogVideoXTransformer3DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([CogVideoXBlock(cfg) for _ in range(cfg.num_layers)])
         self.norm_final = nn.LayerNorm(d, cfg.norm_eps, True)
         self.norm_out = AdaLayerNorm(cfg.time_embed_dim, d, cfg.norm_eps)
-        self.proj_out = nn.Linear(d, cfg.patch_size * cfg.patch_size * cfg.out_channels)
+        self.proj_out = nn.Linear(d, cfg.patch_size * cfg.patch_size * cfg.out_channels * (cfg.patch_size_t or 1))
+        # CogVideoX 1.5: Timesteps(ofs_embed_dim, flip_sin_to_cos=True, freq_shift=0) -> TimestepEmbedding(ofs_embed_dim, ofs_embed_dim), added to the time embedding
+        self.ofs_embedding = TimestepEmbedding(cfg.ofs_embed_dim, cfg.ofs_embed_dim) if cfg.ofs_embed_dim is not None else None
 
     @property
     def device(self):
@@ -331,6 +344,9 @@ class CogVideoXTransformer3DModel(nn.Module):
         b, f, ch, h, w = hidden_states.shape
         t_emb = get_timestep_embedding(timestep, self.cfg.inner_dim).to(dtype=hidden_states.dtype)  # flip_sin_to_cos=True, freq_shift=0
         emb = self.time_embedding(t_emb)
+        if self.ofs_embedding is not None:
+            ofs_emb = get_timestep_embedding(ofs, self.cfg.ofs_embed_dim).to(dtype=hidden_states.dtype)
+            emb = emb + self.ofs_embedding(ofs_emb)
         x = self.patch_embed(encoder_hidden_states, hidden_states)
         text_len = encoder_hidden_states.shape[1]
         enc, x = x[:, :text_len], x[:, text_len:]
@@ -341,8 +357,11 @@ class CogVideoXTransformer3DModel(nn.Module):
         else:
             x = self.norm_final(torch.cat([enc, x], dim=1))[:, text_len:]
         x = self.proj_out(self.norm_out(x, temb=emb))
-        p = self.cfg.patch_size
-        out = x.reshape(b, f, h // p, w // p, -1, p, p).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+        p, pt = self.cfg.patch_size, self.cfg.patch_size_t
+        if pt is None:
+            out = x.reshape(b, f, h // p, w // p, -1, p, p).permute(0, 1, 4, 2, 5, 3, 6).flatten(5, 6).flatten(3, 4)
+        else:
+            out = x.reshape(b, (f + pt - 1) // pt, h // p, w // p, -1, pt, p, p).permute(0, 1, 5, 4, 2, 6, 3, 7).flatten(6, 7).flatten(4, 5).flatten(1, 2)
         return (out,) if not return_dict else {"sample": out}
 
 

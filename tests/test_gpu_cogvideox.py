@@ -317,9 +317,11 @@ def test_patchify_roundtrip_and_position_table():
     assert torch.equal(timestep_embedding(t, 1920), ltx.get_timestep_embedding(t, 1920))
 
 
-@pytest.mark.parametrize("rotary,layers,native", [(False, 2, True), (True, 2, True), (False, 30, True), (True, 2, False)])
+@pytest.mark.parametrize("rotary,layers,native", [(False, 2, True), (True, 2, True), (False, 30, True), (True, 2, False), ("1.5", 2, True)])
 def test_model_step_parity_two_blocks(rotary, layers, native):
-    """(rotary = False: the 2b sincos-table architecture, BASELINE config 3; True: the 5b-style rotary embedding on the video rows of q / k.)
+    """(rotary = False: the 2b sincos-table architecture, BASELINE config 3; True: the 5b-style rotary embedding on the video rows of q / k; "1.5": the
+    CogVideoX-1.5 architecture -- patches over two latent frames embedded by a bias-free Linear, ofs embedding, integer-position rotary tables, the
+    specification's frame padding.)
     The whole CogVideoX-2b-width SFT forward + backward at 2 blocks: spec ops (scaling, DDIM noising), patch embed + sincos table, time
     embedding, blocks, final norms, proj_out, un-patchify, velocity -> x0, weighted loss, and every LoRA gradient, against oracle/cogvideox.py."""
     from finetrainers_amd.cogvideox import CogVideoXTransformerConfig, MI355XCogVideoXSpecOps, MI355XCogVideoXTransformer3DModel
@@ -328,7 +330,9 @@ def test_model_step_parity_two_blocks(rotary, layers, native):
 
     dev = _dev()
     # layers = 30: the CogVideoX-2b architecture of BASELINE config 3 at its full depth (width 1920, 30 heads, 30 blocks), small clip
-    kw = dict(num_layers=layers, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16, use_rotary_positional_embeddings=rotary)
+    kw = dict(num_layers=layers, sample_width=12, sample_height=8, sample_frames=9, max_text_seq_length=16, use_rotary_positional_embeddings=bool(rotary))
+    if rotary == "1.5":
+        kw.update(patch_size_t=2, ofs_embed_dim=512, patch_bias=False)
     ocfg = cvx.CogVideoXConfig(**kw)
     omodel = cvx.build_model(ocfg, seed=0, rank=64, alpha=64.0, lora_b_std=0.02)
     with torch.no_grad():
@@ -346,7 +350,8 @@ def test_model_step_parity_two_blocks(rotary, layers, native):
     g = torch.Generator().manual_seed(11)
     B, F_, C, H, W = 2, 3, 16, 8, 12
     lat = torch.randn(B, F_, C, H, W, generator=g).to(bf16)
-    noise = torch.randn(B, F_, C, H, W, generator=g).to(bf16)
+    F_pad = F_ + (2 - F_ % 2) if rotary == "1.5" else F_  # the specification pads the latent frames to a multiple of patch_size_t before the noise is drawn
+    noise = torch.randn(B, F_pad, C, H, W, generator=g).to(bf16)
     text = torch.randn(B, 16, 4096, generator=g).to(bf16)
     sig = torch.tensor([0.21, 0.77])
     osch = cvx.CogVideoXDDIMScheduler()

@@ -829,3 +829,24 @@ def test_stream_k_plan_invariants(ntiles, nk, ov):
     if sk * (nk + ov) >= G * 2 * (ov + 2 * minp):  # enough work for every workgroup: balanced within a forbidden zone
         mean = sum(cost) / G
         assert max(cost) <= mean + (ov + 2 * minp) + pc + ac, (max(cost), mean)
+
+
+def test_cogvideox_15_host_tables_and_patch_layout():
+    """CogVideoX 1.5 host logic against the oracle restatement: the integer-position rotary tables (finetrainers/models/cogvideox/utils.py:38-51, the
+    ``patch_size_t`` branch -> [upstream] get_3d_rotary_pos_embed(grid_type="slice")) bit for bit, and the (channel, frame, row, column) patch layout of the
+    Linear patch embedding / proj_out, forth and back."""
+    from finetrainers_amd.cogvideox.model import CogVideoXTransformerConfig, patches_3d, rotary_tables, unpatches_3d
+    from oracle import cogvideox as cvx
+
+    cfg = CogVideoXTransformerConfig(num_attention_heads=2, num_layers=1, sample_width=12, sample_height=8, patch_size_t=2, use_rotary_positional_embeddings=True)
+    for frames, h, w in ((4, 8, 12), (3, 6, 10)):
+        cos, sin = rotary_tables(cfg, h, w, frames)
+        co, so = cvx.prepare_rotary_positional_embeddings(h * 8, w * 8, frames, 8, 2, 2, 64, cfg.sample_height * 8, cfg.sample_width * 8)
+        assert torch.equal(cos, co) and torch.equal(sin, so)
+    x = torch.randn(2, 4, 16, 8, 12)
+    t = patches_3d(x, 2, 2)
+    ref = x.permute(0, 1, 3, 4, 2).reshape(2, 2, 2, 4, 2, 6, 2, 16).permute(0, 1, 3, 5, 7, 2, 4, 6).flatten(4, 7).flatten(1, 3)  # [upstream] CogVideoXPatchEmbed
+    assert torch.equal(t, ref)
+    assert torch.equal(unpatches_3d(t, 4, 16, 8, 12, 2, 2), x)
+    back = t.reshape(2, 2, 4, 6, -1, 2, 2, 2).permute(0, 1, 5, 4, 2, 6, 3, 7).flatten(6, 7).flatten(4, 5).flatten(1, 2)  # [upstream] the model's final reshape
+    assert torch.equal(back, x)
