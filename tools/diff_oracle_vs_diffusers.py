@@ -107,7 +107,22 @@ def run_cogvideox():
     text = torch.randn(B, 16, 32, generator=g)
     rope = cvx.prepare_rotary_positional_embeddings(H * 8, W * 8, F_, 8, 2, None, cfg.attention_head_dim, cfg.sample_width, cfg.sample_height)
     kw = dict(hidden_states=x, encoder_hidden_states=text, timestep=torch.tensor([310, 840]), image_rotary_emb=rope, return_dict=False)
-    return compare("CogVideoX", om(**kw)[0], up(**kw)[0], om, up, ff_names)
+    rc = compare("CogVideoX", om(**kw)[0], up(**kw)[0], om, up, ff_names)
+    # the 1.5 architecture: patches over two latent frames (Linear patch embedding without bias), ofs embedding, integer-position rotary tables
+    import dataclasses
+
+    cfg15 = dataclasses.replace(cfg, patch_size_t=2, ofs_embed_dim=2, patch_bias=False)
+    torch.manual_seed(0)
+    up15 = CogVideoXTransformer3DModel(num_attention_heads=4, attention_head_dim=16, in_channels=4, out_channels=4, time_embed_dim=2, text_embed_dim=32,
+                                       num_layers=2, sample_width=24, sample_height=24, sample_frames=9, patch_size=2, patch_size_t=2, patch_bias=False,
+                                       ofs_embed_dim=2, temporal_compression_ratio=4, max_text_seq_length=16, use_rotary_positional_embeddings=True).float()
+    om15 = cvx.CogVideoXTransformer3DModel(cfg15).float()
+    load_into_oracle(om15, up15, ff_names)
+    x15 = torch.randn(B, 4, 4, H, W, generator=g)
+    rope15 = cvx.prepare_rotary_positional_embeddings(H * 8, W * 8, 4, 8, 2, 2, cfg.attention_head_dim, cfg.sample_height * 8, cfg.sample_width * 8)
+    kw15 = dict(hidden_states=x15, encoder_hidden_states=text, timestep=torch.tensor([310, 840]), image_rotary_emb=rope15, ofs=torch.full((B,), 2.0), return_dict=False)
+    rc15 = compare("CogVideoX 1.5", om15(**kw15)[0], up15(**kw15)[0], om15, up15, ff_names)
+    return max(rc[0], rc15[0]), max(rc[1], rc15[1])
 
 
 def run_wan():
