@@ -197,7 +197,9 @@ def test_wan_block_c_call_matches_the_python_composition(B, S, T):
     r0, r1 = res
     for i, n in enumerate(("output", "d tokens", "d text")):
         assert torch.equal(r0[i], r1[i]), f"{n} differs: {_rel(r1[i], r0[i]):.2e}"
-    assert _rel(r1[3], r0[3]) < 1e-5, "d time projection"  # (column sums: fp32 atomics)
+    # d time projection: fp32 column sums built with atomics (their order differs run to run by ~1e-7), handed back in bf16 -- a few of the 3 072 entries
+    # land on the other side of a rounding boundary (1 ulp = 4e-3 of one entry; 2e-4 overall was seen)
+    assert _rel(r1[3], r0[3]) < 2e-3, "d time projection"
     for k, v in r0[4].items():
         d = float((v - r1[4][k]).norm() / v.norm().clamp_min(1e-30))
         assert d < 2e-6, (k, d)
