@@ -60,6 +60,7 @@ struct SkPlan {
     unsigned* err;          // [1]: set when a poll gave up
     unsigned epoch;
     unsigned long long* trace;  // debugging (FTMI_SK_TRACE): [G][TRACE_N] s_memtime stamps of workgroup v, or null
+    int order;      // 1: share index = G - 1 - blockIdx (every hand-off wait is on an earlier-dispatched workgroup); 0: XCD-contiguous numbering
 };
 constexpr int TRACE_N = 16;
 // work[v] = {t0, k0, t1, k1, kinds, n_fsk, contrib_mask, 0}: the share starts at K iteration k0 of stream-K tile t0 and ends before k1 of t1;
@@ -79,7 +80,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_sk_kernel(GemmNtArgs p, SkPlan 
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, g = lane >> 5;
     const int gx = s.G >> 3;
-    const int v = (blockIdx.x & 7) * gx + (blockIdx.x >> 3);  // block b runs on XCD b % 8 (observed; speed only): XCD-contiguous ids
+    // Which share of the stream-K work this workgroup takes.  A share's owner piece waits for the partials of shares v + 1, v + 2, ...; workgroups are
+    // dispatched in blockIdx order, so with v = G - 1 - blockIdx every wait is on a workgroup that was dispatched EARLIER (and whose first action is to
+    // publish exactly that partial): the launch makes progress whatever else occupies the device (s.order = 1, default).  s.order = 0 is the first
+    // numbering -- XCD-contiguous ids (block b runs on XCD b % 8), better L2 locality between neighbouring shares, but a share then waits for
+    // LATER-dispatched workgroups and needs all G of them resident, which other spinning kernels on the device can prevent.
+    const int v = s.order ? s.G - 1 - (int)blockIdx.x : (int)(blockIdx.x & 7) * gx + (int)(blockIdx.x >> 3);
 
     int trace_i = 0;
     auto stamp = [&]() {  // (debug) one clock stamp per call, lane 0 of wave 0
@@ -527,11 +533,11 @@ std::mutex g_sk_mu;
 unsigned long long* g_sk_trace = nullptr;
 int g_sk_trace_G = 0;
 std::unordered_map<uint64_t, SkScratch> g_sk_scratch;  // one per (device, stream): launches on one stream are ordered, so one set of slots suffices
-// A persistent launch polls flags of workgroups with HIGHER ids, so it makes progress only if all of its G workgroups become resident.  Two such
-// launches racing on two streams can each hold half of the CUs and wait for the other half for ever (found by the concurrent-stream test in a busy
-// process: the polls gave up after their ~1 s bound and said so in the status word).  So stream-K launches of one device are chained: a launch on
-// another stream than the previous one first waits (device side, hipStreamWaitEvent) for that one's completion event.  Kernels of OTHER kinds on
-// other streams only delay a persistent launch: they finish without waiting for anybody.
+// With the XCD-contiguous share numbering (FTMI_SK_ORDER=0) a persistent launch polls flags of LATER-dispatched workgroups, so it makes progress only
+// if all of its G workgroups become resident: two such launches racing on two streams can each hold half of the CUs and wait for the other half for
+// ever, and so can a foreign kernel that spin-waits for its own workgroups.  For that numbering stream-K launches of one device are chained (a launch
+// on another stream first waits, device side, for the previous one's completion event).  The default numbering (share = G - 1 - blockIdx, see the
+// kernel) needs none of this: every wait is on an earlier-dispatched workgroup whose first action is to publish the awaited partial.
 uint64_t g_sk_last_key[64] = {0};
 bool g_sk_last_valid[64] = {false};
 std::unordered_map<std::string, SkTables> g_sk_tables;  // one per (device, tile grid, K iterations, cost constants)
@@ -687,6 +693,8 @@ int gemm_nt_sk(const GemmNtArgs& a, hipStream_t st) {
     const int cus = sk_cus(dev);
     if (cus < 8) return set_error(FTMI_ERR_LAUNCH, "gemm_nt_sk: cannot read the CU count");
     SkPlan s;
+    static const int order = env_int("FTMI_SK_ORDER", 1);
+    s.order = order;
     s.G = cus - cus % 8;
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
     const int ntiles = ntm * ntn;
@@ -759,7 +767,7 @@ int gemm_nt_sk(const GemmNtArgs& a, hipStream_t st) {
         g_sk_trace_G = s.G;
     }
     const uint64_t my_key = ((uint64_t)(uintptr_t)st) * 64 + (uint64_t)dev;
-    {   // never two persistent launches side by side on one device (see g_sk_last_key)
+    if (!s.order) {  // XCD-contiguous numbering only: never two persistent launches side by side on one device (see g_sk_last_key)
         std::lock_guard<std::mutex> lk(g_sk_mu);
         const int d = dev & 63;
         if (g_sk_last_valid[d] && g_sk_last_key[d] != my_key) {

@@ -123,8 +123,9 @@ int ftmi_gemm_sk_plan(int ntiles, int n_workgroups, int nk, int owner_cost, int 
                       int* work /* [n_workgroups][8] */);
 /* 0 = every stream-K hand-off since the previous call completed; 1 = a bounded wait for a partial gave up (results of that launch are wrong);
  * < 0 = error.  Reads and clears the word; call it after synchronising the streams that ran stream-K launches (tests and debugging only).
- * Persistent launches of one device are chained across streams (a launch waits, device side, for the previous one's completion event): two of
- * them side by side could each hold half of the CUs and poll the other half's flags for ever. */
+ * Liveness: a workgroup takes share G - 1 - blockIdx of the stream-K work, so the partials it waits for belong to workgroups that were dispatched before
+ * it and publish them as their first action -- the launch makes progress whatever else occupies the device (FTMI_SK_ORDER=0 selects the first,
+ * XCD-contiguous numbering, whose launches are chained across streams instead). */
 int ftmi_gemm_sk_status(void);
 /* Debugging aid (FTMI_SK_TRACE=1): shader-clock stamps of the last stream-K launch, out[n_workgroups][16] (start, end of each K phase,
  * hand-off waits, segment ends; 0 = unused); returns n_workgroups, 0 if nothing was traced.  Synchronises the device. */

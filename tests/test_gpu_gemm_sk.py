@@ -127,9 +127,8 @@ def test_sk_repeated_and_concurrent_launches():
     (each stream has its own partial slots; persistent launches of one device are chained through completion events, so they never run side by side), then
     the same with a third stream's unrelated kernels in between.  TWO input sets alternate, so that a consumer which read a stale partial (the previous
     launch's, of the other input set) would produce a wrong tile: every result is compared with its input set's first result.  The hand-off status word is
-    printed per phase and must be clean where this kernel has the device to itself; next to foreign kernels it is reported only -- a persistent launch
-    makes progress only while all of its workgroups can become resident, and in 2 of 4 whole-suite runs of round 3 one of its bounded polls gave up
-    (results were right every time); that liveness condition is why the kernel stays opt-in."""
+    printed per phase.  With the default share numbering (share = G - 1 - blockIdx: every wait is on an earlier-dispatched workgroup) it must be clean
+    in all three; the first numbering (FTMI_SK_ORDER=0) raised it in 2 of 4 whole-suite runs of round 3."""
     from finetrainers_amd import _lib, ops
 
     lib = _lib.load()
@@ -168,9 +167,14 @@ def test_sk_repeated_and_concurrent_launches():
     st2 = two_streams(False)
     st3 = two_streams(True)
     print(f"[sk] hand-off status after 40 launches on one stream: {st1}; after 24 launches alternating on two streams: {st2}; with a third stream's matmuls in between: {st3}")
-    assert st1 >= 0 and st2 >= 0 and st3 >= 0  # (< 0: the status query itself failed)
-    if st1 or st2:
-        pytest.xfail(f"a bounded hand-off poll gave up without foreign kernels on the device (status {st1} / {st2}); every result was right")
+    import os
+
+    if os.environ.get("FTMI_SK_ORDER", "1") == "0":
+        assert st1 >= 0 and st2 >= 0 and st3 >= 0  # (< 0: the status query itself failed)
+        if st1 or st2 or st3:
+            pytest.xfail(f"XCD-contiguous share numbering: a bounded hand-off poll gave up (status {st1} / {st2} / {st3}); every result was right")
+    else:
+        assert st1 == 0 and st2 == 0 and st3 == 0
 
 
 def test_sk_refuses_what_it_cannot_do():
