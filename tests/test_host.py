@@ -850,3 +850,35 @@ def test_cogvideox_15_host_tables_and_patch_layout():
     assert torch.equal(unpatches_3d(t, 4, 16, 8, 12, 2, 2), x)
     back = t.reshape(2, 2, 4, 6, -1, 2, 2, 2).permute(0, 1, 5, 4, 2, 6, 3, 7).flatten(6, 7).flatten(4, 5).flatten(1, 2)  # [upstream] the model's final reshape
     assert torch.equal(back, x)
+
+
+def test_block_orchestrator_planners_agree_with_the_python_layouts():
+    """Host-only entry points of the per-block C orchestrators (no kernel is launched): the Wan block's flat parameter layout has the same length in C
+    (csrc/wan_dit.hip Offsets) as in Python (WanBlockLayout) for several geometries, and the saved / scratch planners of the three block kinds return sizes
+    that cover at least the tensors the Python compositions keep."""
+    import ctypes
+
+    from finetrainers_amd import _lib
+    from finetrainers_amd.wan.block import WanBlockLayout
+
+    lib = _lib.load()
+    for D, H, F in ((256, 2, 512), (1536, 12, 8960), (5120, 40, 13824)):
+        if D > 4096:  # the row-wise kernels' width limit: the planner still answers, the forward would refuse
+            continue
+        cfg = _lib.WanBlockConfig(B=1, S=256, T=64, D=D, H=H, F=F, eps=1e-6, gemm_variant=8)
+        assert lib.ftmi_wan_block_param_elements(ctypes.byref(cfg)) == WanBlockLayout(D, F).total
+        M, Mt = 256, 64
+        kept = 2 * (M * D * 13 + M * 3 * D + Mt * 3 * D + 2 * M * F) + 2 * 4 * H * M  # n1 qkv qn kn o1 a1 x1 n2 q2 q2n o2 x2 n3 f | kv2 k2n | act pre | lse
+        saved = lib.ftmi_wan_block_saved_bytes(ctypes.byref(cfg))
+        assert kept <= saved <= kept + 64 * 256, (D, kept, saved)
+        assert lib.ftmi_wan_block_scratch_bytes(ctypes.byref(cfg)) >= 2 * (7 * D * D + 2 * D * F)  # the seven transposed weights alone
+    hs = _lib.HySingleConfig(B=1, T=256, S=1024, D=3072, H=24, mlp=12288, r=64, lora_scale=1.0, eps=1e-6, gemm_variant=8)
+    M = 1280
+    kept = 2 * M * 3072 * 7 + 2 * M * 12288 + 3 * 2 * M * 192 + 4 * 24 * M  # n q k v qn kn o | pre | xa x 3 | lse
+    saved = lib.ftmi_hy_single_saved_bytes(ctypes.byref(hs))
+    assert kept <= saved <= kept + 64 * 256 + 6 * 2 * 3072
+    assert lib.ftmi_hy_single_scratch_bytes(ctypes.byref(hs)) >= 2 * M * (3072 + 12288)  # the [attention | MLP] feature buffer
+    hd = _lib.HyDualConfig(T=256, S=1024, D=3072, H=24, mlp=12288, r=64, lora_scale=1.0, eps=1e-6, gemm_variant=8)
+    assert lib.ftmi_hy_dual_saved_bytes(ctypes.byref(hd)) > 2 * (1024 * 3072 * 4 + 1280 * 3072 * 4 + 1280 * 12288)
+    bad = _lib.HySingleConfig(B=1, T=8, S=64, D=3072, H=23, mlp=12288, r=64, lora_scale=1.0, eps=1e-6, gemm_variant=8)  # heads x 128 != width
+    assert lib.ftmi_hy_single_saved_bytes(ctypes.byref(bad)) > 0  # planners do not validate; the forward does (FTMI_ERR_UNSUPPORTED)
