@@ -6,6 +6,7 @@ that imports oracle/, and only inside the cpu_baseline functions."""
 
 from __future__ import annotations
 
+import os
 import time
 from typing import Any, Callable, Dict
 
@@ -144,7 +145,7 @@ def build_wan(args, par, dev) -> Dict[str, Any]:
                                + ("" if layers == 30 else " -- REDUCED depth"),
                    "model": "Wan2.1-T2V-1.3B DiT: 30 blocks, width 1536, 12 x 128 heads, 1.42 B trainable bf16 parameters", "seq_len": S,
                    "parallelism_note": f"fsdp{W_}: parameters sharded per unit (bf16 all-gather / fp32 reduce-scatter)" if W_ > 1 else "one GPU: whole shards, no collective",
-                   "activation_checkpointing": False, "orchestration": "python, per block over the C ABI"},
+                   "activation_checkpointing": False, "orchestration": ("one C call per block and direction (ftmi_wan_block_forward / _backward)" if os.environ.get("FTMI_NATIVE_BLOCKS", "1") != "0" else "python, per kernel over the C ABI")},
         "layers": layers,
     }
 
@@ -238,7 +239,7 @@ def build_hunyuan(args, par, dev) -> Dict[str, Any]:
                                f"{nd} dual-stream + {ns} single-stream blocks (BASELINE configs[4])" + ("" if full else " -- REDUCED depth"),
                    "model": "HunyuanVideo DiT: 20 dual + 40 single blocks, width 3072, 24 x 128 heads, 12.8 B frozen parameters", "seq_len": N,
                    "activation_checkpointing": ckpt, "weight_storage": "float8_e4m3fn bytes in HBM, per-block up-cast into a shared bf16 arena",
-                   "orchestration": "python, per block over the C ABI"},
+                   "orchestration": ("one C call per block and direction (ftmi_hy_single_* / ftmi_hy_dual_*)" if os.environ.get("FTMI_NATIVE_BLOCKS", "1") != "0" else "python, per kernel over the C ABI")},
         "layers": nd + ns,
         "dual_single": (nd, ns, dual, single),
     }
