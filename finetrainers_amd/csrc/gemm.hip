@@ -234,6 +234,169 @@ FTMI_DEVICE void nt_run_k2_seg(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hand-placed K loop for 256 x 256 x 64 stages (round 4).  One asm statement per instruction: hipcc allocates the registers, the
+// ORDER of the stream is ours (volatile asm statements are never reordered against each other).
+//
+//   WM x WN = 2 x 2: four waves, ONE PER SIMD, 128 x 128 per wave -- 16 accumulator tiles = 256 registers in the accumulator file
+//             (AGPRs), fragments double-buffered in 64 VGPRs.  Per stage and wave: 64 MFMAs, 32 ds_read_b128 (128 KB per CU: a third
+//             less LDS traffic than 8 waves x 128 x 64), 16 direct-to-LDS loads.
+//   WM x WN = 2 x 4: the same stream for eight waves (128 x 64 per wave, two waves per SIMD) -- the A/B partner.
+//
+// A stage is four k-slices of 16.  The fragments of slice j+1 are read while the MFMAs of slice j issue (one read per gap), so inside
+// a single in-order wave every read is issued >= 8 MFMAs (256 cycles) before its consumer.  Two LDS slots of 64 KB; the one
+// rendezvous per stage sits at the START OF SLICE 3 (not at the stage end):
+//     P_s :  s_waitcnt vmcnt(0)  -- this wave's loads of stage s+1 (issued in slice 3 of stage s-1 and slice 0 of stage s) have landed
+//            s_barrier           -- ... everyone's have, and everyone has READ all of stage s (slice 3's fragments are in registers)
+//   after P_s, during slice 3 of stage s: the fragments of slice 0 of stage s+1 are read from the other slot (no read latency is ever
+//   exposed at a stage boundary) and the loads of stage s+2 start into the slot of stage s; they finish issuing in slice 0 (.. 1) of
+//   stage s+1 and have until P_{s+1} to land: >= 2 slices (1024 MFMA cycles) for the last one.
+// The loads of stages past the end re-stage the last tile into slots nobody reads any more (branch-free tail).
+// ------------------------------------------------------------------------------------------------
+FTMI_DEVICE void pl_ds_read(s16x8& d, uint32_t a, int t) {  // t * 4096 = immediate offset (t is a constant after unrolling)
+    switch (t) {
+        case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); break;
+        case 1: asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(d) : "v"(a)); break;
+        case 2: asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(d) : "v"(a)); break;
+        default: asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(d) : "v"(a)); break;
+    }
+}
+template <bool AGPR>
+FTMI_DEVICE void pl_mfma(f32x16& c, const s16x8& a, const s16x8& b) {
+    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int WM, int WN, int DSP, bool EXT, class MID>
+FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M,
+                               const bf16_t* __restrict__ W, long ldw, int nk1, const bf16_t* __restrict__ X2, long ldx2,
+                               const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TM = 256 / WM / 32, TN = 256 / WN / 32, NW = WM * WN;
+    constexpr int NMF = TM * TN, NRD = TM + TN;
+    constexpr int XI = 32 / NW, LPT = 2 * XI;  // 1-KiB loads per wave and stage: XI of X, then XI of W
+    constexpr bool AG = NW == 4;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, g = lane >> 5;
+    const int S = nk1 + (EXT ? nk2 : 0);
+
+    uint32_t off[LPT], off2[EXT ? LPT : 1];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const bool isx = i < XI;
+        const int blk = wave * XI + (isx ? i : i - XI);
+        const int row = blk * 8 + (lane >> 3), cs = lane & 7;
+        const int c = cs ^ ((row >> 1) & 7);
+        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
+        if constexpr (EXT) off2[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx2 + c * 8) * 2) : (uint32_t)(((long)row * ldw2 + c * 8) * 2);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    const auto xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? X2 : X), (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? W2 : W), (short)0, 0x7fffffff, 0x00020000);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+    // load i of stage t (any t >= 0) -> slot t & 1
+    auto dma = [&](int i, int t) {
+        const int tt = min(t, S - 1);
+        const bool isx = i < XI;
+        const uint32_t dst = lds0 + (uint32_t)(t & 1) * 65536u + (isx ? 0u : 32768u) + (uint32_t)(wave * XI + (isx ? i : i - XI)) * 1024u;
+        // one statement, operands selected by scalar conditions (no branch around the load)
+        const bool seg2 = EXT && tt >= nk1;
+        const int soff = (seg2 ? tt - nk1 : tt) * 128;
+        const uint32_t vo = seg2 ? off2[EXT ? i : 0] : off[i];
+        if (isx) {
+            const auto rs = seg2 ? xrs2 : xrs;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+        } else {
+            const auto rs = seg2 ? wrs2 : wrs;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+        }
+    };
+    // fragment addresses inside slot 0: one register per k-slice and operand; the tile index is an immediate offset (4096 B per 32 rows)
+    uint32_t raw[4], rax[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int ch = (kk * 2 + g) ^ ((li >> 1) & 7);
+        raw[kk] = lds0 + 32768u + (uint32_t)((wn * TN * 32 + li) * 128 + (ch << 4));
+        rax[kk] = lds0 + (uint32_t)((wm * TM * 32 + li) * 128 + (ch << 4));
+    }
+    // hipcc does not know what the MFMA statements write or when: every accumulator passes through this statement (so no ordinary read of
+    // one can be scheduled above it) and the wait states of the last MFMAs' results sit inside it
+    auto acc_fence = [&]() {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            if constexpr (AG) {
+                if constexpr (TM == 4) asm volatile("s_nop 7" : "+a"(acc[tn][0]), "+a"(acc[tn][1]), "+a"(acc[tn][2]), "+a"(acc[tn][3]));
+            } else {
+                if constexpr (TM == 4) asm volatile("s_nop 7" : "+v"(acc[tn][0]), "+v"(acc[tn][1]), "+v"(acc[tn][2]), "+v"(acc[tn][3]));
+            }
+        }
+        static_assert(TM == 4, "acc_fence is written for four row tiles per wave");
+    };
+    s16x8 F[2][NRD];  // [slice parity][W fragments 0..TN-1, X fragments TN..]
+    // read r of k-slice kk of the slot at byte offset so into fragment buffer par
+    auto rd = [&](int par, int r, int kk, uint32_t so) {
+        if (r < TN) pl_ds_read(F[par][r], raw[kk] + so, r);
+        else pl_ds_read(F[par][r], rax[kk] + so, r - TN);
+    };
+
+    // prologue: stage 0 and the part of stage 1 that "slice 3 of stage -1" would have issued
+    constexpr int D3 = (NW == 8) ? 4 : (DSP == 3 ? 6 : 8);  // loads of stage s+2 issued in slice 3 of stage s
+    constexpr int D0 = (NW == 8) ? 4 : (DSP == 3 ? 5 : 8);  // ... in slice 0 of stage s+1 (the rest, if any, in slice 1)
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) dma(i, 0);
+#pragma unroll
+    for (int i = 0; i < D3; ++i) dma(i, 1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) rd(0, r, 0, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    uint32_t so = 0;  // byte offset of the current stage's slot
+    for (int s = 0; s < S; ++s) {
+        if constexpr (EXT) {
+            if (s == nk1) {
+                acc_fence();  // the last MFMAs' results, before ordinary code reads the accumulators
+                mid();
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            if (sl == 3) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
+            const int par = sl & 1;
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                pl_mfma<AG>(acc[m / TM][m % TM], F[par][m / TM], F[par][TN + m % TM]);
+                // fragment reads of the next slice
+                int r = -1;
+                if constexpr (NW == 4) { if ((m & 1) == 0) r = m >> 1; }
+                else { if (m < NRD) r = m; }
+                if (r >= 0 && r < NRD) {
+                    if (sl < 3) rd(par ^ 1, r, sl + 1, so);
+                    else rd(par ^ 1, r, 0, so ^ 65536u);
+                }
+                // direct-to-LDS loads: stage s+2 from slice 3 on, continued in slices 0 (1) of the next stage (= stage s+1 seen from here)
+                int j = -1;
+                if constexpr (NW == 4) { if (m & 1) j = m >> 1; }
+                else { if (m >= 4) j = m - 4; }
+                if (j >= 0) {
+                    if (sl == 3 && j < D3) dma(j, s + 2);
+                    if (sl == 0 && j < D0) dma(D3 + j, s + 1);
+                    if (sl == 1 && j < LPT - D3 - D0) dma(D3 + D0 + j, s + 1);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        so ^= 65536u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    acc_fence();
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // K-loop selector of gemm_nt_kernel (template parameter LOOP).  KL_GEN2_BUF is the production loop; the others are kept as
 // bit-identical A/B partners (tools/bench_gemm.py, tools/ab_variants.sh) and as the timing experiments quoted in DESIGN.md.
 // ------------------------------------------------------------------------------------------------
@@ -259,6 +422,8 @@ enum : int {
     KL_GEN2_REG2 = 20,        // nt_run_k2_reg2: register-staged, two-tile global prefetch
     KL_ASM_RING4 = 22,        // nt_run_k_asm: hand-placed 4-stage ring (256 x 256 x 32, 8 waves)
     KL_ASM_2STAGE = 23,       // nt_run_k_asm2: hand-placed 2-stage loop (256 x 256 x 64, 8 waves)
+    KL_PIPE2 = 24,            // nt_run_k_pipe: hand-placed software pipeline, rendezvous at slice 3, loads spread over 2 slices
+    KL_PIPE3 = 25,            // ... over 3 slices
 };
 constexpr int kl_lds_stages(int loop) { return (loop == KL_RING4 || loop == KL_RING4_PIPE || loop == KL_ASM_RING4) ? 4 : (loop == KL_RING3) ? 3 : (loop == KL_PINGPONG) ? 4 : 2; }
 
@@ -298,7 +463,7 @@ FTMI_DEVICE void nt_k_loop(f32x16 (&acc)[BN / WN / 32][BM / WM / 32], char* smem
         nt_run_k<BM, BN, BK, WM, WN, GLDS, LOOP == KL_2STAGE_PIN,
                  (LOOP == KL_DBG_NOLOAD ? 1 : LOOP == KL_DBG_NOMFMA ? 2 : LOOP == KL_DBG_LDSONLY ? 3 : 0)>(acc, smem, X, ldx, m0, M, W, ldw, 0, nk, tid);
 #else
-    static_assert(LOOP == KL_GEN2_BUF, "the product build ships the production K loop only");
+    static_assert(LOOP == KL_GEN2_BUF, "nt_k_loop: the product build ships nt_run_k2 (the hand-placed nt_run_k_pipe is called by the kernel directly)");
     nt_run_k2<BM, BN, BK, WM, WN, 2, false, true>(acc, smem, X, ldx, m0, M, W, ldw, nk, tid);
 #endif
 }
@@ -340,47 +505,60 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
 
     // first row of this tile's weight panel (rows may live in strided groups; a tile never straddles a group)
     const bf16_t* Wt = p.w_grp_n > 0 ? p.W + (long)(n0 / p.w_grp_n) * p.w_grp_stride + (long)(n0 % p.w_grp_n) * p.ldw : p.W + (long)n0 * p.ldw;
-    {
-        const bf16_t* X = p.X;
-        if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-        if constexpr (!(EXT && LOOP == KL_GEN2_BUF))
-            nt_k_loop<BM, BN, BK, WM, WN, GLDS, LOOP>(acc, smem, X, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
-    }
-
-    if constexpr (EXT) {
-        // reference: result = base(x) [rounded to bf16]; result = result + lora (fp32) -> rounded to bf16
-        auto mid_round = [&]() {
+    const bf16_t* X1 = p.X;
+    if (p.xk_grp_n > 0) X1 += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
+    // reference: result = base(x) [rounded to bf16]; result = result + lora (fp32) -> rounded to bf16
+    constexpr bool PIPE = LOOP == KL_PIPE2 || LOOP == KL_PIPE3;
+    constexpr bool ACC_AGPR = PIPE && WM * WN == 4;  // the hand-placed 4-wave loop keeps the accumulators in the accumulator file
+    auto mid_round = [&]() {
 #pragma unroll
-        for (int tn = 0; tn < T::TN; ++tn)
+        for (int tn = 0; tn < T::TN; ++tn) {
+            float bv[4][4];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const int n = n0 + (wn * T::TN + tn) * 32 + rq * 8 + 4 * g;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                bv[rq][0] = bv[rq][1] = bv[rq][2] = bv[rq][3] = 0.f;
                 if (p.bias) {
                     u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n);
-                    bv[0] = bf2f((bf16_t)(raw[0] & 0xffff));
-                    bv[1] = bf2f((bf16_t)(raw[0] >> 16));
-                    bv[2] = bf2f((bf16_t)(raw[1] & 0xffff));
-                    bv[3] = bf2f((bf16_t)(raw[1] >> 16));
+                    bv[rq][0] = bf2f((bf16_t)(raw[0] & 0xffff));
+                    bv[rq][1] = bf2f((bf16_t)(raw[0] >> 16));
+                    bv[rq][2] = bf2f((bf16_t)(raw[1] & 0xffff));
+                    bv[rq][3] = bf2f((bf16_t)(raw[1] >> 16));
                 }
-#pragma unroll
-                for (int tm = 0; tm < T::TM; ++tm)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[tn][tm][rq * 4 + j] = rbf(acc[tn][tm][rq * 4 + j] * p.alpha + bv[j]);
             }
-        };
+#pragma unroll
+            for (int tm = 0; tm < T::TM; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tn][tm][r] = rbf(acc[tn][tm][r] * p.alpha + bv[r >> 2][r & 3]);
+                // one accumulator tile at a time (256 live accumulators would otherwise be pulled into VGPRs at once and spill)
+                if constexpr (ACC_AGPR) asm volatile("" : "+a"(acc[tn][tm]));
+            }
+        }
+    };
+    if constexpr (PIPE) {
+        static_assert(BM == 256 && BN == 256 && BK == 64, "the hand-placed loop is written for 256 x 256 x 64 stages");
         const bf16_t* X2 = p.X2;
-        if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
-        const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
-                                           : p.W2 + (long)n0 * p.ldw2;
-        if constexpr (LOOP == KL_GEN2_BUF) {
-            const bf16_t* X1 = p.X;
-            if (p.xk_grp_n > 0) X1 += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
-            nt_run_k2_seg<BM, BN, BK, WM, WN>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, X2, p.ldx2, W2t, p.ldw2, p.K2 / BK, tid, mid_round);
-        } else {
-            mid_round();
-            nt_k_loop<BM, BN, BK, WM, WN, GLDS, (LOOP == KL_DBG_NOLOAD || LOOP == KL_DBG_NOMFMA || LOOP == KL_DBG_LDSONLY) ? KL_2STAGE : LOOP>(
-                acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+        const bf16_t* W2t = p.W2;
+        if constexpr (EXT) {
+            if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
+            W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2 : p.W2 + (long)n0 * p.ldw2;
+        }
+        nt_run_k_pipe<WM, WN, LOOP == KL_PIPE3 ? 3 : 2, EXT>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / BK : 0, tid,
+                                                              mid_round);
+    } else {
+        if constexpr (!(EXT && LOOP == KL_GEN2_BUF)) nt_k_loop<BM, BN, BK, WM, WN, GLDS, LOOP>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
+        if constexpr (EXT) {
+            const bf16_t* X2 = p.X2;
+            if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
+            const bf16_t* W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2
+                                               : p.W2 + (long)n0 * p.ldw2;
+            if constexpr (LOOP == KL_GEN2_BUF) {
+                nt_run_k2_seg<BM, BN, BK, WM, WN>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, X2, p.ldx2, W2t, p.ldw2, p.K2 / BK, tid, mid_round);
+            } else {
+                mid_round();
+                nt_k_loop<BM, BN, BK, WM, WN, GLDS, (LOOP == KL_DBG_NOLOAD || LOOP == KL_DBG_NOMFMA || LOOP == KL_DBG_LDSONLY) ? KL_2STAGE : LOOP>(
+                    acc, smem, X2, p.ldx2, m0, p.M, W2t, p.ldw2, p.K2 / BK, tid);
+            }
         }
     }
 
@@ -885,6 +1063,11 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: group width must be a multiple of 64");
     if (wide) {
         int variant = a.variant == 61 ? 8 : a.variant;
+        // FTMI_NT_FORCE=<variant>: every launch the automatic choice would make takes this kernel instead (in-step A/B: tools/ab_env.sh)
+        static const int force_all = env_int("FTMI_NT_FORCE", 0);
+        auto g256 = [](int g) { return g <= 0 || g % 256 == 0; };
+        const bool ok256 = a.N % 256 == 0 && g256(a.w_grp_n) && g256(a.w2_grp_n) && g256(a.xk_grp_n) && g256(a.x2_grp_n);  // 256-wide column tiles allowed
+        if (variant == 8 && force_all > 0 && a.M >= 1024 && ok256) variant = force_all;
         if (variant == 8) {
             // auto: pick the tile by the measured cost model of DESIGN.md section 6 -- a K-tile costs its SIMD 32 cycles per MFMA
             // plus ~85 issue cycles per 1-KiB direct-to-LDS load, tiles run in rounds of (256 CUs x workgroups per CU):
@@ -897,8 +1080,6 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             if (a.M < 1024 || n192 < few192) {
                 variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
             } else {
-                auto g256 = [](int g) { return g <= 0 || g % 256 == 0; };
-                const bool ok256 = a.N % 256 == 0 && g256(a.w_grp_n) && g256(a.w2_grp_n) && g256(a.xk_grp_n) && g256(a.x2_grp_n);
                 struct Cand { int variant, bm, bn, per_cu; };
                 const Cand cands[3] = {{force192 ? force192 : 42, 192, 128, 2}, {49, 192, 256, 1}, {force256 ? force256 : 47, 256, 256, 1}};
                 double best = 0;
@@ -932,6 +1113,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         }
 #ifdef FTMI_EXPERIMENTAL
         switch (variant) {
+            case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
+            case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
+            case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
             case 0: return launch_nt<128, 128, 64, 2, 2, false, 1>(a, st);
             case 2: return launch_nt<128, 128, 32, 2, 2, true, 1>(a, st);
             case 3: return launch_nt<128, 128, 32, 2, 2, true, 3>(a, st);
@@ -977,6 +1161,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     }
 #else
         switch (variant) {
+            case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
+            case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
+            case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
             case 44: return launch_nt<128, 128, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // 128 x 128 tiles (few rows)
             case 47: if (a.N % 256 == 0) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_GEN2_BUF>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 8 waves x (128 x 64)
             default: return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 42: 192 x 128, 2 workgroups per CU

@@ -32,9 +32,10 @@ def report(name, got, ref, rel_tol, max_ulp_frac=None):
     return err
 
 
-# the tiled-GEMM kernels the product library ships: 8 = automatic choice (production), 42 / 44 / 47 pin 192x128 / 128x128 / 256x256 tiles
-# (the research variants of tools/gemm_experimental.hip.h are not in the product build)
-SHIPPED_VARIANTS = [8, 42, 44, 47]
+# the tiled-GEMM kernels the product library ships: 8 = automatic choice (production), 42 / 44 / 47 pin 192x128 / 128x128 / 256x256 tiles,
+# 70 / 71 = the hand-placed 4-wave pipeline (128 x 128 per wave, accumulators in AGPRs; loads spread over 2 / 3 k-slices), 72 = the same
+# stream on 8 waves (the research variants of tools/gemm_experimental.hip.h are not in the product build)
+SHIPPED_VARIANTS = [8, 42, 44, 47, 70, 71, 72]
 
 
 def rnd(shape, gen, scale=1.0, dtype=bf16):
