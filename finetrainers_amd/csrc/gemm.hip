@@ -13,6 +13,7 @@
 // launched by the reference step (SURVEY 2c K6,K7,K10,K14,K15,K17,K18,K19,K21).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.hip.h"
@@ -266,7 +267,9 @@ FTMI_DEVICE void pl_mfma(f32x16& c, const s16x8& a, const s16x8& b) {
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
-template <int WM, int WN, int DSP, bool EXT, class MID>
+// DBG (tools/gemm_lab.hip only; results are wrong on purpose): 1 = no loads inside the loop, 2 = no rendezvous (vmcnt / barrier) inside the loop,
+// 3 = no fragment reads inside the loop, 4 = waves staggered by 16 cycles after every rendezvous (results right)
+template <int WM, int WN, int DSP, bool EXT, int DBG = 0, class MID>
 FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M,
                                const bf16_t* __restrict__ W, long ldw, int nk1, const bf16_t* __restrict__ X2, long ldx2,
                                const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid) {
@@ -306,12 +309,17 @@ FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char
         const bool seg2 = EXT && tt >= nk1;
         const int soff = (seg2 ? tt - nk1 : tt) * 128;
         const uint32_t vo = seg2 ? off2[EXT ? i : 0] : off[i];
+        // M0 (the LDS destination) is written at the first X and the first W load of a stage and advanced by 1 KiB after every load: two
+        // instructions per load instead of four in a 16-cycle MFMA cadence (hipcc writes M0 nowhere inside the K loop: checked in the listing)
+        const bool first = (i == 0 || i == XI);
         if (isx) {
             const auto rs = seg2 ? xrs2 : xrs;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+            if (first) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
+            else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
         } else {
             const auto rs = seg2 ? wrs2 : wrs;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+            if (first) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
+            else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
         }
     };
     // fragment addresses inside slot 0: one register per k-slice and operand; the tile index is an immediate offset (4096 B per 32 rows)
@@ -364,7 +372,14 @@ FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char
         }
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-            if (sl == 3) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
+            if (sl == 3 && DBG != 2) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
+                if constexpr (DBG == 4) {
+                    if (wave == 1) asm volatile("s_nop 15" ::: "memory");
+                    if (wave == 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                    if (wave == 3) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+                }
+            }
             const int par = sl & 1;
 #pragma unroll
             for (int m = 0; m < NMF; ++m) {
@@ -373,7 +388,7 @@ FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char
                 int r = -1;
                 if constexpr (NW == 4) { if ((m & 1) == 0) r = m >> 1; }
                 else { if (m < NRD) r = m; }
-                if (r >= 0 && r < NRD) {
+                if (r >= 0 && r < NRD && DBG != 3) {
                     if (sl < 3) rd(par ^ 1, r, sl + 1, so);
                     else rd(par ^ 1, r, 0, so ^ 65536u);
                 }
@@ -381,7 +396,7 @@ FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char
                 int j = -1;
                 if constexpr (NW == 4) { if (m & 1) j = m >> 1; }
                 else { if (m >= 4) j = m - 4; }
-                if (j >= 0) {
+                if (j >= 0 && DBG != 1) {
                     if (sl == 3 && j < D3) dma(j, s + 2);
                     if (sl == 0 && j < D0) dma(D3 + j, s + 1);
                     if (sl == 1 && j < LPT - D3 - D0) dma(D3 + D0 + j, s + 1);
@@ -425,7 +440,7 @@ enum : int {
     KL_PIPE2 = 24,            // nt_run_k_pipe: hand-placed software pipeline, rendezvous at slice 3, loads spread over 2 slices
     KL_PIPE3 = 25,            // ... over 3 slices
 };
-constexpr int kl_lds_stages(int loop) { return (loop == KL_RING4 || loop == KL_RING4_PIPE || loop == KL_ASM_RING4) ? 4 : (loop == KL_RING3) ? 3 : (loop == KL_PINGPONG) ? 4 : 2; }
+constexpr int kl_lds_stages(int loop) { return loop >= 100 ? 2 : (loop == KL_RING4 || loop == KL_RING4_PIPE || loop == KL_ASM_RING4) ? 4 : (loop == KL_RING3) ? 3 : (loop == KL_PINGPONG) ? 4 : 2; }
 
 // Research scaffolding (alternative K loops, hand-placed asm loops, timing experiments with deliberately wrong results) lives in
 // tools/gemm_experimental.hip.h and is compiled only with -DFTMI_EXPERIMENTAL (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build):
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     const bf16_t* X1 = p.X;
     if (p.xk_grp_n > 0) X1 += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
     // reference: result = base(x) [rounded to bf16]; result = result + lora (fp32) -> rounded to bf16
-    constexpr bool PIPE = LOOP == KL_PIPE2 || LOOP == KL_PIPE3;
+    constexpr bool PIPE = LOOP % 100 == KL_PIPE2 || LOOP % 100 == KL_PIPE3;  // + 100 * DBG in tools/gemm_lab.hip
     constexpr bool ACC_AGPR = PIPE && WM * WN == 4;  // the hand-placed 4-wave loop keeps the accumulators in the accumulator file
     auto mid_round = [&]() {
 #pragma unroll
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
             W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2 : p.W2 + (long)n0 * p.ldw2;
         }
-        nt_run_k_pipe<WM, WN, LOOP == KL_PIPE3 ? 3 : 2, EXT>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / BK : 0, tid,
+        nt_run_k_pipe<WM, WN, LOOP % 100 == KL_PIPE3 ? 3 : 2, EXT, LOOP / 100>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / BK : 0, tid,
                                                               mid_round);
     } else {
         if constexpr (!(EXT && LOOP == KL_GEN2_BUF)) nt_k_loop<BM, BN, BK, WM, WN, GLDS, LOOP>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / BK, tid);
@@ -750,12 +765,542 @@ static int launch_nt2(const GemmNtArgs& a, hipStream_t st) {
 }
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int LOOP = KL_GEN2_BUF>
 static int launch_nt(const GemmNtArgs& a, hipStream_t st) {
+#ifdef FTMI_LAB  // tools/gemm_lab.hip: plain-store kernels only (compile time)
+    return launch_nt3<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE, false, LOOP>(a, st);
+#endif
     switch (a.epi) {
         case EPI_STORE: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_STORE, LOOP>(a, st);
         case EPI_GELU: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_GELU, LOOP>(a, st);
         case EPI_RESID: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_RESID, LOOP>(a, st);
         default: return launch_nt2<BM, BN, BK, WM, WN, GLDS, MINW, EPI_DGELU, LOOP>(a, st);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tiles on v_mfma_f32_16x16x32_bf16 (round 4).  The chip is POWER-limited under matrix load -- what a GEMM buys is
+// (matrix-pipe busy) x (clock), and the clock governor takes back what the pipe gains (profiles/r04_gemm_power.txt) -- and on random bf16
+// data the 16 x 16 x 32 instruction delivers ~16 % more FLOP/s at the power limit than 32 x 32 x 16 (register-only loops: 1 990 vs
+// 1 715 TF/s, tools/probe_mfma_power.hip).  Same LDS image, same direct-to-LDS loads, same hand-placed pipeline as nt_run_k_pipe
+// (4 waves, one per SIMD, 128 x 128 per wave); what changes is the fragment / accumulator layout:
+//   A slot = W rows (n), B slot = X rows (tokens): fragment of 16 rows x 32 k, lane l holds row (l & 15), 16-byte k-chunk (l >> 4)
+//   C/D 16 x 16: lane l holds token row (l & 15) of the tile, registers r = 0..3 hold columns n = 4 * (l >> 4) + r
+//   accumulators: 8 x 8 tiles of 4 registers = 256 AGPRs;  a stage (K = 64) = two k-slices of 32: 2 x 64 MFMAs, 2 x 16 ds_read_b128
+// The ds_read_b128 lane groups stay conflict free on the unchanged swizzle (rows r and chunks c, c + 1 of a group map to 16 distinct slots).
+// Rendezvous P_s at the start of the SECOND slice of stage s; after it the first slice of stage s+1 is read from the other slot and the
+// loads of stage s+2 are issued, one every DG-th MFMA.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+FTMI_DEVICE void pl_ds_read16(s16x8& d, uint32_t a, int t) {  // t * 2048 = immediate offset (t is a constant after unrolling)
+    switch (t) {
+        case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); break;
+        case 1: asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(d) : "v"(a)); break;
+        case 2: asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(d) : "v"(a)); break;
+        case 3: asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(d) : "v"(a)); break;
+        case 4: asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(d) : "v"(a)); break;
+        case 5: asm volatile("ds_read_b128 %0, %1 offset:10240" : "=v"(d) : "v"(a)); break;
+        case 6: asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(d) : "v"(a)); break;
+        default: asm volatile("ds_read_b128 %0, %1 offset:14336" : "=v"(d) : "v"(a)); break;
+    }
+}
+FTMI_DEVICE void pl_mfma16(f32x4_t& c, const s16x8& a, const s16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+
+// every accumulator passes through these statements (no ordinary read of one can be scheduled above them); the wait states of the last
+// MFMAs' results sit inside
+template <int TMW>
+FTMI_DEVICE void acc_fence16(f32x4_t (&acc)[8][TMW]) {
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn) {
+        if constexpr (TMW == 8)
+            asm volatile("s_nop 3" : "+a"(acc[tn][0]), "+a"(acc[tn][1]), "+a"(acc[tn][2]), "+a"(acc[tn][3]), "+a"(acc[tn][4]), "+a"(acc[tn][5]), "+a"(acc[tn][6]), "+a"(acc[tn][7]));
+        else
+            asm volatile("s_nop 3" : "+a"(acc[tn][0]), "+a"(acc[tn][1]), "+a"(acc[tn][2]), "+a"(acc[tn][3]), "+a"(acc[tn][4]), "+a"(acc[tn][5]));
+    }
+}
+
+// TMW = 16-row tiles per wave along the token dimension: 8 -> 256 x 256 tiles, 6 -> 192 x 256 (M = 5376 = 28 x 192: 224 tiles at N = 2048)
+// DBG (tools/gemm_lab.hip only; results wrong on purpose): 1 = no loads inside the loop, 2 = no rendezvous, 3 = no fragment reads
+template <int TMW, bool EXT, int DBG = 0, class MID>
+FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
+                                 int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int XI = TMW;           // 1-KiB loads per wave and stage: (32 TMW rows x 128 B) / 4 waves of X ...
+    constexpr int LPT = XI + 8;       // ... then 8 of W
+    constexpr int NMF = 8 * TMW;      // MFMAs per k-slice of 32
+    constexpr int NRD = 8 + TMW;      // fragment reads per k-slice
+    constexpr int RG = NMF / NRD;     // one read (and one load) every RG-th MFMA: 4 (TMW 8), 3 (TMW 6)
+    static_assert(TMW == 8 || TMW == 6, "192- or 256-row tiles");
+    static_assert(NMF / RG >= NRD && NMF / RG >= LPT, "gaps");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int S = nk1 + (EXT ? nk2 : 0);
+
+    uint32_t off[LPT], off2[EXT ? LPT : 1];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const bool isx = i < XI;
+        const int blk = isx ? wave * XI + i : wave * 8 + (i - XI);
+        const int row = blk * 8 + (lane >> 3), cs = lane & 7;
+        const int c = cs ^ ((row >> 1) & 7);
+        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
+        if constexpr (EXT) off2[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx2 + c * 8) * 2) : (uint32_t)(((long)row * ldw2 + c * 8) * 2);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    const auto xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? X2 : X), (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? W2 : W), (short)0, 0x7fffffff, 0x00020000);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+    // load i of stage t (any t >= 0) -> slot t & 1 (64 KB apart: X image at +0, W image at +32 KB); stages past the end re-stage the last tile into
+    // slots nobody reads any more (branch-free tail); one statement, operands selected by scalar conditions
+    auto dma = [&](int i, int t) {
+        const int tt = min(t, S - 1);
+        const bool isx = i < XI;
+        const uint32_t dst = lds0 + (uint32_t)(t & 1) * 65536u + (isx ? (uint32_t)(wave * XI + i) * 1024u : 32768u + (uint32_t)(wave * 8 + (i - XI)) * 1024u);
+        const bool seg2 = EXT && tt >= nk1;
+        const int soff = (seg2 ? tt - nk1 : tt) * 128;
+        const uint32_t vo = seg2 ? off2[EXT ? i : 0] : off[i];
+        // M0 (the LDS destination) is written at the first X and the first W load of a stage and advanced by 1 KiB after every load: two
+        // instructions per load instead of four in a 16-cycle MFMA cadence (hipcc writes M0 nowhere inside the K loop: checked in the listing)
+        const bool first = (i == 0 || i == XI);
+        if (isx) {
+            const auto rs = seg2 ? xrs2 : xrs;
+            if (first) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
+            else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
+        } else {
+            const auto rs = seg2 ? wrs2 : wrs;
+            if (first) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
+            else asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_add_u32 m0, m0, 0x400" ::"v"(vo), "s"(rs), "s"(soff) : "memory", "scc");
+        }
+    };
+    // fragment addresses inside slot 0: one register per k-slice and operand; the 16-row tile index is an immediate offset (2048 B)
+    uint32_t raw[2], rax[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ch = (kk * 4 + grp) ^ ((l15 >> 1) & 7);
+        raw[kk] = lds0 + 32768u + (uint32_t)((wn * 128 + l15) * 128 + (ch << 4));
+        rax[kk] = lds0 + (uint32_t)((wm * 16 * TMW + l15) * 128 + (ch << 4));
+    }
+    s16x8 F[2][NRD];  // [slice parity][W fragments 0..7, X fragments 8..]
+    // q-th read of a slice, in the order the first MFMAs need them: W0, X0 .. X(TMW-1), W1 .. W7
+    auto rd = [&](int par, int q, int kk, uint32_t so) {
+        const int r = q == 0 ? 0 : (q <= TMW ? 7 + q : q - TMW);
+        if (r < 8) pl_ds_read16(F[par][r], raw[kk] + so, r);
+        else pl_ds_read16(F[par][r], rax[kk] + so, r - 8);
+    };
+
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) dma(i, 0);
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) dma(i, 1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < NRD; ++q) rd(0, q, 0, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    uint32_t so = 0;
+    for (int s = 0; s < S; ++s) {
+        if constexpr (EXT) {
+            if (s == nk1) {
+                acc_fence16<TMW>(acc);
+                mid();
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (sl == 1 && DBG != 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
+                if (m % RG == 0 && m / RG < NRD && DBG != 3) {  // fragment reads of the next slice
+                    if (sl == 0) rd(1, m / RG, 1, so);
+                    else rd(0, m / RG, 0, so ^ 65536u);
+                }
+                if (sl == 1 && m % RG == RG / 2 && m / RG < LPT && DBG != 1) dma(m / RG, s + 2);  // the loads of stage s+2, right after P_s
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        so ^= 65536u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    acc_fence16<TMW>(acc);
+#endif
+}
+
+// The same stream on a FIVE-slot ring of K = 32 stages (5 x 32 KB = the whole 160 KB LDS).  Why: with two 64-KB slots the loads of a stage are
+// issued 1-2 k-slices (1 000-2 000 cycles) before the rendezvous that needs them -- enough for L2 hits, not for the Infinity-Cache / HBM
+// latency of operands that were just written by the previous kernel (in the step every GEMM input is cold; one workgroup per CU has nobody to
+// cover the wait: in-step the two-slot kernel lost what it won in the warm micro-benchmark, profiles/r04_gemm_ab.txt).  Here the loads of stage
+// s+5 are issued during stage s, into the slot whose fragments were read during stage s-1, and are needed by the reads of stage s+4: four
+// stages = 4 096 MFMA cycles of latency budget for every load, issue spread evenly (one load per 8 MFMAs: the CU's vector-memory path at
+// 50 %), retired by a COUNTED vmcnt (three stages stay in flight across every barrier).
+//   stage s:  P_s = { s_waitcnt vmcnt(3 LP) : my loads of stage s+1 have landed;  s_barrier : everyone's have, and everyone has read stage s }
+//             MFMAs of stage s  ||  fragment reads of stage s+1 (slot (s+1) % 5)  ||  loads of stage s+5 -> slot s % 5
+// LDS image of a stage: rows of 64 bytes (four 16-byte chunks), X rows at +0, W rows at +16 KB; chunk c of row r sits in slot c ^ f(r) with
+// f = (0, 3, 2, 1)[(r >> 2) & 3], which keeps the 16 x 32 fragment reads (16 rows x 4 chunks) conflict free.
+template <int TMW, bool EXT, int DBG = 0, class MID>
+FTMI_DEVICE void nt_run_k_ring16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
+                                 int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int XI = TMW / 2;       // 1-KiB loads (16 rows x 64 B) per wave and stage: (32 TMW rows) / 16 / 4 waves of X ...
+    constexpr int LP = XI + 4;        // ... then 4 of W
+    constexpr int NMF = 8 * TMW, NRD = 8 + TMW;
+    constexpr int RG = NMF / NRD;     // one read every RG-th MFMA
+    constexpr int NS = 5, SLOT = 32768;
+    static_assert(TMW == 8 || TMW == 6, "192- or 256-row tiles");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int S = nk1 + (EXT ? nk2 : 0);
+    auto fsw = [](int row) { return (4 - ((row >> 2) & 3)) & 3; };
+
+    uint32_t off[LP], off2[EXT ? LP : 1];
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const bool isx = i < XI;
+        const int blk = isx ? wave * XI + i : wave * 4 + (i - XI);
+        const int row = blk * 16 + (lane >> 2), cs = lane & 3;
+        const int c = cs ^ fsw(row);
+        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
+        if constexpr (EXT) off2[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx2 + c * 8) * 2) : (uint32_t)(((long)row * ldw2 + c * 8) * 2);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    const auto xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? X2 : X), (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? W2 : W), (short)0, 0x7fffffff, 0x00020000);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+    // load i of stage t into the slot at byte offset slot_off (stages past the end re-stage the last one where nobody reads any more)
+    auto dma = [&](int i, int t, uint32_t slot_off) {
+        const int tt = min(t, S - 1);
+        const bool isx = i < XI;
+        const uint32_t dst = lds0 + slot_off + (isx ? (uint32_t)(wave * XI + i) * 1024u : 16384u + (uint32_t)(wave * 4 + (i - XI)) * 1024u);
+        const bool seg2 = EXT && tt >= nk1;
+        const int soff = (seg2 ? tt - nk1 : tt) * 64;
+        const uint32_t vo = seg2 ? off2[EXT ? i : 0] : off[i];
+        if (isx) {
+            const auto rs = seg2 ? xrs2 : xrs;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+        } else {
+            const auto rs = seg2 ? wrs2 : wrs;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+        }
+    };
+    // fragment addresses inside a slot: lane = row (l & 15), chunk (l >> 4); the 16-row tile index is an immediate offset (1024 B)
+    const int ch = grp ^ fsw(l15);
+    const uint32_t raw = lds0 + 16384u + (uint32_t)((wn * 128 + l15) * 64 + (ch << 4));
+    const uint32_t rax = lds0 + (uint32_t)((wm * 16 * TMW + l15) * 64 + (ch << 4));
+    s16x8 F[2][NRD];
+    auto rd1 = [&](s16x8& d, uint32_t a, int t) {
+        switch (t) {
+            case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(a)); break;
+            case 1: asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(d) : "v"(a)); break;
+            case 2: asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(d) : "v"(a)); break;
+            case 3: asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(d) : "v"(a)); break;
+            case 4: asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(d) : "v"(a)); break;
+            case 5: asm volatile("ds_read_b128 %0, %1 offset:5120" : "=v"(d) : "v"(a)); break;
+            case 6: asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(d) : "v"(a)); break;
+            default: asm volatile("ds_read_b128 %0, %1 offset:7168" : "=v"(d) : "v"(a)); break;
+        }
+    };
+    auto rd = [&](int par, int q, uint32_t so) {  // q-th read of a stage: W0, X0 .. X(TMW-1), W1 .. W7
+        const int r = q == 0 ? 0 : (q <= TMW ? 7 + q : q - TMW);
+        if (r < 8) rd1(F[par][r], raw + so, r);
+        else rd1(F[par][r], rax + so, r - 8);
+    };
+
+    // prologue: stages 0..4 in flight, stage 0 landed, its fragments in registers
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int i = 0; i < LP; ++i) dma(i, t, (uint32_t)t * SLOT);
+    if constexpr (LP == 8) asm volatile("s_waitcnt vmcnt(32)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < NRD; ++q) rd(0, q, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    uint32_t so = 0;  // slot of the current stage
+    auto stage = [&](int s, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        if constexpr (EXT) {
+            if (s == nk1) {
+                acc_fence16<TMW>(acc);
+                mid();
+            }
+        }
+        if constexpr (DBG != 2) {
+            if constexpr (LP == 8) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");  // P_s
+            else asm volatile("s_waitcnt vmcnt(21)\n\ts_barrier" ::: "memory");
+        }
+        const uint32_t son = so + SLOT == NS * SLOT ? 0u : so + SLOT;  // slot of stage s+1
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            pl_mfma16(acc[m / TMW][m % TMW], F[par][m / TMW], F[par][8 + m % TMW]);
+            if (m % RG == 0 && m / RG < NRD && DBG != 3) rd(par ^ 1, m / RG, son);
+            if (m % (2 * RG) == RG / 2 + 1 && m / (2 * RG) < LP && DBG != 1) dma(m / (2 * RG), s + NS, so);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        so = son;
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int s = 0;
+    for (; s + 1 < S; s += 2) {
+        stage(s, P0{});
+        stage(s + 1, P1{});
+    }
+    if (s < S) {  // odd number of stages: the fragments end up in the other buffer, nothing reads them
+        stage(s, P0{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    acc_fence16<TMW>(acc);
+#endif
+}
+
+template <int TMW, int EPI, bool EXT, int DBG, bool RING = false>
+__global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, grp = lane >> 4;
+    constexpr int BM = 32 * TMW, BN = 256, WROWS = 16 * TMW;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
+    int tile_m, tile_n;
+    {  // tile -> XCD rasterisation: as gemm_nt_kernel
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xm = xcd / p.map_gn, xn = xcd % p.map_gn;
+        constexpr int GN = 4;
+        const int gsz = p.map_rm * GN;
+        const int grpi = idx / gsz, r = idx - grpi * gsz;
+        const int cols = min(GN, p.map_rn - grpi * GN);
+        tile_m = xm * p.map_rm + r / cols;
+        tile_n = xn * p.map_rn + grpi * GN + r % cols;
+    }
+    if (tile_m >= ntm || tile_n >= ntn) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    f32x4_t acc[8][TMW];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < TMW; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* Wt = p.w_grp_n > 0 ? p.W + (long)(n0 / p.w_grp_n) * p.w_grp_stride + (long)(n0 % p.w_grp_n) * p.ldw : p.W + (long)n0 * p.ldw;
+    const bf16_t* X1 = p.X;
+    if (p.xk_grp_n > 0) X1 += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
+    // bias of this lane's columns: n = n0 + (wn * 8 + tn) * 16 + 4 * grp + j  (loaded where it is used: 32 registers that must not stay live
+    // across the K loop)
+    auto load_bias = [&](auto& bv) {
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) {
+            bv[tn][0] = bv[tn][1] = bv[tn][2] = bv[tn][3] = 0.f;
+            if (p.bias) {
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(p.bias + n0 + (wn * 8 + tn) * 16 + 4 * grp);
+                bv[tn][0] = bf2f((bf16_t)(raw[0] & 0xffff));
+                bv[tn][1] = bf2f((bf16_t)(raw[0] >> 16));
+                bv[tn][2] = bf2f((bf16_t)(raw[1] & 0xffff));
+                bv[tn][3] = bf2f((bf16_t)(raw[1] >> 16));
+            }
+        }
+    };
+    // reference: result = base(x) [rounded to bf16]; result = result + lora (fp32) -> rounded to bf16.  With a K-extension the bias is needed in
+    // the MIDDLE of the K loop: loaded up front (a load there would expose its latency to all four SIMDs)
+    float bvx[EXT ? 8 : 1][4];
+    if constexpr (EXT) load_bias(bvx);
+    auto mid_round = [&]() {
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tn][tm][r] = rbf(acc[tn][tm][r] * p.alpha + bvx[EXT ? tn : 0][r]);
+                asm volatile("" : "+a"(acc[tn][tm]));  // one accumulator tile at a time (no bulk migration into VGPRs)
+            }
+    };
+    // Row-wise epilogue inputs (residual / GELU pre-activation: whole lines, 32 rows x 256 B per wave and block) are read one block AHEAD into
+    // registers: block 0 before the K loop (its HBM latency disappears behind the whole loop -- with one workgroup per CU nothing else would
+    // cover it, and in the step these tensors are cold), block b+1 while block b is processed.
+    constexpr bool HAS_IN = EPI == EPI_RESID || EPI == EPI_DGELU;
+    const int srow = lane >> 4, schunk = lane & 15;
+    const int ncol0 = n0 + wn * 128;  // first column of the wave
+    const bf16_t* in_src = EPI == EPI_RESID ? p.resid : p.aux;
+    const long in_ld = EPI == EPI_RESID ? p.ldr : p.ldaux;
+    u32x4 pre[HAS_IN ? 8 : 1];
+    auto fetch_regs = [&](int blk) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int mm = min(m0 + wm * WROWS + blk * 32 + it * 4 + srow, p.M - 1);
+            pre[HAS_IN ? it : 0] = *reinterpret_cast<const u32x4*>(in_src + (long)mm * in_ld + ncol0 + schunk * 8);
+        }
+    };
+    if constexpr (HAS_IN) fetch_regs(0);
+    {
+        const bf16_t* X2 = p.X2;
+        const bf16_t* W2t = p.W2;
+        if constexpr (EXT) {
+            if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
+            W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2 : p.W2 + (long)n0 * p.ldw2;
+        }
+        if constexpr (RING)
+            nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
+        else
+            nt_run_k_pipe16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round);
+    }
+
+    // ---------------- epilogue ----------------
+    // Per 32-token block of the wave's tile: every lane packs its 4 consecutive columns of a 16 x 16 accumulator tile to 8 bytes and drops them
+    // into the wave's LDS scratch (row-major 32 x 256 B, 16-byte chunks XOR-swizzled), then the wave stores 4 rows x 256 contiguous bytes per
+    // instruction: whole 128-byte lines, as the 32 x 32 kernels do.  Row-wise inputs (residual, GELU pre-activation) come in the same way
+    // through the second scratch block.
+    char* scr = smem + wave * 8192;
+    char* scr_in = smem + 4 * 8192 + wave * 8192;
+    auto scr_off = [&](int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); };
+    auto fetch_put = [&]() {  // the block read ahead -> second scratch block
+#pragma unroll
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4*>(scr_in + scr_off(it * 4 + srow, schunk)) = pre[HAS_IN ? it : 0];
+    };
+    auto flush = [&](const char* from, bf16_t* dst, long ld, int blk) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + srow;
+            const u32x4 w = *reinterpret_cast<const u32x4*>(from + scr_off(row, schunk));
+            const int mm = m0 + wm * WROWS + blk * 32 + row;
+            if (mm < p.M) *reinterpret_cast<u32x4*>(dst + (long)mm * ld + ncol0 + schunk * 8) = w;
+        }
+    };
+    float bv[8][4];
+    if constexpr (!EXT) load_bias(bv);
+#pragma unroll
+    for (int blk = 0; blk < TMW / 2; ++blk) {
+        if constexpr (HAS_IN) {
+            fetch_put();
+            if (blk + 1 < TMW / 2) fetch_regs(blk + 1);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tm = blk * 2 + h, rl = h * 16 + l15;
+            const int m = min(m0 + wm * WROWS + blk * 32 + rl, p.M - 1);  // rows past M compute on row M-1 and are dropped by flush()
+            const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
+#pragma unroll
+            for (int tn = 0; tn < 8; ++tn) {
+                const int n = ncol0 + tn * 16 + 4 * grp;
+                const int so8 = scr_off(rl, tn * 2 + (grp >> 1)) + (grp & 1) * 8;  // this lane's 8 bytes inside the scratch image
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[tn][tm][j];
+                if constexpr (!EXT) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * p.alpha + bv[tn][j];
+                }
+                float o[4];
+                u32x2 pkz;
+                bool have_z = false;
+                if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = v[j];
+                } else if constexpr (EPI == EPI_GELU) {
+                    float z[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        z[j] = rbf(v[j]);
+                        o[j] = gelu_tanh_f(z[j]);
+                    }
+                    pkz[0] = pack2bf(z[0], z[1]);
+                    pkz[1] = pack2bf(z[2], z[3]);
+                    have_z = true;
+                } else if constexpr (EPI == EPI_RESID) {
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(scr_in + so8);
+                    const float rv[4] = {bf2f((bf16_t)(rr[0] & 0xffff)), bf2f((bf16_t)(rr[0] >> 16)), bf2f((bf16_t)(rr[1] & 0xffff)), bf2f((bf16_t)(rr[1] >> 16))};
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = rbf(v[j]);
+                    if (p.gate) {
+                        const u32x2 gg = *reinterpret_cast<const u32x2*>(p.gate + (long)b * p.gate_bstride + n);
+                        const float gv[4] = {bf2f((bf16_t)(gg[0] & 0xffff)), bf2f((bf16_t)(gg[0] >> 16)), bf2f((bf16_t)(gg[1] & 0xffff)), bf2f((bf16_t)(gg[1] >> 16))};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = rbf(y[j] * gv[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = rv[j] + y[j];
+                    if (p.out2) {
+                        const u32x2 g2 = *reinterpret_cast<const u32x2*>(p.gate2 + (long)b * p.gate2_bstride + n);
+                        const float g2v[4] = {bf2f((bf16_t)(g2[0] & 0xffff)), bf2f((bf16_t)(g2[0] >> 16)), bf2f((bf16_t)(g2[1] & 0xffff)), bf2f((bf16_t)(g2[1] >> 16))};
+                        pkz[0] = pack2bf(rbf(o[0]) * g2v[0], rbf(o[1]) * g2v[1]);
+                        pkz[1] = pack2bf(rbf(o[2]) * g2v[2], rbf(o[3]) * g2v[3]);
+                        have_z = true;
+                    }
+                } else {  // EPI_DGELU: grad_in = grad_out * gelu'(z)
+                    const u32x2 zz = *reinterpret_cast<const u32x2*>(scr_in + so8);
+                    const float zv[4] = {bf2f((bf16_t)(zz[0] & 0xffff)), bf2f((bf16_t)(zz[0] >> 16)), bf2f((bf16_t)(zz[1] & 0xffff)), bf2f((bf16_t)(zz[1] >> 16))};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = rbf(v[j]) * gelu_tanh_grad_f(zv[j]);
+                }
+                u32x2 pk;
+                pk[0] = pack2bf(o[0], o[1]);
+                pk[1] = pack2bf(o[2], o[3]);
+                *reinterpret_cast<u32x2*>(scr + so8) = pk;
+                if (have_z) *reinterpret_cast<u32x2*>(scr_in + so8) = pkz;  // second output / pre-activation stash (this position's input is consumed)
+            }
+        }
+        flush(scr, p.out, p.ldo, blk);
+        if constexpr (EPI == EPI_GELU || EPI == EPI_RESID) {
+            if (p.out2) flush(scr_in, p.out2, p.ldo2, blk);
+        }
+    }
+}
+
+// tile -> XCD rasterisation shared by the tiled kernels: choose the XCD grid gm x gn = 8 by predicted fabric->L2 operand traffic
+static void choose_xcd_map(GemmNtArgs& a, int BM, int BN) {
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+    long best = -1;
+    static const int force_gm = env_int("FTMI_MAP_GM", 0);
+    for (int gm = 1; gm <= 8; gm *= 2) {
+        if (force_gm > 0 && gm != force_gm) continue;
+        const int gn = 8 / gm;
+        const int rm = (ntm + gm - 1) / gm, rn = (ntn + gn - 1) / gn;
+        const long resident = 64;
+        const long rounds = ((long)rm * rn + resident - 1) / resident;
+        const long cols_per_round = (rn + rounds - 1) / rounds;
+        const long x_reads = (long)rm * BM * ((rn + cols_per_round - 1) / cols_per_round);
+        const long w_reads = (long)rn * BN;
+        const long waste = (long)rm * rn * 8 - (long)ntm * ntn;
+        const long cost = (x_reads + w_reads) * 8 + waste * 64;
+        if (best < 0 || cost < best) {
+            best = cost;
+            a.map_gm = gm; a.map_gn = gn; a.map_rm = rm; a.map_rn = rn;
+        }
+    }
+}
+
+template <int TMW, int EPI, bool EXT, int DBG, bool RING>
+static int launch_nt16_3(const GemmNtArgs& a0, hipStream_t st) {
+    GemmNtArgs a = a0;
+    choose_xcd_map(a, 32 * TMW, 256);
+    constexpr int kSmem = RING ? 163840 : 131072;
+    ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * ((double)a.K + (double)a.K2 / 3.0), st);
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
+    if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL((gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING>), dim3(8 * a.map_rm * a.map_rn), dim3(256), kSmem, st, a);
+    return check_launch("gemm_nt16");
+}
+template <int TMW, int DBG = 0, bool RING = false>
+static int launch_nt16(const GemmNtArgs& a, hipStream_t st) {
+#ifdef FTMI_LAB
+    return launch_nt16_3<TMW, EPI_STORE, false, DBG, RING>(a, st);
+#else
+    static_assert(DBG == 0, "ablation builds exist in tools/gemm_lab.hip only");
+    const bool ext = a.K2 > 0;
+    switch (a.epi) {
+        case EPI_STORE: return ext ? launch_nt16_3<TMW, EPI_STORE, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_STORE, false, 0, RING>(a, st);
+        case EPI_GELU: return ext ? launch_nt16_3<TMW, EPI_GELU, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_GELU, false, 0, RING>(a, st);
+        case EPI_RESID: return ext ? launch_nt16_3<TMW, EPI_RESID, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_RESID, false, 0, RING>(a, st);
+        default: return ext ? launch_nt16_3<TMW, EPI_DGELU, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_DGELU, false, 0, RING>(a, st);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1077,7 +1622,25 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             // 336 tiles of 128 x 128 put a second workgroup on a third of the CUs -- 36.6 vs 39.1 us (K = 2048), 110 vs 121 us (K = 8192), tools/bench_gemm.py
             static const int few192 = env_int("FTMI_NT128_BELOW", 342);
             const long n192 = (long)((a.M + 191) / 192) * (a.N / 128);
-            if (a.M < 1024 || n192 < few192) {
+            // Round 4: the hand-placed 4-wave pipeline on 16 x 16 x 32 MFMAs (gemm_nt16_kernel) wherever 256-wide column tiles are allowed and the
+            // launch is long enough for one workgroup per CU to pay: 256- or 192-row tiles by which quantises better on 256 CUs (M = 5376:
+            // N = 2048 -> 224 tiles of 192 x 256 in one round; N = 6144 -> 504 tiles of 256 x 256 in two).  Measured against the kernels below
+            // on the step's shapes (profiles/r04_gemm_ab.txt): N >= 6144 7-12 % faster, N = 2048 / K = 8192 6-9 %; the single-round
+            // K = 2048 launches are equal within noise (the residual epilogue 5 % slower), so those keep the 192 x 128 tiles, 2 workgroups per CU.
+            // FTMI_NT16 is a mask of launch classes: 1 = several rounds of tiles and K <= 2048 (+ extension) without a row-wise epilogue input,
+            // 2 = the same with one (GELU' / residual), 4 = long K (6144 / 8192) or a single round.  In the step (profiles/r04_gemm_ab.txt, per-kernel
+            // tables) class 4 LOSES what the warm micro-benchmark promised: its activations (88 MB at K = 8192) arrive cold from the previous
+            // kernel, and one workgroup per CU has nobody to cover the vector-memory path while misses are outstanding -- the 192 x 128 kernel
+            // with two workgroups per CU keeps those launches.
+            static const int use16 = env_int("FTMI_NT16", 7);
+            const long t256 = (long)((a.M + 255) / 256) * (a.N / 256), t192 = (long)((a.M + 191) / 192) * (a.N / 256);
+            const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;  // rounds x rows per tile
+            const bool one_round_short = std::min(c256, c192) <= 256 && a.K + a.K2 <= 2304;
+            const bool multi_short = std::min(c256, c192) > 256 && a.K + a.K2 <= 2304;
+            const int cls = multi_short ? ((a.epi == EPI_DGELU || a.epi == EPI_RESID) ? 2 : 1) : 4;
+            if ((use16 & cls) && ok256 && a.M >= 1024 && !one_round_short) {
+                variant = c192 < c256 ? 86 : 80;
+            } else if (a.M < 1024 || n192 < few192) {
                 variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
             } else {
                 struct Cand { int variant, bm, bn, per_cu; };
@@ -1111,8 +1674,35 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
                 }
             }
         }
-#ifdef FTMI_EXPERIMENTAL
+#if defined(FTMI_LAB)
         switch (variant) {
+            case 47: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_GEN2_BUF>(a, st);
+            case 70: return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st);
+            case 71: return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st);
+            case 72: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st);
+            case 80: return launch_nt16<8>(a, st);   // 16 x 16 x 32 MFMA, 256 x 256 tiles
+            case 90: return launch_nt16<8, 0, true>(a, st);   // ... on the five-slot K = 32 ring
+            case 96: return launch_nt16<6, 0, true>(a, st);
+            case 190: return launch_nt16<8, 1, true>(a, st);
+            case 290: return launch_nt16<8, 2, true>(a, st);
+            case 86: return launch_nt16<6>(a, st);   // ... 192 x 256 tiles
+            case 180: return launch_nt16<8, 1>(a, st);
+            case 280: return launch_nt16<8, 2>(a, st);
+            case 380: return launch_nt16<8, 3>(a, st);
+            case 170: return launch_nt<256, 256, 64, 2, 2, true, 1, 100 + KL_PIPE2>(a, st);  // no loads in the loop
+            case 270: return launch_nt<256, 256, 64, 2, 2, true, 1, 200 + KL_PIPE2>(a, st);  // no rendezvous in the loop
+            case 370: return launch_nt<256, 256, 64, 2, 2, true, 1, 300 + KL_PIPE2>(a, st);  // no fragment reads in the loop
+            case 470: return launch_nt<256, 256, 64, 2, 2, true, 1, 400 + KL_PIPE2>(a, st);  // staggered waves
+            case 172: return launch_nt<256, 256, 64, 2, 4, true, 1, 100 + KL_PIPE2>(a, st);
+            case 272: return launch_nt<256, 256, 64, 2, 4, true, 1, 200 + KL_PIPE2>(a, st);
+            case 372: return launch_nt<256, 256, 64, 2, 4, true, 1, 300 + KL_PIPE2>(a, st);
+            default: return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);
+        }
+    }
+#elif defined(FTMI_EXPERIMENTAL)
+        switch (variant) {
+            case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
+            case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
@@ -1161,6 +1751,8 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     }
 #else
         switch (variant) {
+            case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
+            case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
