@@ -15,6 +15,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 from .. import ops
+from ..utils.reference_base import as_drop_in, keep_or_default
 
 
 from ..ltx_video.specification import IGNORE_KEYS_FOR_COLLATION  # modeling_utils.py: keys passed through from the first sample
@@ -139,8 +140,8 @@ class MI355XCogVideoXModelSpecification(MI355XCogVideoXSpecOps):
         self.tokenizer_id, self.text_encoder_id, self.transformer_id, self.vae_id = tokenizer_id, text_encoder_id, transformer_id, vae_id
         self.text_encoder_dtype, self.transformer_dtype, self.vae_dtype = text_encoder_dtype, transformer_dtype, vae_dtype
         self.revision, self.cache_dir = revision, cache_dir
-        self.condition_model_processors = condition_model_processors or []
-        self.latent_model_processors = latent_model_processors or []
+        self.condition_model_processors = keep_or_default(self, "condition_model_processors", condition_model_processors, [])
+        self.latent_model_processors = keep_or_default(self, "latent_model_processors", latent_model_processors, [])
         self.transformer_config = transformer_config
 
     def load_diffusion_models(self, state_dict: Optional[Dict[str, torch.Tensor]] = None, device: Optional[torch.device] = None) -> Dict[str, object]:
@@ -211,11 +212,7 @@ class MI355XCogVideoXModelSpecification(MI355XCogVideoXSpecOps):
                 json.dump({"_class_name": "CogVideoXDDIMScheduler", "num_train_timesteps": scheduler.config.num_train_timesteps, "beta_start": 0.00085,
                            "beta_end": 0.012, "beta_schedule": "scaled_linear", "snr_shift_scale": 3.0, "prediction_type": "v_prediction"}, f, indent=2)
 
-    def load_condition_models(self):
-        raise NotImplementedError("text encoders are outside the MI355X hot path; use the reference specification")
 
-    def load_latent_models(self):
-        raise NotImplementedError("the VAE is outside the MI355X hot path; use the reference specification")
-
-    def validation(self, *a, **k):
-        raise NotImplementedError("inference / validation is outside the MI355X hot path; use the reference specification")
+# The public class: these overrides on top of the reference's own CogVideoXModelSpecification when finetrainers is importable (prepare_conditions,
+# prepare_latents, load_condition_models, load_latent_models, load_pipeline, validation are then inherited), on StandaloneModelSpecification otherwise
+MI355XCogVideoXModelSpecification = as_drop_in(MI355XCogVideoXModelSpecification, "finetrainers.models.cogvideox", "CogVideoXModelSpecification")

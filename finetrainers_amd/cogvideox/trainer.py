@@ -65,6 +65,16 @@ class MI355XCogVideoXSFTStep:
         tr.grad_bucket_blocks = self.grad_bucket_blocks
         try:
             loss = self.spec.loss_backward(pred, target, sigmas)
+        except BaseException:
+            # a backward that raised after issuing some buckets: every rank issued the same collectives, so they complete -- wait for them and
+            # drop the handles (the next step must not race RCCL's stream on the gradient buffer, nor re-divide a tensor): GradBucketReducer.abort
+            for work, _ in pending:
+                try:
+                    work.wait()
+                except Exception:
+                    pass
+            pending.clear()
+            raise
         finally:
             tr._grad_bucket_hook = None
             for blk in tr.transformer_blocks:

@@ -79,6 +79,16 @@ class MI355XHunyuanVideoSFTStep:
             blk._grad_hook = done if dp else None
         try:
             loss = self.spec.loss_backward(pred, target)
+        except BaseException:
+            # a backward that raised after issuing some buckets: every rank issued the same collectives, so they complete -- wait for them and
+            # drop the handles (the next step must not race RCCL's stream on the gradient buffer, nor re-divide a tensor): GradBucketReducer.abort
+            for work, _ in pending:
+                try:
+                    work.wait()
+                except Exception:
+                    pass
+            pending.clear()
+            raise
         finally:
             for blk in blocks:
                 blk._grad_hook = None

@@ -20,6 +20,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 
 from .. import ops
+from ..utils.reference_base import as_drop_in, keep_or_default
 from .transformer import LTXTransformerConfig, MI355XLTXVideoTransformer3DModel
 
 # finetrainers/models/modeling_utils.py:22
@@ -70,8 +71,8 @@ class MI355XLTXVideoModelSpecification:
         self.tokenizer_id, self.text_encoder_id, self.transformer_id, self.vae_id = tokenizer_id, text_encoder_id, transformer_id, vae_id
         self.text_encoder_dtype, self.transformer_dtype, self.vae_dtype = text_encoder_dtype, transformer_dtype, vae_dtype
         self.revision, self.cache_dir = revision, cache_dir
-        self.condition_model_processors = condition_model_processors or []
-        self.latent_model_processors = latent_model_processors or []
+        self.condition_model_processors = keep_or_default(self, "condition_model_processors", condition_model_processors, [])
+        self.latent_model_processors = keep_or_default(self, "latent_model_processors", latent_model_processors, [])
         self.transformer_config = transformer_config or LTXTransformerConfig()
         self.vae_config = None
         self.gemm_variant = gemm_variant
@@ -127,32 +128,7 @@ class MI355XLTXVideoModelSpecification:
             with open(os.path.join(sdir, "scheduler_config.json"), "w") as f:  # FlowMatchEulerDiscreteScheduler().save_pretrained equivalent
                 json.dump({"_class_name": "FlowMatchEulerDiscreteScheduler", "num_train_timesteps": scheduler.config.num_train_timesteps, "shift": 1.0}, f, indent=2)
 
-    def load_condition_models(self):
-        raise NotImplementedError("text encoders are outside the MI355X hot path; use the reference specification")
 
-    def load_latent_models(self):
-        raise NotImplementedError("the VAE is outside the MI355X hot path; use the reference specification")
-
-    @staticmethod
-    def _collate(data: List[Dict[str, Any]]) -> Dict[str, Any]:
-        """modeling_utils.py:156-181."""
-        keys = list(data[0].keys())
-        out = {}
-        for key in keys:
-            if key in IGNORE_KEYS_FOR_COLLATION:
-                out[key] = data[0][key]
-                continue
-            vals = [d[key] for d in data]
-            if isinstance(vals[0], torch.Tensor):
-                vals = torch.cat(vals)
-            out[key] = vals
-        return out
-
-    def collate_conditions(self, data):
-        return self._collate(data)
-
-    def collate_latents(self, data):
-        return self._collate(data)
 
     def forward(
         self,
@@ -233,5 +209,7 @@ class MI355XLTXVideoModelSpecification:
         )[0]
         return pred, target, sigmas_bs1
 
-    def validation(self, *a, **k):
-        raise NotImplementedError("inference/validation is outside the MI355X hot path; use the reference specification")
+
+# The public class: these overrides on top of the reference's own LTXVideoModelSpecification when finetrainers is importable (prepare_conditions,
+# prepare_latents, load_condition_models, load_latent_models, load_pipeline, validation are then inherited), on StandaloneModelSpecification otherwise
+MI355XLTXVideoModelSpecification = as_drop_in(MI355XLTXVideoModelSpecification, "finetrainers.models.ltx_video", "LTXVideoModelSpecification")

@@ -161,6 +161,11 @@ class _LTXDiTFunction(torch.autograd.Function):
             if hook is not None:
                 hook(lo, hi, ga[lo:hi], gb[lo:hi])
             hi = lo
+        # MI355XParallelBackend.apply_ddp installs the exchange permanently, the way DDP's reducer sits on the module: the backward then also
+        # ends it (the compute stream waits for the last bucket), so an unmodified loop may clip and step right after loss.backward()
+        fin = module._grad_bucket_finish
+        if hook is not None and fin is not None:
+            fin()
         module._release_workspace(ctx.ws)
         ctx.ws = None
         if foreign is not None:
@@ -220,6 +225,7 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         # data-parallel gradient exchange (finetrainers_amd.trainer.MI355XSFTStep installs these): when set, the backward runs in ranges
         # of `grad_bucket_blocks` blocks and calls hook(l_lo, l_hi, grad_A[l_lo:l_hi], grad_B[l_lo:l_hi]) as soon as a range is final
         self._grad_bucket_hook = None
+        self._grad_bucket_finish = None
         self.grad_bucket_blocks = 7
         self._ws_pool = []  # idle activation workspaces (uint8 tensors), see _acquire_workspace
         self.lora_flat = None

@@ -172,3 +172,268 @@ class GradBucketReducer:
             except Exception:
                 pass
         self._pending.clear()
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------------------
+# The reference's ``BaseParallelBackend`` surface (finetrainers/parallel/base.py:9-115), so that ``--parallel_backend mi355x`` selects this
+# backend in the unmodified trainer (selection: parallel/__init__.py:17; use: trainer/sft_trainer/trainer.py:185-189, 210-228, 336-358, 512-528).
+# ----------------------------------------------------------------------------------------------------------------------------------------------
+from contextlib import contextmanager  # noqa: E402
+from typing import Any, List  # noqa: E402
+
+from .utils.reference_base import reference_class  # noqa: E402
+
+_RefBaseParallelBackend = reference_class("finetrainers.parallel.base", "BaseParallelBackend")
+
+
+class _StandaloneParallelBase:
+    """``BaseParallelBackend`` (parallel/base.py:9-60) where the reference package is not installed: tracker plumbing only."""
+
+    def __init__(self):
+        self.tracker = None
+
+    def initialize_trackers(self, trackers: List[str], experiment_name: str, config: Dict[str, Any], log_dir: str):
+        self.tracker = _ListTracker() if self.is_main_process else _NullTracker()
+
+    def log(self, metrics: Dict[str, Any], step: int) -> None:
+        if self.is_main_process and self.tracker is not None:
+            self.tracker.log(metrics, step)
+
+
+class _NullTracker:
+    def log(self, metrics, step):
+        pass
+
+    def finish(self):
+        pass
+
+
+class _ListTracker(_NullTracker):
+    """Stand-in for the reference's trackers (wandb / none) where they are not installed: keeps what was logged."""
+
+    def __init__(self):
+        self.records = []
+
+    def log(self, metrics, step):
+        self.records.append((int(step), dict(metrics)))
+
+
+class MI355XCheckpointer:
+    """``PTDCheckpointer`` (parallel/ptd.py:296-420) for the MI355X step: same constructor keywords, ``save(step, force, _device=, _is_main_process=)``
+    / ``load(step)``, same directory naming and purge rule; the files are the reference's DCP layout (``wire.save_training_state``)."""
+
+    def __init__(self, dataloader=None, model_parts=None, optimizers=None, schedulers=None, states: Optional[Dict[str, Any]] = None,
+                 checkpointing_steps: int = 500, checkpointing_limit: Optional[int] = None, output_dir: str = ".", enable: bool = True,
+                 _callback_fn=None, _prefix: str = "finetrainers_step", sft_step=None) -> None:
+        import pathlib
+
+        self.dataloader, self.model_parts, self.states = dataloader, list(model_parts or []), dict(states or {})
+        self.sft_step = sft_step if sft_step is not None else optimizers  # the fused clip + AdamW state lives in MI355XSFTStep
+        self.checkpointing_steps, self.checkpointing_limit = checkpointing_steps, checkpointing_limit
+        self.output_dir = pathlib.Path(output_dir)
+        self.enable, self._callback_fn, self._prefix = enable, _callback_fn, _prefix
+
+    def _dir(self, step: int):
+        return self.output_dir / f"{self._prefix}_{step}"
+
+    def save(self, step: int = -1, force: bool = False, *, _device=None, _is_main_process: bool = True) -> Optional[str]:
+        from . import wire
+
+        if not self.enable or (not force and step % self.checkpointing_steps != 0):
+            return None
+        if self.sft_step is None or not hasattr(self.sft_step, "exp_avg"):
+            raise RuntimeError("MI355XCheckpointer.save needs the MI355XSFTStep (pass it as `optimizers=` or `sft_step=`): it owns the AdamW moments")
+        ts = self.states.get("train_state")
+        train_state = None if ts is None else {k: getattr(ts, k) for k in ("step", "observed_data_samples", "global_avg_losses", "global_max_losses", "log_steps") if hasattr(ts, k)}
+        dl_state = self.dataloader.state_dict() if hasattr(self.dataloader, "state_dict") else None
+        path = wire.save_training_state(str(self.output_dir), step, self.model_parts[0], self.sft_step, train_state=train_state, dataloader_state=dl_state)
+        self._purge()
+        if self._callback_fn is not None and _is_main_process:
+            self._callback_fn({k: v.detach().cpu() for k, v in self.model_parts[0].state_dict().items()})
+        return path
+
+    def load(self, step: int = -1) -> bool:
+        from . import wire
+
+        if not self.enable or not self.output_dir.exists():
+            return False
+        if step == -1:
+            found = sorted(self.output_dir.glob(f"{self._prefix}_*"), key=lambda x: int(x.name.split("_")[-1]))
+            if not found:
+                return False
+            step = int(found[-1].name.split("_")[-1])
+        if not self._dir(step).exists():
+            return False
+        got = wire.load_training_state(str(self._dir(step)), self.model_parts[0], self.sft_step)
+        ts = self.states.get("train_state")
+        if ts is not None:
+            for k, v in got.items():
+                if hasattr(ts, k):
+                    setattr(ts, k, v)
+        return True
+
+    def _purge(self) -> None:
+        import shutil
+
+        if not self.checkpointing_limit or self.checkpointing_limit <= 0:
+            return
+        found = sorted(self.output_dir.glob(f"{self._prefix}_*"), key=lambda x: int(x.name.split("_")[-1]), reverse=True)
+        for stale in found[self.checkpointing_limit:]:
+            shutil.rmtree(stale, ignore_errors=True)
+
+
+class MI355XParallelBackend(_RefBaseParallelBackend if _RefBaseParallelBackend is not None else _StandaloneParallelBase):
+    """``PytorchDTensorParallelBackend``'s constructor and methods (parallel/ptd.py:41-279) for the path this backend implements: batch-sharded
+    data parallelism of the LoRA step over RCCL (one process per GPU).  Degrees this path does not implement are refused at construction."""
+
+    def __init__(self, world_size: int, pp_degree: int = 1, dp_degree: int = 1, dp_shards: int = -1, cp_degree: int = 1, tp_degree: int = 1,
+                 backend: str = "nccl", timeout: int = 180, logging_dir: Optional[str] = None, output_dir: Optional[str] = None,
+                 gradient_accumulation_steps: Optional[int] = None, exercise_collectives: bool = False) -> None:
+        super().__init__()
+        import pathlib
+
+        dp_shards = 1 if dp_shards in (-1, None) else dp_shards
+        for name, degree in (("pp_degree", pp_degree), ("cp_degree", cp_degree), ("tp_degree", tp_degree), ("dp_shards", dp_shards)):
+            if degree != 1:
+                raise NotImplementedError(f"MI355XParallelBackend: {name}={degree} -- this backend implements replicated data parallelism of the LoRA step "
+                                          "(SURVEY 8(e)); sharded full fine-tuning is finetrainers_amd.wan.sharding, CP / TP / PP are out of scope")
+        if dp_degree != world_size:
+            raise ValueError(f"World size {world_size} must equal dp_degree ({dp_degree}) for this backend")
+        use_gpu = backend == "nccl" and torch.cuda.is_available()
+        self._dp = DataParallelBackend(backend=backend if use_gpu or backend != "nccl" else "gloo", timeout_s=timeout, exercise_collectives=exercise_collectives)
+        if self._dp.world_size != world_size:
+            raise ValueError(f"WORLD_SIZE in the environment is {self._dp.world_size}, the backend was built for {world_size}")
+        self._world_size, self._degree = world_size, dp_degree
+        self._output_dir = pathlib.Path(output_dir) if output_dir is not None else None
+        self._logging_dir = self._output_dir / logging_dir if output_dir is not None and logging_dir is not None else None
+        self._gas = gradient_accumulation_steps
+        self._mesh = None
+        self.reducer: Optional[GradBucketReducer] = None
+
+    # ---- model / data / optimizer preparation ------------------------------------------------------------------------------------------------
+    def enable_determinism(self, seed: int) -> None:
+        """parallel/ptd.py:93-95 + utils/torch.py enable_determinism: every rank the same seed (replicated weights, different data)."""
+        import random
+
+        random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+
+    def apply_ddp(self, model, device_mesh=None, grad_bucket_blocks: int = 7):
+        """``replicate(model, bucket_cap_mb=100)`` (parallel/ptd.py:462-463) for the MI355X transformer: broadcast the adapters from rank 0 and
+        install the bucketed, overlapped gradient exchange on the block-range backward (``GradBucketReducer``)."""
+        if not hasattr(model, "lora_flat") or model.lora_A is None:
+            raise ValueError("apply_ddp: attach a LoRA adapter first (only the adapters are replicated and exchanged)")
+        if self._dp.active:
+            self._dp.broadcast_(model.lora_flat, src=0)
+            model._lora_versions = None
+            model.grad_bucket_blocks = grad_bucket_blocks
+            self.reducer = GradBucketReducer(self._dp)
+            model._grad_bucket_hook = self.reducer.bucket_ready
+            model._grad_bucket_finish = self.reducer.finish
+        return model
+
+    def apply_fsdp2(self, *args, **kwargs):
+        raise NotImplementedError("MI355XParallelBackend: parameter sharding is finetrainers_amd.wan.sharding (Wan full fine-tune); the LoRA step replicates")
+
+    def apply_context_parallel(self, *args, **kwargs):
+        raise NotImplementedError("MI355XParallelBackend: context parallelism is out of scope (SURVEY 2a)")
+
+    def prepare_model(self, model):
+        return model
+
+    def prepare_dataset(self, dataset):
+        """parallel/ptd.py:136-143: rank-strided split of an iterable dataset (``split_dataset_by_node``)."""
+        if self._degree == 1:
+            return dataset
+        if hasattr(dataset, "_data"):
+            import datasets.distributed
+
+            dataset._data = datasets.distributed.split_dataset_by_node(dataset._data, self.rank, self._world_size)
+            return dataset
+        raise TypeError("prepare_dataset: expected the reference's iterable dataset wrapper (an object with `_data`)")
+
+    def prepare_dataloader(self, dataset, batch_size: int, num_workers: int, pin_memory: bool = False):
+        """parallel/ptd.py:145-155.  The reference's DPDataLoader is a torchdata StatefulDataLoader; where torchdata is not installed a plain
+        DataLoader with the same batching serves the step (no mid-epoch resume state)."""
+        try:
+            from finetrainers.data import DPDataLoader  # type: ignore
+
+            return DPDataLoader(self.rank if self._degree > 1 else 0, dataset, batch_size=batch_size, num_workers=num_workers)
+        except Exception:
+            return torch.utils.data.DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=pin_memory)
+
+    def prepare_optimizer(self, optimizer, lr_scheduler):
+        return optimizer, lr_scheduler
+
+    def get_mesh(self, name: Optional[str] = None):
+        """parallel/ptd.py:161-209 for a one-dimensional replicate mesh (flattened names "dp" / "dp_cp" resolve to it)."""
+        if self._degree == 1 or not dist.is_initialized():
+            return None
+        if self._mesh is None:
+            dev = "cuda" if self._dp.backend == "nccl" else "cpu"
+            self._mesh = torch.distributed.device_mesh.init_device_mesh(dev, mesh_shape=[self._degree], mesh_dim_names=["dp_replicate"])
+        return self._mesh
+
+    def get_checkpointer(self, *args, **kwargs) -> MI355XCheckpointer:
+        return MI355XCheckpointer(*args, **kwargs)
+
+    # ---- the step's collectives (what DDP's reducer and parallel/utils.py:6-19 do) -----------------------------------------------------------
+    def reduce_step_metrics(self, loss, grad_norm):
+        return self._dp.reduce_step_metrics(loss, grad_norm)
+
+    @property
+    def data_parallel(self) -> DataParallelBackend:
+        return self._dp
+
+    def wait_for_everyone(self):
+        return self._dp.wait_for_everyone()
+
+    @contextmanager
+    def main_process_first(self):
+        if self.is_main_process:
+            yield
+            self.wait_for_everyone()
+        else:
+            self.wait_for_everyone()
+            yield
+
+    def destroy(self):
+        if self.is_main_process and getattr(self, "tracker", None) is not None and hasattr(self.tracker, "finish"):
+            self.tracker.finish()
+        return self._dp.destroy()
+
+    # ---- properties (parallel/ptd.py:214-279) ------------------------------------------------------------------------------------------------
+    world_size = property(lambda self: self._world_size)
+    rank = property(lambda self: self._dp.rank)
+    local_rank = property(lambda self: self._dp.local_rank)
+    is_main_process = property(lambda self: self._dp.rank == 0)
+    is_local_main_process = property(lambda self: self._dp.local_rank == 0)
+    device = property(lambda self: self._dp.device)
+    pipeline_parallel_enabled = property(lambda self: False)
+    data_parallel_enabled = property(lambda self: self._degree > 1)
+    data_replication_enabled = property(lambda self: self._degree > 1)
+    data_sharding_enabled = property(lambda self: False)
+    context_parallel_enabled = property(lambda self: False)
+    tensor_parallel_enabled = property(lambda self: False)
+    _dp_degree = property(lambda self: self._degree)
+
+
+def register_into_finetrainers() -> bool:
+    """Make ``--parallel_backend mi355x`` resolve to ``MI355XParallelBackend`` in the reference (finetrainers/parallel/__init__.py:11-23): needs the
+    enum member ``ParallelBackendEnum.MI355X = "mi355x"``; wraps ``get_parallel_backend_cls``.  False when the reference is not installed."""
+    try:
+        import finetrainers.parallel as ref  # type: ignore
+    except Exception:
+        return False
+    member = getattr(ref.ParallelBackendEnum, "MI355X", None)
+    if member is None:
+        raise RuntimeError('finetrainers.parallel.ParallelBackendEnum lacks MI355X = "mi355x" (INTEGRATION.md)')
+    original = ref.get_parallel_backend_cls
+
+    def get_parallel_backend_cls(backend):
+        return MI355XParallelBackend if backend == member else original(backend)
+
+    ref.get_parallel_backend_cls = get_parallel_backend_cls
+    return True

@@ -311,7 +311,7 @@ def _lora_param_views(lora_rank: int, a_full: torch.Tensor, b_full: torch.Tensor
 def training_state_dict(model_state_dict: Dict[str, torch.Tensor], lora_paths: List[str], lora_rank: int, exp_avg_a: torch.Tensor,
                         exp_avg_b: torch.Tensor, exp_avg_sq_a: torch.Tensor, exp_avg_sq_b: torch.Tensor, step_count: int, hyper: Dict[str, Any],
                         lr_scheduler_state: Optional[Dict[str, Any]] = None, train_state: Optional[Dict[str, Any]] = None,
-                        dataloader_state: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+                        dataloader_state: Optional[Dict[str, Any]] = None, dp_rank: int = 0) -> Dict[str, Any]:
     """The nested dictionary the reference hands to ``torch.distributed.checkpoint.save``.  ``exp_avg_a`` ... are the moments in the
     transformer's (rank-padded) parameter storage shapes; ``hyper``: lr, betas, eps, weight_decay; ``train_state``: step,
     observed_data_samples, global_avg_losses, global_max_losses, log_steps."""
@@ -324,7 +324,10 @@ def training_state_dict(model_state_dict: Dict[str, torch.Tensor], lora_paths: L
         opt[f"state.{fqn}.step"] = torch.tensor(float(step_count), dtype=torch.float32)
         opt[f"state.{fqn}.exp_avg"] = m1[fqn]
         opt[f"state.{fqn}.exp_avg_sq"] = m2[fqn]
-    for fqn in m1:
+    # The reference builds its optimizer over ALL model.parameters() (finetrainers/optimizer.py:36-38), frozen base weights included, so
+    # get_optimizer_state_dict(flatten=True) carries param_groups.<fqn>.* for every parameter of the model (and state.* only for the trained
+    # ones).  A checkpoint without those keys would make the reference's strict dcp.load raise "Missing key in checkpoint state_dict".
+    for fqn in list(model_state_dict) + [f for f in m1 if f not in model_state_dict]:
         grp = {"lr": float(hyper["lr"]), "betas": tuple(float(b) for b in hyper["betas"]), "eps": float(hyper["eps"]), "weight_decay": float(hyper["weight_decay"]),
                **_ADAMW_GROUP_DEFAULTS, "initial_lr": float(hyper.get("initial_lr", hyper["lr"]))}
         for k, v in grp.items():
@@ -343,8 +346,12 @@ def training_state_dict(model_state_dict: Dict[str, torch.Tensor], lora_paths: L
                           "observed_data_samples": torch.tensor(int(ts.get("observed_data_samples", 0)), dtype=torch.int32),
                           "global_avg_losses": blob(ts.get("global_avg_losses", [])), "global_max_losses": blob(ts.get("global_max_losses", [])),
                           "log_steps": blob(ts.get("log_steps", []))}
-    if dataloader_state is not None:
-        out["dataloader"] = dict(dataloader_state)
+    # PTDCheckpointer.states always holds the DPDataLoader, whose state_dict() is {"dp_rank_<r>": pickle.dumps(<StatefulDataLoader state>)}
+    # (finetrainers/data/dataloader.py:27-40): the entry is always written -- an empty inner state (= "start the stream over", the only
+    # state a precomputed-sample feeder has between epochs) unless the caller hands one over.
+    import pickle
+
+    out["dataloader"] = dict(dataloader_state) if dataloader_state is not None else {f"dp_rank_{int(dp_rank)}": pickle.dumps({})}
     return out
 
 

@@ -269,3 +269,80 @@ def test_dp_step_two_ranks_sharing_one_gpu_gloo():
     device).  Everything but the transport is the product path: LoRA broadcast, block-range backward, bucket hooks, async handles,
     finish(), metric reduction."""
     _run_two_ranks("gloo", one_gpu=True)
+
+
+def test_unmodified_trainer_loop_drives_the_drop_in_classes():
+    """The way SFTTrainer._train calls the plug-ins (finetrainers/trainer/sft_trainer/trainer.py:436-528, restated statement by statement with the
+    reference's own names -- /root/reference does not exist on the GPU box): MI355XParallelBackend.apply_ddp on the transformer,
+    model_specification.forward(transformer=, scheduler=, condition_model_conditions=, latent_model_conditions=, sigmas=, compute_posterior=),
+    the torch loss, loss.backward(), clip over transformer.parameters(), a torch AdamW(fused=False) built over ALL parameters, optimizer.step /
+    lr_scheduler.step / zero_grad, the backend's properties and log().  Three steps must give the losses and gradient norms of MI355XSFTStep
+    (the fused path) on the same inputs: same kernels up to the clip, torch's clip + AdamW against the fused kernel after it."""
+    from finetrainers_amd.parallel import MI355XParallelBackend
+    from finetrainers_amd.trainer import MI355XSFTStep
+    from finetrainers_amd.utils import diffusion as diffusion_utils
+
+    steps, lr, max_grad_norm = 3, 1e-3, 1.0
+    gen_data = torch.Generator().manual_seed(7)
+    noises = [torch.randn((2, 128, 2, 4, 6), generator=gen_data).to(bf16).to(_dev()) for _ in range(steps)]
+    sigs = [torch.tensor([0.3 + 0.1 * i, 0.8 - 0.1 * i], device=_dev()) for i in range(steps)]
+
+    # ---- (a) the fused MI355X step --------------------------------------------------------------------------------------------------------
+    spec, model, cond, latd, _, _ = _model_and_batch(3, 2, 2, 4, 6)
+    stepper = MI355XSFTStep(model, spec, lr=lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-4, max_grad_norm=max_grad_norm)
+    fused = []
+    for i in range(steps):
+        out = stepper.step(dict(cond), dict(latd), sigmas=sigs[i], noise=noises[i], force_first_frame_branch=False)
+        fused.append((float(out["loss"]), float(out["grad_norm"])))
+    fused_params = model.lora_flat.detach().clone()
+
+    # ---- (b) the reference loop, its statements in its order -------------------------------------------------------------------------------
+    spec, model, cond, latd, _, _ = _model_and_batch(3, 2, 2, 4, 6)
+    os.environ.setdefault("MASTER_PORT", "29533")
+    parallel_backend = MI355XParallelBackend(world_size=1, dp_degree=1, backend="nccl", exercise_collectives=True)  # a one-rank RCCL communicator
+    try:
+        transformer = parallel_backend.apply_ddp(model, parallel_backend.get_mesh())  # trainer.py:185-189
+        assert transformer._grad_bucket_hook is not None and parallel_backend.reducer is not None
+        model_parts = [transformer]
+        optimizer = torch.optim.AdamW([p for m in model_parts for p in m.parameters()], lr=lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-4, fused=False)
+        lr_scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda s: 1.0)
+        optimizer, lr_scheduler = parallel_backend.prepare_optimizer(optimizer, lr_scheduler)  # trainer.py:228
+        parallel_backend.initialize_trackers([], "t", {}, ".")
+        scheduler = spec.load_diffusion_models(device=_dev(), random_init_seed=0)["scheduler"] if False else type("S", (), {"config": type("C", (), {"num_train_timesteps": 1000})()})()
+        device, dtype = _dev(), bf16
+        loop = []
+        for i in range(steps):
+            sigmas = sigs[i]  # trainer.py:436-448 (prepare_sigmas is pinned to the reference's fixtures in tests/test_host.py)
+            sigmas = sigmas.reshape(-1, 1, 1, 1, 1)  # utils.expand_tensor_dims(sigmas, latents.ndim)
+            pred, target, sigmas = spec.forward(transformer=transformer, scheduler=scheduler, condition_model_conditions=dict(cond),
+                                                latent_model_conditions=dict(latd), sigmas=sigmas, compute_posterior=True,
+                                                noise=noises[i], force_first_frame_branch=False)  # trainer.py:452-461 (+ the parity hooks)
+            weights = diffusion_utils.compute_loss_weighting_for_sd3("none", sigmas)  # utils.prepare_loss_weights
+            while weights.ndim < pred.ndim:
+                weights = weights.unsqueeze(-1)
+            loss = weights.float() * (pred.float() - target.float()).pow(2)  # trainer.py:473-481
+            loss = loss.mean(list(range(1, loss.ndim)))
+            loss = loss.mean()
+            loss.backward()
+            accumulated_loss = loss.detach().item()
+            grad_norm = torch.nn.utils.clip_grad_norm_([p for m in model_parts for p in m.parameters()], max_grad_norm, foreach=True)  # trainer.py:487-492
+            optimizer.step()  # trainer.py:498-503
+            lr_scheduler.step()
+            optimizer.zero_grad()
+            transformer._lora_versions = None  # torch changed the parameters: the bf16 working copies are refreshed at the next forward
+            grad_norm = grad_norm.detach().item()
+            logs = {"train/global_avg_loss": accumulated_loss, "train/global_max_loss": accumulated_loss, "train/grad_norm": grad_norm}
+            assert not (parallel_backend.data_replication_enabled or parallel_backend.data_sharding_enabled or parallel_backend.context_parallel_enabled)
+            parallel_backend.log(logs, step=i + 1)  # trainer.py:548
+            loop.append((accumulated_loss, grad_norm))
+        assert parallel_backend.reducer.buckets_issued == steps * 1 and not parallel_backend.reducer._pending  # 3 blocks < 7: one bucket per backward, ended by it
+        assert [s for s, _ in parallel_backend.tracker.records] == [1, 2, 3]
+        loop_params = transformer.lora_flat.detach().clone()
+    finally:
+        parallel_backend.destroy()
+    for i, ((lf, gf), (ll, gl)) in enumerate(zip(fused, loop)):
+        print(f"[trainer-loop] step {i + 1}: loss fused {lf:.6f} loop {ll:.6f} | grad norm fused {gf:.6f} loop {gl:.6f}")
+        assert abs(lf - ll) <= 2e-5 * max(1.0, abs(lf)) and abs(gf - gl) <= 1e-4 * max(1.0, abs(gf))
+    rel = ((fused_params - loop_params).norm() / fused_params.norm()).item()
+    print(f"[trainer-loop] parameters after {steps} steps: rel {rel:.2e}")
+    assert rel < 1e-5

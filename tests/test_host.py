@@ -701,7 +701,8 @@ def test_training_state_checkpoint_is_the_reference_dcp_layout(tmp_path):
         m = Tiny()
         for n, p in m.named_parameters():
             p.requires_grad_("lora_" in n)
-        opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, fused=False)
+        # as the reference does (finetrainers/optimizer.py:36-38): the optimizer is built over ALL parameters, the frozen ones included
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, fused=False)
         sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0 / (1 + s))
         return m, opt, sch
 
@@ -771,8 +772,20 @@ def test_training_state_checkpoint_is_the_reference_dcp_layout(tmp_path):
     m2, opt2, sch2 = make(1)  # different weights, empty optimizer
     m2(torch.randn(3, D)).sum().backward()
     opt2.step(); opt2.zero_grad()  # the reference loads after the optimizer exists; its state gets overwritten
-    states = {"model": ModelWrapper(m2), "optimizer": OptimizerWrapper(m2, opt2), "lr_scheduler": sch2}
-    dcp.load(states, checkpoint_id=ckpt)
+    class DataLoaderState(Stateful):  # DPDataLoader's Stateful face (finetrainers/data/dataloader.py:27-40)
+        loaded = None
+
+        def state_dict(self):
+            return {"dp_rank_0": b""}
+
+        def load_state_dict(self, sd):
+            import pickle
+            self.loaded = pickle.loads(sd["dp_rank_0"])
+
+    dl = DataLoaderState()
+    states = {"model": ModelWrapper(m2), "optimizer": OptimizerWrapper(m2, opt2), "lr_scheduler": sch2, "dataloader": dl}
+    dcp.load(states, checkpoint_id=ckpt)  # strict planner: every key the reference asks for is in the checkpoint
+    assert dl.loaded == {}
     for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
         assert n1 == n2 and torch.equal(p1, p2), n1
     for p1, p2 in zip([p for p in m.parameters() if p.requires_grad], [p for p in m2.parameters() if p.requires_grad]):
@@ -882,3 +895,114 @@ def test_block_orchestrator_planners_agree_with_the_python_layouts():
     assert lib.ftmi_hy_dual_saved_bytes(ctypes.byref(hd)) > 2 * (1024 * 3072 * 4 + 1280 * 3072 * 4 + 1280 * 12288)
     bad = _lib.HySingleConfig(B=1, T=8, S=64, D=3072, H=23, mlp=12288, r=64, lora_scale=1.0, eps=1e-6, gemm_variant=8)  # heads x 128 != width
     assert lib.ftmi_hy_single_saved_bytes(ctypes.byref(bad)) > 0  # planners do not validate; the forward does (FTMI_ERR_UNSUPPORTED)
+
+
+def test_spec_classes_subclass_the_reference_when_it_is_importable():
+    """B1 as a drop-in: the MI355X specification classes are the MI355X overrides ON TOP of the reference's own specification class when one is
+    importable.  The reference package cannot be imported here (no diffusers), so its ModelSpecification base + LTXVideoModelSpecification are
+    compiled out of /root/reference with stubbed third-party names (the make_golden.py technique) and injected as the base."""
+    import ast
+    import types
+
+    ref_root = os.environ.get("FTMI_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref_root):
+        pytest.skip("the reference tree is not on this machine (GPU box)")
+    from finetrainers_amd.ltx_video import specification as ltx_spec
+    from finetrainers_amd.utils.reference_base import StandaloneModelSpecification, as_drop_in
+
+    def compile_classes(relpath, names, ns):
+        tree = ast.parse(open(os.path.join(ref_root, relpath)).read())
+        body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+        loads = {n.id for c in body for n in ast.walk(c) if isinstance(n, ast.Name)}
+        import builtins
+        for name in loads:  # every third-party name the class bodies mention becomes an inert stub
+            if name not in ns and not hasattr(builtins, name):
+                ns[name] = type(name, (), {"__init__": lambda self, *a, **k: None})
+        for c in body:
+            for f in ast.walk(c):
+                if isinstance(f, ast.FunctionDef):
+                    f.decorator_list = [d for d in f.decorator_list if isinstance(d, ast.Name) and d.id == "property"]
+        mod = ast.Module(body=body, type_ignores=[])
+        ast.fix_missing_locations(mod)
+        exec(compile(mod, relpath, "exec"), ns)
+        return ns
+
+    import typing
+    ns = {k: getattr(typing, k) for k in ("Any", "Dict", "List", "Optional", "Tuple", "Union")}
+    ns.update(torch=torch, logger=types.SimpleNamespace(warning=lambda *a, **k: None), IGNORE_KEYS_FOR_COLLATION=ltx_spec.IGNORE_KEYS_FOR_COLLATION)
+    compile_classes("finetrainers/models/modeling_utils.py", {"ModelSpecification"}, ns)
+    ns["ModelSpecification"]._load_configs = lambda self: None  # the hub lookup of the constructor
+    compile_classes("finetrainers/models/ltx_video/base_specification.py", {"LTXVideoModelSpecification"}, ns)
+    Ref = ns["LTXVideoModelSpecification"]
+
+    overrides = ltx_spec.MI355XLTXVideoModelSpecification.MI355X_OVERRIDES
+    Spec = as_drop_in(overrides, "finetrainers.models.ltx_video", "LTXVideoModelSpecification", base_override=Ref)
+    spec = Spec(pretrained_model_name_or_path="somewhere/LTX-Video", transformer_dtype=torch.bfloat16)
+    assert isinstance(spec, Ref) and isinstance(spec, ns["ModelSpecification"]) and Spec.IS_REFERENCE_SUBCLASS
+    # inherited from the reference, untouched: what SFTTrainer calls outside the denoiser path (trainer.py:380-383, 834-835, 877, 896)
+    for name in ("prepare_conditions", "prepare_latents", "load_condition_models", "load_latent_models", "load_pipeline", "validation", "collate_conditions",
+                 "collate_latents", "_trainer_init"):
+        assert getattr(Spec, name) is getattr(Ref, name) or getattr(Spec, name) is getattr(ns["ModelSpecification"], name), name
+    # overridden by the MI355X backend
+    for name in ("load_diffusion_models", "forward", "_save_lora_weights"):
+        assert getattr(Spec, name) is getattr(overrides, name) and getattr(Spec, name) is not getattr(Ref, name), name
+    # the reference constructor ran: its default processors are in place (two stub instances), ours did not wipe them
+    assert len(spec.condition_model_processors) == 1 and len(spec.latent_model_processors) == 1 and spec._resolution_dim_keys == {"latents": (2, 3, 4)}
+    assert spec.pretrained_model_name_or_path == "somewhere/LTX-Video" and spec.first_frame_conditioning_p == 0.1
+
+    # without the reference: the same overrides on the generic half of ModelSpecification; the model-specific loaders raise the base's error
+    assert not ltx_spec.MI355XLTXVideoModelSpecification.IS_REFERENCE_SUBCLASS and issubclass(ltx_spec.MI355XLTXVideoModelSpecification, StandaloneModelSpecification)
+    alone = ltx_spec.MI355XLTXVideoModelSpecification()
+    with pytest.raises(NotImplementedError, match="load_condition_models"):
+        alone.load_condition_models()
+    assert alone.prepare_latents(processors=[lambda **kw: {"latents": kw["image"] * 2}], image=torch.ones(1))["latents"].item() == 2.0  # the generic processor loop
+    for mod, cls in (("cogvideox", "MI355XCogVideoXModelSpecification"), ("wan", "MI355XWanModelSpecification"), ("hunyuan_video", "MI355XHunyuanVideoModelSpecification")):
+        import importlib
+        C = getattr(importlib.import_module(f"finetrainers_amd.{mod}.specification"), cls)
+        assert issubclass(C, StandaloneModelSpecification) and hasattr(C, "prepare_conditions") and hasattr(C, "load_pipeline") and hasattr(C, "apply_tensor_parallel")
+
+
+def test_parallel_backend_has_the_reference_surface():
+    """N2: every method / property of BaseParallelBackend (finetrainers/parallel/base.py:9-115) exists on MI355XParallelBackend with the
+    reference's signatures where the trainer passes arguments; degrees the path does not implement are refused at construction."""
+    import ast
+    import inspect
+
+    from finetrainers_amd.parallel import MI355XCheckpointer, MI355XParallelBackend
+
+    ref_root = os.environ.get("FTMI_REFERENCE", "/root/reference")
+    if os.path.isdir(ref_root):
+        tree = ast.parse(open(os.path.join(ref_root, "finetrainers/parallel/base.py")).read())
+        base = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "BaseParallelBackend")
+        names = [f.name for f in base.body if isinstance(f, ast.FunctionDef) and f.name != "__init__"]
+        ptd = ast.parse(open(os.path.join(ref_root, "finetrainers/parallel/ptd.py")).read())
+        ctor = next(f for c in ptd.body if isinstance(c, ast.ClassDef) and c.name == "PytorchDTensorParallelBackend" for f in c.body
+                    if isinstance(f, ast.FunctionDef) and f.name == "__init__")
+        ref_ctor_args = [a.arg for a in ctor.args.args[1:]]
+        ckpt = next(f for c in ptd.body if isinstance(c, ast.ClassDef) and c.name == "PTDCheckpointer" for f in c.body if isinstance(f, ast.FunctionDef) and f.name == "__init__")
+        ref_ckpt_args = [a.arg for a in ckpt.args.args[1:]]
+    else:  # GPU box: the lists as of the surveyed reference
+        names = ["enable_determinism", "apply_ddp", "apply_fsdp2", "apply_context_parallel", "prepare_model", "prepare_dataset", "prepare_dataloader", "prepare_optimizer",
+                 "get_mesh", "get_checkpointer", "initialize_trackers", "log", "wait_for_everyone", "main_process_first", "destroy", "world_size", "rank", "local_rank",
+                 "is_main_process", "is_local_main_process", "device", "pipeline_parallel_enabled", "data_parallel_enabled", "data_replication_enabled",
+                 "data_sharding_enabled", "context_parallel_enabled", "tensor_parallel_enabled"]
+        ref_ctor_args = ["world_size", "pp_degree", "dp_degree", "dp_shards", "cp_degree", "tp_degree", "backend", "timeout", "logging_dir", "output_dir", "gradient_accumulation_steps"]
+        ref_ckpt_args = ["dataloader", "model_parts", "optimizers", "schedulers", "states", "checkpointing_steps", "checkpointing_limit", "output_dir", "enable", "_callback_fn", "_prefix"]
+    assert len(names) >= 27
+    for n in names:
+        assert n in MI355XParallelBackend.__dict__ or any(n in k.__dict__ for k in MI355XParallelBackend.__mro__[1:-1]), n
+    own = list(inspect.signature(MI355XParallelBackend.__init__).parameters)[1:]
+    assert own[:len(ref_ctor_args)] == ref_ctor_args
+    assert list(inspect.signature(MI355XCheckpointer.__init__).parameters)[1:1 + len(ref_ckpt_args)] == ref_ckpt_args
+    b = MI355XParallelBackend(world_size=1, dp_degree=1, backend="gloo", output_dir="/tmp/x", logging_dir="logs")
+    assert (b.world_size, b.rank, b.local_rank, b.is_main_process, b.is_local_main_process) == (1, 0, 0, True, True)
+    assert not (b.pipeline_parallel_enabled or b.data_parallel_enabled or b.data_replication_enabled or b.data_sharding_enabled or b.context_parallel_enabled or b.tensor_parallel_enabled)
+    assert b.get_mesh() is None and b._dp_degree == 1 and b.prepare_optimizer(1, 2) == (1, 2) and b.prepare_model("m") == "m"
+    with b.main_process_first():
+        pass
+    for kw in (dict(pp_degree=2), dict(cp_degree=2), dict(tp_degree=2), dict(dp_shards=2)):
+        with pytest.raises(NotImplementedError):
+            MI355XParallelBackend(world_size=2, dp_degree=1, **kw)
+    with pytest.raises(ValueError):
+        MI355XParallelBackend(world_size=2, dp_degree=1)
+    assert isinstance(b.get_checkpointer(output_dir="/tmp/x", checkpointing_steps=5), MI355XCheckpointer)
