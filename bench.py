@@ -129,6 +129,12 @@ def cpu_baseline(args):
     out["cfg2_bf16"] = {"step_s_measured": ts_bf, "blocks": nl, "samples_per_s_scaled": 1.0 / (dt_bf * scale), "step_ms_scaled": dt_bf * scale * 1e3}
     out["cfg2_fp32"] = {"step_s_measured": ts_32, "blocks": nl, "samples_per_s_scaled": 1.0 / (dt_32 * scale), "step_ms_scaled": dt_32 * scale * 1e3}
     out["cfg1_bf16_full_depth"] = {"step_s_measured": ts_c1, "blocks": 28, "samples_per_s": 1.0 / dt_c1, "step_ms": dt_c1 * 1e3}
+    full = _profile_json("r04_cpu_baseline_full.json")  # tools/cpu_baseline_full.py: cfg 2 exactly (batch 2, all 28 blocks), measured once, not scaled
+    if full:
+        out["measured_full"] = True
+        out["cfg2_bf16_full_depth_batch2"] = {k: full[k] for k in ("step_s_measured", "step_s", "samples_per_s", "cores", "warmup_steps", "timed_steps") if k in full}
+        out["sample"] += (f"; the same step measured ONCE at full size (batch 2, 28 blocks, {full.get('cores')} threads, profiles/r04_cpu_baseline_full.json): "
+                          f"{full['step_s']:.1f} s/step = {full['samples_per_s']:.4f} samples/s")
     return out
 
 

@@ -147,9 +147,6 @@ _SIGS = {
     "ftmi_linear_lora_bwd": (c_int, [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 10 + [c_int, c_void_p]),
     "ftmi_gemm_nt": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p, c_long, c_int,
                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p]),
-    "ftmi_gemm_sk_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
-    "ftmi_gemm_sk_status": (c_int, []),
-    "ftmi_gemm_sk_trace": (c_int, [POINTER(ctypes.c_ulonglong), c_int]),
     "ftmi_gemm_tn": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_float, c_void_p]),
     "ftmi_fp8_upcast": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ftmi_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -218,6 +215,13 @@ _SIGS = {
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
 
+# research builds only (FTMI_EXPERIMENTAL=1): bound when the library exports them (the #ifdef FTMI_EXPERIMENTAL section of include/ftmi355.h)
+_EXPERIMENTAL_SIGS = {
+    "ftmi_gemm_sk_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    "ftmi_gemm_sk_status": (c_int, []),
+    "ftmi_gemm_sk_trace": (c_int, [POINTER(ctypes.c_ulonglong), c_int]),
+}
+
 _lib: Optional[ctypes.CDLL] = None
 
 
@@ -243,6 +247,11 @@ def load() -> ctypes.CDLL:
             raise RuntimeError(f"libftmi355.so does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _EXPERIMENTAL_SIGS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

@@ -242,6 +242,7 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
     return gemm_nt(a, (hipStream_t)stream);
 }
 
+#ifdef FTMI_EXPERIMENTAL
 int ftmi_gemm_sk_plan(int ntiles, int n_workgroups, int nk, int owner_cost, int min_piece, int partial_cost, int add_cost, int* work) {
     if (!work || ntiles < 0 || n_workgroups < 1 || nk < 1 || owner_cost < 0 || min_piece < 1 || 2 * min_piece > nk + 1 || partial_cost < 0 || add_cost < 0)
         return set_error(FTMI_ERR_INVALID, "ftmi_gemm_sk_plan: bad arguments");
@@ -252,6 +253,7 @@ int ftmi_gemm_sk_plan(int ntiles, int n_workgroups, int nk, int owner_cost, int 
 int ftmi_gemm_sk_status(void) { return gemm_nt_sk_status(); }
 
 int ftmi_gemm_sk_trace(unsigned long long* out, int capacity) { return gemm_nt_sk_trace(out, capacity); }
+#endif
 
 int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, long ldv, float* c, long ldc, float scale, ftmi_stream stream) {
     if (!u || !v || !c) return set_error(FTMI_ERR_INVALID, "ftmi_gemm_tn: null tensor");

@@ -9,7 +9,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm_sk.hip", "attention.hip", "rowwise.hip", "cast.hip", "cogvideox.hip", "ltx_dit.hip", "cog_dit.hip", "hy_dit.hip", "wan.hip", "wan_dit.hip", "api.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "cast.hip", "cogvideox.hip", "ltx_dit.hip", "cog_dit.hip", "hy_dit.hip", "wan.hip", "wan_dit.hip", "api.hip"]
 HEADERS = ["common.hip.h", "kernels.h", os.path.join("..", "..", "include", "ftmi355.h")]
 LIB = os.path.join(HERE, "..", "libftmi355.so")
 FLAGS = [
@@ -29,7 +29,8 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 # tools/ab_variants.sh).  Never set for the product library.
 if os.environ.get("FTMI_EXPERIMENTAL", "0") not in ("", "0"):
     FLAGS.append("-DFTMI_EXPERIMENTAL")
-    SOURCES.insert(2, "gemm_skinny.hip")  # the 64 x 128-tile LoRA down-projection kernel (measured slower than the shipped one: profiles/r03_skinny_experiments.txt)
+    SOURCES.insert(1, "gemm_skinny.hip")  # the 64 x 128-tile LoRA down-projection kernel (measured slower than the shipped one: profiles/r03_skinny_experiments.txt)
+    SOURCES.insert(1, "gemm_sk.hip")      # the persistent stream-K GEMM (5-25 % slower than the shipped kernels: profiles/r03_gemm_streamk.txt)
     HEADERS.append(os.path.join("..", "..", "tools", "gemm_experimental.hip.h"))
 
 

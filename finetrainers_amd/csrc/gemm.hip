@@ -1559,6 +1559,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     // SLOWER than the one-tile kernels -- a persistent workgroup waits for its own 128 KB of output stores (vmcnt counts stores in order with
     // the next tile's loads: ~7 us per tile at the ~11 B/clk a CU stores), which a one-tile workgroup leaves draining behind its s_endpgm
     // while its successor on the CU already computes; the fp32 fix-up of a 256 x 256 partial costs another ~6 us per hand-off.
+#ifdef FTMI_EXPERIMENTAL
     if (a.variant == 60) {
         if (!gemm_nt_sk_eligible(a)) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: the stream-K kernel needs N % 256 == 0, M >= 1024, K >= 256 and 256-wide groups");
         return gemm_nt_sk(a, st);
@@ -1567,6 +1568,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         static const int use_sk = env_int("FTMI_SK", 0);
         if (use_sk && gemm_nt_sk_eligible(a)) return gemm_nt_sk(a, st);
     }
+#else
+    if (a.variant == 60) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: the stream-K kernel (variant 60) exists in FTMI_EXPERIMENTAL builds only");
+#endif
     if (a.split_r > 0) {  // fp32-equivalent LoRA down-projection: always the LDS-ring skinny kernel (any M, any N, grouped W allowed)
         if (a.K2 != 0 || a.epi != EPI_STORE || a.bias || a.K < 256 || a.split_r % 64 != 0 || (a.N / 2) % a.split_r != 0)
             return set_error(FTMI_ERR_UNSUPPORTED, "gemm_nt: split (hi/lo) mode needs a plain store, K >= 256 and whole groups of split_r outputs");

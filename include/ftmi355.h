@@ -112,6 +112,9 @@ int ftmi_linear_lora_bwd(int M, int K, int N, int r, float lora_scale, const voi
 int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha,
                  void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
                  const void* aux, long ld_side, int variant, ftmi_stream stream);
+#ifdef FTMI_EXPERIMENTAL
+/* Research build only (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build): the persistent stream-K GEMM (csrc/gemm_sk.hip, variant 60) --
+ * parity-green and 5-25 % slower than the shipped kernels on the step's shapes (profiles/r03_gemm_streamk.txt); not part of the product ABI. */
 /* The stream-K split of the persistent GEMM as a pure host function (no device needed; tests): the last `ntiles mod n_workgroups` tiles of
  * a launch form a cost line of (nk + owner_cost) units per tile -- nk K iterations, owner_cost = what finishing the tile (LoRA extension +
  * epilogue) costs in K-iteration units -- cut into n_workgroups shares of equal cost; a cut inside a tile charges partial_cost to the workgroup
@@ -130,6 +133,7 @@ int ftmi_gemm_sk_status(void);
 /* Debugging aid (FTMI_SK_TRACE=1): shader-clock stamps of the last stream-K launch, out[n_workgroups][16] (start, end of each K phase,
  * hand-off waits, segment ends; 0 = unused); returns n_workgroups, 0 if nothing was traced.  Synchronises the device. */
 int ftmi_gemm_sk_trace(unsigned long long* out, int capacity);
+#endif /* FTMI_EXPERIMENTAL */
 /* c[P,Q] (fp32) += scale * u[M,P]^T v[M,Q] */
 int ftmi_gemm_tn(int M, int P, int Q, const void* u, long ldu, const void* v, long ldv, float* c, long ldc, float scale,
                  ftmi_stream stream);

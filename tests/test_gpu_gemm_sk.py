@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 bf16 = torch.bfloat16
 
 
+@pytest.fixture(autouse=True)
+def _needs_the_research_build():
+    """The stream-K kernel is a measured negative result (profiles/r03_gemm_streamk.txt): it ships only in FTMI_EXPERIMENTAL builds of the library."""
+    from finetrainers_amd import _lib
+
+    if not hasattr(_lib.load(), "ftmi_gemm_sk_status"):
+        pytest.skip("libftmi355.so was built without FTMI_EXPERIMENTAL: no stream-K kernel")
+
+
 def _dev():
     return torch.device("cuda", 0)
 

@@ -40,4 +40,4 @@ for (M, N, K) in shapes:
         med, best = statistics.median(res[v]), min(res[v])
         extra = " (incl. the skinny down-projection launch)" if lora else ""
         print(f"M{M} N{N} K{K} {'lora ' if lora else ''}variant {v}: median {med*1e3:7.1f} us = {2*M*N*K/med/1e9:7.1f} TF/s   best {best*1e3:7.1f} us = {2*M*N*K/best/1e9:7.1f} TF/s{extra}", flush=True)
-print("sk status", _lib.load().ftmi_gemm_sk_status())
+print("sk status", _lib.load().ftmi_gemm_sk_status() if hasattr(_lib.load(), "ftmi_gemm_sk_status") else "n/a (product build)")
