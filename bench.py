@@ -184,8 +184,11 @@ def _build_ltx(args, par, dev):
 
     S = args.frames * args.height * args.width
     full_shape = (args.layers == 28 and S == 2688 and args.rank == 64)
+    if step.reducer is not None:
+        step.reducer.measure_exposed = True
     return {
         "one_step": lambda: step.step(cond, lat),
+        "reducer": step.reducer,
         "samples_per_step": B,
         "step_tflop": STEP_TFLOP_PER_SAMPLE * B * (args.layers / 28.0),
         "metric": "train samples/sec (+ step ms) LTX-Video LoRA 49x512x768 @1/2/4/8 MI355X",
@@ -271,6 +274,8 @@ def main():
     if prof:
         lib.ftmi_prof_enable(0)
 
+    reducer = ctx.get("reducer")
+    exposed = reducer.exposed_ms() if reducer is not None else None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if par.world_size > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -300,6 +305,11 @@ def main():
             "peak_memory_gib": torch.cuda.max_memory_allocated() / 2**30,
             "mfma_utilisation_step": step_tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS,
             "final_loss": loss,
+            # data parallelism: what the exchange ran on and how long the compute stream WAITED for it per step (events around the reducer's
+            # finish(): the part of the bucketed all-reduce the backward did not cover; null on one GPU)
+            "exchange": par.describe() if par.world_size > 1 else None,
+            "exposed_comm_ms": exposed,
+            "buckets_per_step": (reducer.buckets_issued / max(1, args.steps + args.warmup)) if reducer is not None else None,
             "step_ms_min_median_max": [round(v, 3) for v in (lambda t: (t[0], t[len(t) // 2], t[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)))],
             # steps that took more than 1.2x the median (index, ms): isolated ~25 ms stalls appear about once in 10 s on the gpurun
             # boxes with and without the in-stream profiler (a box-level pause, not part of the step)
@@ -364,6 +374,9 @@ def main():
                     a_fl = kern["attn_fwd"]["tflops"] * kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["tflops"] * kern["attn_bwd"]["ms_per_step"]
                     res["attention_roofline"] = {"achieved": a_fl / a_ms, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a_fl / a_ms / PEAK_BF16_TFLOPS,
                                                  "share_of_step": a_ms / ms}
+        pr = _profile_json("r04_bench_noprof.json")  # the same command with --no-prof on the evidence box: the instrument's cost as a stated quantity
+        if prof and pr and args.workload == "ltx":
+            res["ms_per_step_without_event_profiler"] = {"ms_per_step": pr.get("ms_per_step"), "source": "profiles/r04_bench_noprof.json (python bench.py --no-prof, same box, same round)"}
         if par.world_size == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = ctx["cpu_baseline"]()

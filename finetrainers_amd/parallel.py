@@ -48,9 +48,25 @@ class DataParallelBackend:
             os.environ.setdefault("MASTER_PORT", "29500")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
             os.environ.pop("NCCL_P2P_DISABLE", None)  # never inherit the reference scripts' setting (keeps xGMI on)
+            # RCCL's algorithm / protocol for the 29-59 MB gradient buckets is left to its tuner unless FTMI_RCCL_ALGO / FTMI_RCCL_PROTO pin it
+            # (on 8 fully connected xGMI peers a ring is per-link bound; what the tuner picks is logged by `describe()`).
+            for var, dst in (("FTMI_RCCL_ALGO", "NCCL_ALGO"), ("FTMI_RCCL_PROTO", "NCCL_PROTO")):
+                if os.environ.get(var):
+                    os.environ[dst] = os.environ[var]
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size,
                                     timeout=datetime.timedelta(seconds=timeout_s))
             self._owns_pg = True
+
+    def describe(self) -> Dict[str, object]:
+        """What the exchange runs on, for the bench line and the multi-GPU tests' logs."""
+        ver = None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if self.backend == "nccl" else None
+        except Exception:
+            pass
+        return {"backend": self.backend, "world_size": self.world_size, "rccl_version": ver, "algo": os.environ.get("NCCL_ALGO", "auto (RCCL tuner)"),
+                "proto": os.environ.get("NCCL_PROTO", "auto (RCCL tuner)"), "p2p_disabled": os.environ.get("NCCL_P2P_DISABLE") == "1",
+                "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
 
     # ---- properties mirroring BaseParallelBackend -------------------------------------------------------------
     @property
@@ -146,6 +162,10 @@ class GradBucketReducer:
         self.backend = backend
         self._pending = []
         self.buckets_issued = 0
+        # measure_exposed: bracket finish() with events on the compute stream -- the time the step actually WAITS for the exchange (what the
+        # backward did not cover); read with exposed_ms().  Off by default (two event records per step).
+        self.measure_exposed = False
+        self._exposed = []
 
     def bucket_ready(self, l_lo: int, l_hi: int, grad_a: torch.Tensor, grad_b: torch.Tensor) -> None:
         """Hook signature of ``MI355XLTXVideoTransformer3DModel._grad_bucket_hook``."""
@@ -157,11 +177,26 @@ class GradBucketReducer:
 
     def finish(self) -> None:
         """Make the current stream wait for every outstanding bucket (device-side wait on RCCL; gloo: host wait + divide)."""
+        ev = None
+        if self.measure_exposed and self._pending and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for work, div in self._pending:
             work.wait()
             if div is not None:
                 div.div_(self.backend.world_size)
         self._pending.clear()
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
+
+    def exposed_ms(self) -> Optional[float]:
+        """Mean time per step the compute stream spent waiting in finish() (call after a synchronize); None if nothing was measured."""
+        if not self._exposed:
+            return None
+        t = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed.clear()
+        return sum(t) / len(t)
 
     def abort(self) -> None:
         """A backward that raised after issuing some buckets: wait for the collectives already in flight (every rank issued them, so they

@@ -541,6 +541,81 @@ class accumulation_order_variant:
         return False
 
 
+class attention_order_variant:
+    """Context manager: every scaled-dot-product attention of the oracle sees its keys (and values, and the mask columns) in a fixed
+    pseudo-random ORDER.  Mathematically the identity; numerically another tile / online-softmax-rescale / accumulation order with the same
+    rounding points -- what any two flash-attention kernels (torch's CPU kernel and a GPU kernel) differ by."""
+
+    def __enter__(self):
+        import sys
+
+        mod = sys.modules[__name__]
+        self._mod, self._orig = mod, mod.native_sdpa
+
+        def permuted(q, k, v, attn_mask):
+            perm = torch.randperm(k.shape[2], generator=torch.Generator().manual_seed(k.shape[2]))
+            m = None if attn_mask is None else attn_mask[..., perm]
+            return self._orig(q, k[:, :, perm], v[:, :, perm], m)
+
+        mod.native_sdpa = permuted
+        return self
+
+    def __exit__(self, *exc):
+        self._mod.native_sdpa = self._orig
+        return False
+
+
+class _FusedQKVBase(torch.autograd.Function):
+    """The three frozen projections of a self-attention with ONE input gradient: dX = dQ Wq + dK Wk + dV Wv summed in fp32 and rounded to
+    bf16 once (eager autograd rounds each of the three products to bf16 and adds them in bf16: two more rounding points)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv):
+        ctx.save_for_backward(wq, wk, wv)
+        return F.linear(x, wq, bq), F.linear(x, wk, bk), F.linear(x, wv, bv)
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        wq, wk, wv = ctx.saved_tensors
+        dx = gq.float() @ wq.float() + gk.float() @ wk.float() + gv.float() @ wv.float()
+        return dx.to(gq.dtype), None, None, None, None, None, None
+
+
+class fused_qkv_dgrad_variant:
+    """Context manager: the self-attentions' q | k | v base projections share one fp32 input-gradient accumulator (``_FusedQKVBase``) -- the
+    MI355X kernels' deliberate difference (ii) of DESIGN.md section 3 (one fused dgrad GEMM over the concatenated weights)."""
+
+    def __enter__(self):
+        self._orig = Attention.forward
+
+        def forward(att, hidden_states, encoder_hidden_states=None, attention_mask=None, image_rotary_emb=None):
+            if encoder_hidden_states is not None or not isinstance(att.to_q, LoraLinear):
+                return self._orig(att, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb)
+            lq, lk, lv = att.to_q, att.to_k, att.to_v
+            qb, kb, vb = _FusedQKVBase.apply(hidden_states, lq.base_layer.weight, lq.base_layer.bias, lk.base_layer.weight, lk.base_layer.bias,
+                                             lv.base_layer.weight, lv.base_layer.bias)
+
+            def lora(l, base):  # LoraLinear.forward with the base result given
+                xx = hidden_states.to(l.lora_A["default"].weight.dtype)
+                return (base + l.lora_B["default"](l.lora_A["default"](xx)) * l.scaling).to(base.dtype)
+
+            query, key, value = lora(lq, qb), lora(lk, kb), lora(lv, vb)
+            query, key = att.norm_q(query), att.norm_k(key)
+            if image_rotary_emb is not None:
+                query, key = apply_rotary_emb(query, image_rotary_emb), apply_rotary_emb(key, image_rotary_emb)
+            sp = lambda z: z.unflatten(2, (att.heads, -1)).transpose(1, 2)
+            import sys
+            o = sys.modules[__name__].native_sdpa(sp(query), sp(key), sp(value), None).transpose(1, 2).flatten(2, 3).to(query.dtype)
+            return att.to_out[1](att.to_out[0](o))
+
+        Attention.forward = forward
+        return self
+
+    def __exit__(self, *exc):
+        Attention.forward = self._orig
+        return False
+
+
 def lora_grads(model: nn.Module, inp: "StepInputs", flow_weighting_scheme: str = "none") -> Tuple[Dict[str, torch.Tensor], float]:
     """({peft name without the adapter infix: gradient}, loss) of one forward + backward of the oracle."""
     for p in model.parameters():

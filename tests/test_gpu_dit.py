@@ -21,8 +21,15 @@ LOSS_RTOL = 1e-3           # north_star: loss within 1e-3 relative (measured: ~1
 # implementations of the reference's bf16 graph.  Every case below measures that floor ON THE SAME INPUTS (oracle vs
 # ltx.accumulation_order_variant) and requires  kernel-vs-oracle <= FLOOR_FACTOR x floor  (global) and <= FLOOR_FACTOR_WORST x floor (the
 # worst single adapter tensor, a max over 16-448 noisy values).
-FLOOR_FACTOR = 1.5
+FLOOR_FACTOR = 1.5          # full-depth cfg 2 (offline yardsticks, linear-order floor only)
 FLOOR_FACTOR_WORST = 2.0
+# Round 4: the small cases measure the floor with ALL order-type freedoms exercised at once (linear summation order, attention key order, fused
+# q|k|v input gradient: singly or together they saturate at the same level) and account for the rounding noise the fused row-wise backward
+# kernels REMOVE (r^2 = |oracle - fp32|^2 - |kernel - fp32|^2 > 0: the kernel sits closer to exact arithmetic).  kernel-vs-oracle is then bounded
+# by EXPLAINED_FACTOR x sqrt(floor^2 + r^2) (observed 1.14-1.18, profiles/r04_parity.txt) and the worst adapter by WORST_FACTOR x its floor
+# (observed 1.16-1.19).
+EXPLAINED_FACTOR = 1.30
+WORST_FACTOR = 1.50
 # full-depth cfg 2 (minutes of oracle time per evaluation): the two yardsticks were measured ONCE on the host CPU by
 # tools/measure_cfg2_yardsticks.py (profiles/r03_cfg2_yardsticks.json: the oracle's own summation-order floor, and the bf16 oracle's distance
 # from the fp32 evaluation of the same graph) together with a strided sample of the fp32 oracle's gradients
@@ -120,6 +127,12 @@ def _build(num_layers, B, F_, H_, W_, first_frame, seed, rank=64, alpha=64.0):
     inp.latents_std = 1.0 + 0.2 * torch.rand(cfg.in_channels, generator=torch.Generator().manual_seed(6))
     if first_frame:
         inp.first_frame_sigma = torch.tensor([0.1, 0.6][:B])
+    if F_ * H_ * W_ == 2688:
+        # sigma draws of --flow_weighting_scheme logit_normal (utils/diffusion.py:38-63 -> finetrainers_amd.utils.diffusion, pinned to the reference's
+        # fixtures in tests/test_host.py): u = sigmoid(N(0, 1)), indices into the 1000-entry table
+        from finetrainers_amd.utils import diffusion as du
+        u = du.compute_density_for_timestep_sampling("logit_normal", B, logit_mean=0.0, logit_std=1.0, generator=torch.Generator().manual_seed(11))
+        inp.sigmas = torch.linspace(1, 1000, 1000).flip(0)[(u * 1000).long().clamp(max=999)] / 1000.0
     spec = MI355XLTXVideoModelSpecification(transformer_config=LTXTransformerConfig(num_layers=num_layers))
     gmodel = spec.load_diffusion_models(state_dict=omodel.state_dict(), device=_dev())["transformer"]
     gmodel.add_adapter(r=rank, lora_alpha=alpha)
@@ -149,6 +162,7 @@ CASES = [
     (1, 2, 2, 8, 10, False),  # 160 tokens: spans two 128-row GEMM tiles and several attention tiles
     (28, 1, 2, 4, 4, False),  # BASELINE config 1 EXACTLY: 28 blocks, batch 1, latents [1,128,2,4,4]
     (28, 1, 2, 4, 4, True),   # ... with the first-frame conditioning branch
+    (4, 2, 7, 16, 24, True),  # BASELINE config 2's clip (2 x 2688 tokens) on 4 blocks, first-frame branch ON, sigmas drawn by the logit-normal scheme
 ]
 
 
@@ -170,10 +184,25 @@ def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trac
     floor_glob = floor_worst = None
     grads_32 = None
     if measure_floor:
-        with ltx.accumulation_order_variant(512):
-            g_ord, _ = ltx.lora_grads(omodel, inp)
-        floor_glob, floor_worst = ltx.grads_rel_l2(g_ord, grads_ref)
-        del g_ord
+        # the floor = the oracle against itself with every ORDER-type freedom an implementation has exercised at once: fp32 summation order of
+        # the frozen linears, key order of the attention (tile / rescale order), and the one documented rounding-point difference (q|k|v input
+        # gradients in one fp32 accumulator).  Measured singly they are each about as large as all three together (a one-ulp change anywhere
+        # decorrelates every downstream bf16 rounding: the noise saturates), so the floor is a property of the graph, not of one kernel.
+        import contextlib
+        parts = {}
+        for name, mk in (("linear order", lambda: [ltx.accumulation_order_variant(512)]), ("attention order", lambda: [ltx.attention_order_variant()]),
+                         ("fused qkv dgrad", lambda: [ltx.fused_qkv_dgrad_variant()]),
+                         ("all three", lambda: [ltx.accumulation_order_variant(512), ltx.attention_order_variant(), ltx.fused_qkv_dgrad_variant()])):
+            if name != "all three" and num_layers > 2:
+                continue  # the single-effect rows only where an oracle evaluation is cheap
+            with contextlib.ExitStack() as st:
+                for c in mk():
+                    st.enter_context(c)
+                g_ord, _ = ltx.lora_grads(omodel, inp)
+            parts[name] = ltx.grads_rel_l2(g_ord, grads_ref)
+            print(f"[dit-floor] {tag}: oracle vs itself, {name:16s}: {parts[name][0]:.3e} / {parts[name][1]:.3e}")
+            del g_ord
+        floor_glob, floor_worst = parts["all three"]
         # the third corner of the triangle: the SAME graph on the same (bf16-valued) weights and inputs evaluated in fp32
         m32 = ltx.build_model(cfg, seed=0, rank=rank, alpha=float(alpha), lora_b_std=0.02, dtype=torch.float32)
         m32.load_state_dict({k: v.float() for k, v in omodel.state_dict().items()})
@@ -241,12 +270,19 @@ def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trac
     if num_layers <= 2:
         for k, g in grads_ref.items():
             print(f"[dit-grad] {k:58s} rel_l2={per[k]:.3e} |g|={g.norm().item():.3e}")
-    floor_s = "" if floor_glob is None else f"; summation-order floor {floor_glob:.3e} / {floor_worst:.3e} -> ratio {glob / floor_glob:.2f} / {worst_adapter / floor_worst:.2f}"
+    floor_s = "" if floor_glob is None else f"; order floor {floor_glob:.3e} / {floor_worst:.3e} -> ratio {glob / floor_glob:.2f} / {worst_adapter / floor_worst:.2f}"
     print(f"[dit] {tag}: global LoRA-grad rel_l2={glob:.3e} worst adapter={worst_adapter:.3e}{floor_s}")
     k32 = o32 = None
+    explained = None
     if grads_32 is not None:
         k32, o32 = ltx.grads_rel_l2(gv, grads_32), ltx.grads_rel_l2(grads_ref, grads_32)
-        print(f"[dit] {tag}: vs the fp32 evaluation of the graph: kernel {k32[0]:.3e} / {k32[1]:.3e}, bf16 oracle {o32[0]:.3e} / {o32[1]:.3e}")
+        # What is left over the floor: the fused row-wise backward kernels keep fp32 between ops where eager autograd rounds every intermediate
+        # gradient to bf16 -- rounding noise REMOVED, which shows as the kernel sitting closer to the fp32 evaluation than the bf16 oracle does.
+        # Noise removed r^2 = |O - F|^2 - |K - F|^2, and it separates K from O in quadrature with the order floor.
+        r2 = max(0.0, o32[0] ** 2 - k32[0] ** 2)
+        explained = (floor_glob ** 2 + r2) ** 0.5
+        print(f"[dit] {tag}: vs the fp32 evaluation of the graph: kernel {k32[0]:.3e} / {k32[1]:.3e}, bf16 oracle {o32[0]:.3e} / {o32[1]:.3e}; "
+              f"rounding noise removed r = {r2 ** 0.5:.3e} -> sqrt(floor^2 + r^2) = {explained:.3e}, kernel / explained = {glob / explained:.2f}")
 
     out_dir = os.environ.get("FTMI_REPORT_DIR", "gpurun_out")
     try:
@@ -270,6 +306,7 @@ def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trac
         # evaluations differ from each other by the floor)
         assert k32[0] < 1.15 * o32[0] + 2e-4, f"kernel vs fp32 oracle {k32[0]:.3e}, bf16 oracle vs fp32 oracle {o32[0]:.3e}"
         assert k32[1] < 1.30 * o32[1] + 5e-4
+    _run_parity_case.last_explained = explained
     return glob, worst_adapter, floor_glob, floor_worst
 
 
@@ -277,8 +314,9 @@ def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trac
 def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
     tag = f"L{num_layers}_B{B}_S{F_ * H_ * W_}{'_ff' if first_frame else ''}"
     glob, worst_adapter, floor_glob, floor_worst = _run_parity_case(num_layers, B, F_, H_, W_, first_frame, True, True, tag)
-    assert glob < FLOOR_FACTOR * floor_glob, f"global LoRA gradient error {glob:.3e} vs summation-order floor {floor_glob:.3e}"
-    assert worst_adapter < FLOOR_FACTOR_WORST * floor_worst, f"worst adapter {worst_adapter:.3e} vs floor {floor_worst:.3e}"
+    explained = _run_parity_case.last_explained
+    assert glob < EXPLAINED_FACTOR * explained, f"global LoRA gradient error {glob:.3e} vs sqrt(floor^2 + removed rounding noise^2) = {explained:.3e}"
+    assert worst_adapter < WORST_FACTOR * floor_worst, f"worst adapter {worst_adapter:.3e} vs floor {floor_worst:.3e}"
 
 
 @pytest.mark.parametrize("rank,alpha", [(128, 128.0), (64, 32.0), (32, 32.0)])
@@ -288,8 +326,9 @@ def test_dit_parity_other_ranks(rank, alpha):
     examples/training/sft/ltx_video/crush_smol_lora/train.sh:75-76) runs on zero-padded rank-64 storage."""
     tag = f"L2_B2_S72_r{rank}_a{int(alpha)}"
     glob, worst_adapter, floor_glob, floor_worst = _run_parity_case(2, 2, 3, 4, 6, False, True, False, tag, rank=rank, alpha=alpha)
-    assert glob < FLOOR_FACTOR * floor_glob, f"global LoRA gradient error {glob:.3e} vs summation-order floor {floor_glob:.3e}"
-    assert worst_adapter < FLOOR_FACTOR_WORST * floor_worst, f"worst adapter {worst_adapter:.3e} vs floor {floor_worst:.3e}"
+    explained = _run_parity_case.last_explained
+    assert glob < EXPLAINED_FACTOR * explained, f"global LoRA gradient error {glob:.3e} vs sqrt(floor^2 + removed rounding noise^2) = {explained:.3e}"
+    assert worst_adapter < WORST_FACTOR * floor_worst, f"worst adapter {worst_adapter:.3e} vs floor {floor_worst:.3e}"
 
 
 def test_rank32_padding_stays_zero_through_optimiser_steps():
