@@ -27,6 +27,17 @@ bool gemm_nt_sk_eligible(const GemmNtArgs&) { return false; }
 int gemm_nt_sk(const GemmNtArgs&, hipStream_t) { return -2; }
 }  // namespace ftmi
 
+// LAB_PREFETCH=1: before every (cold-weight) launch a small kernel streams that weight copy once -- does a read through the memory-side
+// Infinity Cache make the GEMM see warm weights?  The GEMM alone is timed (events around each launch).
+__global__ void lab_prefetch_kernel(const u32x4* p, size_t n16, int getenv_nt) {
+    u32x4 acc = {0, 0, 0, 0};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 v = getenv_nt ? __builtin_nontemporal_load(p + i) : p[i];
+        acc ^= v;
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) __builtin_trap();  // keeps the loads
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 static uint16_t f2bf_host(float f) {
@@ -59,7 +70,7 @@ int main(int argc, char** argv) {
         std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
         fill_random(hx, 1, 1.f);
         fill_random(hw, 2, 1.f / sqrtf((float)K));
-        const int ncopy = std::max(1, (int)(6e8 / ((double)N * K * 2)));
+        const int ncopy = getenv("LAB_WARMW") ? 1 : std::max(1, (int)(6e8 / ((double)N * K * 2)));  // LAB_WARMW=1: one weight copy (stays in the Infinity Cache)
         uint16_t *dx, *dw, *dout, *dref;
         // LAB_COLDX=1: the activations rotate through > 600 MB of copies as well (in the step a GEMM's input was just written by the previous
         // kernel and is read once; a fixed X stays resident in the 256 MB Infinity Cache across launches and hides HBM latency)
@@ -74,7 +85,7 @@ int main(int argc, char** argv) {
         auto run = [&](int v, uint16_t* out, bool fixed) {
             ftmi::GemmNtArgs a;
             if (!fixed) it = (it + 1) % ncopy;
-            a.X = dx + (size_t)(fixed ? 0 : it % nxcopy) * hx.size(); a.ldx = K; a.W = dw + (size_t)(fixed ? 0 : it) * hw.size(); a.ldw = K;
+            static int itx = 0; if (!fixed) itx = (itx + 1) % nxcopy; a.X = dx + (size_t)(fixed ? 0 : itx) * hx.size(); a.ldx = K; a.W = dw + (size_t)(fixed ? 0 : it) * hw.size(); a.ldw = K;
             a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = N; a.alpha = 1.f; a.epi = ftmi::EPI_STORE; a.variant = v;
             if (ftmi::gemm_nt(a, st) != 0) exit(2);
         };
@@ -100,8 +111,24 @@ int main(int argc, char** argv) {
         for (int rnd = 0; rnd < (fast ? 1 : 5); ++rnd)
             for (size_t i = 0; i < variants.size(); ++i) {
                 for (int k = 0; k < (fast ? 0 : 8); ++k) run(variants[i], dout, false);
-                CK(hipEventRecord(e0, st));
                 const int n = fast ? 4 : 30;
+                if (getenv("LAB_PREFETCH")) {
+                    const int pf_wgs = atoi(getenv("LAB_PREFETCH"));
+                    float tot = 0.f;
+                    for (int k = 0; k < n; ++k) {
+                        const int nxt = (it + 1) % ncopy;
+                        hipLaunchKernelGGL(lab_prefetch_kernel, dim3(pf_wgs > 1 ? pf_wgs : 256), dim3(256), 0, st, (const u32x4*)(dw + (size_t)nxt * hw.size()), hw.size() * 2 / 16, getenv("LAB_PREFETCH_NT") ? 1 : 0);
+                        CK(hipEventRecord(e0, st));
+                        run(variants[i], dout, false);
+                        CK(hipEventRecord(e1, st));
+                        CK(hipEventSynchronize(e1));
+                        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                        tot += ms;
+                    }
+                    res[i].push_back(tot / n);
+                    continue;
+                }
+                CK(hipEventRecord(e0, st));
                 for (int k = 0; k < n; ++k) run(variants[i], dout, false);
                 CK(hipEventRecord(e1, st));
                 CK(hipEventSynchronize(e1));
