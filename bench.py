@@ -76,13 +76,17 @@ def _profile_json(name: str):
         return None
 
 
+NT_CLASS = "gemm_nt (all NT GEMM kernels)"
+
+
 def _pmc_traffic(kernel: str):
     """PMC counters cannot be read from inside the process being measured: the per-launch HBM traffic of the dominant kernel is
     taken from the committed rocprofv3 --pmc summary of this same command (tools/gpu_pmc.sh); None if absent."""
-    for name in ("r03_pmc_traffic.json", "r02_b_pmc_traffic.json", "r02_a_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json", "r02_a_pmc_traffic.json", "r01_pmc_traffic.json"):
         d = _profile_json(name)
-        if d and kernel in d:
-            return d[kernel].get("hbm_bytes_per_launch"), name
+        for key in (NT_CLASS, kernel):  # round 4 on: one entry for every NT GEMM launch (16x16x32 and 32x32x16 kernels together)
+            if d and key in d:
+                return d[key].get("hbm_bytes_per_launch"), name
     return None, None
 
 
@@ -344,7 +348,8 @@ def main():
             if args.workload == "ltx" and "gemm_nt" in kern:
                 g_ = kern["gemm_nt"]
                 res["roofline"] = {
-                    "kernel": "ftmi::gemm_nt_kernel (bf16 MFMA GEMM + fused LoRA/epilogues; every Linear forward and dgrad)",
+                    "kernel": "ftmi::gemm_nt16_kernel + ftmi::gemm_nt_kernel (bf16 MFMA NT GEMM + fused LoRA/epilogues; every Linear forward and dgrad -- the "
+                              "16x16x32 hand-placed pipeline where N % 256 == 0 and M >= 1024, the 32x32x16 kernels elsewhere)",
                     "bound": "mfma",
                     "achieved": g_["tflops"],
                     "peak": PEAK_BF16_TFLOPS,
@@ -357,16 +362,16 @@ def main():
                     "share_of_step": g_["ms_per_step"] / ms,
                     "note": f"achieved = sum of algorithmic FLOPs (2*M*N*(K + r) per launch: the LoRA K-extension executes 3r deep -- hi / lo planes -- and counts r) / "
                             f"sum of HIP-event durations over every {args.prof_stride}-th launch of the kernel, events recorded on the launch stream inside the timed "
-                            "region (the stride, coprime to the per-block launch counts, cycles through every shape; compare with the gemm_nt_kernel<...> rows of "
-                            "profiles/r03_kernel_stats.csv and profiles/r03_step_kernels.csv)",
+                            "region (the stride, coprime to the per-block launch counts, cycles through every shape; compare with the gemm_nt16_kernel<...> / gemm_nt_kernel<...> "
+                            "rows of profiles/r04_kernel_stats.csv and profiles/r04_step_kernels.csv)",
                 }
-                mf_name = next((n for n in ("r03_pmc_mfma.json", "r02_b_pmc_mfma.json", "r02_a_pmc_mfma.json") if _profile_json(n)), None)
+                mf_name = next((n for n in ("r04_pmc_mfma.json", "r03_pmc_mfma.json", "r02_b_pmc_mfma.json", "r02_a_pmc_mfma.json") if _profile_json(n)), None)
                 mf = _profile_json(mf_name) if mf_name else None
                 if mf:  # counter-derived figures of the same command (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ..., tools/gpu_profile_r02.sh)
                     keep = ("mfma_util", "valu_issue_share_of_simd_time", "wave_wait_share", "wave_issue_stall_share", "launches_in_trace")
-                    res["roofline"]["counters"] = {k: mf.get("gemm_nt_kernel", {}).get(k) for k in keep}
-                    res["roofline"]["counters"]["source"] = (f"profiles/{mf_name} (rocprofv3 --pmc passes of this command, tools/gpu_profile_r03.sh; the GEMM kernels are unchanged "
-                                                             "since round 2): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
+                    res["roofline"]["counters"] = {k: mf.get(NT_CLASS, mf.get("gemm_nt_kernel", {})).get(k) for k in keep}
+                    res["roofline"]["counters"]["source"] = (f"profiles/{mf_name} (rocprofv3 --pmc passes of this command, tools/gpu_profile_r04.sh): "
+                                                             "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
                     res["mfma_utilisation_counters"] = {"step": mf.get("step", {}).get("mfma_util_over_kernel_time"),
                                                         **{k: v.get("mfma_util") for k, v in mf.items() if isinstance(v, dict) and v.get("mfma_util")}}
                 if "attn_fwd" in kern and "attn_bwd" in kern:

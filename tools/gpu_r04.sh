@@ -73,5 +73,20 @@ PY
       echo "== $1=$v"; head -30 /tmp/st_$v.txt
     done
     ;;
+  t)  # the GPU suites other than the kernel / DiT parity files (those run in steps d and on their own), then smoke()
+    timeout 1500 python -m pytest tests/test_gpu_wire.py tests/test_gpu_cogvideox.py tests/test_gpu_wan.py tests/test_gpu_hunyuan.py tests/test_gpu_fullsize.py tests/test_gpu_dp.py tests/test_gpu_gemm_sk.py -q -m gpu > gpurun_out/r04t_suites.log 2>&1; echo "suites rc=$?"; tail -5 gpurun_out/r04t_suites.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r04t_smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/r04t_smoke.log
+    ;;
+  T)  # the whole GPU suite as the driver runs it
+    timeout 2400 python -m pytest tests/ -x -q -m gpu > gpurun_out/r04T_gpu_suite.log 2>&1; echo "suite rc=$?"; tail -5 gpurun_out/r04T_gpu_suite.log
+    ;;
+  e)  # evidence: default bench line (+ CPU baseline), --no-prof line, FTMI_NT16 A/B, rocprof statistics + counter passes, the other workloads
+    timeout 900 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/r04_bench_default.json
+    timeout 300 python bench.py --no-prof --no-cpu-baseline > gpurun_out/r04_bench_noprof.json 2> gpurun_out/r04_bench_noprof.err; echo "noprof rc=$?"; cut -c1-300 gpurun_out/r04_bench_noprof.json
+    for rnd in 1 2; do for v in 0 3 7; do
+      FTMI_NT16=$v timeout 300 python bench.py --steps 20 --warmup 5 --no-prof --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FTMI_NT16=$v ms_per_step', d['ms_per_step'], d['step_ms_min_median_max'])"
+    done; done > gpurun_out/r04_nt16_ab.txt 2>&1; cat gpurun_out/r04_nt16_ab.txt
+    bash tools/gpu_profile_r04.sh r04 > gpurun_out/r04_profile.log 2>&1; tail -60 gpurun_out/r04_profile.log | cut -c1-260
+    ;;
   *) echo "unknown step $step"; exit 1;;
 esac
