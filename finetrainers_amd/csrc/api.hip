@@ -547,9 +547,9 @@ int ftmi_cog_blocks_backward(const ftmi_cog_config* cfg, const ftmi_cog_weights*
 }
 
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample, float grad_scale,
-                  ftmi_stream stream) {
-    if (!pred || !target || !loss) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");
-    return mse_loss_fwd_bwd((const bf16_t*)pred, (const bf16_t*)target, weight, loss, (bf16_t*)dpred, B, per_sample, grad_scale, (hipStream_t)stream);
+                  float* scratch, ftmi_stream stream) {
+    if (!pred || !target || !loss || !scratch) return set_error(FTMI_ERR_INVALID, "ftmi_mse_loss: null argument");
+    return mse_loss_fwd_bwd((const bf16_t*)pred, (const bf16_t*)target, weight, loss, (bf16_t*)dpred, B, per_sample, grad_scale, scratch, (hipStream_t)stream);
 }
 
 int ftmi_clip_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_norm, float lr, float beta1,

@@ -184,7 +184,7 @@ int noise_pack(const bf16_t* latents, const bf16_t* noise, const float* mean, co
 
 // loss (fp32 scalar, accumulated) and dpred
 int mse_loss_fwd_bwd(const bf16_t* pred, const bf16_t* target, const float* weight, float* loss, bf16_t* dpred, int B,
-                     long per_sample, float grad_scale, hipStream_t st);
+                     long per_sample, float grad_scale, float* partials, hipStream_t st);
 
 // CogVideoX DDIM noising (mode 0: x0 = bf(a * scale), out = bf(sa x0) + bf(so b)) / get_velocity (mode 1: out = bf(sa b) - bf(so a))
 int ddim_mix(const bf16_t* a, const bf16_t* b, const float* sa, const float* so, float scale, bf16_t* x0_out, bf16_t* out, int B, long per_sample,

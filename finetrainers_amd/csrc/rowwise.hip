@@ -9,8 +9,6 @@
 // tail of patches/models/ltx_video/patch.py:118-123; patches/dependencies/diffusers/rms_norm.py:17-29;
 // apply_rotary_emb patch.py:23-33; models/ltx_video/base_specification.py:295-320,427-459;
 // functional/diffusion.py:4-11; trainer/sft_trainer/trainer.py:463-481 (loss).
-#include <mutex>
-#include <unordered_map>
 #include <utility>
 
 #include "common.hip.h"
@@ -444,28 +442,13 @@ __global__ __launch_bounds__(64) void mse_loss_finish_kernel(const float* __rest
     if (threadIdx.x == 0) *loss = acc;
 }
 int mse_loss_fwd_bwd(const bf16_t* pred, const bf16_t* target, const float* weight, float* loss, bf16_t* dpred, int B, long per_sample,
-                     float grad_scale, hipStream_t st) {
+                     float grad_scale, float* partials, hipStream_t st) {
     if (per_sample % 8) return set_error(FTMI_ERR_UNSUPPORTED, "mse_loss: per-sample size % 8");
     long blocks = (per_sample / 8 + 255) / 256;
-    if (blocks > 256) blocks = 256;
-    // per-workgroup partials: a small library-owned scratch per (device, stream), made on first use (launches on one stream are ordered)
+    if (blocks > FTMI_MSE_SCRATCH_FLOATS_PER_SAMPLE) blocks = FTMI_MSE_SCRATCH_FLOATS_PER_SAMPLE;
+    // per-workgroup partials live in CALLER-owned scratch (>= FTMI_MSE_SCRATCH_FLOATS_PER_SAMPLE * B floats): nothing is allocated on the launch
+    // path, so the call is legal during stream capture and never synchronises the device
     const long need = blocks * B;
-    float* partials = nullptr;
-    {
-        static std::mutex mu;
-        static std::unordered_map<uint64_t, std::pair<float*, long>> scratch;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "mse_loss: no device");
-        std::lock_guard<std::mutex> lk(mu);
-        auto& e = scratch[((uint64_t)(uintptr_t)st) * 64 + (uint64_t)dev];
-        if (e.second < need) {
-            float* p = nullptr;
-            const long cap = need < 4096 ? 4096 : need;
-            if (hipMalloc((void**)&p, (size_t)cap * sizeof(float)) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "mse_loss: cannot allocate the partial sums");
-            e = {p, cap};  // (a smaller predecessor, if any, stays allocated: launches that use it may still be queued)
-        }
-        partials = e.first;
-    }
     const float inv_count = 1.0f / ((float)per_sample * (float)B);
     hipLaunchKernelGGL(mse_loss_kernel, dim3((unsigned)blocks, B), dim3(256), 0, st, pred, target, weight, partials, dpred, per_sample, inv_count,
                        inv_count * grad_scale);

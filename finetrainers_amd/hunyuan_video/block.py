@@ -267,13 +267,19 @@ class _Fp8StorageMixin:
 
     @torch.no_grad()
     def store_weights_fp8(self) -> int:
+        if self._w8 is not None:
+            return 0  # already stored (a second apply_layerwise_casting is a no-op)
         names = self._weight_names_2d()
         self._w8 = {n: getattr(self, n).to(torch.float8_e4m3fn).contiguous() for n in names}
         self._shapes = {n: tuple(getattr(self, n).shape) for n in names}
-        for n in names:
-            setattr(self, n, None)
-        for n in self._transposed_names():
-            setattr(self, n + "_t", None)
+        # The bf16 copies a block computes with are views of ONE arena shared by all blocks, valid only between this block's up-cast and the next
+        # block's.  They must not be module buffers: state_dict() / named_buffers() / .to() would then report whichever block was materialised
+        # last as the weights of every block.  The names leave ``_buffers`` and become plain attributes; state_dict() exports the exact up-cast of
+        # the stored bytes instead (hook below).
+        for n in names + [t + "_t" for t in self._transposed_names()]:
+            self._buffers.pop(n, None)
+            object.__setattr__(self, n, None)
+        self._register_state_dict_hook(_fp8_state_dict_hook)
         return len(names)
 
     def _materialize_fwd(self) -> None:
@@ -282,7 +288,7 @@ class _Fp8StorageMixin:
         off = 0
         for n, w8 in self._w8.items():
             k = w8.numel()
-            setattr(self, n, ops.fp8_upcast(w8, out=self._arena_fwd[off:off + k]))
+            object.__setattr__(self, n, ops.fp8_upcast(w8, out=self._arena_fwd[off:off + k]))
             off += k
 
     def _materialize_bwd(self) -> None:
@@ -292,8 +298,15 @@ class _Fp8StorageMixin:
         for n in self._transposed_names():
             w8 = self._w8[n]
             k = w8.numel()
-            setattr(self, n + "_t", ops.fp8_upcast(w8, out=self._arena_bwd[off:off + k], transpose=True))
+            object.__setattr__(self, n + "_t", ops.fp8_upcast(w8, out=self._arena_bwd[off:off + k], transpose=True))
             off += k
+
+
+def _fp8_state_dict_hook(module, state_dict, prefix, local_metadata):
+    """state_dict() of a block whose weights live as e4m3fn bytes: the exact bf16 up-cast of the stored values under the buffers' own names."""
+    for n, w8 in (module._w8 or {}).items():
+        state_dict[prefix + n] = w8.to(bf16)
+    return state_dict
 
 
 class MI355XHunyuanSingleBlock(_FlatGradMixin, _Fp8StorageMixin, nn.Module):

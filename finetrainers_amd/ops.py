@@ -368,12 +368,16 @@ def posterior_sample(moments, eps):
     return out
 
 
+MSE_SCRATCH_FLOATS_PER_SAMPLE = 256  # FTMI_MSE_SCRATCH_FLOATS_PER_SAMPLE of include/ftmi355.h
+
+
 def mse_loss(pred, target, weight: Optional[torch.Tensor], want_grad: bool = True, grad_scale: float = 1.0):
     B = pred.shape[0]
     per = pred[0].numel()
     loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
-    check(_lib.load().ftmi_mse_loss(ptr(pred), ptr(target), ptr(weight), ptr(loss), ptr(dpred), B, per, float(grad_scale), stream_ptr()),
+    scratch = torch.empty((MSE_SCRATCH_FLOATS_PER_SAMPLE * B,), dtype=torch.float32, device=pred.device)  # caller-owned partial sums (ftmi355.h)
+    check(_lib.load().ftmi_mse_loss(ptr(pred), ptr(target), ptr(weight), ptr(loss), ptr(dpred), B, per, float(grad_scale), ptr(scratch), stream_ptr()),
           "ftmi_mse_loss")
     return loss, dpred
 

@@ -58,6 +58,8 @@ class PrecomputedSampleFeeder:
     MI355X-side design: the disk read, the collation and the host->device copy run ``prefetch`` batches ahead on a worker thread
     (pinned staging buffers, its own HIP stream); ``__next__`` only waits on an event."""
 
+    MAX_PINNED_RINGS = 16  # distinct (tensor name, shape, dtype) staging rings kept page-locked at a time
+
     def __init__(self, save_dir: str, rank: int, world_size: int, batch_size: int, collate_conditions: Callable, collate_latents: Callable,
                  resolution_dim_keys: Optional[Dict[str, Tuple[int, ...]]] = None, device: Optional[torch.device] = None, prefetch: int = 2):
         self.dir = save_dir if os.path.basename(os.path.normpath(save_dir)) == PRECOMPUTED_DATA_DIR else os.path.join(save_dir, PRECOMPUTED_DATA_DIR)
@@ -97,7 +99,15 @@ class PrecomputedSampleFeeder:
         (``Tensor.pin_memory()`` = hipHostMalloc + hipHostFree) synchronises with the device and cost the consumer ~10 % of a 36 ms step.  A slot
         is rewritten only after the host saw its last host-to-device copy complete."""
         ring_key = (key, tuple(like.shape), like.dtype)
-        ring = self._pinned.setdefault(ring_key, {"slots": [], "events": [], "next": 0})
+        ring = self._pinned.pop(ring_key, None) or {"slots": [], "events": [], "next": 0}
+        self._pinned[ring_key] = ring  # most recently used last (dicts keep insertion order)
+        while len(self._pinned) > self.MAX_PINNED_RINGS:
+            # multi-resolution / bucketed datasets, varying text lengths: every distinct shape has its own ring, so page-locked host memory would
+            # grow without bound -- drop the least recently used ring once the copies out of it have completed
+            old = self._pinned.pop(next(iter(self._pinned)))
+            for ev in old["events"]:
+                if ev is not None:
+                    ev.synchronize()
         n = self._q.maxsize + 2
         if len(ring["slots"]) < n:
             ring["slots"].append(torch.empty(like.shape, dtype=like.dtype, pin_memory=True))

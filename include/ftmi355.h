@@ -328,9 +328,12 @@ int ftmi_cog_unpatchify(const void* tokens, void* latents, int B, int F, int C, 
  * models/ltx_video/base_specification.py:285-289 ([upstream] diffusers DiagonalGaussianDistribution.sample). */
 int ftmi_posterior_sample(const void* moments, const void* eps, void* out, int B, long per_sample, ftmi_stream stream);
 
-/* loss (device fp32 scalar) = mean_b mean w_b (pred-target)^2 ; dpred = d(loss*grad_scale)/dpred (bf16), may be NULL */
+/* loss (device fp32 scalar) = mean_b mean w_b (pred-target)^2 ; dpred = d(loss*grad_scale)/dpred (bf16), may be NULL.
+ * scratch: caller-owned device memory, >= FTMI_MSE_SCRATCH_FLOATS_PER_SAMPLE * B floats (per-workgroup partial sums, added in a fixed order:
+ * the loss is bitwise reproducible); the library allocates nothing on this path, so the call is legal inside a stream capture. */
+#define FTMI_MSE_SCRATCH_FLOATS_PER_SAMPLE 256
 int ftmi_mse_loss(const void* pred, const void* target, const float* weight, float* loss, void* dpred, int B, long per_sample,
-                  float grad_scale, ftmi_stream stream);
+                  float grad_scale, float* scratch, ftmi_stream stream);
 
 /* Global L2 clip (max_norm <= 0 disables) + AdamW over flat fp32 buffers; scratch: >= FTMI_CLIP_SCRATCH_FLOATS floats (device).
  * The norm is reduced in a fixed order (block partials in scratch, last block adds them): the same gradients give the same

@@ -554,7 +554,7 @@ def test_real_fp8_weight_storage_is_bit_identical_and_smaller():
     cond = {"encoder_hidden_states": torch.randn(B, T, 64, generator=g).to(bf16).to(dev), "encoder_attention_mask": torch.tensor([[1, 1, 1, 1, 1, 0, 0, 0], [1] * 8]).to(dev),
             "pooled_projections": torch.randn(B, 64, generator=g).to(bf16).to(dev)}
     sig = torch.tensor([0.25, 0.75], device=dev)
-    outs = []
+    outs, sds = [], []
     for real in (False, True):
         torch.manual_seed(3)
         m = MI355XHunyuanVideoTransformer3DModel(HunyuanVideoTransformerConfig(**kw), device=dev)
@@ -574,9 +574,21 @@ def test_real_fp8_weight_storage_is_bit_identical_and_smaller():
         spec.loss_backward(pred, target)
         torch.cuda.synchronize()
         outs.append((pred.detach().clone(), {k: v.clone() for k, v in m.lora_grad_state_dict().items()}, saved))
+        sds.append({k: v.clone() for k, v in m.state_dict().items() if "transformer_blocks" in k and "lora" not in k})
         if real:
             blk = m.single_transformer_blocks[0]
             assert blk._w8["wq"].dtype == torch.float8_e4m3fn and blk._w8["wq"].element_size() == 1
+            # the arena views the kernels compute with are NOT module buffers (they hold whichever block ran last) ...
+            assert "wq" not in dict(blk.named_buffers()) and "wq_t" not in dict(blk.named_buffers())
+            # ... and a second cast finds the weights already stored: only the biases are (idempotently) rounded again
+            assert m.apply_layerwise_casting(real_storage=True) < 2 * 24 + 3 * 10
+            assert blk._w8["wq"].numel() == 256 * 256
+    # state_dict() of the fp8-stored model = every block's OWN weights (exact up-cast of its bytes), key for key what the bf16-stored model reports
+    assert sds[0].keys() == sds[1].keys() and len(sds[0]) > 0
+    for k in sds[0]:
+        assert torch.equal(sds[0][k], sds[1][k]), k
+    w0, w1 = sds[1]["single_transformer_blocks.0.wq"], sds[1]["single_transformer_blocks.1.wq"]
+    assert not torch.equal(w0, w1)
     (p0, g0, s0), (p1, g1, s1) = outs
     assert torch.equal(p0, p1)
     for k in g0:
