@@ -298,7 +298,11 @@ def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trac
 
     assert tgt_equal, "flow-match target must be bit-exact"
     if trace is not None:
-        assert worst < 2e-2 * max(1.0, num_layers / 4), f"an activation diverged (worst rel_l2 {worst:.3e})"
+        # rounding noise of independent bf16 roundings grows like a random walk over the depth: 1.5e-2 * sqrt(L / 2) (observed on MI355X: 4.2e-3 at
+        # 2 blocks, 7.0e-3 on the residual stream after 28) -- the round-3 bound 2e-2 * L / 4 (0.14 at 28 blocks) could not localise anything
+        worst_name = max(rows, key=lambda r: r[1])[0]
+        print(f"[dit-trace-worst] {tag}: {worst_name} rel_l2={worst:.3e} (bound {1.5e-2 * max(1.0, num_layers / 2) ** 0.5:.3e})")
+        assert worst < 1.5e-2 * max(1.0, num_layers / 2) ** 0.5, f"an activation diverged ({worst_name}: rel_l2 {worst:.3e})"
     assert pred_err < 1e-2 * max(1.0, num_layers / 7)
     assert loss_rel < LOSS_RTOL, f"loss {loss.item()} vs oracle {loss_ref_v}"
     if k32 is not None:
