@@ -88,5 +88,15 @@ PY
     done; done > gpurun_out/r04_nt16_ab.txt 2>&1; cat gpurun_out/r04_nt16_ab.txt
     bash tools/gpu_profile_r04.sh r04 > gpurun_out/r04_profile.log 2>&1; tail -60 gpurun_out/r04_profile.log | cut -c1-260
     ;;
+  g)  # GEMM evidence of the round in one visit: MFMA power probe, the lab table (round-3 256x256 8-wave kernel 47, hand-placed 32x32x16 pipeline 70,
+      # 16x16x32 kernels 80 / 86, their ablations 180 = no DMA / 280 = no rendezvous / 380 = no fragment reads), cold activations, warm weights
+    timeout 200 tools/bin/probe_mfma_power > gpurun_out/r04_gemm_power.txt 2>&1; cat gpurun_out/r04_gemm_power.txt
+    SH="5376x2048x2048,5376x6144x2048,5376x8192x2048,5376x2048x8192,5376x2048x6144,8192x8192x8192"
+    { echo "# weights cold (rotating copies), activations fixed (Infinity-Cache resident)"; timeout 300 tools/bin/gemm_lab "$SH" 47,70,80,86
+      echo "# ablations of the 16x16x32 pipeline (results wrong on purpose): 180 no DMA in the loop, 280 no rendezvous, 380 no fragment reads"; timeout 200 tools/bin/gemm_lab "5376x8192x2048,8192x8192x8192" 80,180,280,380
+      echo "# LAB_COLDX=1: activations rotate as well (what a step's launch sees: its input was written by the previous kernel, read once)"; LAB_COLDX=1 timeout 300 tools/bin/gemm_lab "$SH" 47,80,86
+      echo "# LAB_WARMW=1: one weight copy (Infinity-Cache resident)"; LAB_WARMW=1 timeout 300 tools/bin/gemm_lab "5376x8192x2048,5376x2048x8192" 47,80,86
+    } > gpurun_out/r04_gemm_lab.txt 2>&1; cat gpurun_out/r04_gemm_lab.txt
+    ;;
   *) echo "unknown step $step"; exit 1;;
 esac
