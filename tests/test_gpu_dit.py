@@ -115,7 +115,7 @@ def _oracle_trace(model, inp):
     return tr
 
 
-def _build(num_layers, B, F_, H_, W_, first_frame, seed, rank=64, alpha=64.0):
+def _build(num_layers, B, F_, H_, W_, first_frame, seed, rank=64, alpha=64.0, sigma_scheme=None):
     from finetrainers_amd.ltx_video import LTXTransformerConfig, MI355XLTXVideoModelSpecification
     from oracle import ltx
 
@@ -127,7 +127,7 @@ def _build(num_layers, B, F_, H_, W_, first_frame, seed, rank=64, alpha=64.0):
     inp.latents_std = 1.0 + 0.2 * torch.rand(cfg.in_channels, generator=torch.Generator().manual_seed(6))
     if first_frame:
         inp.first_frame_sigma = torch.tensor([0.1, 0.6][:B])
-    if F_ * H_ * W_ == 2688:
+    if sigma_scheme == "logit_normal":  # (only the 4-block cfg-2-size case: the full-depth cfg-2 test keeps sigma {0.25, 0.7}, which its committed fp32 sample was made with)
         # sigma draws of --flow_weighting_scheme logit_normal (utils/diffusion.py:38-63 -> finetrainers_amd.utils.diffusion, pinned to the reference's
         # fixtures in tests/test_host.py): u = sigmoid(N(0, 1)), indices into the 1000-entry table
         from finetrainers_amd.utils import diffusion as du
@@ -166,11 +166,11 @@ CASES = [
 ]
 
 
-def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trace_activations, tag, rank=64, alpha=64.0, keep_gpu_grads=None):
+def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trace_activations, tag, rank=64, alpha=64.0, keep_gpu_grads=None, sigma_scheme=None):
     from finetrainers_amd.trainer import sft_loss
     from oracle import ltx
 
-    cfg, omodel, inp, spec, gmodel = _build(num_layers, B, F_, H_, W_, first_frame, seed=3, rank=rank, alpha=alpha)
+    cfg, omodel, inp, spec, gmodel = _build(num_layers, B, F_, H_, W_, first_frame, seed=3, rank=rank, alpha=alpha, sigma_scheme=sigma_scheme)
     S = F_ * H_ * W_
     D = 2048
 
@@ -298,11 +298,11 @@ def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trac
 
     assert tgt_equal, "flow-match target must be bit-exact"
     if trace is not None:
-        # rounding noise of independent bf16 roundings grows like a random walk over the depth: 1.5e-2 * sqrt(L / 2) (observed on MI355X: 4.2e-3 at
-        # 2 blocks, 7.0e-3 on the residual stream after 28) -- the round-3 bound 2e-2 * L / 4 (0.14 at 28 blocks) could not localise anything
+        # rounding noise of independent bf16 roundings grows like a random walk over the depth: 1.0e-2 * sqrt(L / 2) (observed on MI355X: 4.2e-3 at
+        # 2 blocks, 3.3e-3 at 4 blocks of the cfg-2 clip, 8.1e-3 at 28 blocks -- the rotated keys of the last block) -- the round-3 bound 2e-2 * L / 4 (0.14 at 28 blocks) could not localise anything
         worst_name = max(rows, key=lambda r: r[1])[0]
-        print(f"[dit-trace-worst] {tag}: {worst_name} rel_l2={worst:.3e} (bound {1.5e-2 * max(1.0, num_layers / 2) ** 0.5:.3e})")
-        assert worst < 1.5e-2 * max(1.0, num_layers / 2) ** 0.5, f"an activation diverged ({worst_name}: rel_l2 {worst:.3e})"
+        print(f"[dit-trace-worst] {tag}: {worst_name} rel_l2={worst:.3e} (bound {1.0e-2 * max(1.0, num_layers / 2) ** 0.5:.3e})")
+        assert worst < 1.0e-2 * max(1.0, num_layers / 2) ** 0.5, f"an activation diverged ({worst_name}: rel_l2 {worst:.3e})"
     assert pred_err < 1e-2 * max(1.0, num_layers / 7)
     assert loss_rel < LOSS_RTOL, f"loss {loss.item()} vs oracle {loss_ref_v}"
     if k32 is not None:
@@ -317,7 +317,8 @@ def _run_parity_case(num_layers, B, F_, H_, W_, first_frame, measure_floor, trac
 @pytest.mark.parametrize("num_layers,B,F_,H_,W_,first_frame", CASES)
 def test_dit_forward_backward_parity(num_layers, B, F_, H_, W_, first_frame):
     tag = f"L{num_layers}_B{B}_S{F_ * H_ * W_}{'_ff' if first_frame else ''}"
-    glob, worst_adapter, floor_glob, floor_worst = _run_parity_case(num_layers, B, F_, H_, W_, first_frame, True, True, tag)
+    scheme = "logit_normal" if F_ * H_ * W_ == 2688 else None  # the cfg-2-size case draws its sigmas the way --flow_weighting_scheme logit_normal does
+    glob, worst_adapter, floor_glob, floor_worst = _run_parity_case(num_layers, B, F_, H_, W_, first_frame, True, True, tag, sigma_scheme=scheme)
     explained = _run_parity_case.last_explained
     assert glob < EXPLAINED_FACTOR * explained, f"global LoRA gradient error {glob:.3e} vs sqrt(floor^2 + removed rounding noise^2) = {explained:.3e}"
     assert worst_adapter < WORST_FACTOR * floor_worst, f"worst adapter {worst_adapter:.3e} vs floor {floor_worst:.3e}"
