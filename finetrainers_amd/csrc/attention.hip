@@ -382,6 +382,144 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
 
 #ifdef FTMI_EXPERIMENTAL
 // ------------------------------------------------------------------------------------------------
+// forward for FEW KEYS (Sk <= 128, head_dim 64: LTX cross-attention) -- EXPERIMENT, not shipped (profiles/r04_cross_attention.txt: 18.2 us against
+// 19.9 us for the general kernel, and the dQ twin below 36.8 against 36.9 us: the few-key launches are NOT bound by their per-workgroup staging chains --
+// both forms move their bytes at the same 2.4 TB/s, the rate of 128-byte pieces at a 4-KB stride, i.e. of the head-interleaved [B, S, H x 64] layout).  attn_fwd_kernel gives every 128 query rows their own workgroup and every
+// workgroup its own K / V staging chain: 1 344 workgroups of ~1 us of arithmetic, 19.5 us per launch for 44 MB.  Here the (at most two) K / V tiles are
+// staged once and stay resident while the workgroup walks `bpw` 128-row query blocks -- no DMA, no barrier in the loop, one round of workgroups.  The
+// arithmetic per block is attn_fwd_kernel<HAS_KB, AF_LAZY | AF_MAX16> statement for statement (two 64-key tiles, lazy rescale): bit-identical outputs.
+// ------------------------------------------------------------------------------------------------
+static constexpr int kFwdResLds = 2 * 16384 + 2 * 256 + 4 * 4096;
+
+template <bool HAS_KB>
+__global__ __launch_bounds__(256, 3) void attn_fwd_res_kernel(AttnArgs a, int nblk, int bpw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (nblk + bpw - 1) / bpw, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const float sl = a.scale * kLog2e;
+    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
+    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
+    const int nt = (a.Sk + 63) / 64;  // 1 or 2
+    char* scratch = smem + 2 * 16384 + 2 * 256 + wave * 4096;
+    {
+        const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
+        for (int t = 0; t < nt; ++t) {
+            char* tb = smem + t * 16384;
+            tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
+            tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+            if constexpr (HAS_KB) {
+                if (tid < 64) {
+                    const int j = t * 64 + tid;
+                    reinterpret_cast<float*>(smem + 2 * 16384)[t * 64 + tid] = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;
+                }
+            }
+        }
+        tile_dma_wait();
+        __syncthreads();
+    }
+    s16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
+
+    const int qb_end = min(nblk, (blk.tile + 1) * bpw);
+    for (int qb = blk.tile * bpw; qb < qb_end; ++qb) {
+        const int i = qb * 128 + wave * 32 + li;
+        const int ic = min(i, a.Sq - 1);
+        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
+        s16x8 qf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x16 oacc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            oacc[0][r] = 0.f;
+            oacc[1][r] = 0.f;
+        }
+        for (int t = 0; t < nt; ++t) {
+            const char* ks = smem + t * 16384;
+            const char* vs = ks + 8192;
+            const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + t * 64;
+            f32x16 st[2];
+#pragma unroll
+            for (int js = 0; js < 2; ++js) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
+                    st[js] = mfma32(kf, qf[c], st[js]);
+                }
+            }
+            float mx = -INFINITY;
+            if constexpr (HAS_KB) {
+#pragma unroll
+                for (int js = 0; js < 2; ++js)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float x = __builtin_fmaf(st[js][rq * 4 + j], sl, b4[j]);
+                            st[js][rq * 4 + j] = x;
+                            mx = fmaxf(mx, x);
+                        }
+                    }
+            } else {
+                mx = fmaxf(max16(st[0]), max16(st[1])) * sl;
+            }
+            mx = xhalf_max(mx);
+            float m_new = fmaxf(m_run, mx);
+            float alpha;
+            const bool grow = (mx - m_run) > 8.0f;  // lazy rescale, as in attn_fwd_kernel (also true for the first tile: m_run = -inf)
+            if (__builtin_amdgcn_ballot_w64(grow) == 0) {
+                m_new = m_run;
+                alpha = 1.0f;
+            } else {
+                const float m_eff0 = (m_new == -INFINITY) ? 0.f : m_new;
+                alpha = fast_exp2(m_run - m_eff0);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
+            const float m_eff = (m_new == -INFINITY) ? 0.f : m_new;
+#pragma unroll
+            for (int js = 0; js < 2; ++js)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[js][r] = HAS_KB ? fast_exp2(st[js][r] - m_eff) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_eff));
+            m_run = m_new;
+            f32x16 lsum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
+#pragma unroll
+            for (int js = 0; js < 2; ++js)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const s16x8 pf = pack_frag(st[js], hh);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
+                        oacc[dt] = mfma32(vf, pf, oacc[dt]);
+                    }
+                    lsum = mfma32(ones, pf, lsum);
+                }
+            l_run = l_run * alpha + lsum[0];
+        }
+        const float inv = 1.0f / l_run;
+        bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
+        store_rows_via_lds(scratch, oacc, inv, ob, a.o_ss, qb * 128 + wave * 32, a.Sq, lane);
+        if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
+    }
+}
+
+#endif  // FTMI_EXPERIMENTAL (few-keys forward)
+
+#ifdef FTMI_EXPERIMENTAL
+// ------------------------------------------------------------------------------------------------
 // forward, two waves per SIMD in opposite phases (head_dim 64, no key bias)
 //
 // What bounds attn_fwd_kernel (profiles/r02_attention_experiments.txt): per 64-key tile a wave issues 20 MFMAs (640
@@ -853,6 +991,23 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
             if (pin) hipLaunchKernelGGL((attn_fwd8_kernel<false, true>), grid8, dim3(512), kFwd8Lds, st, a);
             else hipLaunchKernelGGL((attn_fwd8_kernel<false, false>), grid8, dim3(512), kFwd8Lds, st, a);
         }
+        return check_launch("attn_fwd");
+    }
+#endif
+#ifdef FTMI_EXPERIMENTAL
+    // few keys (LTX cross-attention): resident K / V, one round of workgroups that each walk bpw 128-row query blocks (FTMI_ATTN_FEWKEYS=1; no gain: see the kernel)
+    const int few = env_int("FTMI_ATTN_FEWKEYS", 0);  // re-read every call (a getenv): the parity test switches inside one process
+    if (few && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 768 && (a.kbias || (a.Sk % 64) == 0)) {
+        static const bool attr_ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdResLds) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdResLds) == hipSuccess;
+        if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_fwd: cannot raise the dynamic LDS limit");
+        const int nblk = (a.Sq + 127) / 128;
+        int bpw = 1;
+        while ((long)((nblk + bpw - 1) / bpw) * a.H * a.B > 768) ++bpw;
+        const dim3 gr(((nblk + bpw - 1) / bpw) * a.H * a.B);
+        if (a.kbias) hipLaunchKernelGGL(attn_fwd_res_kernel<true>, gr, dim3(256), kFwdResLds, st, a, nblk, bpw);
+        else hipLaunchKernelGGL(attn_fwd_res_kernel<false>, gr, dim3(256), kFwdResLds, st, a, nblk, bpw);
         return check_launch("attn_fwd");
     }
 #endif
@@ -1333,6 +1488,125 @@ __global__ __launch_bounds__(256, ND) void attn_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
+#ifdef FTMI_EXPERIMENTAL
+// ------------------------------------------------------------------------------------------------
+// backward dQ for FEW KEYS (Sk <= 128, head_dim 64: LTX cross-attention, 128 text tokens against 2 688 video tokens per sample) -- EXPERIMENT, not
+// shipped: bit-identical to the general kernel and exactly as fast (36.8 against 36.9 us, profiles/r04_cross_attention.txt); the hypothesis below was wrong.
+// The general kernels give such a problem one workgroup per 128 / 256 query rows, and every one of them walks the same latency chain --
+// K / V tile DMA, Q / dO / O loads, two 64-key tiles behind workgroup barriers -- for 1.5 us of arithmetic: 36.7 us per launch for 88 MB
+// (2.4 TB/s), 704 workgroups on 512 slots.  Here the two K / V tiles (32 KB) are staged ONCE and stay resident; the workgroup then walks
+// `bpw` 128-row query blocks (32 rows per wave, the first-generation register budget: three waves per SIMD) with no DMA and no barrier
+// in the loop, and `bpw` is chosen by the host so that the grid is a single round.  Same arithmetic, same order per element as
+// attn_bwd_dq_kernel<HAS_KB, 1>; delta = rowsum(dO * O) is published for the dK / dV kernel as before.
+// ------------------------------------------------------------------------------------------------
+static constexpr int kDqResLds = 2 * 16384 + 2 * 256 + 4 * 4096;  // two resident (K, V) tiles + two key-bias rows + per-wave store scratch
+
+template <bool HAS_KB>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_res_kernel(AttnArgs a, int nblk, int bpw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (nblk + bpw - 1) / bpw, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const float sl = a.scale * kLog2e;
+    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
+    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
+    const int nt = (a.Sk + 63) / 64;  // 1 or 2
+    char* scratch = smem + 2 * 16384 + 2 * 256 + wave * 4096;
+
+    {
+        const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
+        for (int t = 0; t < nt; ++t) {
+            char* tb = smem + t * 16384;
+            tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
+            tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
+            if constexpr (HAS_KB) {
+                if (tid < 64) {
+                    const int j = t * 64 + tid;
+                    reinterpret_cast<float*>(smem + 2 * 16384)[t * 64 + tid] = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;  // -inf => p = 0 for padded keys
+                }
+            }
+        }
+        tile_dma_wait();
+        __syncthreads();
+    }
+
+    const int qb_end = min(nblk, (blk.tile + 1) * bpw);
+    for (int qb = blk.tile * bpw; qb < qb_end; ++qb) {
+        const int i = qb * 128 + wave * 32 + li;
+        const int ic = min(i, a.Sq - 1);
+        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
+        const bf16_t* dop = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)ic * a.do_ss;
+        const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)ic * a.o_ss;
+        s16x8 qf[4], dof[4];
+        float del_i = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+            dof[c] = *reinterpret_cast<const s16x8*>(dop + c * 16 + g * 8);
+            const s16x8 of = *reinterpret_cast<const s16x8*>(op + c * 16 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) del_i += bf2f((bf16_t)dof[c][e]) * bf2f((bf16_t)of[e]);
+        }
+        const float lse_i = a.lse2[((long)b * a.H + h) * a.Sq + ic];
+        del_i += __shfl_xor(del_i, 32, 64);
+        if (g == 0 && i < a.Sq) a.delta[((long)b * a.H + h) * a.Sq + i] = del_i;
+
+        f32x16 dqt[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dqt[0][r] = 0.f;
+            dqt[1][r] = 0.f;
+        }
+        for (int t = 0; t < nt; ++t) {
+            const char* ks = smem + t * 16384;
+            const char* vs = ks + 8192;
+            const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + t * 64;
+#pragma unroll
+            for (int js = 0; js < 2; ++js) {
+                f32x16 sacc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = 0.f;
+                    dp[r] = 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
+                    sacc = mfma32(kf, qf[c], sacc);
+                    const s16x8 vf = read_row_frag(vs, js * 32 + li, c, g);
+                    dp = mfma32(vf, dof[c], dp);
+                }
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (HAS_KB) b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = rq * 4 + j;
+                        const float p = HAS_KB ? fast_exp2(__builtin_fmaf(sacc[r], sl, b4[j] - lse_i)) : fast_exp2(__builtin_fmaf(sacc[r], sl, -lse_i));
+                        dp[r] = p * (dp[r] - del_i);
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const s16x8 dsf = pack_frag(dp, hh);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const s16x8 ktf = read_tr_frag(ks, dt * 32, js * 32 + hh * 16, lane);
+                        dqt[dt] = mfma32(ktf, dsf, dqt[dt]);
+                    }
+                }
+            }
+        }
+        bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
+        store_rows_via_lds(scratch, dqt, a.scale, dqb, a.dq_ss, qb * 128 + wave * 32, a.Sq, lane);  // (per-wave scratch, in-order LDS: no barrier needed)
+    }
+}
+
+#endif  // FTMI_EXPERIMENTAL (few-keys dQ)
+
 // ------------------------------------------------------------------------------------------------
 // backward dQ, second generation: 64 query rows per wave (same reasoning as attn_fwd2_kernel: the loop is bound by the issue of its
 // non-matrix instructions, so every K / V row fragment and every K^T fragment read from LDS now feeds two MFMAs).  Per 32 keys and
@@ -1691,7 +1965,28 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
 #else
     const int dq_gen = 2;
 #endif
-    if (dq_gen == 2) {
+#ifdef FTMI_EXPERIMENTAL
+    // few keys (LTX cross-attention): resident K / V, one round of workgroups that each walk bpw 128-row query blocks (FTMI_ATTN_FEWKEYS=1; no gain: see the kernel)
+    const bool few_keys = env_int("FTMI_ATTN_FEWKEYS", 0) && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 768;
+#else
+    constexpr bool few_keys = false;
+#endif
+    if (few_keys) {
+#ifdef FTMI_EXPERIMENTAL
+        static const bool attr_ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDqResLds) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_res_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDqResLds) == hipSuccess;
+        if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
+        const int nblk = (a.Sq + 127) / 128;
+        int bpw = 1;  // smallest walk that fits every workgroup into one round of 3 x 256 slots
+        while ((long)((nblk + bpw - 1) / bpw) * a.H * a.B > 768) ++bpw;
+        const dim3 gr(((nblk + bpw - 1) / bpw) * a.H * a.B);
+        if (a.kbias || (a.Sk % 64) != 0)
+            hipLaunchKernelGGL(attn_bwd_dq_res_kernel<true>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
+        else
+            hipLaunchKernelGGL(attn_bwd_dq_res_kernel<false>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
+#endif
+    } else if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
         if (a.kbias)
             hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, grid2, dim3(256), kDqLds, st, a);

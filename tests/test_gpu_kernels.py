@@ -191,6 +191,9 @@ ATTN_CASES = [
     (2, 4, 2688, 128, True),   # cfg 2 cross-attention with text mask (few keys: split-query dK/dV kernel)
     (1, 2, 600, 77, True),     # split-query dK/dV kernel, ragged queries (last 128-block holds 88) and keys
     (1, 1, 520, 33, False),    # split-query dK/dV kernel, second 64-row tile of the last block wholly past the end
+    (2, 8, 1000, 128, False),  # few keys without a bias (two full key tiles), ragged last query block
+    (1, 8, 640, 64, False),    # ... a single key tile
+    (1, 3, 700, 128, True),    # ... with a mask, B * H = 3 (plain block order)
     (3, 5, 257, 65, False),    # one row / one key past a tile boundary; B * H = 15 is not a multiple of the 8 XCDs (plain block order)
     (1, 1, 1, 1, False),       # a single query and a single key
     (2, 2, 129, 191, True),    # ragged both ways with per-sample masks, keys one short of three tiles
@@ -226,6 +229,36 @@ def test_attention_fwd_bwd(B, H, Sq, Sk, biased):
     report(tag + " dq", dq, dq_ref, 1e-2)
     report(tag + " dk", dk, dk_ref, 1e-2)
     report(tag + " dv", dv, dv_ref, 1e-2)
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 32, 2688, 128, True), (2, 8, 1000, 128, False), (1, 2, 600, 77, True), (1, 8, 640, 64, False)])
+def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, Sq, Sk, biased, monkeypatch):
+    """LTX cross-attention (128 text keys): the resident-K/V forward and dQ kernels (one staging of K / V per workgroup, a walk over several
+    128-row query blocks) do the arithmetic of the general kernels statement for statement -- outputs, log-sum-exp, delta-dependent dK / dV and
+    dQ must be the same bits as with FTMI_ATTN_FEWKEYS=0 (the general 128-row forward and 64-row dQ kernels)."""
+    from finetrainers_amd import _lib, ops
+
+    if not hasattr(_lib.load(), "ftmi_gemm_sk_status"):  # (an entry point only the FTMI_EXPERIMENTAL build exports)
+        pytest.skip("the resident few-keys kernels live in the FTMI_EXPERIMENTAL build (measured: no faster than the general kernels, profiles/r04_cross_attention.txt)")
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    q, k, v = rnd((B, H, Sq, 64), g).to(dev), rnd((B, H, Sk, 64), g).to(dev), rnd((B, H, Sk, 64), g).to(dev)
+    dout = rnd((B, H, Sq, 64), g).to(dev)
+    bias = None
+    if biased:
+        mask = torch.zeros(B, Sk)
+        for b in range(B):
+            mask[b, : max(1, (Sk * (b + 1)) // (B + 1))] = 1
+        bias = ((1 - mask.to(bf16)) * -10000.0).float().to(dev)
+    res = {}
+    for few in ("1", "0"):
+        monkeypatch.setenv("FTMI_ATTN_FEWKEYS", few)
+        out, lse = ops.attn_fwd(q, k, v, bias)
+        dq, dk, dv = ops.attn_bwd(q, k, v, out, lse, dout, bias)
+        torch.cuda.synchronize()
+        res[few] = (out, lse, dq, dk, dv)
+    for name, x, y in zip(("out", "lse", "dq", "dk", "dv"), res["1"], res["0"]):
+        assert torch.equal(x, y), f"{name}: resident few-keys kernels differ from the general kernels (max |diff| {(x.float() - y.float()).abs().max().item():.3e})"
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 3, 300, 257, True), (1, 2, 128, 128, False), (1, 2, 200, 330, False), (1, 4, 2688, 2688, False),
