@@ -389,10 +389,10 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
 // staged once and stay resident while the workgroup walks `bpw` 128-row query blocks -- no DMA, no barrier in the loop, one round of workgroups.  The
 // arithmetic per block is attn_fwd_kernel<HAS_KB, AF_LAZY | AF_MAX16> statement for statement (two 64-key tiles, lazy rescale): bit-identical outputs.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kFwdResLds = 2 * 16384 + 2 * 256 + 4 * 4096;
+static constexpr int kFwdResLds = 2 * 16384 + 2 * 256 + 2 * 16384;  // resident (K, V) tiles + key-bias rows + two 128-row Q staging buffers
 
 template <bool HAS_KB>
-__global__ __launch_bounds__(256, 3) void attn_fwd_res_kernel(AttnArgs a, int nblk, int bpw) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_res_kernel(AttnArgs a, int nblk, int bpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
@@ -403,7 +403,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_res_kernel(AttnArgs a, int nb
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
     const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
     const int nt = (a.Sk + 63) / 64;  // 1 or 2
-    char* scratch = smem + 2 * 16384 + 2 * 256 + wave * 4096;
+    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
+    char* stg = smem + 2 * 16384 + 2 * 256;
+    const int n64 = (a.Sq + 63) / 64;
+    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane);  // Q through LDS with row-contiguous DMA (whole lines), not per-lane row gathers
+    auto stage_rows = [&](int qb, int buf) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int t64 = min(2 * qb + half, n64 - 1);
+            tile_dma_issue(qd, qbase, a.q_ss, t64, t64 == n64 - 1, stg + buf * 16384 + half * 8192, wave);
+        }
+    };
+    const int qb0 = blk.tile * bpw, qb_end = min(nblk, qb0 + bpw);
     {
         const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
         for (int t = 0; t < nt; ++t) {
@@ -417,6 +428,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_res_kernel(AttnArgs a, int nb
                 }
             }
         }
+        if (qb0 < qb_end) stage_rows(qb0, 0);
         tile_dma_wait();
         __syncthreads();
     }
@@ -424,14 +436,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_res_kernel(AttnArgs a, int nb
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
 
-    const int qb_end = min(nblk, (blk.tile + 1) * bpw);
-    for (int qb = blk.tile * bpw; qb < qb_end; ++qb) {
+    for (int qb = qb0; qb < qb_end; ++qb) {
+        const int cur = (qb - qb0) & 1;
+        if (qb + 1 < qb_end) stage_rows(qb + 1, cur ^ 1);
+        char* qs = stg + cur * 16384 + (wave >> 1) * 8192;
+        const int is = wave & 1;
         const int i = qb * 128 + wave * 32 + li;
-        const int ic = min(i, a.Sq - 1);
-        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
         s16x8 qf[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+        for (int c = 0; c < 4; ++c) qf[c] = read_row_frag(qs, is * 32 + li, c, g);
         float m_run = -INFINITY, l_run = 0.f;
         f32x16 oacc[2];
 #pragma unroll
@@ -511,8 +524,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_res_kernel(AttnArgs a, int nb
         }
         const float inv = 1.0f / l_run;
         bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
-        store_rows_via_lds(scratch, oacc, inv, ob, a.o_ss, qb * 128 + wave * 32, a.Sq, lane);
+        store_rows_via_lds(qs + is * 4096, oacc, inv, ob, a.o_ss, qb * 128 + wave * 32, a.Sq, lane);  // scratch = this wave's own 32 Q rows (fragments are in registers)
         if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
+        tile_dma_wait();
+        __syncthreads();  // the next block's Q landed, and every wave is done with the current buffer
     }
 }
 
@@ -997,14 +1012,14 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
 #ifdef FTMI_EXPERIMENTAL
     // few keys (LTX cross-attention): resident K / V, one round of workgroups that each walk bpw 128-row query blocks (FTMI_ATTN_FEWKEYS=1; no gain: see the kernel)
     const int few = env_int("FTMI_ATTN_FEWKEYS", 0);  // re-read every call (a getenv): the parity test switches inside one process
-    if (few && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 768 && (a.kbias || (a.Sk % 64) == 0)) {
+    if (few && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 512 && (a.kbias || (a.Sk % 64) == 0)) {
         static const bool attr_ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdResLds) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdResLds) == hipSuccess;
         if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_fwd: cannot raise the dynamic LDS limit");
         const int nblk = (a.Sq + 127) / 128;
-        int bpw = 1;
-        while ((long)((nblk + bpw - 1) / bpw) * a.H * a.B > 768) ++bpw;
+        int bpw = 1;  // one round at two workgroups per CU
+        while ((long)((nblk + bpw - 1) / bpw) * a.H * a.B > 512) ++bpw;
         const dim3 gr(((nblk + bpw - 1) / bpw) * a.H * a.B);
         if (a.kbias) hipLaunchKernelGGL(attn_fwd_res_kernel<true>, gr, dim3(256), kFwdResLds, st, a, nblk, bpw);
         else hipLaunchKernelGGL(attn_fwd_res_kernel<false>, gr, dim3(256), kFwdResLds, st, a, nblk, bpw);
@@ -1499,10 +1514,10 @@ __global__ __launch_bounds__(256, ND) void attn_bwd_dq_kernel(AttnArgs a) {
 // in the loop, and `bpw` is chosen by the host so that the grid is a single round.  Same arithmetic, same order per element as
 // attn_bwd_dq_kernel<HAS_KB, 1>; delta = rowsum(dO * O) is published for the dK / dV kernel as before.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kDqResLds = 2 * 16384 + 2 * 256 + 4 * 4096;  // two resident (K, V) tiles + two key-bias rows + per-wave store scratch
+static constexpr int kDqResLds = 2 * 16384 + 2 * 256 + 2 * 49152;  // resident (K, V) tiles + key-bias rows + two (Q, dO, O) 128-row staging buffers
 
 template <bool HAS_KB>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_res_kernel(AttnArgs a, int nblk, int bpw) {
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_res_kernel(AttnArgs a, int nblk, int bpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
@@ -1511,10 +1526,27 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_res_kernel(AttnArgs a, int
     const float sl = a.scale * kLog2e;
     const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
+    const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
+    const bf16_t* obase = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
     const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
     const int nt = (a.Sk + 63) / 64;  // 1 or 2
-    char* scratch = smem + 2 * 16384 + 2 * 256 + wave * 4096;
-
+    char* stg = smem + 2 * 16384 + 2 * 256;
+    const int n64 = (a.Sq + 63) / 64;
+    // Q, dO and O arrive like the K / V tiles do: row-contiguous direct-to-LDS loads (8 lanes per 128-byte row piece = whole lines), NOT per-lane row
+    // gathers (32 half-used lines per wave instruction: 2.4-3.2 TB/s on this layout, profiles/r04_cross_attention.txt); the MFMA fragments are read from LDS
+    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane), od = tile_dma_setup(a.o_ss, a.Sq, wave, lane);
+    auto stage_rows = [&](int qb, int buf) {  // buffer: [Q rows 0-63][Q rows 64-127][dO ...][dO ...][O ...][O ...]; a tile wholly past the end re-reads the last one
+        char* tb = stg + buf * 49152;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int t64 = min(2 * qb + half, n64 - 1);
+            tile_dma_issue(qd, qbase, a.q_ss, t64, t64 == n64 - 1, tb + half * 8192, wave);
+            tile_dma_issue(dod, dobase, a.do_ss, t64, t64 == n64 - 1, tb + 16384 + half * 8192, wave);
+            tile_dma_issue(od, obase, a.o_ss, t64, t64 == n64 - 1, tb + 32768 + half * 8192, wave);
+        }
+    };
+    const int qb0 = blk.tile * bpw, qb_end = min(nblk, qb0 + bpw);
     {
         const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
         for (int t = 0; t < nt; ++t) {
@@ -1528,24 +1560,28 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_res_kernel(AttnArgs a, int
                 }
             }
         }
+        if (qb0 < qb_end) stage_rows(qb0, 0);
         tile_dma_wait();
         __syncthreads();
     }
 
-    const int qb_end = min(nblk, (blk.tile + 1) * bpw);
-    for (int qb = blk.tile * bpw; qb < qb_end; ++qb) {
+    for (int qb = qb0; qb < qb_end; ++qb) {
+        const int cur = (qb - qb0) & 1;
+        if (qb + 1 < qb_end) stage_rows(qb + 1, cur ^ 1);  // (every wave passed the barrier below: nobody reads that buffer any more)
+        char* tb = stg + cur * 49152;
+        char* qs = tb + (wave >> 1) * 8192;  // this wave's 64-row tile, and the 32-row half of it
+        const char* dos = tb + 16384 + (wave >> 1) * 8192;
+        const char* os_ = tb + 32768 + (wave >> 1) * 8192;
+        const int is = wave & 1;
         const int i = qb * 128 + wave * 32 + li;
         const int ic = min(i, a.Sq - 1);
-        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
-        const bf16_t* dop = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)ic * a.do_ss;
-        const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)ic * a.o_ss;
         s16x8 qf[4], dof[4];
         float del_i = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
-            dof[c] = *reinterpret_cast<const s16x8*>(dop + c * 16 + g * 8);
-            const s16x8 of = *reinterpret_cast<const s16x8*>(op + c * 16 + g * 8);
+            qf[c] = read_row_frag(qs, is * 32 + li, c, g);
+            dof[c] = read_row_frag(dos, is * 32 + li, c, g);
+            const s16x8 of = read_row_frag(os_, is * 32 + li, c, g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) del_i += bf2f((bf16_t)dof[c][e]) * bf2f((bf16_t)of[e]);
         }
@@ -1601,10 +1637,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_res_kernel(AttnArgs a, int
             }
         }
         bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
-        store_rows_via_lds(scratch, dqt, a.scale, dqb, a.dq_ss, qb * 128 + wave * 32, a.Sq, lane);  // (per-wave scratch, in-order LDS: no barrier needed)
+        // store scratch = this wave's own 32 Q rows of the current buffer (4 KB; their fragments are in registers, no other wave reads them)
+        store_rows_via_lds(qs + is * 4096, dqt, a.scale, dqb, a.dq_ss, qb * 128 + wave * 32, a.Sq, lane);
+        tile_dma_wait();
+        __syncthreads();  // the next block's rows landed, and every wave is done with the current buffer
     }
 }
-
 #endif  // FTMI_EXPERIMENTAL (few-keys dQ)
 
 // ------------------------------------------------------------------------------------------------
@@ -1967,7 +2005,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
 #endif
 #ifdef FTMI_EXPERIMENTAL
     // few keys (LTX cross-attention): resident K / V, one round of workgroups that each walk bpw 128-row query blocks (FTMI_ATTN_FEWKEYS=1; no gain: see the kernel)
-    const bool few_keys = env_int("FTMI_ATTN_FEWKEYS", 0) && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 768;
+    const bool few_keys = env_int("FTMI_ATTN_FEWKEYS", 0) && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 256;
 #else
     constexpr bool few_keys = false;
 #endif
@@ -1978,8 +2016,8 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_res_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDqResLds) == hipSuccess;
         if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
         const int nblk = (a.Sq + 127) / 128;
-        int bpw = 1;  // smallest walk that fits every workgroup into one round of 3 x 256 slots
-        while ((long)((nblk + bpw - 1) / bpw) * a.H * a.B > 768) ++bpw;
+        int bpw = 1;  // smallest walk that fits every workgroup into one round (128.5 KB of LDS: one workgroup per CU)
+        while ((long)((nblk + bpw - 1) / bpw) * a.H * a.B > 256) ++bpw;
         const dim3 gr(((nblk + bpw - 1) / bpw) * a.H * a.B);
         if (a.kbias || (a.Sk % 64) != 0)
             hipLaunchKernelGGL(attn_bwd_dq_res_kernel<true>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
