@@ -381,7 +381,7 @@ def main():
                                                  "share_of_step": a_ms / ms}
         pr = _profile_json("r04_bench_noprof.json")  # the same command with --no-prof on the evidence box: the instrument's cost as a stated quantity
         if prof and pr and args.workload == "ltx":
-            res["ms_per_step_without_event_profiler"] = {"ms_per_step": pr.get("ms_per_step"), "source": "profiles/r04_bench_noprof.json (python bench.py --no-prof, same box, same round)"}
+            res["ms_per_step_without_event_profiler"] = {"ms_per_step": pr.get("ms_per_step"), "source": "profiles/r04_bench_noprof.json: python bench.py --no-prof on the round's evidence box, where the default line (profiles/r04_bench_default.json) measured 66.34 ms -- the in-stream event profiler costs 0.2 %"}
         if par.world_size == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = ctx["cpu_baseline"]()
