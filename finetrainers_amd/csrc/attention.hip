@@ -1199,11 +1199,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnArgs a) {
 // waves split every 128-query block four ways (wave w takes queries 32w .. 32w+31 of the block), so there are 4x more
 // workgroups with 4x shorter loops; the four partial dK / dV are summed through LDS in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
-static constexpr int kDkvSqLds = 2 * 32768 + 2 * 1024;  // two (Q, dO) 128-row buffers + two (lse, delta) 128-entry rows
+static constexpr int kDkvSqLds = 2 * 32768 + 2 * 1024;  // per wave group: two (Q, dO) 128-row buffers + two (lse, delta) 128-entry rows
 
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// NG = wave groups per workgroup.  One group (4 waves, one per SIMD) walks every 128-query block as a dependent chain -- stage, 4 chained score MFMAs, exp2,
+// pack, 8 MFMAs, barrier: ~1.5 us per block with nothing to overlap it (a deeper DMA ring changed nothing: profiles/r03_attention_experiments.txt).  With
+// NG = 2 (8 waves, two per SIMD) the groups take alternate query blocks through their own staging buffers, so every SIMD interleaves two independent chains;
+// the eight partial dK / dV are summed through LDS in a fixed order.
+template <int NG>
+__global__ __launch_bounds__(256 * NG) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int tid_all = threadIdx.x, lane = tid_all & 63, wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);
+    const int grp = wave_all >> 2, wave = wave_all & 3, tid = tid_all & 255;  // group-local wave / thread index
+    char* smem = smem_all + grp * kDkvSqLds;
     const int li = lane & 31, g = lane >> 5;
     const AttnBlock blk = attn_block(blockIdx.x, (a.Sk + 31) / 32, a.H, a.B);
     const int h = blk.h, b = blk.b;
@@ -1269,18 +1276,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
         settle(vf[c]);
     }
     settle(bias_j);
-    stage(0, 0);
+    stage(grp, 0);  // (a group without a first block stages clamped rows: finite data, never used)
     stage_commit(0);
     tile_dma_wait();
     __syncthreads();
-    auto body = [&](int t, auto CUR) {
+    auto body = [&](int t, auto CUR, bool live) {
         constexpr int cur = decltype(CUR)::value;
         const char* qs = smem + cur * 32768 + (wave >> 1) * 8192;        // this wave's 64-row tile ...
         const char* dos = smem + cur * 32768 + 16384 + (wave >> 1) * 8192;
         const int is = wave & 1;                                          // ... and 32-row half of it
         const float* lses = reinterpret_cast<const float*>(smem + 2 * 32768) + cur * 256 + wave * 32;
         const float* dels = lses + 128;
-        if (t + 1 < nb) stage(t + 1, cur ^ 1);
+        if (t + NG < nb) stage(t + NG, cur ^ 1);
+        if (live) {
         f32x16 s, dp;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -1317,26 +1325,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
                 dkt[dt] = mfma32(qtf, dsf, dkt[dt]);
             }
         }
-        if (t + 1 < nb) stage_commit(cur ^ 1);
+        }
+        if (t + NG < nb) stage_commit(cur ^ 1);
         tile_dma_wait();
         __syncthreads();
     };
-    for (int t = 0; t < nb; t += 2) {
-        body(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nb) body(t + 1, std::integral_constant<int, 1>{});
+    // group grp takes blocks grp, grp + NG, ...; every wave of the workgroup passes the same number of barriers (a group without a block left idles through them)
+    const int niter = (nb + NG - 1) / NG;
+    for (int it = 0; it < niter; it += 2) {
+        const int t0 = it * NG + grp, t1 = (it + 1) * NG + grp;
+        body(t0, std::integral_constant<int, 0>{}, t0 < nb);
+        if (it + 1 < niter) body(t1, std::integral_constant<int, 1>{}, t1 < nb);
     }
 
-    // cross-wave reduction: red[wave][array: dk0, dk1, dv0, dv1][register][lane]; wave w then finalises array w
-    float* red = reinterpret_cast<float*>(smem);
+    // cross-wave reduction: red[wave of the workgroup][array: dk0, dk1, dv0, dv1][register][lane]; wave w (< 4) then finalises array w
+    float* red = reinterpret_cast<float*>(smem_all);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        red[((wave * 4 + 0) * 16 + r) * 64 + lane] = dkt[0][r];
-        red[((wave * 4 + 1) * 16 + r) * 64 + lane] = dkt[1][r];
-        red[((wave * 4 + 2) * 16 + r) * 64 + lane] = dvt[0][r];
-        red[((wave * 4 + 3) * 16 + r) * 64 + lane] = dvt[1][r];
+        red[((wave_all * 4 + 0) * 16 + r) * 64 + lane] = dkt[0][r];
+        red[((wave_all * 4 + 1) * 16 + r) * 64 + lane] = dkt[1][r];
+        red[((wave_all * 4 + 2) * 16 + r) * 64 + lane] = dvt[0][r];
+        red[((wave_all * 4 + 3) * 16 + r) * 64 + lane] = dvt[1][r];
     }
     __syncthreads();
-    if (j < a.Sk) {
+    if (j < a.Sk && grp == 0) {
         const int arr = wave, dt = arr & 1;
         const bool is_dk = arr < 2;
         bf16_t* op = is_dk ? a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh + (long)j * a.dk_ss
@@ -1349,7 +1361,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_sq_kernel(AttnArgs a) {
             for (int jj = 0; jj < 4; ++jj) {
                 const int r = rq * 4 + jj;
                 auto R = [&](int w) { return red[((w * 4 + arr) * 16 + r) * 64 + lane]; };
-                v[jj] = ((R(0) + R(1)) + (R(2) + R(3))) * mul;
+                if constexpr (NG == 2) v[jj] = (((R(0) + R(1)) + (R(2) + R(3))) + ((R(4) + R(5)) + (R(6) + R(7)))) * mul;
+                else v[jj] = ((R(0) + R(1)) + (R(2) + R(3))) * mul;
             }
             u32x2 pk;
             pk[0] = pack2bf(v[0], v[1]);
@@ -2041,9 +2054,14 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     const long wg128 = (long)((a.Sk + 127) / 128) * a.H * a.B;
     if (wg128 < 256 && a.Sq >= 512) {  // few keys: split the queries across the waves instead (see the kernel's header)
         static const bool attr_ok =  // once, thread-safe (forward and backward run on different host threads)
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_sq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSqLds) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_sq_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkvSqLds) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_sq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kDkvSqLds) == hipSuccess;
         if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL(attn_bwd_dkdv_sq_kernel, dim3(((a.Sk + 31) / 32) * a.H * a.B), dim3(256), kDkvSqLds, st, a);
+        static const int ng = env_int("FTMI_DKVSQ_GROUPS", 2);  // wave groups per workgroup (1 = the round-3 kernel: in-step A/B)
+        if (ng == 2 && a.Sq > 128)
+            hipLaunchKernelGGL(attn_bwd_dkdv_sq_kernel<2>, dim3(((a.Sk + 31) / 32) * a.H * a.B), dim3(512), 2 * kDkvSqLds, st, a);
+        else
+            hipLaunchKernelGGL(attn_bwd_dkdv_sq_kernel<1>, dim3(((a.Sk + 31) / 32) * a.H * a.B), dim3(256), kDkvSqLds, st, a);
     } else {
 #ifdef FTMI_EXPERIMENTAL
         if (attn_gen("FTMI_ATTN_DKV_GEN", 1) == 2)
