@@ -381,6 +381,77 @@ def test_bucketed_gradient_exchange_world_size_2_gloo():
         assert order == [(6, 10), (2, 6), (0, 2)] and n == 3   # same schedule on every rank: a function of L alone
 
 
+def _backend_worker(rank, world, port, q):
+    """Two ranks drive MI355XParallelBackend the way SFTTrainer does (trainer.py:185-189, 333-336): construct with the PTD arguments, apply_ddp on the
+    model, then a 'backward' that reports block ranges through the hooks apply_ddp installed and ends the exchange itself."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from finetrainers_amd.parallel import MI355XParallelBackend
+
+    class _Model:  # what apply_ddp touches of MI355XLTXVideoTransformer3DModel: the flat adapter buffer, the two parameters, the hook attributes
+        def __init__(self):
+            L, per = 8, 4
+            self.lora_flat = torch.full((2 * L * per,), float(rank + 1))  # ranks start with DIFFERENT adapters (peft draws A per process)
+            self.lora_A, self.lora_B = self.lora_flat[: L * per].view(L, per), self.lora_flat[L * per:].view(L, per)
+            self.grad = torch.zeros_like(self.lora_flat)
+            self._grad_bucket_hook = self._grad_bucket_finish = None
+            self._lora_versions = "stale"
+
+        def backward(self, blocks_per_range):
+            L, per = self.lora_A.shape
+            ga, gb = self.grad[: L * per].view(L, per), self.grad[L * per:].view(L, per)
+            hi = L
+            while hi > 0:
+                lo = max(0, hi - blocks_per_range)
+                ga[lo:hi] = float(rank + 1) * torch.arange(lo, hi, dtype=torch.float32)[:, None]
+                gb[lo:hi] = -float(rank + 1)
+                if self._grad_bucket_hook is not None:
+                    self._grad_bucket_hook(lo, hi, ga[lo:hi], gb[lo:hi])
+                hi = lo
+            if self._grad_bucket_finish is not None:
+                self._grad_bucket_finish()
+
+    b = MI355XParallelBackend(world_size=world, pp_degree=1, dp_degree=world, dp_shards=-1, cp_degree=1, tp_degree=1, backend="gloo", timeout=60,
+                              logging_dir="logs", output_dir="/tmp/ftmi_backend_test", gradient_accumulation_steps=1)
+    try:
+        b.enable_determinism(1234)
+        m = b.apply_ddp(_Model(), b.get_mesh())
+        after_bcast = m.lora_flat.clone()
+        m.backward(m.grad_bucket_blocks if hasattr(m, "grad_bucket_blocks") else 3)
+        metrics = b.reduce_step_metrics(torch.tensor(1.0 + rank), torch.tensor(3.0))
+        with b.main_process_first():
+            pass
+        b.wait_for_everyone()
+        q.put((rank, after_bcast.tolist(), m.grad.tolist(), b.reducer.buckets_issued, m._lora_versions, {k: v.item() for k, v in metrics.items()},
+               (b.world_size, b.rank, b.data_parallel_enabled, b.data_replication_enabled, b.data_sharding_enabled, b._dp_degree)))
+    finally:
+        b.destroy()
+
+
+def test_parallel_backend_drives_the_exchange_world_size_2_gloo():
+    """N2 / a17: the BaseParallelBackend-shaped backend on two real processes (gloo here, RCCL on GPUs): apply_ddp broadcasts rank 0's adapters and
+    installs the hooks; after the model's backward every rank holds the rank-AVERAGED gradient -- DDP's contract at that point of the trainer loop."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_backend_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    L, per = 8, 4
+    want = [1.5 * l for l in range(L) for _ in range(per)] + [-1.5] * (L * per)
+    for rank, bcast, grad, nb, ver, metrics, props in res:
+        assert bcast == [1.0] * (2 * L * per)      # rank 0's adapters everywhere
+        assert grad == want                        # mean over the two ranks, A and B slices of every bucket
+        assert nb == 2 and ver is None             # default 7 blocks per range over 8 blocks -> 2 buckets; stale operand copies invalidated
+        assert metrics["global_avg_loss"] == 1.5 and metrics["global_max_loss"] == 2.0
+        assert props == (2, rank, True, True, False, 2)
+
+
 def test_wire_formats_roundtrip(tmp_path):
     """LoRA checkpoint (transformer.-prefixed peft keys + lora_config / format metadata), diffusers transformer directory
     (sharded safetensors + index), precomputed-sample files and the prefetching feeder."""
