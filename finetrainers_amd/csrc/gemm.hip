@@ -1632,10 +1632,11 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             // on the step's shapes (profiles/r04_gemm_ab.txt): N >= 6144 7-12 % faster, N = 2048 / K = 8192 6-9 %; the single-round
             // K = 2048 launches are equal within noise (the residual epilogue 5 % slower), so those keep the 192 x 128 tiles, 2 workgroups per CU.
             // FTMI_NT16 is a mask of launch classes: 1 = several rounds of tiles and K <= 2048 (+ extension) without a row-wise epilogue input,
-            // 2 = the same with one (GELU' / residual), 4 = long K (6144 / 8192) or a single round.  In the step (profiles/r04_gemm_ab.txt, per-kernel
-            // tables) class 4 LOSES what the warm micro-benchmark promised: its activations (88 MB at K = 8192) arrive cold from the previous
-            // kernel, and one workgroup per CU has nobody to cover the vector-memory path while misses are outstanding -- the 192 x 128 kernel
-            // with two workgroups per CU keeps those launches.
+            // 2 = the same with one (GELU' / residual), 4 = long K (6144 / 8192) or a single round of long K.  In the step the classes are worth less than in
+            // the warm micro-benchmark -- a launch finds its activations cold (just written by the previous kernel, read once) and one workgroup per CU has
+            // nobody to cover the vector-memory path while misses are outstanding (LAB_COLDX rows of profiles/r04_gemm_lab.txt) -- but with the epilogue inputs
+            // prefetched every class still wins: FTMI_NT16 = 0 / 3 / 7 measured 66.8 / 66.2 / 66.2 ms per step on one box, 69.3 / 68.3 / 67.3 on another
+            // (profiles/r04_nt16_ab.txt, r04_gemm_ab.txt).  Default: all three.
             static const int use16 = env_int("FTMI_NT16", 7);
             const long t256 = (long)((a.M + 255) / 256) * (a.N / 256), t192 = (long)((a.M + 191) / 192) * (a.N / 256);
             const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;  // rounds x rows per tile
