@@ -380,11 +380,27 @@ __global__ __launch_bounds__(256, MINW) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// s_waitcnt vmcnt(n) for the few values the resident few-keys kernels use (the immediate must be a constant; n is wave-uniform).  The vector-memory queue
+// retires in order, so "leave the n youngest in flight" = "everything issued before them has completed": used to wait for the NEXT block's row DMA
+// (issued an iteration ago) while this block's output stores -- and the DMA issued after them -- stay in flight.
+FTMI_DEVICE void vm_wait_leave(int n) {
+    switch (n) {
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 #ifdef FTMI_EXPERIMENTAL
 // ------------------------------------------------------------------------------------------------
 // forward for FEW KEYS (Sk <= 128, head_dim 64: LTX cross-attention) -- EXPERIMENT, not shipped (profiles/r04_cross_attention.txt: 18.2 us against
-// 19.9 us for the general kernel, and the dQ twin below 36.8 against 36.9 us: the few-key launches are NOT bound by their per-workgroup staging chains --
-// both forms move their bytes at the same 2.4 TB/s, the rate of 128-byte pieces at a 4-KB stride, i.e. of the head-interleaved [B, S, H x 64] layout).  attn_fwd_kernel gives every 128 query rows their own workgroup and every
+// 19.9 us for the general kernel in its first form, 19.5 against 18.4 us with Q through the row DMA and counted waits: the forward reads only Q (22 MB) and
+// its arithmetic hides the loads either way.  The dQ twin below, which reads three tensors, gains 22 % from the same changes and IS shipped).  attn_fwd_kernel gives every 128 query rows their own workgroup and every
 // workgroup its own K / V staging chain: 1 344 workgroups of ~1 us of arithmetic, 19.5 us per launch for 44 MB.  Here the (at most two) K / V tiles are
 // staged once and stay resident while the workgroup walks `bpw` 128-row query blocks -- no DMA, no barrier in the loop, one round of workgroups.  The
 // arithmetic per block is attn_fwd_kernel<HAS_KB, AF_LAZY | AF_MAX16> statement for statement (two 64-key tiles, lazy rescale): bit-identical outputs.
@@ -429,6 +445,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_res_kernel(AttnArgs a, int nb
             }
         }
         if (qb0 < qb_end) stage_rows(qb0, 0);
+        if (qb0 + 1 < qb_end) stage_rows(qb0 + 1, 1);
         tile_dma_wait();
         __syncthreads();
     }
@@ -438,7 +455,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_res_kernel(AttnArgs a, int nb
 
     for (int qb = qb0; qb < qb_end; ++qb) {
         const int cur = (qb - qb0) & 1;
-        if (qb + 1 < qb_end) stage_rows(qb + 1, cur ^ 1);
         char* qs = stg + cur * 16384 + (wave >> 1) * 8192;
         const int is = wave & 1;
         const int i = qb * 128 + wave * 32 + li;
@@ -526,8 +542,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_res_kernel(AttnArgs a, int nb
         bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
         store_rows_via_lds(qs + is * 4096, oacc, inv, ob, a.o_ss, qb * 128 + wave * 32, a.Sq, lane);  // scratch = this wave's own 32 Q rows (fragments are in registers)
         if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
-        tile_dma_wait();
-        __syncthreads();  // the next block's Q landed, and every wave is done with the current buffer
+        if (qb + 1 < qb_end) {
+            // (raw barriers: __syncthreads() carries a release fence, i.e. an s_waitcnt vmcnt(0) that would drain the stores just issued)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the current buffer
+            const bool more = qb + 2 < qb_end;
+            if (more) stage_rows(qb + 2, cur);  // 4 DMA instructions per wave, younger than this block's stores
+            // wait for block qb + 1's Q (issued an iteration ago); a full block left exactly 4 output stores (+ 1 lse store) per wave in flight
+            const bool full = qb * 128 + 128 <= a.Sq;
+            vm_wait_leave(full ? (more ? 4 : 0) + 4 + (a.lse2 ? 1 : 0) : 0);
+            asm volatile("s_barrier" ::: "memory");
+        }
     }
 }
 
@@ -1010,8 +1034,8 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     }
 #endif
 #ifdef FTMI_EXPERIMENTAL
-    // few keys (LTX cross-attention): resident K / V, one round of workgroups that each walk bpw 128-row query blocks (FTMI_ATTN_FEWKEYS=1; no gain: see the kernel)
-    const int few = env_int("FTMI_ATTN_FEWKEYS", 0);  // re-read every call (a getenv): the parity test switches inside one process
+    // few keys (LTX cross-attention): resident K / V, one round of workgroups that each walk bpw 128-row query blocks (FTMI_ATTN_FEWKEYS_FWD=1; no gain: see the kernel)
+    const int few = env_int("FTMI_ATTN_FEWKEYS_FWD", 0);  // (experimental build only; re-read every call)
     if (few && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 512 && (a.kbias || (a.Sk % 64) == 0)) {
         static const bool attr_ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdResLds) == hipSuccess &&
@@ -1516,18 +1540,22 @@ __global__ __launch_bounds__(256, ND) void attn_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
-#ifdef FTMI_EXPERIMENTAL
 // ------------------------------------------------------------------------------------------------
-// backward dQ for FEW KEYS (Sk <= 128, head_dim 64: LTX cross-attention, 128 text tokens against 2 688 video tokens per sample) -- EXPERIMENT, not
-// shipped: bit-identical to the general kernel and exactly as fast (36.8 against 36.9 us, profiles/r04_cross_attention.txt); the hypothesis below was wrong.
-// The general kernels give such a problem one workgroup per 128 / 256 query rows, and every one of them walks the same latency chain --
-// K / V tile DMA, Q / dO / O loads, two 64-key tiles behind workgroup barriers -- for 1.5 us of arithmetic: 36.7 us per launch for 88 MB
-// (2.4 TB/s), 704 workgroups on 512 slots.  Here the two K / V tiles (32 KB) are staged ONCE and stay resident; the workgroup then walks
-// `bpw` 128-row query blocks (32 rows per wave, the first-generation register budget: three waves per SIMD) with no DMA and no barrier
-// in the loop, and `bpw` is chosen by the host so that the grid is a single round.  Same arithmetic, same order per element as
-// attn_bwd_dq_kernel<HAS_KB, 1>; delta = rowsum(dO * O) is published for the dK / dV kernel as before.
+// backward dQ for FEW KEYS (Sk <= 128, head_dim 64: LTX cross-attention, 128 text tokens against 2 688 video tokens per sample).
+// The general kernel gives such a problem one workgroup per 256 query rows and runs at 36 us per launch for 88 MB -- not because of its staging chain (a first
+// version of this kernel that only kept K / V resident ran exactly as fast) but because of the SHAPE of its loads: per-lane row gathers of Q / dO / O ask for 32
+// half-used 128-byte lines per wave instruction (2.4-3.2 TB/s on the head-interleaved layout; profiles/r04_cross_attention.txt).  Here
+//   * K / V (at most two 64-key tiles, 32 KB) are staged once and stay resident; the workgroup walks `bpw` 128-row query blocks, one round of workgroups;
+//   * Q, dO and O come in through LDS with the row-contiguous tile DMA (8 lanes per 128-byte row piece: whole lines, 4.0 TB/s), double-buffered per block,
+//     and the MFMA fragments are read from LDS;
+//   * the loop never waits for its own output: the vector-memory queue retires in order, so a counted s_waitcnt that leaves this block's dQ stores (and the
+//     row DMA issued after them) in flight is exactly "the next block's rows have landed"; the barriers are raw s_barrier (no release fence);
+//   * the lse rows of all blocks are staged up front, so hipcc has no global load inside the loop to wait for.
+// Statement for statement the arithmetic of attn_bwd_dq_kernel<HAS_KB, 1> / attn_bwd_dq2_kernel: dQ and delta are BIT-IDENTICAL to the general kernel's
+// (tests/test_gpu_kernels.py::test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones).  27.9 us per launch against 35.9 us.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kDqResLds = 2 * 16384 + 2 * 256 + 2 * 49152;  // resident (K, V) tiles + key-bias rows + two (Q, dO, O) 128-row staging buffers
+static constexpr int kDqResMaxBlocks = 8;  // 128-row blocks a workgroup walks at most (their lse rows are staged up front)
+static constexpr int kDqResLds = 2 * 16384 + 2 * 256 + 2 * 49152 + kDqResMaxBlocks * 512;  // resident (K, V) tiles + key-bias rows + two (Q, dO, O) 128-row staging buffers + lse rows
 
 template <bool HAS_KB>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_res_kernel(AttnArgs a, int nblk, int bpw) {
@@ -1574,13 +1602,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_res_kernel(AttnArgs a, int
             }
         }
         if (qb0 < qb_end) stage_rows(qb0, 0);
+        if (qb0 + 1 < qb_end) stage_rows(qb0 + 1, 1);
+        // the lse rows of every block this workgroup walks, once (a global load inside the loop would make hipcc wait for it with a vmcnt that also
+        // drains the previous block's output stores: the point of the loop's counted waits)
+        float* lse_s = reinterpret_cast<float*>(stg + 2 * 49152);
+        for (int r = tid; r < (qb_end - qb0) * 128; r += 256) lse_s[r] = a.lse2[((long)b * a.H + h) * a.Sq + min(qb0 * 128 + r, a.Sq - 1)];
         tile_dma_wait();
         __syncthreads();
     }
+    const float* lse_s = reinterpret_cast<const float*>(stg + 2 * 49152);
 
     for (int qb = qb0; qb < qb_end; ++qb) {
         const int cur = (qb - qb0) & 1;
-        if (qb + 1 < qb_end) stage_rows(qb + 1, cur ^ 1);  // (every wave passed the barrier below: nobody reads that buffer any more)
         char* tb = stg + cur * 49152;
         char* qs = tb + (wave >> 1) * 8192;  // this wave's 64-row tile, and the 32-row half of it
         const char* dos = tb + 16384 + (wave >> 1) * 8192;
@@ -1598,7 +1631,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_res_kernel(AttnArgs a, int
 #pragma unroll
             for (int e = 0; e < 8; ++e) del_i += bf2f((bf16_t)dof[c][e]) * bf2f((bf16_t)of[e]);
         }
-        const float lse_i = a.lse2[((long)b * a.H + h) * a.Sq + ic];
+        const float lse_i = lse_s[(qb - qb0) * 128 + wave * 32 + li];
         del_i += __shfl_xor(del_i, 32, 64);
         if (g == 0 && i < a.Sq) a.delta[((long)b * a.H + h) * a.Sq + i] = del_i;
 
@@ -1652,12 +1685,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_res_kernel(AttnArgs a, int
         bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
         // store scratch = this wave's own 32 Q rows of the current buffer (4 KB; their fragments are in registers, no other wave reads them)
         store_rows_via_lds(qs + is * 4096, dqt, a.scale, dqb, a.dq_ss, qb * 128 + wave * 32, a.Sq, lane);
-        tile_dma_wait();
-        __syncthreads();  // the next block's rows landed, and every wave is done with the current buffer
+        if (qb + 1 < qb_end) {
+            // (raw barriers: __syncthreads() carries a release fence, i.e. an s_waitcnt vmcnt(0) that would drain the stores just issued)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the current buffer (fragments in registers, store scratch read back)
+            const bool more = qb + 2 < qb_end;
+            if (more) stage_rows(qb + 2, cur);  // 12 DMA instructions per wave, younger than this block's stores
+            // Wait for block qb + 1's rows (issued an iteration ago) WITHOUT waiting for this block's output: a full block issued exactly 4 dQ stores
+            // per wave (+ the delta store, older than them), which stay in flight together with the 12 loads just issued.  A ragged block (only the
+            // last one of a head) may have skipped stores: plain vmcnt(0) there.
+            const bool full = qb * 128 + 128 <= a.Sq;
+            vm_wait_leave(full ? (more ? 16 : 4) : 0);
+            asm volatile("s_barrier" ::: "memory");  // ... for every wave's share of the DMA
+        }
     }
 }
-#endif  // FTMI_EXPERIMENTAL (few-keys dQ)
-
 // ------------------------------------------------------------------------------------------------
 // backward dQ, second generation: 64 query rows per wave (same reasoning as attn_fwd2_kernel: the loop is bound by the issue of its
 // non-matrix instructions, so every K / V row fragment and every K^T fragment read from LDS now feeds two MFMAs).  Per 32 keys and
@@ -2016,27 +2057,23 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
 #else
     const int dq_gen = 2;
 #endif
-#ifdef FTMI_EXPERIMENTAL
-    // few keys (LTX cross-attention): resident K / V, one round of workgroups that each walk bpw 128-row query blocks (FTMI_ATTN_FEWKEYS=1; no gain: see the kernel)
-    const bool few_keys = env_int("FTMI_ATTN_FEWKEYS", 0) && a.Sk <= 128 && a.Sq >= 512 && (long)a.H * a.B <= 256;
-#else
-    constexpr bool few_keys = false;
-#endif
+    // few keys (LTX cross-attention): resident K / V, row-DMA'd Q / dO / O, one round of workgroups that each walk bpw 128-row query blocks.
+    // FTMI_ATTN_FEWKEYS is re-read every call (a getenv): the bit-identity test switches between the two kernels inside one process.
+    int few_bpw = 1;  // smallest walk that fits every workgroup into one round (one workgroup per CU); its lse rows must fit the staging array
+    while ((long)(((a.Sq + 127) / 128 + few_bpw - 1) / few_bpw) * a.H * a.B > 256 && few_bpw <= kDqResMaxBlocks) ++few_bpw;
+    const bool few_keys = env_int("FTMI_ATTN_FEWKEYS", 1) && a.Sk <= 128 && a.Sq >= 512 && few_bpw <= kDqResMaxBlocks;
     if (few_keys) {
-#ifdef FTMI_EXPERIMENTAL
         static const bool attr_ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDqResLds) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_res_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDqResLds) == hipSuccess;
         if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
         const int nblk = (a.Sq + 127) / 128;
-        int bpw = 1;  // smallest walk that fits every workgroup into one round (128.5 KB of LDS: one workgroup per CU)
-        while ((long)((nblk + bpw - 1) / bpw) * a.H * a.B > 256) ++bpw;
+        const int bpw = few_bpw;
         const dim3 gr(((nblk + bpw - 1) / bpw) * a.H * a.B);
         if (a.kbias || (a.Sk % 64) != 0)
             hipLaunchKernelGGL(attn_bwd_dq_res_kernel<true>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
         else
             hipLaunchKernelGGL(attn_bwd_dq_res_kernel<false>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
-#endif
     } else if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
         if (a.kbias)
