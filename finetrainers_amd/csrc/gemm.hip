@@ -1545,6 +1545,73 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
     }
 }
 
+// The automatic kernel choice for a "wide" NT launch (N % 128 == 0), as a pure function of the launch description (and of the FTMI_NT* switches, read once):
+// what gemm_nt() runs for variant 8 / 61, and what ftmi_gemm_nt_plan reports to the host tests.  Returns a variant number of the switch in gemm_nt().
+static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
+    int variant = 8;
+    // auto: pick the tile by the measured cost model of DESIGN.md section 6 -- a K-tile costs its SIMD 32 cycles per MFMA
+    // plus ~85 issue cycles per 1-KiB direct-to-LDS load, tiles run in rounds of (256 CUs x workgroups per CU):
+    //   192 x 128 (2 WG / CU), 192 x 256 and 256 x 256 (8 waves, 1 WG / CU; need 256-wide column groups)
+    static const int force192 = env_int("FTMI_NT192", 0), force256 = env_int("FTMI_NT256", 0), use_model = env_int("FTMI_NT_AUTO", 3);
+    // 192 x 128 tiles leave a half-empty machine when there are few of them (batch 1: M = 2688, N = 2048 gives 224 tiles for 512 slots): the
+    // 336 tiles of 128 x 128 put a second workgroup on a third of the CUs -- 36.6 vs 39.1 us (K = 2048), 110 vs 121 us (K = 8192), tools/bench_gemm.py
+    static const int few192 = env_int("FTMI_NT128_BELOW", 342);
+    const long n192 = (long)((a.M + 191) / 192) * (a.N / 128);
+    // Round 4: the hand-placed 4-wave pipeline on 16 x 16 x 32 MFMAs (gemm_nt16_kernel) wherever 256-wide column tiles are allowed and the
+    // launch is long enough for one workgroup per CU to pay: 256- or 192-row tiles by which quantises better on 256 CUs (M = 5376:
+    // N = 2048 -> 224 tiles of 192 x 256 in one round; N = 6144 -> 504 tiles of 256 x 256 in two).  Measured against the kernels below
+    // on the step's shapes (profiles/r04_gemm_ab.txt): N >= 6144 7-12 % faster, N = 2048 / K = 8192 6-9 %; the single-round
+    // K = 2048 launches are equal within noise (the residual epilogue 5 % slower), so those keep the 192 x 128 tiles, 2 workgroups per CU.
+    // FTMI_NT16 is a mask of launch classes: 1 = several rounds of tiles and K <= 2048 (+ extension) without a row-wise epilogue input,
+    // 2 = the same with one (GELU' / residual), 4 = long K (6144 / 8192) or a single round of long K.  In the step the classes are worth less than in
+    // the warm micro-benchmark -- a launch finds its activations cold (just written by the previous kernel, read once) and one workgroup per CU has
+    // nobody to cover the vector-memory path while misses are outstanding (LAB_COLDX rows of profiles/r04_gemm_lab.txt) -- but with the epilogue inputs
+    // prefetched every class still wins: FTMI_NT16 = 0 / 3 / 7 measured 66.8 / 66.2 / 66.2 ms per step on one box, 69.3 / 68.3 / 67.3 on another
+    // (profiles/r04_nt16_ab.txt, r04_gemm_ab.txt).  Default: all three.
+    static const int use16 = env_int("FTMI_NT16", 7);
+    const long t256 = (long)((a.M + 255) / 256) * (a.N / 256), t192 = (long)((a.M + 191) / 192) * (a.N / 256);
+    const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;  // rounds x rows per tile
+    const bool one_round_short = std::min(c256, c192) <= 256 && a.K + a.K2 <= 2304;
+    const bool multi_short = std::min(c256, c192) > 256 && a.K + a.K2 <= 2304;
+    const int cls = multi_short ? ((a.epi == EPI_DGELU || a.epi == EPI_RESID) ? 2 : 1) : 4;
+    if ((use16 & cls) && ok256 && a.M >= 1024 && !one_round_short) {
+        variant = c192 < c256 ? 86 : 80;
+    } else if (a.M < 1024 || n192 < few192) {
+        variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
+    } else {
+        struct Cand { int variant, bm, bn, per_cu; };
+        const Cand cands[3] = {{force192 ? force192 : 42, 192, 128, 2}, {49, 192, 256, 1}, {force256 ? force256 : 47, 256, 256, 1}};
+        double best = 0;
+        variant = cands[0].variant;
+        // FTMI_NT_AUTO: 1 = model on every launch, 2 = only launches without a LoRA K-extension (+ 256 x 256 where 192 x 128
+        // quantises >5 % worse), 3 (default) = like 2 but never the 192 x 256 tile, 0 = always 192 x 128.  Measured inside
+        // the step (tools/ab_env.sh FTMI_NT_AUTO "0 2 3 1"): 67.0 / 67.2 / 66.45 / 68.4 ms -- the one-workgroup-per-CU tiles
+        // win the L2-warm micro-benchmark on every shape but lose in the step wherever a second workgroup on the CU would
+        // have covered the K-extension restart, the epilogue and the HBM latency of cold weights.
+        const bool ext = a.K2 > 0;
+        for (int ci = 0; ci < (ok256 && use_model ? 3 : 1); ++ci) {
+            const Cand& cd = cands[ci];
+            if (ci == 1 && (use_model == 3 || (use_model == 2 && ext))) continue;
+            if (ci == 2 && use_model >= 2 && ext) {
+                const long t192 = (long)((a.M + 191) / 192) * (a.N / 128), t256 = (long)((a.M + 255) / 256) * (a.N / 256);
+                const double e192 = (double)t192 / (double)(((t192 + 511) / 512) * 512), e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+                if (!(e256 > e192 + 0.05)) continue;
+            }
+            const long tiles = (long)((a.M + cd.bm - 1) / cd.bm) * (a.N / cd.bn);
+            const double per_tile = (double)cd.bm * cd.bn / 1024.0 * 4 * 32 / 4 + 85.0 * (cd.bm + cd.bn) * 128.0 / 1024.0 / 4;  // per K = 64
+            const long full = tiles / (256L * cd.per_cu), rem = tiles % (256L * cd.per_cu);
+            // a partially filled last round of a 2-per-CU tile runs one workgroup per CU at full speed
+            const double rounds = full * cd.per_cu + (rem == 0 ? 0 : (rem <= 256 ? 1 : cd.per_cu));
+            const double cost = rounds * per_tile;
+            if (ci == 0 || cost < best * 0.97) {  // prefer the default unless clearly better
+                if (ci == 0 || cost < best) best = cost;
+                variant = cd.variant;
+            }
+        }
+    }
+    return variant;
+}
+
 // variant: 0 = 128x128 BK64 register-staged, 1 = 128x128 BK64 direct-to-LDS, 2/3 = 128x128 BK32 direct-to-LDS,
 // 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 128x64 per wave), 6 = 256x256 (8 waves, 64x128 per wave),
 // 7 = 192x128 (4 waves, 96x64 per wave), 8 = auto (7 for M >= 1024 else 1)
@@ -1617,68 +1684,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         auto g256 = [](int g) { return g <= 0 || g % 256 == 0; };
         const bool ok256 = a.N % 256 == 0 && g256(a.w_grp_n) && g256(a.w2_grp_n) && g256(a.xk_grp_n) && g256(a.x2_grp_n);  // 256-wide column tiles allowed
         if (variant == 8 && force_all > 0 && a.M >= 1024 && ok256) variant = force_all;
-        if (variant == 8) {
-            // auto: pick the tile by the measured cost model of DESIGN.md section 6 -- a K-tile costs its SIMD 32 cycles per MFMA
-            // plus ~85 issue cycles per 1-KiB direct-to-LDS load, tiles run in rounds of (256 CUs x workgroups per CU):
-            //   192 x 128 (2 WG / CU), 192 x 256 and 256 x 256 (8 waves, 1 WG / CU; need 256-wide column groups)
-            static const int force192 = env_int("FTMI_NT192", 0), force256 = env_int("FTMI_NT256", 0), use_model = env_int("FTMI_NT_AUTO", 3);
-            // 192 x 128 tiles leave a half-empty machine when there are few of them (batch 1: M = 2688, N = 2048 gives 224 tiles for 512 slots): the
-            // 336 tiles of 128 x 128 put a second workgroup on a third of the CUs -- 36.6 vs 39.1 us (K = 2048), 110 vs 121 us (K = 8192), tools/bench_gemm.py
-            static const int few192 = env_int("FTMI_NT128_BELOW", 342);
-            const long n192 = (long)((a.M + 191) / 192) * (a.N / 128);
-            // Round 4: the hand-placed 4-wave pipeline on 16 x 16 x 32 MFMAs (gemm_nt16_kernel) wherever 256-wide column tiles are allowed and the
-            // launch is long enough for one workgroup per CU to pay: 256- or 192-row tiles by which quantises better on 256 CUs (M = 5376:
-            // N = 2048 -> 224 tiles of 192 x 256 in one round; N = 6144 -> 504 tiles of 256 x 256 in two).  Measured against the kernels below
-            // on the step's shapes (profiles/r04_gemm_ab.txt): N >= 6144 7-12 % faster, N = 2048 / K = 8192 6-9 %; the single-round
-            // K = 2048 launches are equal within noise (the residual epilogue 5 % slower), so those keep the 192 x 128 tiles, 2 workgroups per CU.
-            // FTMI_NT16 is a mask of launch classes: 1 = several rounds of tiles and K <= 2048 (+ extension) without a row-wise epilogue input,
-            // 2 = the same with one (GELU' / residual), 4 = long K (6144 / 8192) or a single round of long K.  In the step the classes are worth less than in
-            // the warm micro-benchmark -- a launch finds its activations cold (just written by the previous kernel, read once) and one workgroup per CU has
-            // nobody to cover the vector-memory path while misses are outstanding (LAB_COLDX rows of profiles/r04_gemm_lab.txt) -- but with the epilogue inputs
-            // prefetched every class still wins: FTMI_NT16 = 0 / 3 / 7 measured 66.8 / 66.2 / 66.2 ms per step on one box, 69.3 / 68.3 / 67.3 on another
-            // (profiles/r04_nt16_ab.txt, r04_gemm_ab.txt).  Default: all three.
-            static const int use16 = env_int("FTMI_NT16", 7);
-            const long t256 = (long)((a.M + 255) / 256) * (a.N / 256), t192 = (long)((a.M + 191) / 192) * (a.N / 256);
-            const long c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;  // rounds x rows per tile
-            const bool one_round_short = std::min(c256, c192) <= 256 && a.K + a.K2 <= 2304;
-            const bool multi_short = std::min(c256, c192) > 256 && a.K + a.K2 <= 2304;
-            const int cls = multi_short ? ((a.epi == EPI_DGELU || a.epi == EPI_RESID) ? 2 : 1) : 4;
-            if ((use16 & cls) && ok256 && a.M >= 1024 && !one_round_short) {
-                variant = c192 < c256 ? 86 : 80;
-            } else if (a.M < 1024 || n192 < few192) {
-                variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
-            } else {
-                struct Cand { int variant, bm, bn, per_cu; };
-                const Cand cands[3] = {{force192 ? force192 : 42, 192, 128, 2}, {49, 192, 256, 1}, {force256 ? force256 : 47, 256, 256, 1}};
-                double best = 0;
-                variant = cands[0].variant;
-                // FTMI_NT_AUTO: 1 = model on every launch, 2 = only launches without a LoRA K-extension (+ 256 x 256 where 192 x 128
-                // quantises >5 % worse), 3 (default) = like 2 but never the 192 x 256 tile, 0 = always 192 x 128.  Measured inside
-                // the step (tools/ab_env.sh FTMI_NT_AUTO "0 2 3 1"): 67.0 / 67.2 / 66.45 / 68.4 ms -- the one-workgroup-per-CU tiles
-                // win the L2-warm micro-benchmark on every shape but lose in the step wherever a second workgroup on the CU would
-                // have covered the K-extension restart, the epilogue and the HBM latency of cold weights.
-                const bool ext = a.K2 > 0;
-                for (int ci = 0; ci < (ok256 && use_model ? 3 : 1); ++ci) {
-                    const Cand& cd = cands[ci];
-                    if (ci == 1 && (use_model == 3 || (use_model == 2 && ext))) continue;
-                    if (ci == 2 && use_model >= 2 && ext) {
-                        const long t192 = (long)((a.M + 191) / 192) * (a.N / 128), t256 = (long)((a.M + 255) / 256) * (a.N / 256);
-                        const double e192 = (double)t192 / (double)(((t192 + 511) / 512) * 512), e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-                        if (!(e256 > e192 + 0.05)) continue;
-                    }
-                    const long tiles = (long)((a.M + cd.bm - 1) / cd.bm) * (a.N / cd.bn);
-                    const double per_tile = (double)cd.bm * cd.bn / 1024.0 * 4 * 32 / 4 + 85.0 * (cd.bm + cd.bn) * 128.0 / 1024.0 / 4;  // per K = 64
-                    const long full = tiles / (256L * cd.per_cu), rem = tiles % (256L * cd.per_cu);
-                    // a partially filled last round of a 2-per-CU tile runs one workgroup per CU at full speed
-                    const double rounds = full * cd.per_cu + (rem == 0 ? 0 : (rem <= 256 ? 1 : cd.per_cu));
-                    const double cost = rounds * per_tile;
-                    if (ci == 0 || cost < best * 0.97) {  // prefer the default unless clearly better
-                        if (ci == 0 || cost < best) best = cost;
-                        variant = cd.variant;
-                    }
-                }
-            }
-        }
+        if (variant == 8) variant = nt_auto_variant(a, ok256);
 #if defined(FTMI_LAB)
         switch (variant) {
             case 47: return launch_nt<256, 256, 64, 2, 4, true, 1, KL_GEN2_BUF>(a, st);
@@ -1768,6 +1774,17 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
     }
 #endif
     return launch_nt<128, 64, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // N % 128 != 0
+}
+
+// Which kernel the automatic choice takes for a plain [M, K] x [N, K]^T launch with an optional K-extension and epilogue (no groups): the variant numbers of
+// gemm_nt()'s switch -- 80 / 86 = gemm_nt16_kernel with 256- / 192-row tiles, 42 = 192 x 128 (two workgroups per CU), 47 = 256 x 256 (8 waves), 44 = 128 x 128,
+// 1 = the 128 x 64 kernel for N % 128 != 0, 0 = a launch the tiled kernels do not take (N % 64, K % 64).  No launch, no device: host tests pin the rule.
+int gemm_nt_plan(int M, int N, int K, int K2, int epi) {
+    if (M <= 0 || N <= 0 || K % 64 != 0 || K2 % 64 != 0 || N % 64 != 0) return 0;
+    if (N % 128 != 0) return 1;
+    GemmNtArgs a;
+    a.M = M; a.N = N; a.K = K; a.K2 = K2; a.epi = epi; a.variant = 8;
+    return nt_auto_variant(a, N % 256 == 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -85,6 +85,7 @@ struct GemmNtArgs {
     int map_gm = 1, map_gn = 8, map_rm = 0, map_rn = 0;
 };
 int gemm_nt(const GemmNtArgs& a, hipStream_t st);
+int gemm_nt_plan(int M, int N, int K, int K2, int epi);  // the automatic kernel choice as a pure host function (tests)
 // persistent 256 x 256 stream-K form of the same contract (gemm_sk.hip); gemm_nt() routes eligible launches to it
 bool gemm_nt_sk_eligible(const GemmNtArgs& a);
 int gemm_nt_sk(const GemmNtArgs& a, hipStream_t st);
