@@ -1861,6 +1861,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     for (int qt = 0; qt < 2; ++qt) store_rows_via_lds(smem + wave * 4096, dqt[qt], a.scale, dqb, a.dq_ss, row0 + qt * 32, a.Sq, lane);
 }
 
+#include "attention_pl.hip.h"
+
 #ifdef FTMI_EXPERIMENTAL
 // ------------------------------------------------------------------------------------------------
 // backward dK / dV, 64 keys per wave (EXPERIMENT, not shipped: 508 us against 445 us for the whole backward with the 32-key kernel -- one
@@ -2057,12 +2059,18 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
 #else
     const int dq_gen = 2;
 #endif
+#ifdef FTMI_LAB
+    const bool lab_skip_dq = env_int("FTMI_ATTN_ONLY", 0) == 2;  // delta must already be in place
+#else
+    const bool lab_skip_dq = false;
+#endif
     // few keys (LTX cross-attention): resident K / V, row-DMA'd Q / dO / O, one round of workgroups that each walk bpw 128-row query blocks.
     // FTMI_ATTN_FEWKEYS is re-read every call (a getenv): the bit-identity test switches between the two kernels inside one process.
     int few_bpw = 1;  // smallest walk that fits every workgroup into one round (one workgroup per CU); its lse rows must fit the staging array
     while ((long)(((a.Sq + 127) / 128 + few_bpw - 1) / few_bpw) * a.H * a.B > 256 && few_bpw <= kDqResMaxBlocks) ++few_bpw;
     const bool few_keys = env_int("FTMI_ATTN_FEWKEYS", 1) && a.Sk <= 128 && a.Sq >= 512 && few_bpw <= kDqResMaxBlocks;
-    if (few_keys) {
+    if (lab_skip_dq) {
+    } else if (few_keys) {
         static const bool attr_ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_res_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDqResLds) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_res_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDqResLds) == hipSuccess;
@@ -2076,7 +2084,20 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(attn_bwd_dq_res_kernel<false>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
     } else if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
-        if (a.kbias)
+        // hand-placed pipeline (attention_pl.hip.h): no key bias, whole key tiles.  FTMI_ATTN_PL: bit 0 = dQ kernel (value >> 4 = stream variant), re-read
+        // every call (a getenv) so that one process can compare the kernels
+        const int pl = env_int("FTMI_ATTN_PL", 0x13);
+        if ((pl & 1) && !a.kbias && (a.Sk % 64) == 0 && a.Sk >= 128) {
+            static const bool attr_ok =
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess;
+            if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
+            const int var = (pl >> 4) & 3;
+            if (var == 0) hipLaunchKernelGGL(attn_bwd_dq_pl_kernel<0>, grid2, dim3(256), kPlLds, st, a);
+            else if (var == 1) hipLaunchKernelGGL(attn_bwd_dq_pl_kernel<1>, grid2, dim3(256), kPlLds, st, a);
+            else hipLaunchKernelGGL(attn_bwd_dq_pl_kernel<2>, grid2, dim3(256), kPlLds, st, a);
+        } else if (a.kbias)
             hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, grid2, dim3(256), kDqLds, st, a);
         else if ((a.Sk % 64) != 0)
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<false, true>), grid2, dim3(256), kDqLds, st, a);
@@ -2088,6 +2109,9 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(((a.Sq + 127) / 128) * a.H * a.B), dim3(256), kDqLds, st, a);
     int rc = check_launch("attn_bwd_dq");
     if (rc) return rc;
+#ifdef FTMI_LAB  // tools/attn_lab.hip times the two kernels separately (the skipped kernel's outputs keep their previous contents)
+    if (env_int("FTMI_ATTN_ONLY", 0) == 1) return 0;
+#endif
     const long wg128 = (long)((a.Sk + 127) / 128) * a.H * a.B;
     if (wg128 < 256 && a.Sq >= 512) {  // few keys: split the queries across the waves instead (see the kernel's header)
         static const bool attr_ok =  // once, thread-safe (forward and backward run on different host threads)

@@ -1,0 +1,224 @@
+// Pipelined ("pl") attention-backward kernels for gfx950, head_dim 64: hand-placed instruction streams (round 5).
+//
+// What was wrong with the compiler-scheduled kernels (attn_bwd_dq2_kernel / attn_bwd_dkdv_kernel): per key tile a wave runs
+// scores -> exp2 / dS -> gradient products as three dependent phases, an in-order wave cannot overlap them, and two or three resident
+// waves per SIMD did not overlap them either -- tile time = matrix cycles + VALU-issue cycles (profiles/r02_attention_experiments.txt),
+// matrix pipe 0.35-0.38 busy.  Here ONE wave per SIMD (512 registers) runs a software pipeline over 32 x 32 score sub-tiles ("units"): in the
+// slot of unit k it issues   A(k+1): the score MFMAs of the next unit,   B(k): the exp2 / dS VALU work of this unit,   C(k-1): the gradient
+// MFMAs of the previous unit, interleaved instruction by instruction.  Every instruction of the loop is its own `asm volatile` statement
+// (tools/gen_attn_pl.py writes the statement lists, attn_pl_*.inc): hipcc allocates registers, the written order is the issue order -- the
+// technique of nt_run_k_pipe16 (gemm.hip).  About five single-issue instructions fit under one v_mfma_f32_32x32x16_bf16
+// (MI355X_MICROARCH.md, "one wave per SIMD"), which is what these loops need (dQ: 56 VALU + 8 LDS reads per 12 MFMAs).
+//
+// Same operand layout trick as attention.hip (a lane owns a query row in the dQ kernel, a key row in the dK/dV kernel; the C-layout registers
+// of dS / P are directly the B-slot operand of the second product), same LDS image (lds_rt_off: row fragments by ds_read_b128, transposed
+// fragments by ds_read_b64_tr_b16), same direct-to-LDS tile DMA -- into a THREE-slot ring, because the pipeline reads tile t+1 before it has
+// finished with tile t: one `s_waitcnt vmcnt(0); s_barrier` per tile in the middle of the tile, the loads of tile t+2 right behind it.
+//
+// Hazards are handled by construction (hipcc inserts no wait states between asm statements): a VALU instruction that reads an MFMA result
+// is placed at least two MFMAs behind the MFMA that wrote it, fragment reads are waited for with explicit lgkmcnt, and the few places outside
+// the steady state carry explicit s_nop.
+//
+// Included by attention.hip (uses its helpers).  Replaces, for Sk % 64 == 0 without a key bias:
+//   attn_bwd_dq2_kernel<false,false>  ->  attn_bwd_dq_pl_kernel     (finetrainers/models/attention_dispatch.py:938-962, autograd backward)
+#pragma once
+// (included inside namespace ftmi)
+
+static constexpr int kPlLds = 3 * 16384;  // three (K, V) [or (Q, dO)] tile slots; the epilogue's per-wave store scratch overlays them
+
+#define FTMI_PL_KTF(hh, dt) __builtin_shufflevector(ktlo[hh][dt], kthi[hh][dt], 0, 1, 2, 3)
+#define FTMI_PL_DSF(q, hh) (u32x4{dsw[q][hh][0], dsw[q][hh][1], dsw[q][hh][2], dsw[q][hh][3]})
+
+// VAR: 0 = exact arithmetic of attn_bwd_dq2_kernel (bit-identical outputs: the pipeline's test), 1 = -delta through the accumulator input of the
+// dP chain, 2 = as 1 with four score elements in flight per pass instead of sixteen
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 255) / 256, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int row0 = blk.tile * 256 + wave * 64;
+    const float sl = a.scale * kLog2e;
+
+    u32x4 qf[2][4], dof[2][4];
+    float nlse[2], del[2];
+    f32x16 ND[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int i = row0 + qt * 32 + li;
+        const int ic = min(i, a.Sq - 1);
+        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
+        const bf16_t* dop = a.dout + (long)b * a.do_sb + (long)h * a.do_sh + (long)ic * a.do_ss;
+        const bf16_t* op = a.o + (long)b * a.o_sb + (long)h * a.o_sh + (long)ic * a.o_ss;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const s16x8 qv = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
+            const s16x8 dv = *reinterpret_cast<const s16x8*>(dop + c * 16 + g * 8);
+            const s16x8 of = *reinterpret_cast<const s16x8*>(op + c * 16 + g * 8);
+            qf[qt][c] = __builtin_bit_cast(u32x4, qv);
+            dof[qt][c] = __builtin_bit_cast(u32x4, dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += bf2f((bf16_t)dv[e]) * bf2f((bf16_t)of[e]);
+        }
+        d = xhalf_sum(d);
+        del[qt] = d;
+        nlse[qt] = -a.lse2[((long)b * a.H + h) * a.Sq + ic];
+        if (g == 0 && i < a.Sq) a.delta[((long)b * a.H + h) * a.Sq + i] = d;  // published for the dK/dV kernel, which runs after this one
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ND[qt][r] = -d;
+    }
+
+    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
+    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
+    const int nt = a.Sk / 64;
+    const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+    // fragment addresses (ring slot 0, key half 0): K image at +0, V image at +8192 of a slot; half js at +4096; hh at +2048 (transposed reads)
+    uint32_t ra[4], tra[2][2];
+    {
+        const int f = (((li >> 1) & 1) << 2) | ((li >> 2) & 3);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ra[c] = lds0 + (uint32_t)(li * 128 + ((((c << 1) | g) ^ f) << 4));
+        const int l16 = lane & 15, grp = (lane >> 4) & 1, j = l16 >> 2, qq = l16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int col = dt * 32 + grp * 16 + 4 * qq;
+            tra[dt][0] = lds0 + (uint32_t)(lds_rt_off(4 * g + j, col >> 3) + (col & 7) * 2);
+            tra[dt][1] = lds0 + (uint32_t)(lds_rt_off(8 + 4 * g + j, col >> 3) + (col & 7) * 2);
+        }
+    }
+
+    // tile DMA: piece i of tile `dma_t` (clamped to the last tile: branch-free tail, re-staged into a slot nobody reads) -> ring slot dma_t % 3
+    int dma_t = 0;
+    uint32_t dma_dst = lds0;
+    const bf16_t *ksrc = kbase, *vsrc = vbase;
+    auto dma_next = [&]() {  // after the pieces of a tile were issued
+        ++dma_t;
+        dma_dst = (dma_dst == lds0 + 2u * 16384u) ? lds0 : dma_dst + 16384u;
+        const long tt = min(dma_t, nt - 1);
+        ksrc = kbase + tt * 64 * a.k_ss;
+        vsrc = vbase + tt * 64 * a.v_ss;
+    };
+#define DMA_PIECE(i)                                                                                                                                   \
+    do {                                                                                                                                               \
+        const uint32_t dst_ = dma_dst + ((i) >= 2 ? 8192u : 0u) + (uint32_t)(wave * 2 + ((i) & 1)) * 1024u;                                           \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst_), "v"(((i) >= 2 ? vd.off : kd.off)[(i) & 1]),        \
+                     "s"((i) >= 2 ? vsrc : ksrc)                                                                                                       \
+                     : "memory", "m0");                                                                                                                \
+        if ((i) == 3) dma_next();                                                                                                                      \
+    } while (0)
+    int rd_slot = 0;
+#define RING_ADVANCE()                                                                          \
+    do {                                                                                        \
+        rd_slot = (rd_slot == 2) ? 0 : rd_slot + 1;                                             \
+        const int delta_ = (rd_slot == 0) ? -32768 : 16384;                                     \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[0]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[1]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[2]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[3]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[0][0]) : "s"(delta_));                   \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[0][1]) : "s"(delta_));                   \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[1][0]) : "s"(delta_));                   \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[1][1]) : "s"(delta_));                   \
+    } while (0)
+#define QFC(x) "v"(x)
+#define KTF(hh, dt) FTMI_PL_KTF(hh, dt)
+#define DSF(q, hh) FTMI_PL_DSF(q, hh)
+
+    f32x16 dqt[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dqt[qt][0][r] = 0.f;
+            dqt[qt][1][r] = 0.f;
+        }
+    f32x16 S[2], DP[2];
+    u32x4 kf[4], vf[4];
+    u32x2 ktlo[2][2], kthi[2][2];
+    uint32_t dsw[2][2][4];
+    float x[16], y[16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            ktlo[i][jj] = u32x2{0u, 0u};  // the first slot's C stage multiplies these zeros (unit -1 does not exist)
+            kthi[i][jj] = u32x2{0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dsw[i][jj][e] = 0u;
+        }
+
+    // ---- prologue: tiles 0 and 1 -> ring slots 0, 1; the K / V row fragments of (tile 0, half 0); A(unit 0) ----
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        settle(__builtin_bit_cast(s16x8, qf[0][c]));
+        settle(__builtin_bit_cast(s16x8, qf[1][c]));
+        settle(__builtin_bit_cast(s16x8, dof[0][c]));
+        settle(__builtin_bit_cast(s16x8, dof[1][c]));
+    }
+    settle(nlse[0]);
+    settle(nlse[1]);
+    settle(del[0]);
+    settle(del[1]);
+    DMA_PIECE(0);
+    DMA_PIECE(1);
+    DMA_PIECE(2);
+    DMA_PIECE(3);
+    DMA_PIECE(0);
+    DMA_PIECE(1);
+    DMA_PIECE(2);
+    DMA_PIECE(3);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[c]) : "v"(ra[c]));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(vf[c]) : "v"(ra[c]));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c == 0) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(S[0]) : "v"(kf[c]), QFC(qf[0][c]));
+            if constexpr (VAR == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(DP[0]) : "v"(vf[c]), QFC(dof[0][c]));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(DP[0]) : "v"(vf[c]), QFC(dof[0][c]), "v"(ND[0]));
+        } else {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S[0]) : "v"(kf[c]), QFC(qf[0][c]));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(DP[0]) : "v"(vf[c]), QFC(dof[0][c]));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    for (int t = 0; t < nt; ++t) {
+        if constexpr (VAR == 0) {
+#include "attn_pl_dq_x0.inc"
+        } else if constexpr (VAR == 1) {
+#include "attn_pl_dq_v1.inc"
+        } else {
+#include "attn_pl_dq_v2.inc"
+        }
+    }
+
+    // ---- tail: C(last unit) = the dQ products of (last tile, half 1, qt 1) ----
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" ::: "memory");
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dqt[1][dt]) : "v"(KTF(hh, dt)), "v"(DSF(1, hh)));
+    // every accumulator passes through these statements: the wait states of the last MFMAs sit inside, and no ordinary read can be scheduled above them
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dqt[0][0]), "+a"(dqt[0][1]), "+a"(dqt[1][0]), "+a"(dqt[1][1]));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the store scratch overlays ring slots other waves may still be reading
+#undef DMA_PIECE
+#undef RING_ADVANCE
+#undef QFC
+#undef KTF
+#undef DSF
+
+    bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) store_rows_via_lds(smem + wave * 4096, dqt[qt], a.scale, dqb, a.dq_ss, row0 + qt * 32, a.Sq, lane);
+}
+

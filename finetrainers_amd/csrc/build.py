@@ -10,7 +10,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "cast.hip", "cogvideox.hip", "ltx_dit.hip", "cog_dit.hip", "hy_dit.hip", "wan.hip", "wan_dit.hip", "api.hip"]
-HEADERS = ["common.hip.h", "kernels.h", os.path.join("..", "..", "include", "ftmi355.h")]
+HEADERS = ["common.hip.h", "kernels.h", os.path.join("..", "..", "include", "ftmi355.h"), "attention_pl.hip.h"]
+HEADERS += sorted(f for f in os.listdir(HERE) if f.startswith("attn_pl_") and f.endswith(".inc"))  # generated statement lists (tools/gen_attn_pl.py)
 LIB = os.path.join(HERE, "..", "libftmi355.so")
 FLAGS = [
     "--offload-arch=gfx950",
