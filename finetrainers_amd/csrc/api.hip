@@ -71,7 +71,7 @@ hipEvent_t g_prof_open_b[PROF_NCLASS];
 
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
+    return (e && *e) ? (int)strtol(e, nullptr, 0) : dflt;  // base 0: decimal, 0x.. or 0.. (bit-mask switches)
 }
 
 bool prof_enabled() { return g_prof_on; }

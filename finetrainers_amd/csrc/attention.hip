@@ -2084,19 +2084,38 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(attn_bwd_dq_res_kernel<false>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
     } else if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
-        // hand-placed pipeline (attention_pl.hip.h): no key bias, whole key tiles.  FTMI_ATTN_PL: bit 0 = dQ kernel (value >> 4 = stream variant), re-read
-        // every call (a getenv) so that one process can compare the kernels
-        const int pl = env_int("FTMI_ATTN_PL", 0x13);
+        // hand-placed pipelines (attention_pl.hip.h): no key bias, whole key tiles.  FTMI_ATTN_PL (re-read every call, a getenv, so that one process can compare
+        // the kernels): bit 0 = dQ kernel, bits 4-7 = stream variant, bit 8 = 64 query rows per wave at one wave per SIMD (default: 32 rows, two waves)
+        const int pl = env_int("FTMI_ATTN_PL", 0x011);
         if ((pl & 1) && !a.kbias && (a.Sk % 64) == 0 && a.Sk >= 128) {
-            static const bool attr_ok =
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess &&
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess &&
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess;
-            if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
-            const int var = (pl >> 4) & 3;
-            if (var == 0) hipLaunchKernelGGL(attn_bwd_dq_pl_kernel<0>, grid2, dim3(256), kPlLds, st, a);
-            else if (var == 1) hipLaunchKernelGGL(attn_bwd_dq_pl_kernel<1>, grid2, dim3(256), kPlLds, st, a);
-            else hipLaunchKernelGGL(attn_bwd_dq_pl_kernel<2>, grid2, dim3(256), kPlLds, st, a);
+            const int var = (pl >> 4) & 15, nq = (pl & 0x100) ? 2 : 1;
+            const dim3 gridp(((a.Sq + 128 * nq - 1) / (128 * nq)) * a.H * a.B);
+#define FTMI_PL_LAUNCH(NQ_, V_)                                                                                                                         \
+    do {                                                                                                                                                \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl_kernel<NQ_, V_>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess; \
+        if (!ok_) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");                                                    \
+        hipLaunchKernelGGL((attn_bwd_dq_pl_kernel<NQ_, V_>), gridp, dim3(256), kPlLds, st, a);                                                          \
+    } while (0)
+            if (nq == 1) {
+                if (var == 0) FTMI_PL_LAUNCH(1, 0);
+                else if (var == 2) FTMI_PL_LAUNCH(1, 2);
+#ifdef FTMI_LAB
+                else if (var == 3) FTMI_PL_LAUNCH(1, 3);
+                else if (var == 4) FTMI_PL_LAUNCH(1, 4);
+                else if (var == 5) FTMI_PL_LAUNCH(1, 5);
+#endif
+                else FTMI_PL_LAUNCH(1, 1);
+            } else {
+                if (var == 0) FTMI_PL_LAUNCH(2, 0);
+                else if (var == 2) FTMI_PL_LAUNCH(2, 2);
+#ifdef FTMI_LAB
+                else if (var == 3) FTMI_PL_LAUNCH(2, 3);
+                else if (var == 4) FTMI_PL_LAUNCH(2, 4);
+                else if (var == 5) FTMI_PL_LAUNCH(2, 5);
+#endif
+                else FTMI_PL_LAUNCH(2, 1);
+            }
+#undef FTMI_PL_LAUNCH
         } else if (a.kbias)
             hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, grid2, dim3(256), kDqLds, st, a);
         else if ((a.Sk % 64) != 0)

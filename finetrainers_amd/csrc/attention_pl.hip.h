@@ -7,8 +7,10 @@
 // slot of unit k it issues   A(k+1): the score MFMAs of the next unit,   B(k): the exp2 / dS VALU work of this unit,   C(k-1): the gradient
 // MFMAs of the previous unit, interleaved instruction by instruction.  Every instruction of the loop is its own `asm volatile` statement
 // (tools/gen_attn_pl.py writes the statement lists, attn_pl_*.inc): hipcc allocates registers, the written order is the issue order -- the
-// technique of nt_run_k_pipe16 (gemm.hip).  About five single-issue instructions fit under one v_mfma_f32_32x32x16_bf16
-// (MI355X_MICROARCH.md, "one wave per SIMD"), which is what these loops need (dQ: 56 VALU + 8 LDS reads per 12 MFMAs).
+// technique of nt_run_k_pipe16 (gemm.hip).  What bounds these loops is the SIMD's VALU issue port (one instruction per ~4.4 cycles whichever
+// wave it comes from, ~12 cycles per MFMA: tools/probe_mfma_valu.hip), so the streams carry the minimum number of VALU instructions per score
+// (dQ: 3.5, against 4.7 in the compiler-scheduled kernel) and nothing else on that port; NQ = 1 runs two such waves per SIMD (32 query rows
+// each) so that one wave's LDS / scalar / wait instructions issue under the other's VALU work, NQ = 2 one wave per SIMD with 64 rows.
 //
 // Same operand layout trick as attention.hip (a lane owns a query row in the dQ kernel, a key row in the dK/dV kernel; the C-layout registers
 // of dS / P are directly the B-slot operand of the second product), same LDS image (lds_rt_off: row fragments by ds_read_b128, transposed
@@ -29,23 +31,26 @@ static constexpr int kPlLds = 3 * 16384;  // three (K, V) [or (Q, dO)] tile slot
 #define FTMI_PL_KTF(hh, dt) __builtin_shufflevector(ktlo[hh][dt], kthi[hh][dt], 0, 1, 2, 3)
 #define FTMI_PL_DSF(q, hh) (u32x4{dsw[q][hh][0], dsw[q][hh][1], dsw[q][hh][2], dsw[q][hh][3]})
 
+// NQ: 32-row query sub-tiles per wave (1: two waves per SIMD, 128 rows per workgroup; 2: one wave per SIMD, 256 rows per workgroup).
 // VAR: 0 = exact arithmetic of attn_bwd_dq2_kernel (bit-identical outputs: the pipeline's test), 1 = -delta through the accumulator input of the
-// dP chain, 2 = as 1 with four score elements in flight per pass instead of sixteen
-template <int VAR>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
+// dP chain, 2 = as 1 with the VALU work in passes over groups of four elements; 3 / 4 / 5 = lab ablations of 1 (no VALU / no LDS reads / no MFMA:
+// results wrong on purpose, tools/attn_lab.hip reads their time only)
+template <int NQ, int VAR>
+__global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, g = lane >> 5;
-    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 255) / 256, a.H, a.B);
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 128 * NQ - 1) / (128 * NQ), a.H, a.B);
     const int h = blk.h, b = blk.b;
-    const int row0 = blk.tile * 256 + wave * 64;
+    const int row0 = blk.tile * (128 * NQ) + wave * (32 * NQ);
     const float sl = a.scale * kLog2e;
+    constexpr bool EXACT = VAR == 0;
 
-    u32x4 qf[2][4], dof[2][4];
-    float nlse[2], del[2];
-    f32x16 ND[2];
+    u32x4 qf[NQ][4], dof[NQ][4];
+    float nlse[NQ], del[NQ];
+    f32x16 ND[NQ];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < NQ; ++qt) {
         const int i = row0 + qt * 32 + li;
         const int ic = min(i, a.Sq - 1);
         const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
@@ -66,8 +71,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
         del[qt] = d;
         nlse[qt] = -a.lse2[((long)b * a.H + h) * a.Sq + ic];
         if (g == 0 && i < a.Sq) a.delta[((long)b * a.H + h) * a.Sq + i] = d;  // published for the dK/dV kernel, which runs after this one
+        if constexpr (!EXACT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ND[qt][r] = -d;
+            for (int r = 0; r < 16; ++r) ND[qt][r] = -d;
+        }
     }
 
     const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
@@ -76,7 +83,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
     const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
 
-    // fragment addresses (ring slot 0, key half 0): K image at +0, V image at +8192 of a slot; half js at +4096; hh at +2048 (transposed reads)
+    // fragment addresses (key half 0): K image at +0, V image at +8192 of a ring slot; half js at +4096; hh at +2048 (transposed reads).
+    // Row-fragment addresses start in ring slot 0; the transposed ones in slot 2, one step behind (their first RING_ADVANCE_TR wraps them to 0).
     uint32_t ra[4], tra[2][2];
     {
         const int f = (((li >> 1) & 1) << 2) | ((li >> 2) & 3);
@@ -86,21 +94,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const int col = dt * 32 + grp * 16 + 4 * qq;
-            tra[dt][0] = lds0 + (uint32_t)(lds_rt_off(4 * g + j, col >> 3) + (col & 7) * 2);
-            tra[dt][1] = lds0 + (uint32_t)(lds_rt_off(8 + 4 * g + j, col >> 3) + (col & 7) * 2);
+            tra[dt][0] = lds0 + 32768u + (uint32_t)(lds_rt_off(4 * g + j, col >> 3) + (col & 7) * 2);
+            tra[dt][1] = lds0 + 32768u + (uint32_t)(lds_rt_off(8 + 4 * g + j, col >> 3) + (col & 7) * 2);
         }
     }
 
-    // tile DMA: piece i of tile `dma_t` (clamped to the last tile: branch-free tail, re-staged into a slot nobody reads) -> ring slot dma_t % 3
+    // tile DMA: the four pieces of tile `dma_t` (clamped to the last tile: branch-free tail, re-staged into a slot nobody reads) -> ring slot dma_t % 3
     int dma_t = 0;
     uint32_t dma_dst = lds0;
-    const bf16_t *ksrc = kbase, *vsrc = vbase;
+    const char *ksrc = (const char*)kbase, *vsrc = (const char*)vbase;
+    const long kstep = 128 * a.k_ss, vstep = 128 * a.v_ss;  // bytes per 64-key tile
     auto dma_next = [&]() {  // after the pieces of a tile were issued
         ++dma_t;
         dma_dst = (dma_dst == lds0 + 2u * 16384u) ? lds0 : dma_dst + 16384u;
-        const long tt = min(dma_t, nt - 1);
-        ksrc = kbase + tt * 64 * a.k_ss;
-        vsrc = vbase + tt * 64 * a.v_ss;
+        const bool more = dma_t < nt;
+        ksrc += more ? kstep : 0;
+        vsrc += more ? vstep : 0;
     };
 #define DMA_PIECE(i)                                                                                                                                   \
     do {                                                                                                                                               \
@@ -110,15 +119,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
                      : "memory", "m0");                                                                                                                \
         if ((i) == 3) dma_next();                                                                                                                      \
     } while (0)
-    int rd_slot = 0;
-#define RING_ADVANCE()                                                                          \
+    int row_slot = 0, tr_slot = 2;
+#define RING_ADVANCE_ROW()                                                                      \
     do {                                                                                        \
-        rd_slot = (rd_slot == 2) ? 0 : rd_slot + 1;                                             \
-        const int delta_ = (rd_slot == 0) ? -32768 : 16384;                                     \
+        row_slot = (row_slot == 2) ? 0 : row_slot + 1;                                          \
+        const int delta_ = (row_slot == 0) ? -32768 : 16384;                                    \
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[0]) : "s"(delta_));                       \
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[1]) : "s"(delta_));                       \
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[2]) : "s"(delta_));                       \
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[3]) : "s"(delta_));                       \
+    } while (0)
+#define RING_ADVANCE_TR()                                                                       \
+    do {                                                                                        \
+        tr_slot = (tr_slot == 2) ? 0 : tr_slot + 1;                                             \
+        const int delta_ = (tr_slot == 0) ? -32768 : 16384;                                     \
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[0][0]) : "s"(delta_));                   \
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[0][1]) : "s"(delta_));                   \
         asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[1][0]) : "s"(delta_));                   \
@@ -128,9 +142,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
 #define KTF(hh, dt) FTMI_PL_KTF(hh, dt)
 #define DSF(q, hh) FTMI_PL_DSF(q, hh)
 
-    f32x16 dqt[2][2];
+    f32x16 dqt[NQ][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < NQ; ++qt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             dqt[qt][0][r] = 0.f;
@@ -153,16 +167,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
 
     // ---- prologue: tiles 0 and 1 -> ring slots 0, 1; the K / V row fragments of (tile 0, half 0); A(unit 0) ----
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        settle(__builtin_bit_cast(s16x8, qf[0][c]));
-        settle(__builtin_bit_cast(s16x8, qf[1][c]));
-        settle(__builtin_bit_cast(s16x8, dof[0][c]));
-        settle(__builtin_bit_cast(s16x8, dof[1][c]));
+    for (int qt = 0; qt < NQ; ++qt) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            settle(__builtin_bit_cast(s16x8, qf[qt][c]));
+            settle(__builtin_bit_cast(s16x8, dof[qt][c]));
+        }
+        settle(nlse[qt]);
+        settle(del[qt]);
     }
-    settle(nlse[0]);
-    settle(nlse[1]);
-    settle(del[0]);
-    settle(del[1]);
     DMA_PIECE(0);
     DMA_PIECE(1);
     DMA_PIECE(2);
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
     for (int c = 0; c < 4; ++c) {
         if (c == 0) {
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(S[0]) : "v"(kf[c]), QFC(qf[0][c]));
-            if constexpr (VAR == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(DP[0]) : "v"(vf[c]), QFC(dof[0][c]));
+            if constexpr (EXACT) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(DP[0]) : "v"(vf[c]), QFC(dof[0][c]));
             else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(DP[0]) : "v"(vf[c]), QFC(dof[0][c]), "v"(ND[0]));
         } else {
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S[0]) : "v"(kf[c]), QFC(qf[0][c]));
@@ -192,33 +205,67 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
     for (int t = 0; t < nt; ++t) {
-        if constexpr (VAR == 0) {
-#include "attn_pl_dq_x0.inc"
-        } else if constexpr (VAR == 1) {
-#include "attn_pl_dq_v1.inc"
+        if constexpr (NQ == 1) {
+            if constexpr (VAR == 0) {
+#include "attn_pl_dq1_x0.inc"
+            } else if constexpr (VAR == 1) {
+#include "attn_pl_dq1_v1.inc"
+            } else if constexpr (VAR == 2) {
+#include "attn_pl_dq1_v2.inc"
+            }
+#ifdef FTMI_LAB
+            else if constexpr (VAR == 3) {
+#include "attn_pl_dq1_a_novalu.inc"
+            } else if constexpr (VAR == 4) {
+#include "attn_pl_dq1_a_nolds.inc"
+            } else {
+#include "attn_pl_dq1_a_nomfma.inc"
+            }
+#endif
         } else {
-#include "attn_pl_dq_v2.inc"
+            if constexpr (VAR == 0) {
+#include "attn_pl_dq2_x0.inc"
+            } else if constexpr (VAR == 1) {
+#include "attn_pl_dq2_v1.inc"
+            } else if constexpr (VAR == 2) {
+#include "attn_pl_dq2_v2.inc"
+            }
+#ifdef FTMI_LAB
+            else if constexpr (VAR == 3) {
+#include "attn_pl_dq2_a_novalu.inc"
+            } else if constexpr (VAR == 4) {
+#include "attn_pl_dq2_a_nolds.inc"
+            } else {
+#include "attn_pl_dq2_a_nomfma.inc"
+            }
+#endif
         }
     }
 
-    // ---- tail: C(last unit) = the dQ products of (last tile, half 1, qt 1) ----
+    // ---- tail: C(last unit) = the dQ products of (last tile, half 1, last query sub-tile); its dS fragments have parity 1 ----
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" ::: "memory");
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dqt[1][dt]) : "v"(KTF(hh, dt)), "v"(DSF(1, hh)));
+            if constexpr (NQ == 1) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dqt[NQ - 1][dt]) : "v"(KTF(hh, dt)), "v"(DSF(1, hh)));
+            else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dqt[NQ - 1][dt]) : "v"(KTF(hh, dt)), "v"(DSF(1, hh)));
     // every accumulator passes through these statements: the wait states of the last MFMAs sit inside, and no ordinary read can be scheduled above them
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dqt[0][0]), "+a"(dqt[0][1]), "+a"(dqt[1][0]), "+a"(dqt[1][1]));
+    // (NQ = 1 keeps the accumulators in VGPRs: hipcc halves a 256-register budget into 128 + 128 as soon as a kernel touches an AGPR)
+#pragma unroll
+    for (int qt = 0; qt < NQ; ++qt) {
+        if constexpr (NQ == 1) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(dqt[qt][0]), "+v"(dqt[qt][1]));
+        else asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dqt[qt][0]), "+a"(dqt[qt][1]));
+    }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the store scratch overlays ring slots other waves may still be reading
 #undef DMA_PIECE
-#undef RING_ADVANCE
+#undef RING_ADVANCE_ROW
+#undef RING_ADVANCE_TR
 #undef QFC
 #undef KTF
 #undef DSF
 
     bf16_t* dqb = a.dq + (long)b * a.dq_sb + (long)h * a.dq_sh;
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) store_rows_via_lds(smem + wave * 4096, dqt[qt], a.scale, dqb, a.dq_ss, row0 + qt * 32, a.Sq, lane);
+    for (int qt = 0; qt < NQ; ++qt) store_rows_via_lds(smem + wave * 4096, dqt[qt], a.scale, dqb, a.dq_ss, row0 + qt * 32, a.Sq, lane);
 }
-

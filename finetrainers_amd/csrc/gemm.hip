@@ -1545,6 +1545,134 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
     }
 }
 
+// Skinny NT GEMM, fourth generation (round 5): the LoRA down-projections (fp32-equivalent split mode only).  The second-generation kernel above is
+// neither bandwidth- nor DMA-bound -- tools/probe_l2_read.hip: every CU can pull an L2-resident panel through the direct-to-LDS path at ~130 GB/s
+// (33 TB/s aggregate), the kernel moves its 129 MB at 6.4 TB/s -- it is short: a workgroup owns 32 rows x 64 weight rows, each wave runs 8 chunks of
+// its K quarter behind a cold first load, then a barrier, a cross-wave reduction and the stores, and 336 such workgroups take 1.3 rounds of the chip.
+// Here a workgroup owns 64 rows x 64 weight rows (both MFMA row tiles share every weight fragment: a third fewer bytes through the CU's vector-memory
+// path, which is what bounds a CU: 64 B / clk), so M = 5376 is 168 workgroups -- ONE round -- and every wave's loop is twice as long per prologue /
+// epilogue.  Same K split (a quarter per wave, private 2-stage LDS ring, counted vmcnt, no barrier in the loop), same MFMA order per accumulator and
+// the same reduction order across the four waves and the two planes: outputs are bit-identical to gemm_nt_skinny2_kernel.
+template <int BK>  // K depth of a ring stage: 64 (two 16-KB stages per wave) or 32 (four 8-KB stages: three loads in flight behind the one being multiplied)
+__global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CH = 256 * BK, NST = 128 / BK;  // bytes per chunk (64 x BK X + 64 x BK W), stages per wave (32 KB per wave either way)
+    constexpr int RPI = 1024 / (BK * 2), NPI = 64 / RPI;  // rows per 1-KiB wave load, loads per operand and chunk
+    constexpr int CPR = BK / 8, KK = BK / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const int ntm = (p.M + 63) / 64, ntn = p.N / 64;
+    const int grp = blockIdx.x / (8 * ntn), lid = blockIdx.x % (8 * ntn);
+    const int in_grp = min(8, ntm - grp * 8);  // row tiles of this group (the last group may be short)
+    const int m0 = (grp * 8 + lid % in_grp) * 64, n0 = (lid / in_grp) * 64;
+    const bf16_t* X = p.X;
+    if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
+    // the four waves split the K / 64 chunks exactly like gemm_nt_skinny2_kernel (same partial sums -> same bits)
+    const int nck64 = p.K / 64, c_lo = (nck64 * wave) / 4, k0 = c_lo * 64, nch = ((nck64 * (wave + 1)) / 4 - c_lo) * (64 / BK);
+    char* ring = smem + wave * (NST * CH);
+
+    uint32_t off[2 * NPI];
+    {
+        const int rr = lane / CPR, cs = lane % CPR;
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            const int row = i * RPI + rr;
+            const int c = BK == 64 ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+            off[i] = (uint32_t)(((long)min(m0 + row, p.M - 1) * p.ldx + k0 + c * 8) * 2);
+            off[NPI + i] = (uint32_t)(((long)row * p.ldw + k0 + c * 8) * 2);
+        }
+    }
+    const bf16_t* Wt = p.w_grp_n > 0 ? p.W + (long)(n0 / p.w_grp_n) * p.w_grp_stride + (long)(n0 % p.w_grp_n) * p.ldw : p.W + (long)n0 * p.ldw;
+    auto issue = [&](int ck) {
+        char* st = ring + (ck % NST) * CH;
+        const char* xb = (const char*)X + (long)ck * (BK * 2);
+        const char* wb = (const char*)Wt + (long)ck * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < NPI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + off[i]),
+                                             (__attribute__((address_space(3))) void*)(st + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb + off[NPI + i]),
+                                             (__attribute__((address_space(3))) void*)(st + CH / 2 + i * 1024), 16, 0, 0);
+    };
+    int xo[2][KK], wo[2][KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xo[t][kk] = nt_lds_off<BK>(t * 32 + li, kk * 2 + g);
+            wo[t][kk] = CH / 2 + nt_lds_off<BK>(t * 32 + li, kk * 2 + g);
+        }
+    f32x16 acc[2][2];  // [row tile][weight sub-tile: 0 = hi plane, 1 = lo plane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+    }
+#pragma unroll
+    for (int s0 = 0; s0 < NST; ++s0)
+        if (s0 < nch) issue(s0);
+    for (int ck = 0; ck < nch; ++ck) {
+        // loads retire in order: leave the chunks behind this one in flight
+        const int ahead = min(NST - 1, nch - 1 - ck);
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * 2 * NPI) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NPI) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* st = ring + (ck % NST) * CH;
+        s16x8 xf[2][KK], wf[2][KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xf[t][kk] = *reinterpret_cast<const s16x8*>(st + xo[t][kk]);
+                wf[t][kk] = *reinterpret_cast<const s16x8*>(st + wo[t][kk]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (ck + NST < nch) issue(ck + NST);  // the stage just read is free again
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                acc[rt][0] = mfma32(wf[0][kk], xf[rt][kk], acc[rt][0]);
+                acc[rt][1] = mfma32(wf[1][kk], xf[rt][kk], acc[rt][1]);
+            }
+    }
+    __syncthreads();  // every wave is done with its ring: reuse the memory for the cross-wave reduction
+    float* red = reinterpret_cast<float*>(smem);  // [wave][row tile][plane][acc register][lane]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave * 2 + rt) * 2 + tn) * 16 + r) * 64 + lane] = acc[rt][tn][r];
+    __syncthreads();
+    // the tile's 64 weight rows are the hi plane (sub-tile 0) and the lo plane (sub-tile 1) of 32 fp32 rows: t = alpha * (x.hi + x.lo) in fp32,
+    // stored as the three bf16 planes (hi(t), lo(t), hi(t)) of the K-extension operand
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int m = m0 + rt * 32 + li;
+        if (m >= p.M) continue;
+        u32x2 hi, lo;
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave * 4 + j;
+            auto R = [&](int w, int tn) { return red[(((w * 2 + rt) * 2 + tn) * 16 + r) * 64 + lane]; };
+            t[j] = (((R(0, 0) + R(1, 0)) + (R(2, 0) + R(3, 0))) + ((R(0, 1) + R(1, 1)) + (R(2, 1) + R(3, 1)))) * p.alpha;
+        }
+        const float h0 = rbf(t[0]), h1 = rbf(t[1]), h2 = rbf(t[2]), h3 = rbf(t[3]);
+        hi[0] = pack2bf(h0, h1); hi[1] = pack2bf(h2, h3);
+        lo[0] = pack2bf(t[0] - h0, t[1] - h1); lo[1] = pack2bf(t[2] - h2, t[3] - h3);
+        const int o = n0 / 2 + wave * 8 + 4 * g;  // output index (32 per tile)
+        bf16_t* dst = p.out + (long)m * p.ldo + (long)(o / p.split_r) * 3 * p.split_r + o % p.split_r;
+        *reinterpret_cast<u32x2*>(dst) = hi;
+        *reinterpret_cast<u32x2*>(dst + p.split_r) = lo;
+        *reinterpret_cast<u32x2*>(dst + 2 * p.split_r) = hi;
+    }
+}
+
 // The automatic kernel choice for a "wide" NT launch (N % 128 == 0), as a pure function of the launch description (and of the FTMI_NT* switches, read once):
 // what gemm_nt() runs for variant 8 / 61, and what ftmi_gemm_nt_plan reports to the host tests.  Returns a variant number of the switch in gemm_nt().
 static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
@@ -1649,6 +1777,19 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         if (use_sk3 && gemm_nt_skinny3_eligible(a)) return gemm_nt_skinny3(a, st);
 #endif
         ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
+        // 64-row tiles (fourth generation) wherever they fill at least a third of the chip; FTMI_SKINNY4 is re-read every call (a getenv) so that one
+        // process can compare the kernels (they are bit-identical: tests/test_gpu_kernels.py)
+        const int sk4 = env_int("FTMI_SKINNY4", 1);  // 1: 64-deep stages, 2: 32-deep stages
+        if (sk4 && (long)((a.M + 63) / 64) * (a.N / 64) >= 84) {
+            constexpr int kSmem4 = 4 * 2 * 16384;
+            static const bool attr_ok4 =
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny4_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem4) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny4_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem4) == hipSuccess;
+            if (!attr_ok4) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
+            if (sk4 == 2) hipLaunchKernelGGL(gemm_nt_skinny4_kernel<32>, dim3(((a.M + 63) / 64) * (a.N / 64)), dim3(256), kSmem4, st, a);
+            else hipLaunchKernelGGL(gemm_nt_skinny4_kernel<64>, dim3(((a.M + 63) / 64) * (a.N / 64)), dim3(256), kSmem4, st, a);
+            return check_launch("gemm_nt_skinny");
+        }
         constexpr int kSmem = 4 * 3 * 12288;
         static const bool attr_ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;

@@ -111,7 +111,9 @@ int main(int argc, char** argv) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const bool fast = getenv("LAB_FAST") != nullptr;
+        const char* lab_only = getenv("LAB_ONLY");  // which timings: any of the characters 0 (whole backward), 1 (dQ kernel), 2 (dK/dV kernel); default all
         for (int only = 0; only < 3; ++only) {
+            if (lab_only && !strchr(lab_only, '0' + only)) continue;
             std::vector<std::vector<float>> res(cfg.size());
             for (int rnd = 0; rnd < (fast ? 1 : 5); ++rnd)
                 for (size_t i = 0; i < cfg.size(); ++i) {

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Generator of the hand-placed instruction streams of the pipelined attention-backward kernels (csrc/attention_pl.hip.h).
 
-Why a generator: hipcc schedules an attention tile as  scores -> softmax -> second product  per wave, and an in-order wave then runs its
-matrix instructions and its VALU instructions one after the other (profiles/r02_attention_experiments.txt: tile time = matrix cycles + VALU
-cycles, nothing overlaps).  The streams written here are software pipelines over 32 x 32 score sub-tiles ("units"): in every slot the wave
-issues the score MFMAs of unit k+1, the exp2 / dS VALU work of unit k and the gradient MFMAs of unit k-1, interleaved instruction by
-instruction -- every instruction is its own `asm volatile` statement, so hipcc allocates registers but the written order IS the issue order
-(the technique of nt_run_k_pipe16 in gemm.hip).  One wave per SIMD (512 registers), four waves per workgroup.
+Why a generator: hipcc schedules an attention tile as  scores -> softmax -> second product  per wave; an in-order wave then runs its
+matrix instructions and its VALU instructions one after the other, and the VALU issue port (one instruction per ~4.4 cycles and SIMD,
+whichever wave it comes from; an MFMA takes ~12 cycles of it) is what bounds these loops at head_dim 64.  The streams written here are
+software pipelines over 32 x 32 score sub-tiles ("units"): in every slot the wave issues the score MFMAs of unit k+1, the exp2 / dS VALU
+work of unit k and the gradient MFMAs of unit k-1, interleaved instruction by instruction, with the minimum number of VALU instructions
+per score element -- every instruction is its own `asm volatile` statement, so hipcc allocates registers but the written order IS the
+issue order (the technique of nt_run_k_pipe16 in gemm.hip).
 
 The emitted .inc files are plain C++ statement lists that are #included inside the kernels' tile loops; the names they use (S, DP, kf, ...)
 are the kernels' local variables.  Regenerate with  `python tools/gen_attn_pl.py`  (the files are committed; the build does not run this).
@@ -36,7 +37,6 @@ class Stream:
         if clob:
             parts.append(clob)
         else:
-            # trim trailing empty operand lists
             while len(parts) > 1 and parts[-1] == "":
                 parts.pop()
         self.lines.append("asm volatile(" + " : ".join(parts) + ");")
@@ -58,101 +58,135 @@ def spread(n_items: int, n_gaps: int, weights=None) -> list[int]:
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-# dQ kernel: a wave owns 64 query rows (qt = 0, 1: 32 each), loops over 64-key tiles (js = 0, 1: 32 keys each).
-# unit u = (t, js, qt).  Slot of unit u:  C(u-1): 4 MFMAs  dqt[q'] += K^T . dS[q'];   A(u+1): 8 MFMAs  S[q'] = K.Q^T, DP[q'] = V.dO^T (- delta);
-# B(u): VALU  dS[q] = exp2(S[q] * sl - lse) * DP[q] -> bf16 fragments.   q = qt, q' = qt ^ 1.
+# dQ kernel: a wave owns 32 * nq query rows (qt = 0 .. nq-1), loops over 64-key tiles (js = 0, 1: 32 keys each).
+# unit u = (t, js, qt), parity p = (unit index in the tile) & 1.  Slot of unit u:
+#   C(u-1): 4 MFMAs  dqt[qt'] += K^T . dS[p^1];   A(u+1): 8 MFMAs  S[p^1] = K.Q^T, DP[p^1] = V.dO^T (- delta);
+#   B(u): VALU  dS[p] = exp2(S[p] * sl - lse) * DP[p] -> bf16 fragments.
 # ------------------------------------------------------------------------------------------------------------------------------
-def dq_valu_ops(q: int, exact: bool, group: int) -> list[tuple[str, str, str]]:
-    """The VALU list of B(u) in issue order: `group` score elements in flight per pass; (text, outs, ins) per instruction.
-    hipcc's hazard recognizer counts an asm statement as zero wait states, so it puts an s_nop in front of the first statement of every
-    pass that reads a register defined by an earlier asm statement: three per group -- the bigger the group, the fewer (group 16: 3 per slot)."""
-    ops = []
-    for m in range(16 // group):
-        rs = [group * m + i for i in range(group)]
-        for r in rs:
-            ops.append(("v_fma_f32 %0, %1, %2, %3", f'"=v"(x[{r}])', f'"v"(S[{q}][{r}]), "v"(sl), "v"(nlse[{q}])'))
-        for r in rs:
-            ops.append(("v_exp_f32 %0, %0", f'"+v"(x[{r}])', ""))
+def dq_valu_ops(par: int, qt: int, exact: bool, order: str) -> list[tuple[str, str, str]]:
+    """The VALU list of B(u) in issue order; (text, outs, ins) per instruction.
+    order "g16" / "g4": passes over groups of 16 / 4 score elements (all fma, all exp2, all mul, the packs);
+    order "roll": a rolling pipeline (fma of element s, exp2 of element s-4, mul of element s-8, pack of a finished pair) -- the exp2s
+    (transcendental unit, ~7 cycles each) never come back to back.
+    hipcc's hazard recognizer counts an asm statement as zero wait states: it puts one s_nop in front of a statement that reads a register
+    defined by an earlier asm statement unless a real instruction sits between them (group 4: 12 per slot, group 16: 3, rolling: ~5)."""
+    S, DP = f"S[{par}]", f"DP[{par}]"
+
+    def F(r):
+        return ("v_fma_f32 %0, %1, %2, %3", f'"=v"(x[{r}])', f'"v"({S}[{r}]), "v"(sl), "v"(nlse[{qt}])')
+
+    def E(r):
+        return ("v_exp_f32 %0, %0", f'"+v"(x[{r}])', "")
+
+    def U(r):
+        return ("v_sub_f32 %0, %1, %2", f'"=v"(y[{r}])', f'"v"({DP}[{r}]), "v"(del[{qt}])')
+
+    def M(r):
         if exact:
-            for r in rs:
-                ops.append(("v_sub_f32 %0, %1, %2", f'"=v"(y[{r}])', f'"v"(DP[{q}][{r}]), "v"(del[{q}])'))
-            for r in rs:
-                ops.append(("v_mul_f32 %0, %0, %1", f'"+v"(x[{r}])', f'"v"(y[{r}])'))
-        else:
-            for r in rs:
-                ops.append(("v_mul_f32 %0, %0, %1", f'"+v"(x[{r}])', f'"v"(DP[{q}][{r}])'))
-        for r in rs[::2]:
-            hh, e = r >> 3, (r & 7) >> 1
-            ops.append(("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(dsw[{q}][{hh}][{e}])', f'"v"(x[{r}]), "v"(x[{r + 1}])'))
+            return ("v_mul_f32 %0, %0, %1", f'"+v"(x[{r}])', f'"v"(y[{r}])')
+        return ("v_mul_f32 %0, %0, %1", f'"+v"(x[{r}])', f'"v"({DP}[{r}])')
+
+    def P(r):  # pair (r, r+1), r even
+        hh, e = r >> 3, (r & 7) >> 1
+        return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(dsw[{par}][{hh}][{e}])', f'"v"(x[{r}]), "v"(x[{r + 1}])')
+
+    ops = []
+    if order.startswith("g"):
+        group = int(order[1:])
+        for m in range(16 // group):
+            rs = [group * m + i for i in range(group)]
+            ops += [F(r) for r in rs] + [E(r) for r in rs]
+            if exact:
+                ops += [U(r) for r in rs]
+            ops += [M(r) for r in rs] + [P(r) for r in rs[::2]]
+    else:
+        L = 4
+        for s in range(16 + 2 * L + 2):
+            if s < 16:
+                ops.append(F(s))
+            if 0 <= s - L < 16:
+                ops.append(E(s - L))
+            if exact and 0 <= s - 2 * L + 2 < 16:
+                ops.append(U(s - 2 * L + 2))
+            if 0 <= s - 2 * L < 16:
+                ops.append(M(s - 2 * L))
+            r = s - 2 * L - 1
+            if 0 <= r < 16 and r % 2 == 1:
+                ops.append(P(r - 1))
+    assert len(ops) == (72 if exact else 56), len(ops)
     return ops
 
 
-def gen_dq(exact: bool, weights: list[float] | None, name: str, group: int = 16):
+def gen_dq(name: str, nq: int, exact: bool, order: str = "roll", weights=None, drop=()):
+    """drop: ablation builds for the lab (results wrong on purpose): 'valu', 'lds', 'dma', 'mfma'."""
     s = Stream()
-    s.emit(f"// GENERATED by tools/gen_attn_pl.py ({name}; exact={int(exact)}) -- do not edit")
-    for js in range(2):
-        for qt in range(2):
-            q, qp = qt, qt ^ 1
-            s.emit(f"// ---- slot (js {js}, qt {qt}): C(u-1) on dqt[{qp}], A(u+1) into S/DP[{qp}], B(u) on S/DP[{q}]")
-            s.emit("{")
-            valu = dq_valu_ops(q, exact, group)
-            # MFMA list
-            mf = []
-            for hh in range(2):
-                for dt in range(2):
-                    mf.append((f"{MFMA} %0, %1, %2, %0", f'"+a"(dqt[{qp}][{dt}])', f'"v"(KTF({hh}, {dt})), "v"(DSF({qp}, {hh}))'))
-            for c in range(4):
-                if c == 0:
-                    mf.append((f"{MFMA} %0, %1, %2, 0", f'"=&v"(S[{qp}])', f'"v"(kf[{c}]), QFC(qf[{qp}][{c}])'))
-                    if exact:
-                        mf.append((f"{MFMA} %0, %1, %2, 0", f'"=&v"(DP[{qp}])', f'"v"(vf[{c}]), QFC(dof[{qp}][{c}])'))
-                    else:
-                        mf.append((f"{MFMA} %0, %1, %2, %3", f'"=&v"(DP[{qp}])', f'"v"(vf[{c}]), QFC(dof[{qp}][{c}]), "v"(ND[{qp}])'))
+    s.emit(f"// GENERATED by tools/gen_attn_pl.py (dq{nq}_{name}: exact={int(exact)} order={order} drop={','.join(drop) or '-'}) -- do not edit")
+    units = [(js, qt) for js in range(2) for qt in range(nq)]
+    n = len(units)
+    # two waves per SIMD share 512 registers: hipcc halves a 256-register budget into 128 VGPRs + 128 AGPRs as soon as a kernel touches an AGPR,
+    # and the stream needs ~200 VGPRs -- so the nq = 1 kernel keeps its accumulators in VGPRs too
+    acc = "v" if nq == 1 else "a"
+    for i, (js, qt) in enumerate(units):
+        par, parn = i & 1, (i & 1) ^ 1
+        jsn, qtn = units[(i + 1) % n]
+        jsp, qtp = units[(i - 1) % n]
+        s.emit(f"// ---- slot {i} (js {js}, qt {qt}): C(u-1) on dqt[{qtp}], A(u+1) into S/DP[{parn}] (js {jsn}, qt {qtn}), B(u) on S/DP[{par}]")
+        s.emit("{")
+        valu = [] if "valu" in drop else dq_valu_ops(par, qt, exact, order)
+        mf = []
+        for hh in range(2):
+            for dt in range(2):
+                mf.append((f"{MFMA} %0, %1, %2, %0", f'"+{acc}"(dqt[{qtp}][{dt}])', f'"v"(KTF({hh}, {dt})), "v"(DSF({parn}, {hh}))'))
+        for c in range(4):
+            if c == 0:
+                mf.append((f"{MFMA} %0, %1, %2, 0", f'"=&v"(S[{parn}])', f'"v"(kf[{c}]), QFC(qf[{qtn}][{c}])'))
+                if exact:
+                    mf.append((f"{MFMA} %0, %1, %2, 0", f'"=&v"(DP[{parn}])', f'"v"(vf[{c}]), QFC(dof[{qtn}][{c}])'))
                 else:
-                    mf.append((f"{MFMA} %0, %1, %2, %0", f'"+v"(S[{qp}])', f'"v"(kf[{c}]), QFC(qf[{qp}][{c}])'))
-                    mf.append((f"{MFMA} %0, %1, %2, %0", f'"+v"(DP[{qp}])', f'"v"(vf[{c}]), QFC(dof[{qp}][{c}])'))
-            ngap = len(mf)
-            counts = spread(len(valu), ngap, weights)
-            # slot head
-            if js == 1 and qt == 0:
-                s.emit("// tile hand-over: my loads of tile t+1 have landed; everyone's have, and nobody reads tile t-1 any more")
-                s.asm("s_waitcnt vmcnt(0)\\n\\ts_barrier", "", "", '"memory"')
-            if js == 1 and qt == 1:
-                s.emit("RING_ADVANCE();  // fragment addresses -> ring slot of tile t+1 (all reads of tile t are issued)")
-            s.asm("s_waitcnt lgkmcnt(0)\\n\\ts_nop 1", "", "", '"memory"')
-            vi = 0
-            for g in range(ngap):
-                t, o, i = mf[g]
-                s.asm(t, o, i)
-                # fragment reads of the NEXT row fragments (K, V of the next 32 keys): slots with qt == 1, behind the first four MFMAs
-                if qt == 1 and g < 4:
-                    njs = js ^ 1  # the 32-key half the next unit works on (js 1 -> next tile's half 0, after RING_ADVANCE)
-                    for c in (2 * (g % 2), 2 * (g % 2) + 1):
-                        which = "kf" if g < 2 else "vf"
-                        off = njs * 4096 + (0 if g < 2 else 8192)
-                        s.asm(f"ds_read_b128 %0, %1 offset:{off}", f'"=v"({which}[{c}])', f'"v"(ra[{c}])')
-                if qt == 1 and g == 3:
-                    pass
-                # transposed K fragments of THIS 32-key half (for the C stage of the next two slots): slots with qt == 0, behind the last four MFMAs
-                if qt == 0 and g >= ngap - 4:
-                    k = g - (ngap - 4)  # 0..3 -> (hh, dt)
-                    hh, dt = k >> 1, k & 1
-                    base = js * 4096 + hh * 2048
-                    s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(ktlo[{hh}][{dt}])', f'"v"(tra[{dt}][0])')
-                    s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(kthi[{hh}][{dt}])', f'"v"(tra[{dt}][1])')
-                # the four DMA pieces of tile t+2, one per gap, behind the hand-over barrier
-                if js == 1 and qt == 0 and 4 <= g < 8:
-                    s.emit(f"DMA_PIECE({g - 4});")
-                if qt == 1 and g == 3:
-                    s.emit("// the next unit's K / V row fragments must have landed before its first MFMA")
-                    s.asm("s_waitcnt lgkmcnt(0)", "", "", '"memory"')
-                for _ in range(counts[g]):
-                    t2, o2, i2 = valu[vi]
-                    s.asm(t2, o2, i2)
-                    vi += 1
-            assert vi == len(valu)
-            s.emit("}")
-    path = os.path.join(OUT, f"attn_pl_dq_{name}.inc")
+                    mf.append((f"{MFMA} %0, %1, %2, %3", f'"=&v"(DP[{parn}])', f'"v"(vf[{c}]), QFC(dof[{qtn}][{c}]), "v"(ND[{qtn}])'))
+            else:
+                mf.append((f"{MFMA} %0, %1, %2, %0", f'"+v"(S[{parn}])', f'"v"(kf[{c}]), QFC(qf[{qtn}][{c}])'))
+                mf.append((f"{MFMA} %0, %1, %2, %0", f'"+v"(DP[{parn}])', f'"v"(vf[{c}]), QFC(dof[{qtn}][{c}])'))
+        ngap = len(mf)
+        counts = spread(len(valu), ngap, weights)
+        early = jsn != js  # the next unit works on another 32-key half: its K / V row fragments are read at the top of this slot
+        late = qt == 0     # first unit of this 32-key half: its transposed K fragments (C stage of the next slots) are read in this slot
+        hand_over = (js, qt) == (1, 0)
+        if (js, qt) == (0, 0):
+            s.emit("RING_ADVANCE_TR();  // transposed-fragment addresses -> ring slot of this tile")
+        if hand_over:
+            s.emit("// tile hand-over: my loads of tile t+1 have landed; everyone's have, and nobody reads tile t-1 any more")
+            s.asm("s_waitcnt vmcnt(0)\\n\\ts_barrier", "", "", '"memory"')
+        if early and jsn == 0:
+            s.emit("RING_ADVANCE_ROW();  // row-fragment addresses -> ring slot of tile t+1")
+        s.asm("s_waitcnt lgkmcnt(0)\\n\\ts_nop 1", "", "", '"memory"')
+        vi = 0
+        for g in range(ngap):
+            if g == 4 and early and "lds" not in drop:
+                s.emit("// the next unit's K / V row fragments must have landed before its first MFMA")
+                s.asm("s_waitcnt lgkmcnt(0)", "", "", '"memory"')
+            t, o, ins = mf[g]
+            if "mfma" not in drop:
+                s.asm(t, o, ins)
+            if early and g < 2 and "lds" not in drop:
+                which, voff = ("kf", 0) if g == 0 else ("vf", 8192)
+                for c in range(4):
+                    s.asm(f"ds_read_b128 %0, %1 offset:{jsn * 4096 + voff}", f'"=v"({which}[{c}])', f'"v"(ra[{c}])')
+            if late and 5 <= g < 9 and "lds" not in drop:
+                k = g - 5
+                hh, dt = k >> 1, k & 1
+                base = js * 4096 + hh * 2048
+                s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(ktlo[{hh}][{dt}])', f'"v"(tra[{dt}][0])')
+                s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(kthi[{hh}][{dt}])', f'"v"(tra[{dt}][1])')
+            if hand_over and 4 <= g < 8 and "dma" not in drop:
+                s.emit(f"DMA_PIECE({g - 4});")
+            for _ in range(counts[g]):
+                t2, o2, i2 = valu[vi]
+                s.asm(t2, o2, i2)
+                vi += 1
+        assert vi == len(valu)
+        s.emit("}")
+    path = os.path.join(OUT, f"attn_pl_dq{nq}_{name}.inc")
     with open(path, "w") as f:
         f.write("\n".join(s.lines) + "\n")
     return path
@@ -160,12 +194,17 @@ def gen_dq(exact: bool, weights: list[float] | None, name: str, group: int = 16)
 
 def main():
     made = []
-    # v0: exact arithmetic of attn_bwd_dq2_kernel (zero accumulator inputs, explicit dp - delta): bit-identical outputs -> the pipeline's test
-    made.append(gen_dq(True, None, "x0"))
-    # v1: -delta through the accumulator input of the dP chain (16 VALU fewer per unit)
-    made.append(gen_dq(False, None, "v1"))
-    # v2: as v1 with four score elements in flight per pass (12 hazard s_nop per slot instead of 3)
-    made.append(gen_dq(False, None, "v2", group=4))
+    for nq in (1, 2):
+        # x0: exact arithmetic of attn_bwd_dq2_kernel (zero accumulator inputs, explicit dp - delta): bit-identical outputs -> the pipeline's test
+        made.append(gen_dq("x0", nq, True))
+        # v1: -delta through the accumulator input of the dP chain (16 VALU fewer per unit); rolling VALU order
+        made.append(gen_dq("v1", nq, False))
+        # v2: as v1, VALU in passes over groups of four elements
+        made.append(gen_dq("v2", nq, False, order="g4"))
+        # ablations of v1 (lab only; results wrong on purpose)
+        made.append(gen_dq("a_novalu", nq, False, drop=("valu",)))
+        made.append(gen_dq("a_nolds", nq, False, drop=("lds",)))
+        made.append(gen_dq("a_nomfma", nq, False, drop=("mfma",)))
     for p in made:
         print(os.path.relpath(p, os.path.join(HERE, "..")))
 

@@ -10,5 +10,15 @@ case "${1:-}" in
     echo "exit $?" >> gpurun_out/r05_attn_lab_$tag.txt
     tail -40 gpurun_out/r05_attn_lab_$tag.txt
     ;;
+  p)  # the MFMA / VALU issue probe of round 2, whole output
+    hipcc --offload-arch=gfx950 -O3 tools/probe_mfma_valu.hip -o /tmp/probe_mfma_valu && timeout 120 /tmp/probe_mfma_valu > gpurun_out/r05_probe_mfma_valu.txt 2>&1
+    cat gpurun_out/r05_probe_mfma_valu.txt
+    ;;
+  s)  # skinny lab: LoRA down-projection kernels
+    tag="${2:-1}"; shapes="${3:-5376x2048x64,5376x2048x192,2688x2048x64}"; cfgs="${4:-0,1}"
+    timeout 300 tools/bin/skinny_lab "$shapes" "$cfgs" > gpurun_out/r05_skinny_lab_$tag.txt 2>&1
+    echo "exit $?" >> gpurun_out/r05_skinny_lab_$tag.txt
+    cat gpurun_out/r05_skinny_lab_$tag.txt
+    ;;
   *) echo "unknown visit"; exit 1;;
 esac
