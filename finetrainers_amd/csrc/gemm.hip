@@ -1553,6 +1553,14 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
 // path, which is what bounds a CU: 64 B / clk), so M = 5376 is 168 workgroups -- ONE round -- and every wave's loop is twice as long per prologue /
 // epilogue.  Same K split (a quarter per wave, private 2-stage LDS ring, counted vmcnt, no barrier in the loop), same MFMA order per accumulator and
 // the same reduction order across the four waves and the two planes: outputs are bit-identical to gemm_nt_skinny2_kernel.
+#ifdef FTMI_LAB
+__device__ unsigned long long g_sk4_trace[512 * 8];  // tools/skinny_lab.hip: s_memtime at the phase boundaries of wave 0 of every workgroup
+#define SK4_T(i) do { if (tid == 0) g_sk4_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 511) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SK4_T(i) do { } while (0)
+#endif
+// (measured and dropped, profiles/r05_skinny_lab_*.txt: 32-deep stages in a four-stage ring -- half-line loads, 15.8 vs 13.1 us; every workgroup starting its K
+// quarters at a different chunk so that the 4-KB-strided rows do not all hit one 128-byte column at a time -- 13.1 vs 13.5 us for the loss of bit identity)
 template <int BK>  // K depth of a ring stage: 64 (two 16-KB stages per wave) or 32 (four 8-KB stages: three loads in flight behind the one being multiplied)
 __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1560,11 +1568,18 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
     constexpr int RPI = 1024 / (BK * 2), NPI = 64 / RPI;  // rows per 1-KiB wave load, loads per operand and chunk
     constexpr int CPR = BK / 8, KK = BK / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SK4_T(0);
     const int li = lane & 31, g = lane >> 5;
-    const int ntm = (p.M + 63) / 64, ntn = p.N / 64;
-    const int grp = blockIdx.x / (8 * ntn), lid = blockIdx.x % (8 * ntn);
-    const int in_grp = min(8, ntm - grp * 8);  // row tiles of this group (the last group may be short)
-    const int m0 = (grp * 8 + lid % in_grp) * 64, n0 = (lid / in_grp) * 64;
+    // grid = (8 * ntn, groups of 8 row tiles): linear block id = y * 8 ntn + x, so block (x, y) runs on XCD x % 8 and the ntn column tiles that share a
+    // 64-row slice of X (x = j * 8 + xcd) meet in one L2 -- the numbering of gemm_nt_skinny2_kernel without its integer divisions (the prologue of
+    // this kernel was 5 000 cycles of its 25 000: four dependent scalar-load round trips and eight divisions in front of the first load)
+    const int ntm = (p.M + 63) / 64;
+    const int grp = blockIdx.y, lid = blockIdx.x;
+    const int in_grp = min(8, ntm - grp * 8);  // row tiles of this group (the last group may be short: its surplus blocks leave)
+    int mt, nt_;
+    if (in_grp == 8) { mt = lid & 7; nt_ = lid >> 3; }
+    else { mt = lid % in_grp; nt_ = lid / in_grp; if (nt_ >= p.N / 64) return; }
+    const int m0 = (grp * 8 + mt) * 64, n0 = nt_ * 64;
     const bf16_t* X = p.X;
     if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
     // the four waves split the K / 64 chunks exactly like gemm_nt_skinny2_kernel (same partial sums -> same bits)
@@ -1612,6 +1627,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
 #pragma unroll
     for (int s0 = 0; s0 < NST; ++s0)
         if (s0 < nch) issue(s0);
+    SK4_T(1);
     for (int ck = 0; ck < nch; ++ck) {
         // loads retire in order: leave the chunks behind this one in flight
         const int ahead = min(NST - 1, nch - 1 - ck);
@@ -1619,6 +1635,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NPI) : "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPI) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ck == 0) SK4_T(2);
         const char* st = ring + (ck % NST) * CH;
         s16x8 xf[2][KK], wf[2][KK];
 #pragma unroll
@@ -1639,7 +1656,9 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
                 acc[rt][1] = mfma32(wf[1][kk], xf[rt][kk], acc[rt][1]);
             }
     }
+    SK4_T(3);
     __syncthreads();  // every wave is done with its ring: reuse the memory for the cross-wave reduction
+    SK4_T(4);
     float* red = reinterpret_cast<float*>(smem);  // [wave][row tile][plane][acc register][lane]
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -1671,6 +1690,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
         *reinterpret_cast<u32x2*>(dst + p.split_r) = lo;
         *reinterpret_cast<u32x2*>(dst + 2 * p.split_r) = hi;
     }
+    SK4_T(5);
 }
 
 // The automatic kernel choice for a "wide" NT launch (N % 128 == 0), as a pure function of the launch description (and of the FTMI_NT* switches, read once):
@@ -1786,8 +1806,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny4_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem4) == hipSuccess &&
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny4_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem4) == hipSuccess;
             if (!attr_ok4) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
-            if (sk4 == 2) hipLaunchKernelGGL(gemm_nt_skinny4_kernel<32>, dim3(((a.M + 63) / 64) * (a.N / 64)), dim3(256), kSmem4, st, a);
-            else hipLaunchKernelGGL(gemm_nt_skinny4_kernel<64>, dim3(((a.M + 63) / 64) * (a.N / 64)), dim3(256), kSmem4, st, a);
+            const dim3 grid4(8 * (a.N / 64), ((a.M + 63) / 64 + 7) / 8);
+            if (sk4 == 2) hipLaunchKernelGGL(gemm_nt_skinny4_kernel<32>, grid4, dim3(256), kSmem4, st, a);
+            else hipLaunchKernelGGL(gemm_nt_skinny4_kernel<64>, grid4, dim3(256), kSmem4, st, a);
             return check_launch("gemm_nt_skinny");
         }
         constexpr int kSmem = 4 * 3 * 12288;
@@ -1922,6 +1943,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
 // 1 = the 128 x 64 kernel for N % 128 != 0, 0 = a launch the tiled kernels do not take (N % 64, K % 64).  No launch, no device: host tests pin the rule.
 int gemm_nt_plan(int M, int N, int K, int K2, int epi) {
     if (M <= 0 || N <= 0 || K % 64 != 0 || K2 % 64 != 0 || N % 64 != 0) return 0;
+    // gemm_nt() routes narrow plain-store launches of many rows to the LDS-ring skinny kernel BEFORE any tile choice (the predicate below is the one in
+    // gemm_nt(), for ungrouped operands): report it with its own code instead of the tile the shape would otherwise get
+    if (N <= 256 && K2 == 0 && epi == EPI_STORE && M >= 512) return 2;
     if (N % 128 != 0) return 1;
     GemmNtArgs a;
     a.M = M; a.N = N; a.K = K; a.K2 = K2; a.epi = epi; a.variant = 8;

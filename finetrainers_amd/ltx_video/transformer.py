@@ -143,6 +143,10 @@ class _LTXDiTFunction(torch.autograd.Function):
               and gb_live.data_ptr() == gflat.data_ptr() + 4 * n_a):
             accumulate = 1  # gradient accumulation: add into the live buffer
         else:  # somebody installed their own .grad tensors: compute into a scratch buffer and let autograd accumulate
+            if module._grad_bucket_hook is not None or module._grad_bucket_finish is not None:
+                raise RuntimeError("the gradient exchange is installed on this model (apply_ddp / a data-parallel step) but lora_A.grad / lora_B.grad are not the "
+                                   "backend's flat gradient buffer: foreign .grad tensors would never be all-reduced and the replicas would diverge silently -- "
+                                   "use optimizer.zero_grad(set_to_none=True) (the reference trainer's default) instead of installing .grad tensors")
             foreign = gflat = torch.empty(n_a + n_b, dtype=torch.float32, device=dpred.device)
             accumulate = 0
         ga = gflat[:n_a].view_as(module._lora_A_full)

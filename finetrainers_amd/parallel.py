@@ -26,6 +26,22 @@ import torch
 import torch.distributed as dist
 
 
+# ROCr reads HSA_ENABLE_IPC_MODE_LEGACY at hsa_init and RCCL reads NCCL_* when its first communicator is created: both have to be in the environment
+# BEFORE this process touches the GPU, so they are set at import (a launcher that already exported them wins).  `describe()` reports what is in the
+# environment AND whether HIP was already initialised when this module was imported (in which case the HSA setting came too late to matter here).
+_HIP_WAS_INITIALISED_AT_IMPORT = bool(getattr(torch.cuda, "is_initialized", lambda: False)())
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+# Defaults for the 29-59 MB gradient buckets on 8 fully connected xGMI peers (a ring is per-link bound, 7 links x ~153 GB/s): RCCL's
+# tuner is left in charge (it picks among ring / tree / direct by message size and topology) unless FTMI_RCCL_ALGO / FTMI_RCCL_PROTO pin a choice; the
+# protocol default for multi-MB messages is Simple (LL / LL128 trade bandwidth for latency below ~1 MB) and is pinned so that a tuner table tuned for
+# small messages cannot pick LL128 for a 59 MB bucket.  What ran is recorded by `describe()` in every bench line.
+for _var, _dst, _dflt in (("FTMI_RCCL_ALGO", "NCCL_ALGO", None), ("FTMI_RCCL_PROTO", "NCCL_PROTO", "Simple")):
+    if os.environ.get(_var):
+        os.environ[_dst] = os.environ[_var]
+    elif _dflt is not None:
+        os.environ.setdefault(_dst, _dflt)
+
+
 class DataParallelBackend:
     def __init__(self, backend: Optional[str] = None, timeout_s: int = 300, device: Optional[torch.device] = None,
                  exercise_collectives: bool = False):
@@ -42,17 +58,13 @@ class DataParallelBackend:
         if use_gpu:
             torch.cuda.set_device(self.device)
         self._owns_pg = False
+        self._rank_devices = None
         self.exercise_collectives = bool(exercise_collectives)
         if (self.world_size > 1 or self.exercise_collectives) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
             os.environ.pop("NCCL_P2P_DISABLE", None)  # never inherit the reference scripts' setting (keeps xGMI on)
-            # RCCL's algorithm / protocol for the 29-59 MB gradient buckets is left to its tuner unless FTMI_RCCL_ALGO / FTMI_RCCL_PROTO pin it
-            # (on 8 fully connected xGMI peers a ring is per-link bound; what the tuner picks is logged by `describe()`).
-            for var, dst in (("FTMI_RCCL_ALGO", "NCCL_ALGO"), ("FTMI_RCCL_PROTO", "NCCL_PROTO")):
-                if os.environ.get(var):
-                    os.environ[dst] = os.environ[var]
+            # (HSA_ENABLE_IPC_MODE_LEGACY and the NCCL_ALGO / NCCL_PROTO pins are set at module import, before the GPU is touched)
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size,
                                     timeout=datetime.timedelta(seconds=timeout_s))
             self._owns_pg = True
@@ -64,9 +76,26 @@ class DataParallelBackend:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if self.backend == "nccl" else None
         except Exception:
             pass
-        return {"backend": self.backend, "world_size": self.world_size, "rccl_version": ver, "algo": os.environ.get("NCCL_ALGO", "auto (RCCL tuner)"),
-                "proto": os.environ.get("NCCL_PROTO", "auto (RCCL tuner)"), "p2p_disabled": os.environ.get("NCCL_P2P_DISABLE") == "1",
-                "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        out = {"backend": self.backend, "world_size": self.world_size, "rccl_version": ver, "algo": os.environ.get("NCCL_ALGO", "auto (RCCL tuner)"),
+               "proto": os.environ.get("NCCL_PROTO", "auto (RCCL tuner)"), "p2p_disabled": os.environ.get("NCCL_P2P_DISABLE") == "1",
+               "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+               "hsa_env_set_before_hip_init": not _HIP_WAS_INITIALISED_AT_IMPORT}
+        # what the COMMUNICATOR itself reports (not the environment): its size and, gathered once, the device every rank sits on -- the driver can
+        # verify "N ranks on N distinct GPUs" from the bench line
+        if dist.is_initialized():
+            out["group_size"] = dist.get_world_size()
+            out["group_rank"] = dist.get_rank()
+            if self._rank_devices is None:
+                mine = {"rank": dist.get_rank(), "local_rank": self.local_rank, "device": str(self.device)}
+                if self.device.type == "cuda":
+                    pr = torch.cuda.get_device_properties(self.device)
+                    mine.update(device_name=pr.name, device_index=self.device.index, pci_bus_id=getattr(pr, "pci_bus_id", None), uuid=str(getattr(pr, "uuid", "")))
+                got = [None] * dist.get_world_size()
+                dist.all_gather_object(got, mine)
+                self._rank_devices = got
+            out["rank_devices"] = self._rank_devices
+            out["distinct_devices"] = len({(d.get("device"), d.get("pci_bus_id"), d.get("uuid")) for d in self._rank_devices})
+        return out
 
     # ---- properties mirroring BaseParallelBackend -------------------------------------------------------------
     @property
@@ -263,7 +292,8 @@ class MI355XCheckpointer:
         import pathlib
 
         self.dataloader, self.model_parts, self.states = dataloader, list(model_parts or []), dict(states or {})
-        self.sft_step = sft_step if sft_step is not None else optimizers  # the fused clip + AdamW state lives in MI355XSFTStep
+        self.sft_step = sft_step if sft_step is not None else optimizers  # MI355XSFTStep (fused clip + AdamW state) or the trainer's own optimizer wrapper
+        self.schedulers = schedulers
         self.checkpointing_steps, self.checkpointing_limit = checkpointing_steps, checkpointing_limit
         self.output_dir = pathlib.Path(output_dir)
         self.enable, self._callback_fn, self._prefix = enable, _callback_fn, _prefix
@@ -271,21 +301,83 @@ class MI355XCheckpointer:
     def _dir(self, step: int):
         return self.output_dir / f"{self._prefix}_{step}"
 
+    # ---- the unmodified SFTTrainer hands over ITS optimizer (trainer.py:309-320: `optimizers=self.optimizer`, an OptimizerWrapper over torch's AdamW) ----
+    def _fused(self) -> bool:
+        return self.sft_step is not None and hasattr(self.sft_step, "exp_avg")
+
+    def _generic_states(self) -> Dict[str, Any]:
+        """What PTDCheckpointer hands to torch.distributed.checkpoint (parallel/ptd.py:313-321) when the optimizer is torch's: Stateful wrappers around
+        the model parts and the optimizer (the reference's OptimizerWrapper is used as it is), the dataloader if it is stateful, scheduler state."""
+        from torch.distributed.checkpoint.state_dict import StateDictOptions, get_optimizer_state_dict, set_optimizer_state_dict
+        from torch.distributed.checkpoint.stateful import Stateful
+
+        parts = self.model_parts
+
+        class _Model(Stateful):
+            def state_dict(self_inner):
+                return {k: v for m in parts for k, v in m.state_dict().items()}
+
+            def load_state_dict(self_inner, sd):
+                for m in parts:
+                    m.load_state_dict(sd, strict=False)
+                    if hasattr(m, "_lora_versions"):
+                        m._lora_versions = None
+
+        opt = self.sft_step
+
+        class _Optim(Stateful):
+            def _each(self_inner):
+                opts = getattr(opt, "optimizers", None) or ([opt] if opt is not None else [])
+                return list(zip(parts, opts))
+
+            def state_dict(self_inner):
+                o = StateDictOptions(flatten_optimizer_state_dict=True)
+                return {k: v for m, oo in self_inner._each() for k, v in get_optimizer_state_dict(m, oo, options=o).items()}
+
+            def load_state_dict(self_inner, sd):
+                o = StateDictOptions(flatten_optimizer_state_dict=True)
+                for m, oo in self_inner._each():
+                    set_optimizer_state_dict(m, oo, optim_state_dict=sd, options=o)
+
+        states = dict(self.states)
+        states["model"] = _Model()
+        if opt is not None:
+            states["optimizer"] = opt if isinstance(opt, Stateful) else _Optim()
+        if self.dataloader is not None and hasattr(self.dataloader, "state_dict") and hasattr(self.dataloader, "load_state_dict"):
+            states["dataloader"] = self.dataloader
+        if self.schedulers is not None and hasattr(self.schedulers, "get_lr_scheduler_state"):
+            states.update(self.schedulers.get_lr_scheduler_state())
+        return states
+
     def save(self, step: int = -1, force: bool = False, *, _device=None, _is_main_process: bool = True) -> Optional[str]:
         from . import wire
 
         if not self.enable or (not force and step % self.checkpointing_steps != 0):
             return None
-        if self.sft_step is None or not hasattr(self.sft_step, "exp_avg"):
-            raise RuntimeError("MI355XCheckpointer.save needs the MI355XSFTStep (pass it as `optimizers=` or `sft_step=`): it owns the AdamW moments")
-        ts = self.states.get("train_state")
-        train_state = None if ts is None else {k: getattr(ts, k) for k in ("step", "observed_data_samples", "global_avg_losses", "global_max_losses", "log_steps") if hasattr(ts, k)}
-        dl_state = self.dataloader.state_dict() if hasattr(self.dataloader, "state_dict") else None
-        path = wire.save_training_state(str(self.output_dir), step, self.model_parts[0], self.sft_step, train_state=train_state, dataloader_state=dl_state)
-        self._purge()
-        if self._callback_fn is not None and _is_main_process:
-            self._callback_fn({k: v.detach().cpu() for k, v in self.model_parts[0].state_dict().items()})
+        path = None
+        try:
+            if self._fused():
+                ts = self.states.get("train_state")
+                train_state = None if ts is None else {k: getattr(ts, k) for k in ("step", "observed_data_samples", "global_avg_losses", "global_max_losses", "log_steps") if hasattr(ts, k)}
+                dl_state = self.dataloader.state_dict() if hasattr(self.dataloader, "state_dict") else None
+                path = wire.save_training_state(str(self.output_dir), step, self.model_parts[0], self.sft_step, train_state=train_state, dataloader_state=dl_state,
+                                                dp_rank=self._dp_rank())
+            else:
+                import torch.distributed.checkpoint as dcp
+
+                path = str(self._dir(step))
+                dcp.save(self._generic_states(), checkpoint_id=path)
+            self._purge()
+        finally:
+            # the trained adapters are written whatever happened to the training-state files (the trainer's final save(force=True) is the only place
+            # the model hook runs: trainer.py:563)
+            if self._callback_fn is not None and _is_main_process and self.model_parts:
+                self._callback_fn({k: v.detach().cpu() for k, v in self.model_parts[0].state_dict().items()})
         return path
+
+    @staticmethod
+    def _dp_rank() -> int:
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
     def load(self, step: int = -1) -> bool:
         from . import wire
@@ -299,7 +391,21 @@ class MI355XCheckpointer:
             step = int(found[-1].name.split("_")[-1])
         if not self._dir(step).exists():
             return False
-        got = wire.load_training_state(str(self._dir(step)), self.model_parts[0], self.sft_step)
+        if not self._fused():
+            import torch.distributed.checkpoint as dcp
+            from torch.distributed.checkpoint.stateful import Stateful
+
+            states = self._generic_states()
+            if step == 0:  # ptd.py:361-362: optimizers / schedulers do not exist yet at step 0
+                states = {"model": states["model"]}
+            keep = {k: v for k, v in states.items() if isinstance(v, Stateful)}
+            dcp.load(states, checkpoint_id=str(self._dir(step)))
+            states.update(keep)
+            for k, v in states.items():  # plain entries (train_state scalars ...) were updated in the copy: hand them back
+                if k in self.states and not isinstance(v, Stateful):
+                    self.states[k] = v
+            return True
+        got = wire.load_training_state(str(self._dir(step)), self.model_parts[0], self.sft_step, dp_rank=self._dp_rank())
         ts = self.states.get("train_state")
         if ts is not None:
             for k, v in got.items():
@@ -403,13 +509,23 @@ class MI355XParallelBackend(_RefBaseParallelBackend if _RefBaseParallelBackend i
         return optimizer, lr_scheduler
 
     def get_mesh(self, name: Optional[str] = None):
-        """parallel/ptd.py:161-209 for a one-dimensional replicate mesh (flattened names "dp" / "dp_cp" resolve to it)."""
+        """parallel/ptd.py:161-209 for a one-dimensional replicate mesh.  The reference trainer INDEXES the mesh it gets back --
+        ``get_mesh()["dp_cp"]`` (trainer.py:512), ``get_mesh()["dp"]`` (trainer.py:595) --, and PTD makes those names exist by flattening the data
+        dimensions onto the mesh (ptd.py:200-205): the same two flattened names are created here."""
         if self._degree == 1 or not dist.is_initialized():
             return None
         if self._mesh is None:
             dev = "cuda" if self._dp.backend == "nccl" else "cpu"
-            self._mesh = torch.distributed.device_mesh.init_device_mesh(dev, mesh_shape=[self._degree], mesh_dim_names=["dp_replicate"])
-        return self._mesh
+            mesh = torch.distributed.device_mesh.init_device_mesh(dev, mesh_shape=[self._degree], mesh_dim_names=["dp_replicate"])
+            mesh[("dp_replicate",)]._flatten(mesh_dim_name="dp")     # data_replication_enabled: dp = dp_cp = (dp_replicate,)
+            mesh[("dp_replicate",)]._flatten(mesh_dim_name="dp_cp")
+            self._mesh = mesh
+        if name is None:
+            return self._mesh
+        try:
+            return self._mesh[name]
+        except (KeyError, RuntimeError):
+            return None if self._mesh.ndim == 0 else self._mesh
 
     def get_checkpointer(self, *args, **kwargs) -> MI355XCheckpointer:
         return MI355XCheckpointer(*args, **kwargs)

@@ -94,6 +94,12 @@ class MI355XSFTStep:
         self._scratch = torch.zeros(ops.CLIP_SCRATCH_FLOATS, dtype=torch.float32, device=dev)
         self.step_count = 0
         self.reducer = None
+        # MI355XParallelBackend.apply_ddp() installs the exchange ON THE MODEL (hook + finish, like DDP's reducer): a step that is handed such a model
+        # leaves those hooks where they are -- the backward then returns with averaged gradients -- and must not bring a second exchange of its own
+        self._model_owns_exchange = getattr(transformer, "_grad_bucket_hook", None) is not None and getattr(transformer, "_grad_bucket_finish", None) is not None
+        if self._model_owns_exchange and parallel is not None and parallel.active:
+            raise ValueError("MI355XSFTStep(parallel=...) on a model that apply_ddp() already wired for the gradient exchange: the gradients would be averaged "
+                             "twice -- pass parallel=None (the model's own hooks do the exchange) or do not call apply_ddp")
         if parallel is not None and parallel.active:
             from .parallel import GradBucketReducer
 
@@ -140,7 +146,10 @@ class MI355XSFTStep:
         loss, dpred = ops.mse_loss(pred.detach(), target, weights, want_grad=True, grad_scale=1.0 / gas)
         loss = loss.reshape(()) / gas if gas > 1 else loss.reshape(())
         exchange = self.reducer is not None and (sync or not self.no_sync_accumulation)
-        tr._grad_bucket_hook = self.reducer.bucket_ready if exchange else None
+        prev_hook, prev_fin = tr._grad_bucket_hook, tr._grad_bucket_finish
+        if not self._model_owns_exchange:  # this step's own reducer (or none): install for the duration of the backward, then put back what was there
+            tr._grad_bucket_hook = self.reducer.bucket_ready if exchange else None
+            tr._grad_bucket_finish = None
         try:
             pred.backward(dpred)  # DP: buckets of finished blocks are all-reduced (AVG) on RCCL's stream while this still runs
         except BaseException:
@@ -148,7 +157,7 @@ class MI355XSFTStep:
                 self.reducer.abort()  # buckets issued before the failure: drained and dropped, never carried into the next step
             raise
         finally:
-            tr._grad_bucket_hook = None
+            tr._grad_bucket_hook, tr._grad_bucket_finish = prev_hook, prev_fin
         if not sync:
             # the reference clips after every backward (trainer.py:487-492), i.e. also the partial sums of an accumulation window -- in place
             # on .grad (under DP on the all-reduced sums, see no_sync_accumulation)

@@ -373,7 +373,7 @@ def lambda_lr_state(base_lr: float, last_epoch: int, current_lr: float) -> Dict[
 
 
 def save_training_state(output_dir: str, step: int, transformer, sft_step, train_state: Optional[Dict[str, Any]] = None,
-                        dataloader_state: Optional[Dict[str, Any]] = None) -> str:
+                        dataloader_state: Optional[Dict[str, Any]] = None, dp_rank: int = 0) -> str:
     """``PTDCheckpointer.save`` for the MI355X step: writes ``<output_dir>/finetrainers_step_<step>/`` (DCP ``.metadata`` + ``*.distcp``).
     ``transformer``: MI355XLTXVideoTransformer3DModel with an adapter; ``sft_step``: MI355XSFTStep."""
     import torch.distributed.checkpoint as dcp
@@ -388,14 +388,37 @@ def save_training_state(output_dir: str, step: int, transformer, sft_step, train
         sft_step.exp_avg_sq[:n_a].view_as(tr._lora_A_full).cpu(), sft_step.exp_avg_sq[n_a:].view_as(tr._lora_B_full).cpu(),
         sft_step.step_count, {"lr": lr_now, "betas": sft_step.betas, "eps": sft_step.eps, "weight_decay": sft_step.weight_decay, "initial_lr": sft_step.lr},
         lr_scheduler_state=None if sched is None else lambda_lr_state(sched.base_lr, sched.last_epoch, lr_now),
-        train_state=train_state, dataloader_state=dataloader_state)
+        train_state=train_state, dataloader_state=dataloader_state, dp_rank=dp_rank)  # every data-parallel rank writes ITS dataloader entry (dp_rank_<r>)
     path = os.path.join(output_dir, f"{DCP_PREFIX}_{step}")
     dcp.save(sd, checkpoint_id=path)
     return path
 
 
+def prune_template_to_checkpoint(tmpl: Dict[str, Any], checkpoint_dir: str, optional_prefixes) -> List[str]:
+    """Remove from a nested DCP load template every leaf under one of ``optional_prefixes`` (dotted key paths) that the checkpoint's ``.metadata``
+    does not list; returns the removed keys.  Everything else stays strict (a missing adapter or moment must still raise)."""
+    import torch.distributed.checkpoint as dcp
+
+    have = set(dcp.FileSystemReader(checkpoint_dir).read_metadata().state_dict_metadata.keys())
+    removed: List[str] = []
+
+    def walk(d, prefix):
+        for k in list(d.keys()):
+            key = f"{prefix}{k}"
+            if isinstance(d[k], dict):
+                walk(d[k], key + ".")
+                if not d[k] and any((key + ".").startswith(p) or p.startswith(key + ".") for p in optional_prefixes):
+                    del d[k]
+            elif key not in have and any(key.startswith(p) for p in optional_prefixes):
+                removed.append(key)
+                del d[k]
+
+    walk(tmpl, "")
+    return removed
+
+
 @torch.no_grad()
-def load_training_state(checkpoint_dir: str, transformer, sft_step) -> Dict[str, Any]:
+def load_training_state(checkpoint_dir: str, transformer, sft_step, dp_rank: int = 0) -> Dict[str, Any]:
     """``PTDCheckpointer.load``: reads a DCP directory written by either implementation into the MI355X transformer + step (base weights
     only if the checkpoint's differ in name set -- they are frozen --, adapters, both moments, the step counter, the schedule clock).
     Returns the ``train_state`` scalars."""
@@ -409,11 +432,15 @@ def load_training_state(checkpoint_dir: str, transformer, sft_step) -> Dict[str,
         torch.zeros_like(tr._lora_A_full, device="cpu"), torch.zeros_like(tr._lora_B_full, device="cpu"),
         torch.zeros_like(tr._lora_A_full, device="cpu"), torch.zeros_like(tr._lora_B_full, device="cpu"),
         0, {"lr": sft_step.lr, "betas": sft_step.betas, "eps": sft_step.eps, "weight_decay": sft_step.weight_decay},
-        lr_scheduler_state=lambda_lr_state(sft_step.lr, 0, sft_step.lr) if getattr(sft_step, "lr_scheduler", None) is not None else None)
+        lr_scheduler_state=lambda_lr_state(sft_step.lr, 0, sft_step.lr) if getattr(sft_step, "lr_scheduler", None) is not None else None, dp_rank=dp_rank)
     tmpl.pop("train_state")
     tmpl["train_state"] = {"step": torch.zeros((), dtype=torch.int32), "observed_data_samples": torch.zeros((), dtype=torch.int32)}
+    # Load what the checkpoint HOLDS: a strict dcp.load raises on every template key the file does not have, and checkpoints differ in their
+    # OPTIONAL parts -- `optimizer.param_groups.<fqn>.*` of the frozen base weights (written since round 4, absent before), the dataloader entry
+    # (one per data-parallel rank: dp_rank_<r>), the scheduler.  Those parts of the template are pruned to the checkpoint's own key set first.
+    prune_template_to_checkpoint(tmpl, checkpoint_dir, optional_prefixes=("optimizer.param_groups.", "dataloader.", "lr_scheduler."))
     dcp.load(tmpl, checkpoint_id=checkpoint_dir)
-    tr.load_state_dict(tmpl["model"], strict=True)
+    tr.load_state_dict(tmpl["model"], strict=False)  # base weights are frozen: a checkpoint may carry only the adapters
     opt = tmpl["optimizer"]
     ea, eb = torch.zeros_like(tr._lora_A_full, device="cpu"), torch.zeros_like(tr._lora_B_full, device="cpu")
     qa, qb = torch.zeros_like(ea), torch.zeros_like(eb)

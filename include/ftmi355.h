@@ -114,7 +114,8 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
                  const void* aux, long ld_side, int variant, ftmi_stream stream);
 /* Which kernel variant 8 takes for a plain launch of this shape (K2 = depth of a fused LoRA K-extension or 0; epilogue as above), as a pure host function
  * (no device, no launch): 80 / 86 = the 16 x 16 x 32 pipeline with 256- / 192-row tiles, 42 = 192 x 128 tiles (two workgroups per CU), 47 = 256 x 256
- * (8 waves), 44 = 128 x 128, 1 = the 128 x 64 kernel of N % 128 != 0, 0 = not a tiled launch (N % 64 or K % 64).  Host tests pin the choice to DESIGN.md. */
+ * (8 waves), 44 = 128 x 128, 2 = a skinny kernel (N <= 256, plain store, no extension, M >= 512: the LDS-ring kernel when K % 256 == 0, else the direct-gather one), 1 = the 128 x 64 kernel of N % 128 != 0,
+ * 0 = not a tiled launch (N % 64 or K % 64).  Host tests pin the choice to DESIGN.md. */
 int ftmi_gemm_nt_plan(int M, int N, int K, int K2, int epilogue);
 #ifdef FTMI_EXPERIMENTAL
 /* Research build only (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build): the persistent stream-K GEMM (csrc/gemm_sk.hip, variant 60) --

@@ -38,6 +38,10 @@ WORST_FACTOR = 1.50
 #   kernel vs fp32 oracle  <= FP32_FACTOR x (bf16 oracle vs fp32 oracle)      -- the kernels may not be further from exact arithmetic
 #                                                                                than the reference's own bf16 path is
 FP32_FACTOR = 1.10
+# ... and the same claim as ABSOLUTE numbers at BASELINE config 2, full depth (measured 1.64e-3 / 8.5e-3; north_star's 1e-3 is below the 1.17e-3 by which
+# the reference's own bf16 graph moves when only its fp32 summation order changes -- BASELINE.md states this as the claimed tolerance)
+CFG2_GLOBAL_ABS = 2.0e-3
+CFG2_WORST_ABS = 1.0e-2
 
 
 def _dev():
@@ -475,8 +479,8 @@ def test_full_depth_config2_parity():
     """BASELINE config 2 EXACTLY: 28 blocks, batch 2, latents [2,128,7,16,24] (2688 tokens), text masks {32, 96}, sigma {0.25, 0.7},
     LoRA rank 64 -- loss and every LoRA gradient against the CPU oracle run on this box's host cores (a few minutes with torch's default
     thread count), and against the fp32 evaluation of the same graph through the committed gradient sample.  Guard: the oracle is first
-    timed on ONE block; if 28 blocks would not fit ORACLE_BUDGET_S the depth is reduced to what fits (never below 8) and the report says
-    so -- a slow or oversubscribed host must not hang the suite (the yardsticks only apply at the full depth)."""
+    timed on ONE block; if 28 blocks would not fit ORACLE_BUDGET_S the depth is reduced to what fits (never below 8), a sanity bound is checked and
+    the test SKIPS with that message -- a slow or oversubscribed host must not hang the suite, and a reduced run must not read as a pass."""
     from oracle import ltx
 
     budget = float(os.environ.get("FTMI_ORACLE_BUDGET_S", "480"))
@@ -494,8 +498,11 @@ def test_full_depth_config2_parity():
     glob, worst_adapter, _, _ = _run_parity_case(depth, 2, 7, 16, 24, False, False, False, "full_cfg2" if depth == 28 else f"full_cfg2_REDUCED_to_L{depth}",
                                                  keep_gpu_grads=keep)
     if depth != 28:
-        assert glob < 2.5e-3 and worst_adapter < 1.3e-2  # reduced depth: round 2's loose bound, the yardsticks do not apply
-        return
+        # a reduced run is NOT the configuration's parity: it must never count as a pass of this test (round-4 review).  The sanity bound still guards
+        # the kernels, then the test reports itself as skipped with the depth it ran.
+        assert glob < 2.5e-3 and worst_adapter < 1.3e-2, f"reduced-depth ({depth} blocks) sanity bound: {glob:.3e} / {worst_adapter:.3e}"
+        pytest.skip(f"full-depth cfg-2 parity NOT run: the host oracle needs {per_block:.1f} s per block, 28 blocks exceed FTMI_ORACLE_BUDGET_S={budget:.0f} s; "
+                    f"ran {depth} blocks instead (global {glob:.3e}, worst adapter {worst_adapter:.3e}: sanity bound only)")
     y, sample = _cfg2_yardsticks()
     stride = int(y["stride"])
     got = {k: v.flatten()[::stride] for k, v in keep["grads"].items()}
@@ -511,6 +518,9 @@ def test_full_depth_config2_parity():
                        "bf16_oracle_vs_fp32_oracle_sampled": [y["bf16_vs_fp32_global_sampled"], y["bf16_vs_fp32_worst_adapter_sampled"]]}, f, indent=1)
     except OSError:
         pass
+    # the CLAIMED tolerance, as absolute numbers ("claimed tolerance"): a regression cannot hide behind a moving yardstick
+    assert glob <= CFG2_GLOBAL_ABS, f"global LoRA gradient error {glob:.3e} above the claimed {CFG2_GLOBAL_ABS:.1e} (north_star asks 1e-3; floor of the bf16 graph {y['floor_global']:.3e})"
+    assert worst_adapter <= CFG2_WORST_ABS, f"worst adapter {worst_adapter:.3e} above the claimed {CFG2_WORST_ABS:.1e}"
     assert glob < FLOOR_FACTOR * y["floor_global"], f"global LoRA gradient error {glob:.3e} vs {FLOOR_FACTOR} x floor {y['floor_global']:.3e}"
     assert worst_adapter < FLOOR_FACTOR_WORST * y["floor_worst_adapter"]
     assert g32 < FP32_FACTOR * y["bf16_vs_fp32_global_sampled"], f"kernel vs fp32 oracle {g32:.3e} vs the bf16 oracle's own distance {y['bf16_vs_fp32_global_sampled']:.3e}"

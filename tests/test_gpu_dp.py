@@ -379,7 +379,8 @@ def test_unmodified_trainer_loop_drives_the_drop_in_classes():
             optimizer.step()  # trainer.py:498-503
             lr_scheduler.step()
             optimizer.zero_grad()
-            transformer._lora_versions = None  # torch changed the parameters: the bf16 working copies are refreshed at the next forward
+            # (nothing tells the transformer that torch changed the adapters: refresh_lora_copies() sees the parameters' _version move, as it must in the
+            #  unmodified SFTTrainer, which never writes a private attribute)
             grad_norm = grad_norm.detach().item()
             logs = {"train/global_avg_loss": accumulated_loss, "train/global_max_loss": accumulated_loss, "train/grad_norm": grad_norm}
             assert not (parallel_backend.data_replication_enabled or parallel_backend.data_sharding_enabled or parallel_backend.context_parallel_enabled)
@@ -398,3 +399,40 @@ def test_unmodified_trainer_loop_drives_the_drop_in_classes():
     rel = ((fused_params - loop_params).norm() / fused_params.norm()).item()
     print(f"[trainer-loop] parameters after {steps} steps: rel {rel:.2e}")
     assert rel < 1e-3
+
+
+def test_fused_step_on_an_apply_ddp_model_keeps_the_models_exchange():
+    """Round-4 advice: MI355XCheckpointer wants the MI355XSFTStep, MI355XParallelBackend.apply_ddp() wires the exchange on the MODEL -- mixing the two is
+    the documented use.  A fused step on such a model must (a) leave the hooks apply_ddp installed in place, step after step, (b) exchange through them
+    (buckets are issued, the backward ends the exchange), (c) refuse a second exchange of its own, and (d) foreign .grad tensors must raise instead of
+    silently skipping the all-reduce."""
+    from finetrainers_amd.parallel import DataParallelBackend, MI355XParallelBackend
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    spec, model, cond, latd, _, _ = _model_and_batch(3, 2, 2, 4, 6)
+    os.environ.setdefault("MASTER_PORT", "29537")
+    backend = MI355XParallelBackend(world_size=1, dp_degree=1, backend="nccl", exercise_collectives=True)  # a one-rank RCCL communicator
+    try:
+        model = backend.apply_ddp(model, backend.get_mesh())
+        hook, fin = model._grad_bucket_hook, model._grad_bucket_finish
+        assert hook is not None and fin is not None
+        with pytest.raises(ValueError, match="averaged twice"):
+            MI355XSFTStep(model, spec, parallel=backend._dp)
+        step = MI355XSFTStep(model, spec, lr=1e-3, parallel=None)
+        sig = torch.tensor([0.3, 0.8], device=_dev())
+        for i in range(2):
+            before = backend.reducer.buckets_issued
+            out = step.step(dict(cond), dict(latd), sigmas=sig, force_first_frame_branch=False)
+            assert torch.isfinite(out["loss"]) and torch.isfinite(out["grad_norm"])
+            assert backend.reducer.buckets_issued == before + 1 and not backend.reducer._pending   # 3 blocks < 7: one bucket, ended by the backward
+            assert model._grad_bucket_hook == hook and model._grad_bucket_finish == fin            # still wired after the step
+        # foreign .grad tensors under an installed exchange: loud
+        model.lora_A.grad = torch.zeros_like(model.lora_A)
+        model.lora_B.grad = torch.zeros_like(model.lora_B)
+        pred, target, sigmas = spec.forward(transformer=model, condition_model_conditions=dict(cond), latent_model_conditions=dict(latd),
+                                            sigmas=sig.reshape(-1, 1, 1, 1, 1), force_first_frame_branch=False)
+        with pytest.raises(RuntimeError, match="foreign .grad"):
+            (pred.float() - target.float()).pow(2).mean().backward()
+        model.lora_A.grad = model.lora_B.grad = None
+    finally:
+        backend.destroy()

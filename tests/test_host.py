@@ -418,6 +418,17 @@ def _backend_worker(rank, world, port, q):
         after_bcast = m.lora_flat.clone()
         m.backward(m.grad_bucket_blocks if hasattr(m, "grad_bucket_blocks") else 3)
         metrics = b.reduce_step_metrics(torch.tensor(1.0 + rank), torch.tensor(3.0))
+        # the reference trainer INDEXES the mesh (trainer.py:512 `get_mesh()["dp_cp"]`, :595 `get_mesh()["dp"]`) and reduces over the sub-mesh
+        # (parallel/utils.py:6-19 dist_mean / dist_max): both flattened names must exist and span both ranks
+        import torch.distributed as dist
+
+        mesh_sums = []
+        for nm in ("dp_cp", "dp"):
+            sub = b.get_mesh()[nm]
+            t = torch.tensor(float(rank + 1))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=sub.get_group())
+            mesh_sums.append((nm, sub.size(), t.item(), b.get_mesh(nm).size()))
+        metrics["mesh"] = torch.tensor(float(all(sz == world and tot == 3.0 and sz2 == world for _, sz, tot, sz2 in mesh_sums)))
         with b.main_process_first():
             pass
         b.wait_for_everyone()
@@ -449,6 +460,7 @@ def test_parallel_backend_drives_the_exchange_world_size_2_gloo():
         assert grad == want                        # mean over the two ranks, A and B slices of every bucket
         assert nb == 2 and ver is None             # default 7 blocks per range over 8 blocks -> 2 buckets; stale operand copies invalidated
         assert metrics["global_avg_loss"] == 1.5 and metrics["global_max_loss"] == 2.0
+        assert metrics["mesh"] == 1.0              # get_mesh()["dp_cp"] / ["dp"] exist, span both ranks, and reduce over them
         assert props == (2, rank, True, True, False, 2)
 
 
@@ -1053,7 +1065,10 @@ def test_gemm_dispatch_rule_matches_the_design(lib):
     assert plan(M, 2048, 2048, 192, EPI_STORE) == 42     # attn2.to_q forward
     assert plan(2688, 2048, 2048, 0, EPI_STORE) == 44    # batch 1: 224 tiles of 192 x 128 would half-fill the machine
     assert plan(256, 4096, 2048, 192, EPI_STORE) == 44   # the text side (few rows)
-    assert plan(M, 192, 2048, 0, EPI_STORE) == 1         # N % 128 != 0
+    assert plan(M, 192, 2048, 0, EPI_STORE) == 2         # narrow plain store over many rows: the LDS-ring skinny kernel, whatever N % 128 is
+    assert plan(M, 128, 2048, 0, EPI_STORE) == 2 and plan(M, 256, 2048, 0, EPI_STORE) == 2
+    assert plan(256, 192, 2048, 0, EPI_STORE) == 1       # few rows, N % 128 != 0: the 128 x 64 tile kernel
+    assert plan(M, 192, 2048, 192, EPI_STORE) == 1       # a K-extension keeps it off the skinny route
     assert plan(M, 2048, 100, 0, EPI_STORE) == 0 and plan(M, 100, 2048, 0, EPI_STORE) == 0
     # Wan-1.3B's widths (1536, 4608, 8960 = 35 x 256) take the same pipeline; CogVideoX-2b's 1920 = 7.5 x 256 keeps the 32 x 32 x 16 kernels
     assert plan(21504, 4608, 1536, 0, EPI_STORE) in (80, 86) and plan(21504, 8960, 1536, 0, EPI_GELU) in (80, 86)
@@ -1104,3 +1119,94 @@ def test_parallel_backend_has_the_reference_surface():
     with pytest.raises(ValueError):
         MI355XParallelBackend(world_size=2, dp_degree=1)
     assert isinstance(b.get_checkpointer(output_dir="/tmp/x", checkpointing_steps=5), MI355XCheckpointer)
+
+
+def test_checkpointer_round_trip_with_the_trainers_own_torch_optimizer(tmp_path):
+    """SFTTrainer hands the checkpointer ITS optimizer (finetrainers/trainer/sft_trainer/trainer.py:309-320: `optimizers=self.optimizer`, an
+    OptimizerWrapper around torch's AdamW), not an MI355XSFTStep: save() must write a DCP training state from it (and ALWAYS run the model hook that
+    writes the adapters), load() must bring model, both AdamW moments, the step counter and the schedule clock back.  CPU, plain torch.optim.AdamW
+    and the reference's wrapper shape (an object with `.optimizers` + Stateful state_dict / load_state_dict)."""
+    import torch.nn as nn
+    from torch.distributed.checkpoint.state_dict import StateDictOptions, get_optimizer_state_dict, set_optimizer_state_dict
+    from torch.distributed.checkpoint.stateful import Stateful
+
+    from finetrainers_amd.parallel import MI355XCheckpointer
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.base = nn.Linear(6, 6)
+            self.lora_A = nn.Parameter(torch.randn(2, 6) * 0.1)
+            self.lora_B = nn.Parameter(torch.randn(6, 2) * 0.1)
+            self.base.requires_grad_(False)
+
+        def forward(self, x):
+            return self.base(x) + x @ self.lora_A.t() @ self.lora_B.t()
+
+    class OptimizerWrapper(Stateful):  # finetrainers/optimizer.py:17-61, restated
+        def __init__(self, parts, opts):
+            self.model_parts, self.optimizers = parts, opts
+
+        def state_dict(self):
+            o = StateDictOptions(flatten_optimizer_state_dict=True)
+            return {k: v for m, oo in zip(self.model_parts, self.optimizers) for k, v in get_optimizer_state_dict(m, oo, options=o).items()}
+
+        def load_state_dict(self, sd):
+            o = StateDictOptions(flatten_optimizer_state_dict=True)
+            for m, oo in zip(self.model_parts, self.optimizers):
+                set_optimizer_state_dict(m, oo, optim_state_dict=sd, options=o)
+
+    class Schedulers:
+        def __init__(self, sch):
+            self.sch = sch
+
+        def get_lr_scheduler_state(self):
+            return {"lr_scheduler": self.sch}  # LRScheduler objects are Stateful-compatible for DCP through state_dict()/load_state_dict()
+
+    class TrainState:
+        step = 0
+        observed_data_samples = 0
+
+    def make(seed, wrap):
+        torch.manual_seed(seed)
+        m = Tiny()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2, betas=(0.9, 0.99), weight_decay=1e-4, fused=False)
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: 1.0 / (1 + s))
+        return m, (OptimizerWrapper([m], [opt]) if wrap else opt), opt, sch
+
+    for wrap in (True, False):  # the reference's wrapper, and a bare torch optimizer
+        out = tmp_path / f"ckpt_{int(wrap)}"
+        m, handed, opt, sch = make(0, wrap)
+        for _ in range(3):
+            m(torch.randn(4, 6)).pow(2).sum().backward()
+            opt.step(); sch.step(); opt.zero_grad()
+        hooked = []
+        ck = MI355XCheckpointer(dataloader=None, model_parts=[m], optimizers=handed, schedulers=None, states={}, checkpointing_steps=2, checkpointing_limit=2,
+                                output_dir=str(out), enable=True, _callback_fn=lambda sd: hooked.append(sorted(sd)))
+        assert ck.save(step=3) is None and not hooked            # not a checkpointing step
+        path = ck.save(step=4)
+        assert path is not None and os.path.isdir(path) and len(hooked) == 1 and "lora_A" in hooked[0]   # the model hook ran
+        assert ck.save(step=5, force=True) is not None and ck.save(step=7, force=True) is not None and len(hooked) == 3
+        assert sorted(p.name for p in out.glob("finetrainers_step_*")) == ["finetrainers_step_5", "finetrainers_step_7"]  # limit 2: the oldest is purged
+        want_a, want_m = m.lora_A.detach().clone(), opt.state[m.lora_A]["exp_avg"].clone()
+
+        m2, handed2, opt2, sch2 = make(1, wrap)  # a FRESH model + optimizer (different weights, no moments)
+        m2(torch.randn(4, 6)).pow(2).sum().backward()
+        opt2.step(); opt2.zero_grad()             # torch needs the state entries to exist before set_optimizer_state_dict fills them
+        ck2 = MI355XCheckpointer(dataloader=None, model_parts=[m2], optimizers=handed2, schedulers=None, states={}, checkpointing_steps=2, checkpointing_limit=2,
+                                 output_dir=str(out), enable=True)
+        assert ck2.load(step=-1) is True          # the latest (step 7)
+        assert torch.equal(m2.lora_A.detach(), want_a) and torch.equal(opt2.state[m2.lora_A]["exp_avg"], want_m)
+        assert float(opt2.state[m2.lora_A]["step"]) == 3.0
+        assert ck2.load(step=6) is False          # no such directory
+
+    # a failing training-state write must not swallow the adapters: the hook still runs
+    class Boom:
+        optimizers = [None]
+
+    m, _, _, _ = make(2, False)
+    hooked = []
+    ck = MI355XCheckpointer(model_parts=[m], optimizers=Boom(), states={}, checkpointing_steps=1, output_dir=str(tmp_path / "boom"), _callback_fn=lambda sd: hooked.append(1))
+    with pytest.raises(Exception):
+        ck.save(step=1, force=True)
+    assert hooked == [1]

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
         std::vector<uint16_t> hx((size_t)M * K), hw((size_t)2 * nout * K);
         fill_random(hx, 1, 1.f);
         fill_random(hw, 2, 1.f / sqrtf((float)K));
-        const int nx = std::max(1, (int)(6e8 / ((double)M * K * 2)));
+        const int nx = getenv("LAB_WARMX") ? 1 : std::max(1, (int)(6e8 / ((double)M * K * 2)));  // LAB_WARMX=1: one copy of X (stays in the 256-MB Infinity Cache)
         uint16_t *dx, *dw, *dout, *dref;
         CK(hipMalloc(&dx, hx.size() * 2 * nx)); CK(hipMalloc(&dw, hw.size() * 2));
         const size_t no = (size_t)M * 3 * nout;
@@ -102,6 +102,28 @@ int main(int argc, char** argv) {
             const double med = res[i][res[i].size() / 2];
             printf("M%d K%d nout %d  FTMI_SKINNY4=%-3s median %7.2f us  best %7.2f us  (X %.1f MB -> %.2f TB/s)   mismatch vs %s: %.2e\n", M, K, nout, cfg[i].c_str(), med * 1e3, res[i][0] * 1e3,
                    (double)M * K * 2 / 1e6, (double)M * K * 2 / med / 1e9, cfg[0].c_str(), mism[i]);
+        }
+        {   // phase timeline of the 64-row kernel (wave 0 of every workgroup; shader cycles relative to the earliest workgroup start)
+            run("1", dout, false);
+            CK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> tr(512 * 8, 0);
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(ftmi::g_sk4_trace), tr.data(), tr.size() * 8));
+            run("1", dout, false);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(ftmi::g_sk4_trace), tr.size() * 8));
+            const int nwg = (((M + 63) / 64 + 7) / 8) * 8 * (2 * nout / 64);
+            unsigned long long t0 = ~0ull;
+            for (int w = 0; w < nwg && w < 512; ++w) t0 = std::min(t0, tr[w * 8]);
+            double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+            const int n = std::min(nwg, 512);
+            int cnt = 0;
+            for (int w = 0; w < n; ++w) {
+                if (tr[w * 8 + 5] <= tr[w * 8]) continue;  // a surplus block of the short last group
+                ++cnt;
+                for (int i = 0; i < 6; ++i) { const double d = (double)(tr[w * 8 + i] - tr[w * 8]); sum[i] += d; mx[i] = std::max(mx[i], d); }  // per-XCD clocks: relative to the workgroup's own start
+            }
+            printf("   timeline (cycles, mean / max over %d workgroups): start %.0f / %.0f | loads issued %.0f / %.0f | first chunk landed %.0f / %.0f | loop done %.0f / %.0f | barrier %.0f / %.0f | end %.0f / %.0f\n", n,
+                   sum[0] / cnt, mx[0], sum[1] / cnt, mx[1], sum[2] / cnt, mx[2], sum[3] / cnt, mx[3], sum[4] / cnt, mx[4], sum[5] / cnt, mx[5]);
         }
         fflush(stdout);
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dout)); CK(hipFree(dref));
