@@ -397,556 +397,15 @@ FTMI_DEVICE void vm_wait_leave(int n) {
 }
 
 #ifdef FTMI_EXPERIMENTAL
-// ------------------------------------------------------------------------------------------------
-// forward for FEW KEYS (Sk <= 128, head_dim 64: LTX cross-attention) -- EXPERIMENT, not shipped (profiles/r04_cross_attention.txt: 18.2 us against
-// 19.9 us for the general kernel in its first form, 19.5 against 18.4 us with Q through the row DMA and counted waits: the forward reads only Q (22 MB) and
-// its arithmetic hides the loads either way.  The dQ twin below, which reads three tensors, gains 22 % from the same changes and IS shipped).  attn_fwd_kernel gives every 128 query rows their own workgroup and every
-// workgroup its own K / V staging chain: 1 344 workgroups of ~1 us of arithmetic, 19.5 us per launch for 44 MB.  Here the (at most two) K / V tiles are
-// staged once and stay resident while the workgroup walks `bpw` 128-row query blocks -- no DMA, no barrier in the loop, one round of workgroups.  The
-// arithmetic per block is attn_fwd_kernel<HAS_KB, AF_LAZY | AF_MAX16> statement for statement (two 64-key tiles, lazy rescale): bit-identical outputs.
-// ------------------------------------------------------------------------------------------------
-static constexpr int kFwdResLds = 2 * 16384 + 2 * 256 + 2 * 16384;  // resident (K, V) tiles + key-bias rows + two 128-row Q staging buffers
-
-template <bool HAS_KB>
-__global__ __launch_bounds__(256, 2) void attn_fwd_res_kernel(AttnArgs a, int nblk, int bpw) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, g = lane >> 5;
-    const AttnBlock blk = attn_block(blockIdx.x, (nblk + bpw - 1) / bpw, a.H, a.B);
-    const int h = blk.h, b = blk.b;
-    const float sl = a.scale * kLog2e;
-    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
-    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
-    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
-    const int nt = (a.Sk + 63) / 64;  // 1 or 2
-    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
-    char* stg = smem + 2 * 16384 + 2 * 256;
-    const int n64 = (a.Sq + 63) / 64;
-    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane);  // Q through LDS with row-contiguous DMA (whole lines), not per-lane row gathers
-    auto stage_rows = [&](int qb, int buf) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int t64 = min(2 * qb + half, n64 - 1);
-            tile_dma_issue(qd, qbase, a.q_ss, t64, t64 == n64 - 1, stg + buf * 16384 + half * 8192, wave);
-        }
-    };
-    const int qb0 = blk.tile * bpw, qb_end = min(nblk, qb0 + bpw);
-    {
-        const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
-        for (int t = 0; t < nt; ++t) {
-            char* tb = smem + t * 16384;
-            tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
-            tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
-            if constexpr (HAS_KB) {
-                if (tid < 64) {
-                    const int j = t * 64 + tid;
-                    reinterpret_cast<float*>(smem + 2 * 16384)[t * 64 + tid] = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;
-                }
-            }
-        }
-        if (qb0 < qb_end) stage_rows(qb0, 0);
-        if (qb0 + 1 < qb_end) stage_rows(qb0 + 1, 1);
-        tile_dma_wait();
-        __syncthreads();
-    }
-    s16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
-
-    for (int qb = qb0; qb < qb_end; ++qb) {
-        const int cur = (qb - qb0) & 1;
-        char* qs = stg + cur * 16384 + (wave >> 1) * 8192;
-        const int is = wave & 1;
-        const int i = qb * 128 + wave * 32 + li;
-        s16x8 qf[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) qf[c] = read_row_frag(qs, is * 32 + li, c, g);
-        float m_run = -INFINITY, l_run = 0.f;
-        f32x16 oacc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            oacc[0][r] = 0.f;
-            oacc[1][r] = 0.f;
-        }
-        for (int t = 0; t < nt; ++t) {
-            const char* ks = smem + t * 16384;
-            const char* vs = ks + 8192;
-            const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + t * 64;
-            f32x16 st[2];
-#pragma unroll
-            for (int js = 0; js < 2; ++js) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
-                    st[js] = mfma32(kf, qf[c], st[js]);
-                }
-            }
-            float mx = -INFINITY;
-            if constexpr (HAS_KB) {
-#pragma unroll
-                for (int js = 0; js < 2; ++js)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float x = __builtin_fmaf(st[js][rq * 4 + j], sl, b4[j]);
-                            st[js][rq * 4 + j] = x;
-                            mx = fmaxf(mx, x);
-                        }
-                    }
-            } else {
-                mx = fmaxf(max16(st[0]), max16(st[1])) * sl;
-            }
-            mx = xhalf_max(mx);
-            float m_new = fmaxf(m_run, mx);
-            float alpha;
-            const bool grow = (mx - m_run) > 8.0f;  // lazy rescale, as in attn_fwd_kernel (also true for the first tile: m_run = -inf)
-            if (__builtin_amdgcn_ballot_w64(grow) == 0) {
-                m_new = m_run;
-                alpha = 1.0f;
-            } else {
-                const float m_eff0 = (m_new == -INFINITY) ? 0.f : m_new;
-                alpha = fast_exp2(m_run - m_eff0);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-            }
-            const float m_eff = (m_new == -INFINITY) ? 0.f : m_new;
-#pragma unroll
-            for (int js = 0; js < 2; ++js)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[js][r] = HAS_KB ? fast_exp2(st[js][r] - m_eff) : fast_exp2(__builtin_fmaf(st[js][r], sl, -m_eff));
-            m_run = m_new;
-            f32x16 lsum;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
-#pragma unroll
-            for (int js = 0; js < 2; ++js)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const s16x8 pf = pack_frag(st[js], hh);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt) {
-                        const s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
-                        oacc[dt] = mfma32(vf, pf, oacc[dt]);
-                    }
-                    lsum = mfma32(ones, pf, lsum);
-                }
-            l_run = l_run * alpha + lsum[0];
-        }
-        const float inv = 1.0f / l_run;
-        bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
-        store_rows_via_lds(qs + is * 4096, oacc, inv, ob, a.o_ss, qb * 128 + wave * 32, a.Sq, lane);  // scratch = this wave's own 32 Q rows (fragments are in registers)
-        if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
-        if (qb + 1 < qb_end) {
-            // (raw barriers: __syncthreads() carries a release fence, i.e. an s_waitcnt vmcnt(0) that would drain the stores just issued)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave is done with the current buffer
-            const bool more = qb + 2 < qb_end;
-            if (more) stage_rows(qb + 2, cur);  // 4 DMA instructions per wave, younger than this block's stores
-            // wait for block qb + 1's Q (issued an iteration ago); a full block left exactly 4 output stores (+ 1 lse store) per wave in flight
-            const bool full = qb * 128 + 128 <= a.Sq;
-            vm_wait_leave(full ? (more ? 4 : 0) + 4 + (a.lse2 ? 1 : 0) : 0);
-            asm volatile("s_barrier" ::: "memory");
-        }
-    }
-}
-
+#include "../../tools/experimental/attention_experimental_1.hip.h"  // forward for FEW KEYS (Sk <= 128, head_dim 64: LTX cross-attention) -- EXPERIMENT, not shipped (profiles/r04_cr
 #endif  // FTMI_EXPERIMENTAL (few-keys forward)
 
 #ifdef FTMI_EXPERIMENTAL
-// ------------------------------------------------------------------------------------------------
-// forward, two waves per SIMD in opposite phases (head_dim 64, no key bias)
-//
-// What bounds attn_fwd_kernel (profiles/r02_attention_experiments.txt): per 64-key tile a wave issues 20 MFMAs (640
-// matrix-pipe cycles) and ~110 VALU + 32 v_exp (~710 issue cycles), one after the other inside its dependence chain scores -> softmax ->
-// P.V, and three free-running waves per SIMD end up taking matrix + VALU time per tile: nothing overlaps.  Here the overlap is built in
-// (MI355X_MICROARCH.md, "Two waves per SIMD"): a workgroup is 8 waves = 256 query rows; waves w and w + 4 share a SIMD and run in
-// OPPOSITE phases of a two-phase loop, workgroup barrier in between:
-//     matrix phase M(t):  P(t-1).V(t-1) and the row sums (12 MFMAs, V fragments by transposing LDS reads), then S(t) = K(t).Q^T (8 MFMAs)
-//     vector phase V(t):  row max of S(t), lazy rescale, exp2, packing P(t) to bf16 fragments          (VALU only, no LDS, no MFMA)
-// so at any time a SIMD's matrix pipe works for one wave while its VALU works for the other: 2 wave-tiles per ~(640 | 710)-cycle pair of
-// half-steps instead of 1 per 1300.  The software pipeline inside a wave (P.V of tile t-1 next to the scores of tile t) needs no extra
-// registers: S(t) overwrites the score registers that P(t-1) was packed out of.  K and V tiles have different lifetimes now (K(t): two
-// half-steps from 2t; V(t): two half-steps from 2t + 2), so they live in two 2-deep rings filled by direct-to-LDS loads issued at the even
-// half-steps, waited for (own vmcnt, then the workgroup barrier) at the end of the following odd one.  Arithmetic per query row is the
-// same sequence of operations as attn_fwd_kernel's (same lazy-rescale rule); the row sum stays on the matrix pipe as ONE accumulator
-// across tiles (rescaled with O when the reference max moves).
-// MEASURED (round 3, profiles/r03_attention_experiments.txt): bit-compatible with attn_fwd_kernel (7.8e-6) and SLOWER -- 180 us against
-// 149 us at cfg 2 (2 x 32 x 2688 x 64), 3.15 ms against 2.67 ms at CogVideoX's 17 776 tokens; the unpinned schedule 173 us / 3.02 ms.
-// Per wave-tile and SIMD the three free-running waves of the 4-wave kernel take ~907 cycles (its waves DO overlap about a third of
-// matrix + vector time statistically); the two phase-locked waves take ~1000: every half-step opens with an exposed LDS-read -> MFMA or
-// MFMA -> row-max latency that a third wave used to cover, and there are two workgroup barriers per tile instead of one.  Kept in the
-// experimental build only (FTMI_ATTN_FWD8=1 | 2 selects it there).
-// ------------------------------------------------------------------------------------------------
-static constexpr int kFwd8Lds = 4 * 8192;  // K ring (2 x 8 KiB) + V ring (2 x 8 KiB); the 8 x 4 KiB store scratch overlays them at the end
-
-struct TileDma8 {
-    uint32_t off, offl;
-};
-FTMI_DEVICE TileDma8 tile_dma8_setup(long stride, int nrows, int wave, int lane) {  // 8 waves x one 1-KiB piece (8 rows x 128 B) per tile
-    TileDma8 d;
-    const int last0 = ((nrows + 63) / 64 - 1) * 64;
-    const int row = wave * 8 + (lane >> 3), slot = lane & 7;
-    const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-    const int chunk = slot ^ f;
-    d.off = (uint32_t)(((long)row * stride + chunk * 8) * 2);
-    d.offl = (uint32_t)(((long)min(row, nrows - 1 - last0) * stride + chunk * 8) * 2);
-    return d;
-}
-FTMI_DEVICE void tile_dma8_issue(const TileDma8& d, const bf16_t* base, long stride, int t, bool last, char* lds, int wave) {
-    const char* b = (const char*)base + (long)t * 64 * stride * 2;
-    const uint32_t o = last ? d.offl : d.off;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + wave * 1024));
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(o), "s"(b) : "memory", "m0");
-}
-
-// PIN: scheduling barriers around every phase barrier, so that hipcc keeps the vector work out of the matrix phase and vice versa
-// (unpinned it sinks about half of the exp2 / pack work below the barrier, in between the MFMAs)
-template <bool RAGGED, bool PIN>
-__global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;  // 0: waves 0-3 (first on their SIMDs), 1: waves 4-7 (their partners), one half-step behind
-    const int li = lane & 31, g = lane >> 5;
-    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 255) / 256, a.H, a.B);
-    const int h = blk.h, b = blk.b;
-    const int i = blk.tile * 256 + wave * 32 + li;
-    const int ic = min(i, a.Sq - 1);
-    const float sl = a.scale * kLog2e;
-
-    const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
-    s16x8 qf[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qf[c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
-    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
-    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
-
-    s16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
-    f32x16 oacc[2], lsum, st[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] = oacc[1][r] = lsum[r] = st[0][r] = st[1][r] = 0.f;
-    s16x8 pf[4];  // P of the previous tile, packed: pf[js * 2 + hh]
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pf[e][k] = 0;
-    float m_run = -INFINITY;
-
-    const int nt = (a.Sk + 63) / 64;
-    const TileDma8 kd = tile_dma8_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma8_setup(a.v_ss, a.Sk, wave, lane);
-    char* kring = smem;
-    char* vring = smem + 2 * 8192;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) settle(qf[c]);
-    tile_dma8_issue(kd, kbase, a.k_ss, 0, nt == 1, kring, wave);
-    tile_dma_wait();
-    __syncthreads();
-
-    // even half-step 2t: K(t+1) and V(t) start their way into the rings (every wave one piece of each)
-    auto issue_even = [&](int t) {
-        if (t + 1 < nt) tile_dma8_issue(kd, kbase, a.k_ss, t + 1, t + 1 == nt - 1, kring + ((t + 1) & 1) * 8192, wave);
-        if (t < nt) tile_dma8_issue(vd, vbase, a.v_ss, t, t == nt - 1, vring + (t & 1) * 8192, wave);
-    };
-    // matrix work: P(t).V(t) + row sums (12 MFMAs, V fragments by transposing LDS reads) / S(t) = K(t).Q^T (8 MFMAs)
-    auto pv = [&](int t) {
-        const char* vs = vring + (t & 1) * 8192;
-#pragma unroll
-        for (int js = 0; js < 2; ++js)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);
-                    oacc[dt] = mfma32(vf, pf[js * 2 + hh], oacc[dt]);
-                }
-                lsum = mfma32(ones, pf[js * 2 + hh], lsum);
-            }
-    };
-    auto qk = [&](int t) {
-        const char* ks = kring + (t & 1) * 8192;
-#pragma unroll
-        for (int js = 0; js < 2; ++js) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[js][r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);
-                st[js] = mfma32(kf, qf[c], st[js]);
-            }
-        }
-    };
-    // vector work: softmax of S(t) in the log2 domain, per lane (= per query row); VALU only, no LDS, no MFMA
-    auto sm = [&](int t) {
-        if constexpr (RAGGED) {
-            if (t == nt - 1) {  // register r of sub-tile js holds key t*64 + js*32 + crow(r, g)
-#pragma unroll
-                for (int js = 0; js < 2; ++js)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (t * 64 + js * 32 + crow(r, g) >= a.Sk) st[js][r] = -INFINITY;
-            }
-        }
-        const float mx = xhalf_max(fmaxf(max16(st[0]), max16(st[1])) * sl);
-        // lazy rescale: keep the old reference max while no row of the wave outgrew it by more than 2^8 (attn_fwd_kernel's rule)
-        float m_new = fmaxf(m_run, mx);
-        const bool grow = (mx - m_run) > 8.0f;  // also true for the first tile (m_run = -inf)
-        if (__builtin_amdgcn_ballot_w64(grow) == 0) {
-            m_new = m_run;
-        } else {
-            const float m_eff0 = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run - m_eff0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                oacc[0][r] *= alpha;
-                oacc[1][r] *= alpha;
-                lsum[r] *= alpha;
-            }
-        }
-        const float m_eff = (m_new == -INFINITY) ? 0.f : m_new;
-#pragma unroll
-        for (int js = 0; js < 2; ++js) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[js][r] = fast_exp2(__builtin_fmaf(st[js][r], sl, -m_eff));
-            pf[js * 2 + 0] = pack_frag(st[js], 0);
-            pf[js * 2 + 1] = pack_frag(st[js], 1);
-        }
-        m_run = m_new;
-    };
-    // The two groups run the SAME sequence of 2 nt + 2 half-steps (one workgroup barrier each), one half-step apart; each group's loop is
-    // straight-line code (a shared loop with "which phase am I in" branches made hipcc copy the accumulators around every branch).
-    // Pieces issued at an even half-step are waited for (own vmcnt) before the barrier that ends the next odd one.
-    auto phase_barrier = [&]() {
-        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
-    };
-    if (grp == 0) {
-        issue_even(0);
-        qk(0);
-        phase_barrier();  // half-step 0
-        for (int t = 0; t + 1 < nt; ++t) {
-            sm(t);
-            tile_dma_wait();
-            phase_barrier();  // 2t + 1
-            issue_even(t + 1);
-            pv(t);
-            qk(t + 1);
-            phase_barrier();  // 2t + 2
-        }
-        sm(nt - 1);
-        tile_dma_wait();
-        phase_barrier();  // 2nt - 1
-        pv(nt - 1);
-        phase_barrier();  // 2nt
-        phase_barrier();  // 2nt + 1: the partner's last matrix phase
-    } else {
-        issue_even(0);
-        phase_barrier();  // half-step 0: the partner's first matrix phase
-        qk(0);
-        tile_dma_wait();
-        phase_barrier();  // 1
-        for (int t = 0; t + 1 < nt; ++t) {
-            issue_even(t + 1);
-            sm(t);
-            phase_barrier();  // 2t + 2
-            pv(t);
-            qk(t + 1);
-            tile_dma_wait();
-            phase_barrier();  // 2t + 3
-        }
-        sm(nt - 1);
-        phase_barrier();  // 2nt
-        pv(nt - 1);
-        phase_barrier();  // 2nt + 1
-    }
-
-    {
-        const float l_run = lsum[0];
-        const float inv = 1.0f / l_run;
-        bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
-        store_rows_via_lds(smem + wave * 4096, oacc, inv, ob, a.o_ss, blk.tile * 256 + wave * 32, a.Sq, lane);
-        if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_run + __log2f(l_run);
-    }
-}
-
+#include "../../tools/experimental/attention_experimental_2.hip.h"  // forward, two waves per SIMD in opposite phases (head_dim 64, no key bias)
 #endif  // FTMI_EXPERIMENTAL
 
 #ifdef FTMI_EXPERIMENTAL
-// ------------------------------------------------------------------------------------------------
-// forward, 64 query rows per wave (EXPERIMENT, not shipped: measured 156.6 us against 148.2 us for the 32-row kernel with the same lazy
-// rescale on the cfg-2 shape -- what it saves in LDS instructions it loses to 704 workgroups on 512 slots; profiles/README.md).
-// Measured on the first generation (tools/bench_attn.py ablations, profiles/README.md): the loop is bound by the ISSUE of its non-matrix
-// instructions -- removing the exp2s, the P.V half or the tile reload each saves its own share, the shares add up to the whole (nothing
-// overlaps), and the matrix pipe sits idle half of the time.  So this version cuts instructions per MFMA instead of adding overlap:
-//   * a wave owns TWO 32-row query tiles: every K row fragment and every V^T fragment read from LDS feeds two MFMAs (half the LDS
-//     instructions per MFMA), the loop overhead / DMA issue / barrier is shared by twice the work;
-//   * LAZY rescale: the running reference max m_ref of a row is only moved when some row of the wave outgrows it by more than 2^8
-//     (probabilities stay <= 2^8, same relative precision in bf16 / fp32); otherwise the tile costs no alpha, no O rescale, no l rescale;
-//   * the row sums stay on the matrix pipe (all-ones A operand) and accumulate across ALL tiles in one MFMA accumulator per query tile
-//     (never zeroed, rescaled only on the rare max move): 2 issue slots per 32 keys instead of 32 adds;
-//   * 3-input max (v_max3_f32), one v_permlane32_swap for the cross-half combine, scores consumed 32 keys at a time (live S: 32 registers).
-// Same LDS images, DMA staging and store path as the first generation.
-// ------------------------------------------------------------------------------------------------
-static constexpr float kLazyThr = 8.0f;  // log2 domain
-
-template <bool HAS_KB>
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, g = lane >> 5;
-    const AttnBlock blk = attn_block(blockIdx.x, (a.Sq + 255) / 256, a.H, a.B);
-    const int h = blk.h, b = blk.b;
-    const int row0 = blk.tile * 256 + wave * 64;  // first query row of this wave
-    const float sl = a.scale * kLog2e;
-
-    s16x8 qf[2][4];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int ic = min(row0 + qt * 32 + li, a.Sq - 1);
-        const bf16_t* qp = a.q + (long)b * a.q_sb + (long)h * a.q_sh + (long)ic * a.q_ss;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) qf[qt][c] = *reinterpret_cast<const s16x8*>(qp + c * 16 + g * 8);
-    }
-    const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
-    const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
-    const float* kbias = a.kbias ? a.kbias + (long)b * a.kb_sb + (long)h * a.kb_sh : nullptr;
-
-    float m_ref[2] = {-INFINITY, -INFINITY};
-    s16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;  // bf16 1.0
-    f32x16 oacc[2][2], lsum[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            oacc[qt][0][r] = 0.f;
-            oacc[qt][1][r] = 0.f;
-            lsum[qt][r] = 0.f;
-        }
-    }
-
-    const int nt = (a.Sk + 63) / 64;
-    const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
-    float kbr = 0.f;
-    auto stage = [&](int t, int buf) {
-        char* tb = smem + buf * 16384;
-        tile_dma_issue(kd, kbase, a.k_ss, t, t == nt - 1, tb, wave);
-        tile_dma_issue(vd, vbase, a.v_ss, t, t == nt - 1, tb + 8192, wave);
-        if constexpr (HAS_KB) {
-            if (tid < 64) {
-                int j = t * 64 + tid;
-                kbr = (j < a.Sk) ? (kbias ? kbias[j] * kLog2e : 0.f) : -INFINITY;
-            }
-        }
-    };
-    auto stage_commit = [&](int buf) {
-        if constexpr (HAS_KB) {
-            if (tid < 64) reinterpret_cast<float*>(smem + 2 * 16384)[buf * 64 + tid] = kbr;
-        }
-    };
-
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        settle(qf[0][c]);
-        settle(qf[1][c]);
-    }
-    stage(0, 0);
-    stage_commit(0);
-    tile_dma_wait();
-    __syncthreads();
-    auto body = [&](int t, auto CUR) {
-        constexpr int cur = decltype(CUR)::value;
-        const char* ks = smem + cur * 16384;
-        const char* vs = ks + 8192;
-        const float* kb = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 64;
-        if (t + 1 < nt) stage(t + 1, cur ^ 1);
-#pragma unroll
-        for (int js = 0; js < 2; ++js) {  // 32 keys at a time
-            f32x16 st[2];
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[qt][r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const s16x8 kf = read_row_frag(ks, js * 32 + li, c, g);  // one LDS read, two MFMAs
-                st[0] = mfma32(kf, qf[0][c], st[0]);
-                st[1] = mfma32(kf, qf[1][c], st[1]);
-            }
-            s16x8 pf[2][2];
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                // x = s * sl (+ bias) in the log2 domain; row max over this lane's 16 keys, then across the two half-waves
-                float mx;
-                if constexpr (HAS_KB) {
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + js * 32 + rq * 8 + 4 * g);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) st[qt][rq * 4 + j] = __builtin_fmaf(st[qt][rq * 4 + j], sl, b4[j]);
-                    }
-                }
-                mx = max16(st[qt]);
-                if constexpr (!HAS_KB) mx *= sl;  // sl > 0
-                mx = xhalf_max(mx);
-                // lazy reference max: move it only when some row of the wave outgrew it by more than 2^kLazyThr (always on the first tile)
-                if (__builtin_amdgcn_ballot_w64((mx - m_ref[qt]) > kLazyThr) != 0) {
-                    const float m_new = fmaxf(m_ref[qt], mx);
-                    // (m_new == -inf only while every key so far carries a -inf bias: those contribute exp2(-inf) = 0 against 0)
-                    const float alpha = fast_exp2(m_ref[qt] - ((m_new == -INFINITY) ? 0.f : m_new));
-                    m_ref[qt] = m_new;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        oacc[qt][0][r] *= alpha;
-                        oacc[qt][1][r] *= alpha;
-                        lsum[qt][r] *= alpha;
-                    }
-                }
-                const float m_eff = (m_ref[qt] == -INFINITY) ? 0.f : m_ref[qt];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    st[qt][r] = HAS_KB ? fast_exp2(st[qt][r] - m_eff) : fast_exp2(__builtin_fmaf(st[qt][r], sl, -m_eff));
-                pf[qt][0] = pack_frag(st[qt], 0);
-                pf[qt][1] = pack_frag(st[qt], 1);
-            }
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const s16x8 vf = read_tr_frag(vs, dt * 32, js * 32 + hh * 16, lane);  // one fragment, two MFMAs
-                    oacc[0][dt] = mfma32(vf, pf[0][hh], oacc[0][dt]);
-                    oacc[1][dt] = mfma32(vf, pf[1][hh], oacc[1][dt]);
-                }
-                // row sums of the bf16-rounded probabilities on the matrix pipe (numerator and denominator use the same numbers)
-                lsum[0] = mfma32(ones, pf[0][hh], lsum[0]);
-                lsum[1] = mfma32(ones, pf[1][hh], lsum[1]);
-            }
-        }
-        if (t + 1 < nt) stage_commit(cur ^ 1);
-        tile_dma_wait();
-        __syncthreads();  // tile t+1 landed (the barrier drains this wave's DMA first) and tile t's buffer is free again
-    };
-    for (int t = 0; t < nt; t += 2) {
-        body(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nt) body(t + 1, std::integral_constant<int, 1>{});
-    }
-
-    bf16_t* ob = a.o + (long)b * a.o_sb + (long)h * a.o_sh;
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const float l = lsum[qt][0];
-        store_rows_via_lds(smem + wave * 4096, oacc[qt], 1.0f / l, ob, a.o_ss, row0 + qt * 32, a.Sq, lane);
-        const int i = row0 + qt * 32 + li;
-        if (i < a.Sq && g == 0 && a.lse2) a.lse2[((long)b * a.H + h) * a.Sq + i] = m_ref[qt] + __log2f(l);
-    }
-}
+#include "../../tools/experimental/attention_experimental_3.hip.h"  // forward, 64 query rows per wave (EXPERIMENT, not shipped: measured 156.6 us against 148.2 us for the 32-row ke
 #endif  // FTMI_EXPERIMENTAL
 
 // Shipped kernels: forward and dK/dV with 32 rows per wave, dQ with 64 rows per wave (each the faster of its two generations on the
@@ -965,32 +424,7 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
     dim3 grid(((a.Sq + 127) / 128) * a.H * a.B);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Sk * a.d, st);
 #ifdef FTMI_EXPERIMENTAL
-    const int fv = env_int("FTMI_ATTN_FWD", 0);  // re-read every call: tools/bench_attn.py switches variants inside one process
-    if (fv && !(a.kbias || (a.Sk % 64) != 0)) {
-        switch (fv) {
-#define FTMI_AF(id, FLAGS, MINW) case id: hipLaunchKernelGGL((attn_fwd_kernel<false, FLAGS, MINW>), grid, dim3(256), kFwdLds, st, a); return check_launch("attn_fwd");
-            FTMI_AF(1, AF_VALU_ROWSUM, 1)
-            FTMI_AF(2, AF_LAZY, 1)
-            FTMI_AF(3, AF_VALU_ROWSUM | AF_LAZY, 1)
-            FTMI_AF(4, AF_ABL_NOEXP, 1)
-            FTMI_AF(5, AF_ABL_NOPV, 1)
-            FTMI_AF(6, AF_ABL_NOLOAD, 1)
-            FTMI_AF(7, AF_ABL_NOEXP | AF_ABL_NOLOAD, 1)
-            FTMI_AF(8, AF_ABL_NOEXP | AF_ABL_NOPV | AF_ABL_NOLOAD, 1)
-            FTMI_AF(10, 0, 2)
-            FTMI_AF(11, 0, 4)
-            FTMI_AF(12, AF_VALU_ROWSUM | AF_LAZY, 2)
-            FTMI_AF(13, AF_VALU_ROWSUM | AF_LAZY, 4)
-            FTMI_AF(14, AF_LAZY, 2)
-            FTMI_AF(15, AF_LAZY, 4)
-            FTMI_AF(16, AF_LAZY | AF_MAX16, 1)
-            FTMI_AF(17, AF_MAX16, 1)
-            FTMI_AF(18, AF_LAZY | AF_MAX16, 2)
-            FTMI_AF(19, AF_LAZY | AF_MAX16 | AF_TIMING, 1)
-#undef FTMI_AF
-            default: break;
-        }
-    }
+#include "../../tools/experimental/attention_experimental_4.hip.h"  // 
 #endif
 #ifdef FTMI_EXPERIMENTAL
     if (attn_gen("FTMI_ATTN_FWD_GEN", 1) == 2) {  // 64 query rows per wave
@@ -1864,164 +1298,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
 #include "attention_pl.hip.h"
 
 #ifdef FTMI_EXPERIMENTAL
-// ------------------------------------------------------------------------------------------------
-// backward dK / dV, 64 keys per wave (EXPERIMENT, not shipped: 508 us against 445 us for the whole backward with the 32-key kernel -- one
-// wave per SIMD leaves the LDS / MFMA latencies of its single in-order stream exposed).  64 keys per wave (two 32-key tiles share every Q / dO row fragment and every Q^T / dO^T
-// fragment read from LDS: 24 LDS reads per 32 MFMAs instead of 48).  The four accumulator sets (dK, dV for two key tiles = 128
-// registers) plus the K / V fragments (64) take the wave past 256 registers, so this kernel runs ONE wave per SIMD with the whole
-// 512-entry register file (one 256-thread workgroup per CU; 704 workgroups at the cfg-2 shape = 2.75 per CU).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv2_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, g = lane >> 5;
-    const AttnBlock blk = attn_block(blockIdx.x, (a.Sk + 255) / 256, a.H, a.B);
-    const int h = blk.h, b = blk.b;
-    const int key0 = blk.tile * 256 + wave * 64;
-    const float sl = a.scale * kLog2e;
-
-    s16x8 kf[2][4], vf[2][4];
-    float bias_j[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const int jc = min(key0 + kt * 32 + li, a.Sk - 1);
-        const bf16_t* kp = a.k + (long)b * a.k_sb + (long)h * a.k_sh + (long)jc * a.k_ss;
-        const bf16_t* vp = a.v + (long)b * a.v_sb + (long)h * a.v_sh + (long)jc * a.v_ss;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            kf[kt][c] = *reinterpret_cast<const s16x8*>(kp + c * 16 + g * 8);
-            vf[kt][c] = *reinterpret_cast<const s16x8*>(vp + c * 16 + g * 8);
-        }
-        bias_j[kt] = a.kbias ? a.kbias[(long)b * a.kb_sb + (long)h * a.kb_sh + jc] * kLog2e : 0.f;
-    }
-
-    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
-    const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
-    const float* lsebase = a.lse2 + ((long)b * a.H + h) * a.Sq;
-    const float* delbase = a.delta + ((long)b * a.H + h) * a.Sq;
-
-    f32x16 dkt[2][2], dvt[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dkt[kt][dt][r] = 0.f;
-                dvt[kt][dt][r] = 0.f;
-            }
-
-    const int ni = (a.Sq + 63) / 64;
-    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane);
-    float lser = 0.f, delr = 0.f;
-    auto stage = [&](int t, int buf) {
-        char* tb = smem + buf * 16384;
-        tile_dma_issue(qd, qbase, a.q_ss, t, t == ni - 1, tb, wave);
-        tile_dma_issue(dod, dobase, a.do_ss, t, t == ni - 1, tb + 8192, wave);
-        if (tid < 64) {
-            int i = t * 64 + tid;
-            lser = (i < a.Sq) ? lsebase[i] : INFINITY;  // +inf => p = 0 for padded query rows
-            delr = (i < a.Sq) ? delbase[i] : 0.f;
-        }
-    };
-    auto stage_commit = [&](int buf) {
-        if (tid < 64) {
-            float* st = reinterpret_cast<float*>(smem + 2 * 16384) + buf * 128;
-            st[tid] = lser;
-            st[64 + tid] = delr;
-        }
-    };
-
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        settle(kf[0][c]);
-        settle(kf[1][c]);
-        settle(vf[0][c]);
-        settle(vf[1][c]);
-    }
-    settle(bias_j[0]);
-    settle(bias_j[1]);
-    stage(0, 0);
-    stage_commit(0);
-    tile_dma_wait();
-    __syncthreads();
-    auto body = [&](int t, auto CUR) {
-        constexpr int cur = decltype(CUR)::value;
-        const char* qs = smem + cur * 16384;
-        const char* dos = qs + 8192;
-        const float* lses = reinterpret_cast<const float*>(smem + 2 * 16384) + cur * 128;
-        const float* dels = lses + 64;
-        if (t + 1 < ni) stage(t + 1, cur ^ 1);
-#pragma unroll
-        for (int is = 0; is < 2; ++is) {  // 32 query rows at a time
-            f32x16 s[2], dp[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[kt][r] = 0.f;
-                    dp[kt][r] = 0.f;
-                }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const s16x8 qf = read_row_frag(qs, is * 32 + li, c, g);
-                s[0] = mfma32(qf, kf[0][c], s[0]);
-                s[1] = mfma32(qf, kf[1][c], s[1]);
-                const s16x8 dof = read_row_frag(dos, is * 32 + li, c, g);
-                dp[0] = mfma32(dof, vf[0][c], dp[0]);
-                dp[1] = mfma32(dof, vf[1][c], dp[1]);
-            }
-            s16x8 pf[2][2], dsf[2][2];
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lses + is * 32 + rq * 8 + 4 * g);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dels + is * 32 + rq * 8 + 4 * g);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = rq * 4 + j;
-                        const float p = fast_exp2(__builtin_fmaf(s[kt][r], sl, bias_j[kt] - l4[j]));
-                        s[kt][r] = p;
-                        dp[kt][r] = p * (dp[kt][r] - d4[j]);
-                    }
-            }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    pf[kt][hh] = pack_frag(s[kt], hh);
-                    dsf[kt][hh] = pack_frag(dp[kt], hh);
-                }
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const s16x8 dotf = read_tr_frag(dos, dt * 32, is * 32 + hh * 16, lane);
-                    dvt[0][dt] = mfma32(dotf, pf[0][hh], dvt[0][dt]);
-                    dvt[1][dt] = mfma32(dotf, pf[1][hh], dvt[1][dt]);
-                    const s16x8 qtf = read_tr_frag(qs, dt * 32, is * 32 + hh * 16, lane);
-                    dkt[0][dt] = mfma32(qtf, dsf[0][hh], dkt[0][dt]);
-                    dkt[1][dt] = mfma32(qtf, dsf[1][hh], dkt[1][dt]);
-                }
-        }
-        if (t + 1 < ni) stage_commit(cur ^ 1);
-        tile_dma_wait();
-        __syncthreads();
-    };
-    for (int t = 0; t < ni; t += 2) {
-        body(t, std::integral_constant<int, 0>{});
-        if (t + 1 < ni) body(t + 1, std::integral_constant<int, 1>{});
-    }
-
-    bf16_t* dkb = a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh;
-    bf16_t* dvb = a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        store_rows_via_lds(smem + wave * 4096, dkt[kt], a.scale, dkb, a.dk_ss, key0 + kt * 32, a.Sk, lane);
-        store_rows_via_lds(smem + wave * 4096, dvt[kt], 1.0f, dvb, a.dv_ss, key0 + kt * 32, a.Sk, lane);
-    }
-}
+#include "../../tools/experimental/attention_experimental_5.hip.h"  // backward dK / dV, 64 keys per wave (EXPERIMENT, not shipped: 508 us against 445 us for the whole backward with
 #endif  // FTMI_EXPERIMENTAL
 
 int attn_bwd(const AttnArgs& a, hipStream_t st) {

@@ -26,13 +26,15 @@ FLAGS = [
 # dS products read/modify them with VALU every tile, and the accumulator-file round trip (v_accvgpr_read/write) was 25-35 %
 # of the loop's instructions in a VALU-bound kernel.
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-# FTMI_EXPERIMENTAL=1: also compile the research K loops / timing experiments of tools/gemm_experimental.hip.h (tools/bench_gemm.py,
+# FTMI_EXPERIMENTAL=1: also compile the research K loops / timing experiments of tools/experimental/gemm_experimental.hip.h (tools/bench_gemm.py,
 # tools/ab_variants.sh).  Never set for the product library.
 if os.environ.get("FTMI_EXPERIMENTAL", "0") not in ("", "0"):
     FLAGS.append("-DFTMI_EXPERIMENTAL")
-    SOURCES.insert(1, "gemm_skinny.hip")  # the 64 x 128-tile LoRA down-projection kernel (measured slower than the shipped one: profiles/r03_skinny_experiments.txt)
-    SOURCES.insert(1, "gemm_sk.hip")      # the persistent stream-K GEMM (5-25 % slower than the shipped kernels: profiles/r03_gemm_streamk.txt)
-    HEADERS.append(os.path.join("..", "..", "tools", "gemm_experimental.hip.h"))
+    _EXP = os.path.join("..", "..", "tools", "experimental")  # research sources live outside csrc/: the product directory holds only what libftmi355.so ships
+    SOURCES.insert(1, os.path.join(_EXP, "gemm_skinny.hip"))  # the 64 x 128-tile LoRA down-projection kernel (measured slower than the shipped one: profiles/r03_skinny_experiments.txt)
+    SOURCES.insert(1, os.path.join(_EXP, "gemm_sk.hip"))      # the persistent stream-K GEMM (5-25 % slower than the shipped kernels: profiles/r03_gemm_streamk.txt)
+    HEADERS.append(os.path.join(_EXP, "gemm_experimental.hip.h"))
+    HEADERS += [os.path.join(_EXP, f) for f in sorted(os.listdir(os.path.join(HERE, _EXP))) if f.startswith("attention_experimental_")]
 
 
 def _hipcc() -> str:
@@ -71,8 +73,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def compile_one(src: str) -> str:
         s = os.path.join(HERE, src)
-        o = os.path.join(objdir, src + ".o")
-        flags = FLAGS + EXTRA_FLAGS.get(src, [])
+        o = os.path.join(objdir, os.path.basename(src) + ".o")
+        flags = FLAGS + EXTRA_FLAGS.get(src, []) + ["-I", HERE]
         dg = _digest([s] + hdrs, " ".join(flags))  # a change of flags (e.g. FTMI_EXPERIMENTAL on / off) invalidates the object
         if force or _stale(o, dg):
             cmd = [hipcc] + flags + ["-c", s, "-o", o]

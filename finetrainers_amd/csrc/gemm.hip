@@ -443,10 +443,10 @@ enum : int {
 constexpr int kl_lds_stages(int loop) { return loop >= 100 ? 2 : (loop == KL_RING4 || loop == KL_RING4_PIPE || loop == KL_ASM_RING4) ? 4 : (loop == KL_RING3) ? 3 : (loop == KL_PINGPONG) ? 4 : 2; }
 
 // Research scaffolding (alternative K loops, hand-placed asm loops, timing experiments with deliberately wrong results) lives in
-// tools/gemm_experimental.hip.h and is compiled only with -DFTMI_EXPERIMENTAL (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build):
+// tools/experimental/gemm_experimental.hip.h and is compiled only with -DFTMI_EXPERIMENTAL (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build):
 // the product library ships the production loop only.
 #ifdef FTMI_EXPERIMENTAL
-#include "../../tools/gemm_experimental.hip.h"
+#include "../../tools/experimental/gemm_experimental.hip.h"
 #endif
 
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int LOOP>

@@ -68,6 +68,11 @@ class DataParallelBackend:
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size,
                                     timeout=datetime.timedelta(seconds=timeout_s))
             self._owns_pg = True
+        if (self.world_size > 1 or self.exercise_collectives) and dist.is_initialized():
+            try:
+                self._gather_rank_devices()
+            except Exception:  # diagnostics only: never take the job down
+                self._rank_devices = None
 
     def describe(self) -> Dict[str, object]:
         """What the exchange runs on, for the bench line and the multi-GPU tests' logs."""
@@ -85,17 +90,20 @@ class DataParallelBackend:
         if dist.is_initialized():
             out["group_size"] = dist.get_world_size()
             out["group_rank"] = dist.get_rank()
-            if self._rank_devices is None:
-                mine = {"rank": dist.get_rank(), "local_rank": self.local_rank, "device": str(self.device)}
-                if self.device.type == "cuda":
-                    pr = torch.cuda.get_device_properties(self.device)
-                    mine.update(device_name=pr.name, device_index=self.device.index, pci_bus_id=getattr(pr, "pci_bus_id", None), uuid=str(getattr(pr, "uuid", "")))
-                got = [None] * dist.get_world_size()
-                dist.all_gather_object(got, mine)
-                self._rank_devices = got
-            out["rank_devices"] = self._rank_devices
-            out["distinct_devices"] = len({(d.get("device"), d.get("pci_bus_id"), d.get("uuid")) for d in self._rank_devices})
+            if self._rank_devices is not None:  # gathered ONCE, collectively, when the group was created (describe() itself is rank-local)
+                out["rank_devices"] = self._rank_devices
+                out["distinct_devices"] = len({(d.get("device"), d.get("pci_bus_id"), d.get("uuid")) for d in self._rank_devices})
         return out
+
+    def _gather_rank_devices(self) -> None:
+        """Collective (every rank calls it, right after the group exists): which device each rank of the communicator sits on."""
+        mine = {"rank": dist.get_rank(), "local_rank": self.local_rank, "device": str(self.device)}
+        if self.device.type == "cuda":
+            pr = torch.cuda.get_device_properties(self.device)
+            mine.update(device_name=pr.name, device_index=self.device.index, pci_bus_id=getattr(pr, "pci_bus_id", None), uuid=str(getattr(pr, "uuid", "")))
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, mine)
+        self._rank_devices = got
 
     # ---- properties mirroring BaseParallelBackend -------------------------------------------------------------
     @property
@@ -206,10 +214,15 @@ class GradBucketReducer:
 
     def finish(self) -> None:
         """Make the current stream wait for every outstanding bucket (device-side wait on RCCL; gloo: host wait + divide)."""
-        ev = None
-        if self.measure_exposed and self._pending and torch.cuda.is_available():
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
+        ev = t_host = None
+        if self.measure_exposed and self._pending:
+            if torch.cuda.is_available() and self.backend.device.type == "cuda":
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            else:  # CPU ranks (gloo): the wait is a host wait
+                import time
+
+                t_host = time.perf_counter()
         for work, div in self._pending:
             work.wait()
             if div is not None:
@@ -218,12 +231,16 @@ class GradBucketReducer:
         if ev is not None:
             ev[1].record()
             self._exposed.append(ev)
+        elif t_host is not None:
+            import time
+
+            self._exposed.append((time.perf_counter() - t_host) * 1e3)
 
     def exposed_ms(self) -> Optional[float]:
         """Mean time per step the compute stream spent waiting in finish() (call after a synchronize); None if nothing was measured."""
         if not self._exposed:
             return None
-        t = [a.elapsed_time(b) for a, b in self._exposed]
+        t = [e if isinstance(e, float) else e[0].elapsed_time(e[1]) for e in self._exposed]
         self._exposed.clear()
         return sum(t) / len(t)
 

@@ -118,7 +118,7 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
  * 0 = not a tiled launch (N % 64 or K % 64).  Host tests pin the choice to DESIGN.md. */
 int ftmi_gemm_nt_plan(int M, int N, int K, int K2, int epilogue);
 #ifdef FTMI_EXPERIMENTAL
-/* Research build only (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build): the persistent stream-K GEMM (csrc/gemm_sk.hip, variant 60) --
+/* Research build only (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build): the persistent stream-K GEMM (tools/experimental/gemm_sk.hip, variant 60) --
  * parity-green and 5-25 % slower than the shipped kernels on the step's shapes (profiles/r03_gemm_streamk.txt); not part of the product ABI. */
 /* The stream-K split of the persistent GEMM as a pure host function (no device needed; tests): the last `ntiles mod n_workgroups` tiles of
  * a launch form a cost line of (nk + owner_cost) units per tile -- nk K iterations, owner_cost = what finishing the tile (LoRA extension +

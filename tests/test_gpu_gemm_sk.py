@@ -1,4 +1,4 @@
-"""The persistent 256 x 256 stream-K GEMM (csrc/gemm_sk.hip, variant 60) against the one-tile-per-workgroup kernels (variant 61) on the
+"""The persistent 256 x 256 stream-K GEMM (tools/experimental/gemm_sk.hip, variant 60) against the one-tile-per-workgroup kernels (variant 61) on the
 SAME inputs, through the C ABI.  Inside a tile both accumulate K in the same order, so every tile a single workgroup computes must come
 out bit-identical; a tile split along K adds its fp32 partials in another order, which may flip the last bf16 bit of a few outputs
 (bounded below).  Also: the hand-off never gave up (ftmi_gemm_sk_status), concurrent launches on two streams, repeated launches

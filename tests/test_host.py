@@ -1210,3 +1210,32 @@ def test_checkpointer_round_trip_with_the_trainers_own_torch_optimizer(tmp_path)
     with pytest.raises(Exception):
         ck.save(step=1, force=True)
     assert hooked == [1]
+
+
+def test_bench_two_ranks_rehearsal_emits_the_multi_gpu_schema():
+    """The first multi-GPU run of bench.py happens on the driver's clock.  Everything that only exists at N > 1 -- the self-spawn under
+    torch.distributed.run on 127.0.0.1, the process group, the adapter broadcast, the bucket schedule of the 28-block backward, barrier + max-over-ranks
+    timing, rank 0's single JSON line with `exchange`, `exposed_comm_ms`, `buckets_per_step` -- is executed here end to end, on CPU over gloo
+    (FTMI_BENCH_REHEARSAL_CPU=1: no kernels, the line says "rehearsal").  The exchange block must come from the COMMUNICATOR (group size, one record per
+    rank), so that the driver can check N ranks on N devices from the line alone."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, FTMI_BENCH_REHEARSAL_CPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # ONE line, from rank 0
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "exchange", "exposed_comm_ms", "buckets_per_step"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "rehearsal" in d and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    ex = d["exchange"]
+    assert ex["backend"] == "gloo" and ex["world_size"] == 2 and ex["group_size"] == 2 and ex["group_rank"] == 0
+    assert sorted(r["rank"] for r in ex["rank_devices"]) == [0, 1] and "algo" in ex and "proto" in ex and "hsa_env_set_before_hip_init" in ex
+    assert d["buckets_per_step"] == 4.0                 # 28 blocks in ranges of 7, every step (warm-up included in the count and in the divisor)
+    assert isinstance(d["exposed_comm_ms"], float) and d["exposed_comm_ms"] >= 0.0
+    assert d["value"] > 0 and d["ms_per_step"] > 0
