@@ -1362,8 +1362,8 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     } else if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
         // hand-placed pipelines (attention_pl.hip.h): no key bias, whole key tiles.  FTMI_ATTN_PL (re-read every call, a getenv, so that one process can compare
-        // the kernels): bit 0 = dQ kernel, bits 4-7 = stream variant, bit 8 = 64 query rows per wave at one wave per SIMD (default: 32 rows, two waves)
-        const int pl = env_int("FTMI_ATTN_PL", 0x011);
+        // the kernels): bit 0 = dQ kernel, bits 4-7 = stream variant, bit 8 = 64 query rows per wave at one wave per SIMD (the default; 0: 32 rows, two waves per SIMD)
+        const int pl = env_int("FTMI_ATTN_PL", 0x111);
         if ((pl & 1) && !a.kbias && (a.Sk % 64) == 0 && a.Sk >= 128) {
             const int var = (pl >> 4) & 15, nq = (pl & 0x100) ? 2 : 1;
             const dim3 gridp(((a.Sq + 128 * nq - 1) / (128 * nq)) * a.H * a.B);

@@ -264,6 +264,68 @@ def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, S
         assert torch.equal(x, y), f"{name}: resident few-keys kernels differ from the general kernels (max |diff| {(x.float() - y.float()).abs().max().item():.3e})"
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 3, 100, 128), (2, 2, 700, 1024), (1, 2, 129, 192), (1, 1, 2688, 64)])
+def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, monkeypatch):
+    """Round 5: the hand-placed dQ pipelines (csrc/attention_pl.hip.h: software pipeline over 32 x 32 units, every instruction of the loop an asm statement,
+    three-slot K / V ring).  Their `x0` streams do the arithmetic of attn_bwd_dq2_kernel statement for statement -- same MFMA chains, fma / exp2 / sub / mul /
+    pack per score -- so dQ (and dK / dV through the delta they publish) must be THE SAME BITS as with FTMI_ATTN_PL=0, for 32 rows x two waves per SIMD
+    (0x001) and 64 rows x one wave (0x101), at whole and ragged query counts, one and many key tiles.  The shipped streams (0x011 / 0x111) put -delta into the
+    accumulator input of the dP chain: one rounding differs per score, checked against the old kernel to 1e-3 and against fp32 autograd like every attention case.
+    Sk = 64 (one tile) keeps the old kernel: the switch must fall through."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    q, k, v = rnd((B, H, Sq, 64), g), rnd((B, H, Sk, 64), g), rnd((B, H, Sk, 64), g)
+    dout = rnd((B, H, Sq, 64), g)
+    qd, kd, vd, dd = q.to(dev), k.to(dev), v.to(dev), dout.to(dev)
+    out, lse = ops.attn_fwd(qd, kd, vd, None)
+    res = {}
+    for pl in ("0", "0x001", "0x101", "0x011", "0x111"):
+        monkeypatch.setenv("FTMI_ATTN_PL", pl)
+        res[pl] = ops.attn_bwd(qd, kd, vd, out, lse, dd, None)
+        torch.cuda.synchronize()
+    for pl in ("0x001", "0x101"):
+        for name, x, y in zip(("dq", "dk", "dv"), res[pl], res["0"]):
+            assert torch.equal(x, y), f"FTMI_ATTN_PL={pl} {name}: not bit-identical to the compiler-scheduled kernel (max |diff| {(x.float() - y.float()).abs().max().item():.3e})"
+    _, dq_ref, dk_ref, dv_ref = _attn_ref(q, k, v, None, dout)
+    for pl in ("0x011", "0x111"):
+        rel = ((res[pl][0].float() - res["0"][0].float()).norm() / res["0"][0].float().norm()).item()
+        print(f"[parity] dq pipeline {pl} vs attn_bwd_dq2_kernel B{B} H{H} {Sq}x{Sk}: rel_l2 {rel:.2e}")
+        assert rel < 1e-3 and torch.equal(res[pl][1], res["0"][1]) and torch.equal(res[pl][2], res["0"][2])  # delta (hence dK / dV) is the same number
+        report(f"attn-pl {pl} B{B} H{H} {Sq}x{Sk} dq", res[pl][0], dq_ref, 1e-2)
+
+
+@pytest.mark.parametrize("M", [5376, 5400, 17776, 2700])
+def test_lora_down_projection_64_row_tiles_are_bit_identical(M, monkeypatch):
+    """Round 5: gemm_nt_skinny4_kernel (64-row tiles, one round of workgroups, two-stage 16-KB ring per wave) keeps the K split, the MFMA order per accumulator
+    and the cross-wave / cross-plane reduction order of gemm_nt_skinny2_kernel: the fp32-equivalent (hi | lo | hi) down-projection must come out bit for bit
+    the same, also with a ragged last row tile (M = 5400, 17776) and where the tile count keeps the launch on the old kernel (M = 2700: both settings equal
+    trivially).  Through the C ABI (ftmi_linear_lora_fwd's x A^T); the three-adapter launch of the fused q|k|v (N = 384) is compared bit for bit by
+    tools/skinny_lab.hip (profiles/r05_skinny_lab_*.txt) and runs in every DiT parity case."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    K, r, s = 2048, 64, 0.5
+    x = rnd((M, K), g).to(dev)
+    A = (torch.randn(r, K, generator=g) / math.sqrt(K)).to(dev)
+    w = rnd((K, K), g, 1 / math.sqrt(K)).to(dev)
+    Bm = (torch.randn(K, r, generator=g) * 0.05).to(dev)
+    got = {}
+    for sk4 in ("0", "1"):
+        monkeypatch.setenv("FTMI_SKINNY4", sk4)
+        y, xa = ops.linear_lora_fwd(x, w, None, A, Bm, s, variant=8)
+        torch.cuda.synchronize()
+        got[sk4] = (y, xa)
+    for name, a_, b_ in zip(("y", "xa"), got["1"], got["0"]):
+        assert torch.equal(a_, b_), f"{name}: 64-row skinny kernel differs from the 32-row kernel (max |diff| {(a_.float() - b_.float()).abs().max().item():.3e})"
+    xa64 = x.double().cpu() @ A.double().cpu().t() * s
+    xa = got["1"][1].float().cpu()
+    err = ((xa[:, :r].double() + xa[:, r:2 * r].double()) - xa64).norm() / xa64.norm()
+    assert err < 2e-5
+
+
 @pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 3, 300, 257, True), (1, 2, 128, 128, False), (1, 2, 200, 330, False), (1, 4, 2688, 2688, False),
                                               (2, 2, 2688, 512, True)])
 def test_attention_head_dim_128_fwd_bwd(B, H, Sq, Sk, biased):
