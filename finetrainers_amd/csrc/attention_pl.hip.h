@@ -269,3 +269,250 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
 #pragma unroll
     for (int qt = 0; qt < NQ; ++qt) store_rows_via_lds(smem + wave * 4096, dqt[qt], a.scale, dqb, a.dq_ss, row0 + qt * 32, a.Sq, lane);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// dK / dV, pipelined: a wave owns 64 keys (two 32-key halves: every Q / dO row fragment, accumulator-input row and transposed fragment read from LDS
+// feeds both -- 64 LDS reads per 64 MFMAs where attn_bwd_dkdv_kernel issues 130), one wave per SIMD, 256 keys per workgroup, loop over 64-query tiles.
+// Arithmetic of attn_bwd_dkdv_kernel<1, 2> statement for statement (the -lse / sl and -delta terms enter through the accumulator inputs): dK and dV are the
+// same bits.  The lse and delta rows of a tile arrive by DMA as they are; wave 0 turns them into -lse / sl and -delta in place right before the hand-over
+// barrier of the tile before (its own vmcnt(0) covers the loads).  (Staging delta raw and moving the sign into the operand -- dO.(-V)^T + delta -- is NOT
+// the same bits: the matrix pipe's internal summation is not sign-symmetric; measured 1.3e-4 of the dK entries off by an ulp.)  Needs Sq % 64 == 0 (a
+// padded query row would need p = 0: the old kernel keeps that case).
+// VAR: 1 = rolling VALU order, 2 = passes over groups of four; 3 / 4 = lab ablations (no VALU / no LDS reads).
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+static constexpr int kPlDkvSlot = 16384 + 512;           // (Q, dO) images + lse row + delta row
+static constexpr int kPlDkvLds = 3 * kPlDkvSlot;         // the epilogue's store scratch (4 x 4 KB) overlays it
+
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pl_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const AttnBlock blk = attn_block(blockIdx.x, (a.Sk + 255) / 256, a.H, a.B);
+    const int h = blk.h, b = blk.b;
+    const int key0 = blk.tile * 256 + wave * 64;
+    const float sl = a.scale * kLog2e;
+    const float ninv_sl = -(1.0f / sl);
+
+    u32x4 kf[2][4], nvf[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int jc = min(key0 + kt * 32 + li, a.Sk - 1);
+        const bf16_t* kp = a.k + (long)b * a.k_sb + (long)h * a.k_sh + (long)jc * a.k_ss;
+        const bf16_t* vp = a.v + (long)b * a.v_sb + (long)h * a.v_sh + (long)jc * a.v_ss;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            kf[kt][c] = *reinterpret_cast<const u32x4*>(kp + c * 16 + g * 8);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(vp + c * 16 + g * 8);
+            nvf[kt][c] = vv;
+        }
+    }
+
+    const bf16_t* qbase = a.q + (long)b * a.q_sb + (long)h * a.q_sh;
+    const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
+    const float* lsebase = a.lse2 + ((long)b * a.H + h) * a.Sq;
+    const float* delbase = a.delta + ((long)b * a.H + h) * a.Sq;
+    const int nt = a.Sq / 64;
+    const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+    // fragment addresses (row half 0): Q image at +0, dO image at +8192, lse row at +16384, delta row at +16640 of a ring slot; half `is` at +4096 (rows: +128);
+    // hh at +2048 (transposed reads).  Row-type addresses start in ring slot 0, the transposed ones one step behind (slot 2).
+    uint32_t ra[4], tra[2][2], la;
+    {
+        const int f = (((li >> 1) & 1) << 2) | ((li >> 2) & 3);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ra[c] = lds0 + (uint32_t)(li * 128 + ((((c << 1) | g) ^ f) << 4));
+        la = lds0 + (uint32_t)(16 * g);
+        const int l16 = lane & 15, grp = (lane >> 4) & 1, j = l16 >> 2, qq = l16 & 3;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int col = dt * 32 + grp * 16 + 4 * qq;
+            tra[dt][0] = lds0 + 2u * kPlDkvSlot + (uint32_t)(lds_rt_off(4 * g + j, col >> 3) + (col & 7) * 2);
+            tra[dt][1] = lds0 + 2u * kPlDkvSlot + (uint32_t)(lds_rt_off(8 + 4 * g + j, col >> 3) + (col & 7) * 2);
+        }
+    }
+
+    // tile DMA: pieces 0-1 Q, 2-3 dO (1 KB each per wave), 4 = the lse and delta rows (64 floats each; wave 0); tile `dma_t` -> ring slot dma_t % 3
+    int dma_t = 0;
+    uint32_t dma_dst = lds0;
+    const char *qsrc = (const char*)qbase, *dosrc = (const char*)dobase, *lsrc = (const char*)lsebase, *dsrc = (const char*)delbase;
+    const long qstep = 128 * a.q_ss, dostep = 128 * a.do_ss;  // bytes per 64-row tile
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    auto dma_next = [&]() {
+        ++dma_t;
+        dma_dst = (dma_dst == lds0 + 2u * kPlDkvSlot) ? lds0 : dma_dst + kPlDkvSlot;
+        const bool more = dma_t < nt;
+        qsrc += more ? qstep : 0;
+        dosrc += more ? dostep : 0;
+        lsrc += more ? 256 : 0;
+        dsrc += more ? 256 : 0;
+    };
+#define DMA_PIECE(i)                                                                                                                                   \
+    do {                                                                                                                                               \
+        if ((i) < 4) {                                                                                                                                 \
+            const uint32_t dst_ = dma_dst + ((i) >= 2 ? 8192u : 0u) + (uint32_t)(wave * 2 + ((i) & 1)) * 1024u;                                       \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst_), "v"(((i) >= 2 ? dod.off : qd.off)[(i) & 1]),    \
+                         "s"((i) >= 2 ? dosrc : qsrc)                                                                                                  \
+                         : "memory", "m0");                                                                                                            \
+        } else {                                                                                                                                       \
+            if (wave == 0) {                                                                                                                           \
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dma_dst + 16384u), "v"(lane4), "s"(lsrc) : "memory", "m0"); \
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dma_dst + 16384u + 256u), "v"(lane4), "s"(dsrc) : "memory", "m0"); \
+            }                                                                                                                                          \
+            dma_next();                                                                                                                                \
+        }                                                                                                                                              \
+    } while (0)
+    // wave 0: the lse / delta rows of ring slot `xf` (landed: vmcnt(0) of this wave) become the accumulator inputs -lse / sl and -delta, in place
+    uint32_t xf = lds0 + 16384u + lane4;  // tile 0's row; advanced after every transform
+    auto transform_row = [&]() {
+        if (wave == 0) {
+            float v;
+            float w;
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)\n\tv_mul_f32 %0, %0, %3\n\tv_xor_b32 %1, 0x80000000, %1\n\t"
+                         "ds_write_b32 %2, %0\n\tds_write_b32 %2, %1 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v), "=&v"(w)
+                         : "v"(xf), "v"(ninv_sl)
+                         : "memory");
+        }
+        xf = (xf >= lds0 + 2u * kPlDkvSlot) ? xf - 2u * kPlDkvSlot : xf + kPlDkvSlot;
+    };
+#define HAND_OVER()                                                 \
+    do {                                                            \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
+        transform_row();                                            \
+        asm volatile("s_barrier" ::: "memory");                     \
+    } while (0)
+    int row_slot = 0, tr_slot = 2;
+#define RING_ADVANCE_ROW()                                                                      \
+    do {                                                                                        \
+        row_slot = (row_slot == 2) ? 0 : row_slot + 1;                                          \
+        const int delta_ = (row_slot == 0) ? -2 * kPlDkvSlot : kPlDkvSlot;                      \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[0]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[1]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[2]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(ra[3]) : "s"(delta_));                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(la) : "s"(delta_));                          \
+    } while (0)
+#define RING_ADVANCE_TR()                                                                       \
+    do {                                                                                        \
+        tr_slot = (tr_slot == 2) ? 0 : tr_slot + 1;                                             \
+        const int delta_ = (tr_slot == 0) ? -2 * kPlDkvSlot : kPlDkvSlot;                       \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[0][0]) : "s"(delta_));                   \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[0][1]) : "s"(delta_));                   \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[1][0]) : "s"(delta_));                   \
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(tra[1][1]) : "s"(delta_));                   \
+    } while (0)
+#define QT(hh, dt) __builtin_shufflevector(qtlo[hh][dt], qthi[hh][dt], 0, 1, 2, 3)
+#define DOT(hh, dt) __builtin_shufflevector(dtlo[hh][dt], dthi[hh][dt], 0, 1, 2, 3)
+#define PF(q, hh) (u32x4{pw[q][hh][0], pw[q][hh][1], pw[q][hh][2], pw[q][hh][3]})
+#define DSF(q, hh) (u32x4{dsw[q][hh][0], dsw[q][hh][1], dsw[q][hh][2], dsw[q][hh][3]})
+#define LSI __builtin_shufflevector(__builtin_shufflevector(lsi[0], lsi[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(lsi[2], lsi[3], 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+#define DLI __builtin_shufflevector(__builtin_shufflevector(dli[0], dli[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(dli[2], dli[3], 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+
+    f32x16 dK[2][2], dV[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dK[kt][0][r] = 0.f; dK[kt][1][r] = 0.f; dV[kt][0][r] = 0.f; dV[kt][1][r] = 0.f;
+        }
+    f32x16 S[2], DP[2];
+    u32x4 qr[4], dor[4];
+    f32x4 lsi[4], dli[4];
+    u32x2 qtlo[2][2], qthi[2][2], dtlo[2][2], dthi[2][2];
+    uint32_t pw[2][2][4], dsw[2][2][4];
+    float x[16], y[16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            qtlo[i][jj] = u32x2{0u, 0u}; qthi[i][jj] = u32x2{0u, 0u}; dtlo[i][jj] = u32x2{0u, 0u}; dthi[i][jj] = u32x2{0u, 0u};  // the first slot's C stage multiplies zeros
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pw[i][jj][e] = 0u; dsw[i][jj][e] = 0u; }
+        }
+
+    // ---- prologue: tiles 0 and 1 -> ring slots 0, 1; tile 0's lse row transformed; the row fragments and accumulator inputs of (tile 0, half 0); A(unit 0) ----
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            settle(__builtin_bit_cast(s16x8, kf[kt][c]));
+            settle(__builtin_bit_cast(s16x8, nvf[kt][c]));
+        }
+    DMA_PIECE(0); DMA_PIECE(1); DMA_PIECE(2); DMA_PIECE(3); DMA_PIECE(4);
+    DMA_PIECE(0); DMA_PIECE(1); DMA_PIECE(2); DMA_PIECE(3); DMA_PIECE(4);
+    HAND_OVER();  // (transforms tile 0's row; tile 1's follows at the first hand-over of the loop)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[c]) : "v"(ra[c]));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dor[c]) : "v"(ra[c]));
+    }
+    asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(lsi[0]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:16416" : "=v"(lsi[1]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:16448" : "=v"(lsi[2]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:16480" : "=v"(lsi[3]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:16640" : "=v"(dli[0]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:16672" : "=v"(dli[1]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:16704" : "=v"(dli[2]) : "v"(la));
+    asm volatile("ds_read_b128 %0, %1 offset:16736" : "=v"(dli[3]) : "v"(la));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c == 0) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(S[0]) : "v"(qr[c]), "v"(kf[0][c]), "v"(LSI));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(DP[0]) : "v"(dor[c]), "v"(nvf[0][c]), "v"(DLI));
+        } else {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S[0]) : "v"(qr[c]), "v"(kf[0][c]));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(DP[0]) : "v"(dor[c]), "v"(nvf[0][c]));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    for (int t = 0; t < nt; ++t) {
+        if constexpr (VAR == 2) {
+#include "attn_pl_dkv_v2.inc"
+        }
+#ifdef FTMI_LAB
+        else if constexpr (VAR == 3) {
+#include "attn_pl_dkv_a_novalu.inc"
+        } else if constexpr (VAR == 4) {
+#include "attn_pl_dkv_a_nolds.inc"
+        }
+#endif
+        else {
+#include "attn_pl_dkv_v1.inc"
+        }
+    }
+
+    // ---- tail: C(last unit) = the dV / dK products of (last tile, half 1, key half 1); its P / dS fragments have parity 1 ----
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1" ::: "memory");
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dV[1][dt]) : "v"(DOT(hh, dt)), "v"(PF(1, hh)));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dK[1][dt]) : "v"(QT(hh, dt)), "v"(DSF(1, hh)));
+        }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dK[kt][0]), "+a"(dK[kt][1]), "+a"(dV[kt][0]), "+a"(dV[kt][1]));
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the store scratch overlays ring slots other waves may still be reading
+#undef DMA_PIECE
+#undef HAND_OVER
+#undef RING_ADVANCE_ROW
+#undef RING_ADVANCE_TR
+#undef QT
+#undef DOT
+#undef PF
+#undef DSF
+#undef LSI
+#undef DLI
+
+    bf16_t* dkb = a.dk + (long)b * a.dk_sb + (long)h * a.dk_sh;
+    bf16_t* dvb = a.dv + (long)b * a.dv_sb + (long)h * a.dv_sh;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        store_rows_via_lds(smem + wave * 4096, dK[kt], a.scale, dkb, a.dk_ss, key0 + kt * 32, a.Sk, lane);
+        store_rows_via_lds(smem + wave * 4096, dV[kt], 1.0f, dvb, a.dv_ss, key0 + kt * 32, a.Sk, lane);
+    }
+}

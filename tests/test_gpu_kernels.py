@@ -296,6 +296,29 @@ def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, monkey
         report(f"attn-pl {pl} B{B} H{H} {Sq}x{Sk} dq", res[pl][0], dq_ref, 1e-2)
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 16, 1024, 2048), (1, 16, 1024, 2000), (1, 64, 128, 512)])
+def test_pipelined_dkdv_kernel_is_bit_identical_to_the_kernel_it_replaces(B, H, Sq, Sk, monkeypatch):
+    """Round 5: attn_bwd_dkdv_pl_kernel (64 keys per wave, one wave per SIMD, the same software pipeline as the dQ kernel; the lse / delta rows arrive by DMA and
+    wave 0 turns them into the accumulator inputs -lse / sl and -delta before the tile's hand-over barrier) does the arithmetic of attn_bwd_dkdv_kernel<1, 2>
+    statement for statement: dK and dV must be the same bits with FTMI_ATTN_PL bit 1 on and off -- whole and ragged key counts, few and many query tiles.
+    (Shapes with fewer than 256 key blocks x heads keep the split-query kernel, ragged query counts and key biases the old one: covered by the other cases.)"""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(13)
+    q, k, v = rnd((B, H, Sq, 64), g).to(dev), rnd((B, H, Sk, 64), g).to(dev), rnd((B, H, Sk, 64), g).to(dev)
+    dout = rnd((B, H, Sq, 64), g).to(dev)
+    out, lse = ops.attn_fwd(q, k, v, None)
+    res = {}
+    for pl in ("0x111", "0x1113", "0x2113"):  # same dQ kernel (it publishes delta), dK / dV kernel old | pipelined, rolling order | pipelined, groups of four
+        monkeypatch.setenv("FTMI_ATTN_PL", pl)
+        res[pl] = ops.attn_bwd(q, k, v, out, lse, dout, None)
+        torch.cuda.synchronize()
+    for pl in ("0x1113", "0x2113"):
+        for name, x, y in zip(("dq", "dk", "dv"), res[pl], res["0x111"]):
+            assert torch.equal(x, y), f"FTMI_ATTN_PL={pl} {name}: not bit-identical (max |diff| {(x.float() - y.float()).abs().max().item():.3e})"
+
+
 @pytest.mark.parametrize("M", [5376, 5400, 17776, 2700])
 def test_lora_down_projection_64_row_tiles_are_bit_identical(M, monkeypatch):
     """Round 5: gemm_nt_skinny4_kernel (64-row tiles, one round of workgroups, two-stage 16-KB ring per wave) keeps the K split, the MFMA order per accumulator

@@ -192,6 +192,138 @@ def gen_dq(name: str, nq: int, exact: bool, order: str = "roll", weights=None, d
     return path
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# dK / dV kernel: a wave owns 64 keys (kt = 0, 1: 32 each), loops over 64-query tiles (is = 0, 1: 32 query rows each).
+# unit u = (t, is, kt), parity p = kt.  Slot of unit u:
+#   C(u-1): 8 MFMAs  dV[kt'] += dO^T . P[p^1],  dK[kt'] += Q^T . dSn[p^1];
+#   A(u+1): 8 MFMAs  S[p^1] = Q.K^T - lse / sl,  DP[p^1] = dO.V^T - delta  (both row terms as accumulator inputs read from LDS);
+#   B(u): VALU  P = exp2(S * sl),  dS = P * DP, both packed to bf16 fragments.
+# Row fragments of Q / dO and the two accumulator-input rows are shared by kt = 0, 1 (read once per `is`); so are the transposed fragments.
+# ------------------------------------------------------------------------------------------------------------------------------
+def dkv_valu_ops(par: int, order: str):
+    S, DP = f"S[{par}]", f"DP[{par}]"
+
+    def M1(r):
+        return ("v_mul_f32 %0, %1, %2", f'"=v"(x[{r}])', f'"v"({S}[{r}]), "v"(sl)')
+
+    def E(r):
+        return ("v_exp_f32 %0, %0", f'"+v"(x[{r}])', "")
+
+    def M2(r):
+        return ("v_mul_f32 %0, %1, %2", f'"=v"(y[{r}])', f'"v"(x[{r}]), "v"({DP}[{r}])')
+
+    def PP(r):
+        hh, e = r >> 3, (r & 7) >> 1
+        return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(pw[{par}][{hh}][{e}])', f'"v"(x[{r}]), "v"(x[{r + 1}])')
+
+    def PD(r):
+        hh, e = r >> 3, (r & 7) >> 1
+        return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(dsw[{par}][{hh}][{e}])', f'"v"(y[{r}]), "v"(y[{r + 1}])')
+
+    ops = []
+    if order.startswith("g"):
+        group = int(order[1:])
+        for m in range(16 // group):
+            rs = [group * m + i for i in range(group)]
+            ops += [M1(r) for r in rs] + [E(r) for r in rs] + [M2(r) for r in rs] + [PP(r) for r in rs[::2]] + [PD(r) for r in rs[::2]]
+    else:
+        L = 4
+        for s_ in range(16 + 2 * L + 2):
+            if s_ < 16:
+                ops.append(M1(s_))
+            if 0 <= s_ - L < 16:
+                ops.append(E(s_ - L))
+            if 0 <= s_ - 2 * L < 16:
+                ops.append(M2(s_ - 2 * L))
+            r = s_ - 2 * L - 1
+            if 0 <= r < 16 and r % 2 == 1:
+                ops.append(PP(r - 1))
+                ops.append(PD(r - 1))
+    assert len(ops) == 64, len(ops)
+    return ops
+
+
+def gen_dkv(name: str, order: str = "roll", drop=()):
+    s = Stream()
+    s.emit(f"// GENERATED by tools/gen_attn_pl.py (dkv_{name}: order={order} drop={','.join(drop) or '-'}) -- do not edit")
+    units = [(is_, kt) for is_ in range(2) for kt in range(2)]
+    n = len(units)
+    for i, (is_, kt) in enumerate(units):
+        par, parn = kt, kt ^ 1
+        isn, ktn = units[(i + 1) % n]
+        isp, ktp = units[(i - 1) % n]
+        s.emit(f"// ---- slot {i} (is {is_}, kt {kt}): C(u-1) on dV/dK[{ktp}], A(u+1) into S/DP[{parn}] (is {isn}, kt {ktn}), B(u) on S/DP[{par}]")
+        s.emit("{")
+        valu = [] if "valu" in drop else dkv_valu_ops(par, order)
+        mf = []
+        for hh in range(2):
+            for dt in range(2):
+                mf.append((f"{MFMA} %0, %1, %2, %0", f'"+a"(dV[{ktp}][{dt}])', f'"v"(DOT({hh}, {dt})), "v"(PF({parn}, {hh}))'))
+                mf.append((f"{MFMA} %0, %1, %2, %0", f'"+a"(dK[{ktp}][{dt}])', f'"v"(QT({hh}, {dt})), "v"(DSF({parn}, {hh}))'))
+        for c in range(4):
+            if c == 0:
+                mf.append((f"{MFMA} %0, %1, %2, %3", f'"=&v"(S[{parn}])', f'"v"(qr[{c}]), "v"(kf[{ktn}][{c}]), "v"(LSI)'))
+                mf.append((f"{MFMA} %0, %1, %2, %3", f'"=&v"(DP[{parn}])', f'"v"(dor[{c}]), "v"(nvf[{ktn}][{c}]), "v"(DLI)'))
+            else:
+                mf.append((f"{MFMA} %0, %1, %2, %0", f'"+v"(S[{parn}])', f'"v"(qr[{c}]), "v"(kf[{ktn}][{c}])'))
+                mf.append((f"{MFMA} %0, %1, %2, %0", f'"+v"(DP[{parn}])', f'"v"(dor[{c}]), "v"(nvf[{ktn}][{c}])'))
+        ngap = len(mf)  # 16
+        counts = spread(len(valu), ngap)
+        early = isn != is_   # the next unit works on the other 32-row half: its Q / dO row fragments and accumulator-input rows are read at the top of this slot
+        late = kt == 0       # first unit of this 32-row half: its transposed Q / dO fragments (C stage of the next two slots) are read in this slot
+        hand_over = (is_, kt) == (1, 0)
+        if (is_, kt) == (0, 0):
+            s.emit("RING_ADVANCE_TR();  // transposed-fragment addresses -> ring slot of this tile")
+        if hand_over:
+            s.emit("// tile hand-over: my loads of tile t+1 have landed (wave 0 then turns the lse row into the accumulator input -lse / sl, in place);")
+            s.emit("// after the barrier everyone's have, and nobody reads tile t-1 any more")
+            s.emit("HAND_OVER();")
+        if early and isn == 0:
+            s.emit("RING_ADVANCE_ROW();  // row-fragment addresses -> ring slot of tile t+1")
+        s.asm("s_waitcnt lgkmcnt(0)\\n\\ts_nop 1", "", "", '"memory"')
+        vi = 0
+        for g in range(ngap):
+            if g == 8 and early and "lds" not in drop:
+                s.emit("// the next unit's row fragments and accumulator inputs must have landed before its first MFMA")
+                s.asm("s_waitcnt lgkmcnt(0)", "", "", '"memory"')
+            t, o, ins = mf[g]
+            if "mfma" not in drop:
+                s.asm(t, o, ins)
+            if early and g < 4 and "lds" not in drop:
+                roff = isn * 4096
+                if g == 0:
+                    for c in range(4):
+                        s.asm(f"ds_read_b128 %0, %1 offset:{roff}", f'"=v"(qr[{c}])', f'"v"(ra[{c}])')
+                elif g == 1:
+                    for c in range(4):
+                        s.asm(f"ds_read_b128 %0, %1 offset:{roff + 8192}", f'"=v"(dor[{c}])', f'"v"(ra[{c}])')
+                elif g == 2:
+                    for rq in range(4):
+                        s.asm(f"ds_read_b128 %0, %1 offset:{16384 + isn * 128 + rq * 32}", f'"=v"(lsi[{rq}])', '"v"(la)')
+                else:
+                    for rq in range(4):
+                        s.asm(f"ds_read_b128 %0, %1 offset:{16384 + 256 + isn * 128 + rq * 32}", f'"=v"(dli[{rq}])', '"v"(la)')
+            if late and 8 <= g < 16 and "lds" not in drop:
+                k = g - 8          # 0..7 -> (image, hh, dt)
+                img, hh, dt = k >> 2, (k >> 1) & 1, k & 1
+                base = is_ * 4096 + hh * 2048 + img * 8192
+                lo, hi = ("qtlo", "qthi") if img == 0 else ("dtlo", "dthi")
+                s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"({lo}[{hh}][{dt}])', f'"v"(tra[{dt}][0])')
+                s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"({hi}[{hh}][{dt}])', f'"v"(tra[{dt}][1])')
+            if hand_over and 8 <= g < 13 and "dma" not in drop:
+                s.emit(f"DMA_PIECE({g - 8});")
+            for _ in range(counts[g]):
+                t2, o2, i2 = valu[vi]
+                s.asm(t2, o2, i2)
+                vi += 1
+        assert vi == len(valu)
+        s.emit("}")
+    path = os.path.join(OUT, f"attn_pl_dkv_{name}.inc")
+    with open(path, "w") as f:
+        f.write("\n".join(s.lines) + "\n")
+    return path
+
+
 def main():
     made = []
     for nq in (1, 2):
@@ -205,6 +337,10 @@ def main():
         made.append(gen_dq("a_novalu", nq, False, drop=("valu",)))
         made.append(gen_dq("a_nolds", nq, False, drop=("lds",)))
         made.append(gen_dq("a_nomfma", nq, False, drop=("mfma",)))
+    made.append(gen_dkv("v1"))
+    made.append(gen_dkv("v2", order="g4"))
+    made.append(gen_dkv("a_novalu", drop=("valu",)))
+    made.append(gen_dkv("a_nolds", drop=("lds",)))
     for p in made:
         print(os.path.relpath(p, os.path.join(HERE, "..")))
 
