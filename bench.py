@@ -479,9 +479,15 @@ def main():
                 hb["dominant_kernel_frac_of_peak"] = hb["dominant_kernel"] / PEAK_HBM_GBPS
             res["hbm_gbps"] = hb
             res["hbm_frac_of_peak"] = hb.get("step_frac_of_peak")
-        pr = _profile_json("r04_bench_noprof.json")  # the same command with --no-prof on the evidence box: the instrument's cost as a stated quantity
-        if prof and pr and args.workload == "ltx":
-            res["ms_per_step_without_event_profiler"] = {"ms_per_step": pr.get("ms_per_step"), "source": "profiles/r04_bench_noprof.json: python bench.py --no-prof on the round's evidence box, where the default line (profiles/r04_bench_default.json) measured 66.34 ms -- the in-stream event profiler costs 0.2 %"}
+        # the same command with --no-prof on the round's evidence box: the instrument's cost as a stated quantity
+        for rr in ("r05", "r04"):
+            pr, pd = _profile_json(f"{rr}_bench_noprof.json"), _profile_json(f"{rr}_bench_default.json")
+            if prof and pr and pd and args.workload == "ltx":
+                res["ms_per_step_without_event_profiler"] = {
+                    "ms_per_step": pr.get("ms_per_step"), "with_profiler_same_box": pd.get("ms_per_step"),
+                    "source": f"profiles/{rr}_bench_noprof.json vs profiles/{rr}_bench_default.json: python bench.py with and without --no-prof on the round's evidence box "
+                              f"({pd.get('ms_per_step', 0):.2f} vs {pr.get('ms_per_step', 0):.2f} ms)"}
+                break
         if par.world_size == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = ctx["cpu_baseline"]()

@@ -20,5 +20,11 @@ case "${1:-}" in
     echo "exit $?" >> gpurun_out/r05_skinny_lab_$tag.txt
     cat gpurun_out/r05_skinny_lab_$tag.txt
     ;;
+  e)  # evidence run: default bench line (with the CPU baseline), the driver's command, --no-prof, rocprofv3 stats + counter passes of the same command
+    python bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; echo "bench default rc=$?"; cut -c1-600 gpurun_out/r05_bench_default.json
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r05_bench_driver_cmd.json 2>/dev/null; cut -c1-300 gpurun_out/r05_bench_driver_cmd.json
+    python bench.py --no-prof --no-cpu-baseline > gpurun_out/r05_bench_noprof.json 2>/dev/null; cut -c1-300 gpurun_out/r05_bench_noprof.json
+    bash tools/gpu_profile_r05.sh r05 2>&1 | tail -60
+    ;;
   *) echo "unknown visit"; exit 1;;
 esac
