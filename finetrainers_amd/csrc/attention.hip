@@ -1361,10 +1361,10 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(attn_bwd_dq_res_kernel<false>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
     } else if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
-        // hand-placed pipelines (attention_pl.hip.h): no key bias, whole key tiles.  FTMI_ATTN_PL (re-read every call, a getenv, so that one process can compare
+        // hand-placed pipelines (attention_pl.hip.h): no key bias (ragged token counts: the DMA zero-fills).  FTMI_ATTN_PL (re-read every call, a getenv, so that one process can compare
         // the kernels): bit 0 = dQ kernel, bits 4-7 = stream variant, bit 8 = 64 query rows per wave at one wave per SIMD (the default; 0: 32 rows, two waves per SIMD)
         const int pl = env_int("FTMI_ATTN_PL", 0x1113);
-        if ((pl & 1) && !a.kbias && (a.Sk % 64) == 0 && a.Sk >= 128) {
+        if ((pl & 1) && !a.kbias && a.Sk >= 128) {
             const int var = (pl >> 4) & 15, nq = (pl & 0x100) ? 2 : 1;
             const dim3 gridp(((a.Sq + 128 * nq - 1) / (128 * nq)) * a.H * a.B);
 #define FTMI_PL_LAUNCH(NQ_, V_)                                                                                                                         \
@@ -1420,10 +1420,10 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         else
             hipLaunchKernelGGL(attn_bwd_dkdv_sq_kernel<1>, dim3(((a.Sk + 31) / 32) * a.H * a.B), dim3(256), kDkvSqLds, st, a);
     } else {
-        // hand-placed pipeline (attention_pl.hip.h): 64 keys per wave, one wave per SIMD.  FTMI_ATTN_PL bit 1 (value >> 12 = stream variant).  Needs whole
-        // query tiles (a padded query row must give p = 0) and no key bias; a.delta was just written by the dQ kernel.
+        // hand-placed pipeline (attention_pl.hip.h): 64 keys per wave, one wave per SIMD.  FTMI_ATTN_PL bit 1 (value >> 12 = stream variant).  No key bias;
+        // a.delta was just written by the dQ kernel.
         const int plk = env_int("FTMI_ATTN_PL", 0x1113);
-        if ((plk & 2) && !a.kbias && (a.Sq % 64) == 0 && a.Sq >= 128 && a.Sk >= 256) {
+        if ((plk & 2) && !a.kbias && a.Sq >= 128 && a.Sk >= 256) {
             const int var = (plk >> 12) & 15;
             const dim3 gridk(((a.Sk + 255) / 256) * a.H * a.B);
 #define FTMI_PLK_LAUNCH(V_)                                                                                                                             \

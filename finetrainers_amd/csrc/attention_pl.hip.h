@@ -21,7 +21,7 @@
 // is placed at least two MFMAs behind the MFMA that wrote it, fragment reads are waited for with explicit lgkmcnt, and the few places outside
 // the steady state carry explicit s_nop.
 //
-// Included by attention.hip (uses its helpers).  Replaces, for Sk % 64 == 0 without a key bias:
+// Included by attention.hip (uses its helpers).  Replaces, without a key bias (any token counts):
 //   attn_bwd_dq2_kernel<false,false>  ->  attn_bwd_dq_pl_kernel     (finetrainers/models/attention_dispatch.py:938-962, autograd backward)
 #pragma once
 // (included inside namespace ftmi)
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
 
     const bf16_t* kbase = a.k + (long)b * a.k_sb + (long)h * a.k_sh;
     const bf16_t* vbase = a.v + (long)b * a.v_sb + (long)h * a.v_sh;
-    const int nt = a.Sk / 64;
+    const int nt = (a.Sk + 63) / 64;
     const TileDma kd = tile_dma_setup(a.k_ss, a.Sk, wave, lane), vd = tile_dma_setup(a.v_ss, a.Sk, wave, lane);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
 
@@ -99,23 +99,31 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
         }
     }
 
-    // tile DMA: the four pieces of tile `dma_t` (clamped to the last tile: branch-free tail, re-staged into a slot nobody reads) -> ring slot dma_t % 3
+    // tile DMA: the four pieces of tile `dma_t` (past the end: the last tile again, into a slot nobody reads -- branch-free tail) -> ring slot dma_t % 3.
+    // Buffer loads with EXACT bounds (descriptor = the rest of this head's rows from the tile on): rows past the end of a ragged last tile arrive as
+    // ZEROS, and zero K rows cancel whatever their scores turn into -- the dQ products read them through the same LDS image (K^T fragments = 0) -- so a
+    // ragged key count needs no masking instruction anywhere in the stream (CogVideoX: 17 776 = 277 x 64 + 48 tokens).
     int dma_t = 0;
     uint32_t dma_dst = lds0;
     const char *ksrc = (const char*)kbase, *vsrc = (const char*)vbase;
     const long kstep = 128 * a.k_ss, vstep = 128 * a.v_ss;  // bytes per 64-key tile
+    long krem = (long)(a.Sk - 1) * a.k_ss * 2 + 128, vrem = (long)(a.Sk - 1) * a.v_ss * 2 + 128;  // valid bytes from the tile's first row on
+    auto srd = [](const char* p_, long rem) { return __builtin_amdgcn_make_buffer_rsrc((void*)p_, (short)0, (int)(rem > 0x7fffffffL ? 0x7fffffffL : rem), 0x00020000); };
     auto dma_next = [&]() {  // after the pieces of a tile were issued
         ++dma_t;
         dma_dst = (dma_dst == lds0 + 2u * 16384u) ? lds0 : dma_dst + 16384u;
         const bool more = dma_t < nt;
         ksrc += more ? kstep : 0;
         vsrc += more ? vstep : 0;
+        krem -= more ? kstep : 0;
+        vrem -= more ? vstep : 0;
     };
 #define DMA_PIECE(i)                                                                                                                                   \
     do {                                                                                                                                               \
         const uint32_t dst_ = dma_dst + ((i) >= 2 ? 8192u : 0u) + (uint32_t)(wave * 2 + ((i) & 1)) * 1024u;                                           \
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst_), "v"(((i) >= 2 ? vd.off : kd.off)[(i) & 1]),        \
-                     "s"((i) >= 2 ? vsrc : ksrc)                                                                                                       \
+        const auto rs_ = (i) >= 2 ? srd(vsrc, vrem) : srd(ksrc, krem);                                                                                 \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst_), "v"(((i) >= 2 ? vd.off : kd.off)[(i) & 1]),   \
+                     "s"(rs_)                                                                                                                          \
                      : "memory", "m0");                                                                                                                \
         if ((i) == 3) dma_next();                                                                                                                      \
     } while (0)
@@ -276,8 +284,8 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
 // Arithmetic of attn_bwd_dkdv_kernel<1, 2> statement for statement (the -lse / sl and -delta terms enter through the accumulator inputs): dK and dV are the
 // same bits.  The lse and delta rows of a tile arrive by DMA as they are; wave 0 turns them into -lse / sl and -delta in place right before the hand-over
 // barrier of the tile before (its own vmcnt(0) covers the loads).  (Staging delta raw and moving the sign into the operand -- dO.(-V)^T + delta -- is NOT
-// the same bits: the matrix pipe's internal summation is not sign-symmetric; measured 1.3e-4 of the dK entries off by an ulp.)  Needs Sq % 64 == 0 (a
-// padded query row would need p = 0: the old kernel keeps that case).
+// the same bits: the matrix pipe's internal summation is not sign-symmetric; measured 1.3e-4 of the dK entries off by an ulp.)  Ragged query
+// counts: the bounds-checked DMA zero-fills the rows past the end (see the DMA comment).
 // VAR: 1 = rolling VALU order, 2 = passes over groups of four; 3 / 4 = lab ablations (no VALU / no LDS reads).
 // ------------------------------------------------------------------------------------------------------------------------------------------------
 static constexpr int kPlDkvSlot = 16384 + 512;           // (Q, dO) images + lse row + delta row
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pl_kernel(AttnArgs a) {
     const bf16_t* dobase = a.dout + (long)b * a.do_sb + (long)h * a.do_sh;
     const float* lsebase = a.lse2 + ((long)b * a.H + h) * a.Sq;
     const float* delbase = a.delta + ((long)b * a.H + h) * a.Sq;
-    const int nt = a.Sq / 64;
+    const int nt = (a.Sq + 63) / 64;
     const TileDma qd = tile_dma_setup(a.q_ss, a.Sq, wave, lane), dod = tile_dma_setup(a.do_ss, a.Sq, wave, lane);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
 
@@ -333,11 +341,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pl_kernel(AttnArgs a) {
         }
     }
 
-    // tile DMA: pieces 0-1 Q, 2-3 dO (1 KB each per wave), 4 = the lse and delta rows (64 floats each; wave 0); tile `dma_t` -> ring slot dma_t % 3
+    // tile DMA: pieces 0-1 Q, 2-3 dO (1 KB each per wave), 4 = the lse and delta rows (64 floats each; wave 0); tile `dma_t` -> ring slot dma_t % 3.
+    // Buffer loads with EXACT bounds: the rows past the end of a ragged last QUERY tile arrive as zeros -- Q = dO = 0 there, so whatever p those rows get,
+    // they add nothing to dV (dO^T fragments = 0) or dK (Q^T fragments = 0): no masking instruction in the stream.
     int dma_t = 0;
     uint32_t dma_dst = lds0;
     const char *qsrc = (const char*)qbase, *dosrc = (const char*)dobase, *lsrc = (const char*)lsebase, *dsrc = (const char*)delbase;
     const long qstep = 128 * a.q_ss, dostep = 128 * a.do_ss;  // bytes per 64-row tile
+    long qrem = (long)(a.Sq - 1) * a.q_ss * 2 + 128, dorem = (long)(a.Sq - 1) * a.do_ss * 2 + 128, lrem = (long)a.Sq * 4;
+    auto srd = [](const char* p_, long rem) { return __builtin_amdgcn_make_buffer_rsrc((void*)p_, (short)0, (int)(rem > 0x7fffffffL ? 0x7fffffffL : rem), 0x00020000); };
     const uint32_t lane4 = (uint32_t)lane * 4u;
     auto dma_next = [&]() {
         ++dma_t;
@@ -347,18 +359,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pl_kernel(AttnArgs a) {
         dosrc += more ? dostep : 0;
         lsrc += more ? 256 : 0;
         dsrc += more ? 256 : 0;
+        qrem -= more ? qstep : 0;
+        dorem -= more ? dostep : 0;
+        lrem -= more ? 256 : 0;
     };
 #define DMA_PIECE(i)                                                                                                                                   \
     do {                                                                                                                                               \
         if ((i) < 4) {                                                                                                                                 \
             const uint32_t dst_ = dma_dst + ((i) >= 2 ? 8192u : 0u) + (uint32_t)(wave * 2 + ((i) & 1)) * 1024u;                                       \
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst_), "v"(((i) >= 2 ? dod.off : qd.off)[(i) & 1]),    \
-                         "s"((i) >= 2 ? dosrc : qsrc)                                                                                                  \
+            const auto rs_ = (i) >= 2 ? srd(dosrc, dorem) : srd(qsrc, qrem);                                                                           \
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst_), "v"(((i) >= 2 ? dod.off : qd.off)[(i) & 1]), \
+                         "s"(rs_)                                                                                                                      \
                          : "memory", "m0");                                                                                                            \
         } else {                                                                                                                                       \
             if (wave == 0) {                                                                                                                           \
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dma_dst + 16384u), "v"(lane4), "s"(lsrc) : "memory", "m0"); \
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dma_dst + 16384u + 256u), "v"(lane4), "s"(dsrc) : "memory", "m0"); \
+                const auto rl_ = srd(lsrc, lrem), rd_ = srd(dsrc, lrem);                                                                               \
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(dma_dst + 16384u), "v"(lane4), "s"(rl_) : "memory", "m0"); \
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(dma_dst + 16384u + 256u), "v"(lane4), "s"(rd_) : "memory", "m0"); \
             }                                                                                                                                          \
             dma_next();                                                                                                                                \
         }                                                                                                                                              \

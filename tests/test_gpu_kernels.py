@@ -264,14 +264,15 @@ def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, S
         assert torch.equal(x, y), f"{name}: resident few-keys kernels differ from the general kernels (max |diff| {(x.float() - y.float()).abs().max().item():.3e})"
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 3, 100, 128), (2, 2, 700, 1024), (1, 2, 129, 192), (1, 1, 2688, 64)])
+@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 3, 100, 128), (2, 2, 700, 1024), (1, 2, 129, 192), (1, 1, 2688, 64), (2, 16, 1000, 1000), (1, 4, 300, 1777)])
 def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, monkeypatch):
     """Round 5: the hand-placed dQ pipelines (csrc/attention_pl.hip.h: software pipeline over 32 x 32 units, every instruction of the loop an asm statement,
     three-slot K / V ring).  Their `x0` streams do the arithmetic of attn_bwd_dq2_kernel statement for statement -- same MFMA chains, fma / exp2 / sub / mul /
     pack per score -- so dQ (and dK / dV through the delta they publish) must be THE SAME BITS as with FTMI_ATTN_PL=0, for 32 rows x two waves per SIMD
     (0x001) and 64 rows x one wave (0x101), at whole and ragged query counts, one and many key tiles.  The shipped streams (0x011 / 0x111) put -delta into the
     accumulator input of the dP chain: one rounding differs per score, checked against the old kernel to 1e-3 and against fp32 autograd like every attention case.
-    Sk = 64 (one tile) keeps the old kernel: the switch must fall through."""
+    Sk = 64 (one tile) keeps the old kernel: the switch must fall through.  Ragged key counts (1000, 1777: CogVideoX's 17 776 = 277 x 64 + 48 in the lab, profiles/
+    r05_attn_lab_4_ragged.txt): the bounds-checked DMA zero-fills the rows past the end, and zero K rows cancel in the dQ products -- same bits as the masking kernel."""
     from finetrainers_amd import ops
 
     dev = _dev()
@@ -296,12 +297,13 @@ def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, monkey
         report(f"attn-pl {pl} B{B} H{H} {Sq}x{Sk} dq", res[pl][0], dq_ref, 1e-2)
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 16, 1024, 2048), (1, 16, 1024, 2000), (1, 64, 128, 512)])
+@pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 16, 1024, 2048), (1, 16, 1024, 2000), (1, 64, 128, 512), (2, 16, 1000, 1000), (1, 32, 777, 1100)])
 def test_pipelined_dkdv_kernel_is_bit_identical_to_the_kernel_it_replaces(B, H, Sq, Sk, monkeypatch):
     """Round 5: attn_bwd_dkdv_pl_kernel (64 keys per wave, one wave per SIMD, the same software pipeline as the dQ kernel; the lse / delta rows arrive by DMA and
     wave 0 turns them into the accumulator inputs -lse / sl and -delta before the tile's hand-over barrier) does the arithmetic of attn_bwd_dkdv_kernel<1, 2>
     statement for statement: dK and dV must be the same bits with FTMI_ATTN_PL bit 1 on and off -- whole and ragged key counts, few and many query tiles.
-    (Shapes with fewer than 256 key blocks x heads keep the split-query kernel, ragged query counts and key biases the old one: covered by the other cases.)"""
+    Ragged QUERY counts (1000, 777): the DMA zero-fills the rows past the end -- Q = dO = 0 there, so they add nothing whatever p they get.
+    (Shapes with fewer than 256 key blocks x heads keep the split-query kernel, key biases the old one: covered by the other cases.)"""
     from finetrainers_amd import ops
 
     dev = _dev()
