@@ -1377,6 +1377,8 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
                 if (var == 0) FTMI_PL_LAUNCH(1, 0);
                 else if (var == 2) FTMI_PL_LAUNCH(1, 2);
 #ifdef FTMI_LAB
+                else if (var == 6) FTMI_PL_LAUNCH(1, 6);
+                else if (var == 7) FTMI_PL_LAUNCH(1, 7);
                 else if (var == 3) FTMI_PL_LAUNCH(1, 3);
                 else if (var == 4) FTMI_PL_LAUNCH(1, 4);
                 else if (var == 5) FTMI_PL_LAUNCH(1, 5);
@@ -1386,6 +1388,8 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
                 if (var == 0) FTMI_PL_LAUNCH(2, 0);
                 else if (var == 2) FTMI_PL_LAUNCH(2, 2);
 #ifdef FTMI_LAB
+                else if (var == 6) FTMI_PL_LAUNCH(2, 6);
+                else if (var == 7) FTMI_PL_LAUNCH(2, 7);
                 else if (var == 3) FTMI_PL_LAUNCH(2, 3);
                 else if (var == 4) FTMI_PL_LAUNCH(2, 4);
                 else if (var == 5) FTMI_PL_LAUNCH(2, 5);

@@ -33,8 +33,8 @@ static constexpr int kPlLds = 3 * 16384;  // three (K, V) [or (Q, dO)] tile slot
 
 // NQ: 32-row query sub-tiles per wave (1: two waves per SIMD, 128 rows per workgroup; 2: one wave per SIMD, 256 rows per workgroup).
 // VAR: 0 = exact arithmetic of attn_bwd_dq2_kernel (bit-identical outputs: the pipeline's test), 1 = -delta through the accumulator input of the
-// dP chain, 2 = as 1 with the VALU work in passes over groups of four elements; 3 / 4 / 5 = lab ablations of 1 (no VALU / no LDS reads / no MFMA:
-// results wrong on purpose, tools/attn_lab.hip reads their time only)
+// dP chain, 2 = as 1 with the VALU work in passes over groups of four elements; lab only: 6 = packed fp32 VALU (same bits, 9 % slower), 3 / 4 / 5 / 7 = ablations of 1
+// (no VALU / no LDS reads / no MFMA / the MFMAs as 16 x 16 x 32 on dummy accumulators: results wrong on purpose, tools/attn_lab.hip reads their time only)
 template <int NQ, int VAR>
 __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,6 +163,12 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
     u32x2 ktlo[2][2], kthi[2][2];
     uint32_t dsw[2][2][4];
     float x[16], y[16];
+    f32x2 x2[8], y2[8];  // (packed-VALU stream, lab only: 9 % slower -- packed fp32 VALU beside MFMAs is an anti-lever, profiles/r05_attn_lab_5_packed_valu.txt)
+    f32x4 d16[8] = {};      // (lab only: dummy accumulators of the 16 x 16 x 32 time ablation)
+    const f32x2 sl2 = {sl, sl};
+    f32x2 nlse2[NQ];
+#pragma unroll
+    for (int qt = 0; qt < NQ; ++qt) nlse2[qt] = f32x2{nlse[qt], nlse[qt]};
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -222,7 +228,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
 #include "attn_pl_dq1_v2.inc"
             }
 #ifdef FTMI_LAB
-            else if constexpr (VAR == 3) {
+            else if constexpr (VAR == 6) {
+#include "attn_pl_dq1_v6.inc"
+            } else if constexpr (VAR == 7) {
+#include "attn_pl_dq1_a_mfma16.inc"
+            } else if constexpr (VAR == 3) {
 #include "attn_pl_dq1_a_novalu.inc"
             } else if constexpr (VAR == 4) {
 #include "attn_pl_dq1_a_nolds.inc"
@@ -239,7 +249,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
 #include "attn_pl_dq2_v2.inc"
             }
 #ifdef FTMI_LAB
-            else if constexpr (VAR == 3) {
+            else if constexpr (VAR == 6) {
+#include "attn_pl_dq2_v6.inc"
+            } else if constexpr (VAR == 7) {
+#include "attn_pl_dq2_a_mfma16.inc"
+            } else if constexpr (VAR == 3) {
 #include "attn_pl_dq2_a_novalu.inc"
             } else if constexpr (VAR == 4) {
 #include "attn_pl_dq2_a_nolds.inc"

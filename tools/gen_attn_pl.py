@@ -91,6 +91,24 @@ def dq_valu_ops(par: int, qt: int, exact: bool, order: str) -> list[tuple[str, s
         return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(dsw[{par}][{hh}][{e}])', f'"v"(x[{r}]), "v"(x[{r + 1}])')
 
     ops = []
+    if order == "pk":
+        # packed fp32 VALU on aligned register pairs (v_pk_fma_f32 / v_pk_mul_f32: two scores per instruction): 40 instead of 56 instructions per unit.
+        # Same arithmetic per element (a packed op rounds each half like the scalar op), so the results are the bits of the scalar streams.
+        assert not exact
+        def FP(r): return ("v_pk_fma_f32 %0, %1, %2, %3", f'"=v"(x2[{r >> 1}])', f'"v"(__builtin_shufflevector({S}, {S}, {r}, {r + 1})), "v"(sl2), "v"(nlse2[{qt}])')
+        def EL(r): return ("v_exp_f32 %0, %1", f'"=v"(x[{r}])', f'"v"(x2[{r >> 1}][{r & 1}])')
+        def MP(r): return ("v_pk_mul_f32 %0, %1, %2", f'"=v"(y2[{r >> 1}])', f'"v"(f32x2{{x[{r}], x[{r + 1}]}}), "v"(__builtin_shufflevector({DP}, {DP}, {r}, {r + 1}))')
+        def PK(r):
+            hh, e = r >> 3, (r & 7) >> 1
+            return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(dsw[{par}][{hh}][{e}])', f'"v"(y2[{r >> 1}][0]), "v"(y2[{r >> 1}][1])')
+        L = 2
+        for s in range(8 + 3 * L + 1):
+            if s < 8: ops.append(FP(2 * s))
+            if 0 <= s - L < 8: ops += [EL(2 * (s - L)), EL(2 * (s - L) + 1)]
+            if 0 <= s - 2 * L < 8: ops.append(MP(2 * (s - 2 * L)))
+            if 0 <= s - 3 * L < 8: ops.append(PK(2 * (s - 3 * L)))
+        assert len(ops) == 40, len(ops)
+        return ops
     if order.startswith("g"):
         group = int(order[1:])
         for m in range(16 // group):
@@ -166,7 +184,15 @@ def gen_dq(name: str, nq: int, exact: bool, order: str = "roll", weights=None, d
                 s.emit("// the next unit's K / V row fragments must have landed before its first MFMA")
                 s.asm("s_waitcnt lgkmcnt(0)", "", "", '"memory"')
             t, o, ins = mf[g]
-            if "mfma" not in drop:
+            if "mfma16" in drop:
+                # time-only ablation: the same FLOPs as two v_mfma_f32_16x16x32_bf16 on dummy 4-register accumulators (same A / B registers): what would the
+                # other MFMA shape cost in this stream (energy per FLOP, issue slots)?  Results are wrong on purpose.
+                ab = ins.split("), ")
+                a_op, b_op = ab[0] + ")", ab[1] if ab[1].endswith(")") else ab[1] + ")"
+                b_op = b_op.replace("QFC(", '"v"(')
+                for h in range(2):
+                    s.asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0", f'"+v"(d16[{(2 * g + h) % 8}])', f"{a_op}, {b_op}")
+            elif "mfma" not in drop:
                 s.asm(t, o, ins)
             if early and g < 2 and "lds" not in drop:
                 which, voff = ("kf", 0) if g == 0 else ("vf", 8192)
@@ -333,10 +359,13 @@ def main():
         made.append(gen_dq("v1", nq, False))
         # v2: as v1, VALU in passes over groups of four elements
         made.append(gen_dq("v2", nq, False, order="g4"))
+        # v6: as v1 with packed fp32 fma / mul (two scores per instruction)
+        made.append(gen_dq("v6", nq, False, order="pk"))
         # ablations of v1 (lab only; results wrong on purpose)
         made.append(gen_dq("a_novalu", nq, False, drop=("valu",)))
         made.append(gen_dq("a_nolds", nq, False, drop=("lds",)))
         made.append(gen_dq("a_nomfma", nq, False, drop=("mfma",)))
+        made.append(gen_dq("a_mfma16", nq, False, drop=("mfma16",)))
     made.append(gen_dkv("v1"))
     made.append(gen_dkv("v2", order="g4"))
     made.append(gen_dkv("a_novalu", drop=("valu",)))
