@@ -417,6 +417,14 @@ static int attn_gen(const char* which, int dflt) {
 }
 #endif
 
+// FTMI_ATTN_PL (re-read every call): bit 0 pipelined dQ, bit 1 pipelined dK / dV, bit 2 pipelined forward (experimental builds only); bits 4-7 dQ stream, bit 8 dQ at 64 rows per wave,
+// bits 12-15 dK / dV stream, bits 16-19 forward stream (lab)
+static constexpr int kAttnPlDefault = 0x1113;
+#include "attention_pl.hip.h"
+#if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
+#include "../../tools/experimental/attention_experimental_6_fwd_pl.hip.h"  // pipelined forward: bit-identical, 4-7 % slower (EXPERIMENT, not shipped)
+#endif
+
 int attn_fwd(const AttnArgs& a, hipStream_t st) {
     if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Sk <= 0) return set_error(FTMI_ERR_INVALID, "attn_fwd: empty problem");
     if ((a.q_ss % 8) || (a.k_ss % 8) || (a.v_ss % 8) || (a.o_ss % 8))
@@ -482,6 +490,30 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
         if (a.kbias) hipLaunchKernelGGL(attn_fwd_res_kernel<true>, gr, dim3(256), kFwdResLds, st, a, nblk, bpw);
         else hipLaunchKernelGGL(attn_fwd_res_kernel<false>, gr, dim3(256), kFwdResLds, st, a, nblk, bpw);
         return check_launch("attn_fwd");
+    }
+#endif
+#if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
+    // pipelined forward (experiment: same bits as the kernels below, 4-7 % slower): FTMI_ATTN_PL bit 2
+    if (!a.kbias && a.Sk >= 128 && a.Sq >= 128) {
+        const int pl = env_int("FTMI_ATTN_PL", kAttnPlDefault);
+        if (pl & 4) {
+            const dim3 gridp(((a.Sq + 255) / 256) * a.H * a.B);
+            const bool ragged = (a.Sk % 64) != 0;
+#define FTMI_FWD_PL(V_)                                                                                                                                       \
+    do {                                                                                                                                                      \
+        static const bool ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pl_kernel<V_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess && \
+                                hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pl_kernel<V_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlLds) == hipSuccess;   \
+        if (!ok_) return set_error(FTMI_ERR_LAUNCH, "attn_fwd: cannot raise the dynamic LDS limit");                                                          \
+        if (ragged) hipLaunchKernelGGL((attn_fwd_pl_kernel<V_, true>), gridp, dim3(256), kPlLds, st, a);                                                      \
+        else hipLaunchKernelGGL((attn_fwd_pl_kernel<V_, false>), gridp, dim3(256), kPlLds, st, a);                                                            \
+    } while (0)
+            const int fv = (pl >> 16) & 15;  // 3 / 4: lab ablations (no VALU / no LDS reads; the stream of 1 outside -DFTMI_LAB)
+            if (fv == 3) FTMI_FWD_PL(3);
+            else if (fv == 4) FTMI_FWD_PL(4);
+            else FTMI_FWD_PL(1);
+#undef FTMI_FWD_PL
+            return check_launch("attn_fwd");
+        }
     }
 #endif
     if (a.kbias)
@@ -1295,7 +1327,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
     for (int qt = 0; qt < 2; ++qt) store_rows_via_lds(smem + wave * 4096, dqt[qt], a.scale, dqb, a.dq_ss, row0 + qt * 32, a.Sq, lane);
 }
 
-#include "attention_pl.hip.h"
 
 #ifdef FTMI_EXPERIMENTAL
 #include "../../tools/experimental/attention_experimental_5.hip.h"  // backward dK / dV, 64 keys per wave (EXPERIMENT, not shipped: 508 us against 445 us for the whole backward with
@@ -1363,7 +1394,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
         // hand-placed pipelines (attention_pl.hip.h): no key bias (ragged token counts: the DMA zero-fills).  FTMI_ATTN_PL (re-read every call, a getenv, so that one process can compare
         // the kernels): bit 0 = dQ kernel, bits 4-7 = stream variant, bit 8 = 64 query rows per wave at one wave per SIMD (the default; 0: 32 rows, two waves per SIMD)
-        const int pl = env_int("FTMI_ATTN_PL", 0x1113);
+        const int pl = env_int("FTMI_ATTN_PL", kAttnPlDefault);
         if ((pl & 1) && !a.kbias && a.Sk >= 128) {
             const int var = (pl >> 4) & 15, nq = (pl & 0x100) ? 2 : 1;
             const dim3 gridp(((a.Sq + 128 * nq - 1) / (128 * nq)) * a.H * a.B);
@@ -1426,7 +1457,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     } else {
         // hand-placed pipeline (attention_pl.hip.h): 64 keys per wave, one wave per SIMD.  FTMI_ATTN_PL bit 1 (value >> 12 = stream variant).  No key bias;
         // a.delta was just written by the dQ kernel.
-        const int plk = env_int("FTMI_ATTN_PL", 0x1113);
+        const int plk = env_int("FTMI_ATTN_PL", kAttnPlDefault);
         if ((plk & 2) && !a.kbias && a.Sq >= 128 && a.Sk >= 256) {
             const int var = (plk >> 12) & 15;
             const dim3 gridk(((a.Sk + 255) / 256) * a.H * a.B);

@@ -547,3 +547,4 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pl_kernel(AttnArgs a) {
         store_rows_via_lds(smem + wave * 4096, dV[kt], 1.0f, dvb, a.dv_ss, key0 + kt * 32, a.Sk, lane);
     }
 }
+

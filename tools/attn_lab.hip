@@ -70,6 +70,14 @@ int main(int argc, char** argv) {
         const size_t n = (size_t)B * S * H * 64;
         std::vector<uint16_t> hq(n), hk(n), hv(n), hdo(n);
         fill_random(hq, 1, 1.f); fill_random(hk, 2, 1.f); fill_random(hv, 3, 1.f); fill_random(hdo, 4, 1.f);
+        if (getenv("LAB_GROW")) {  // keys grow along the sequence: the running row max outgrows the lazy reference by 2^8 several times (the forward's rare path)
+            for (int bb = 0; bb < B; ++bb)
+                for (int j = 0; j < S; ++j)
+                    for (int e = 0; e < H * 64; ++e) {
+                        uint16_t& x = hk[((size_t)bb * S + j) * H * 64 + e];
+                        x = f2bf_host(bf2f_host(x) * (1.f + 10.f * (float)j / (float)S));
+                    }
+        }
         uint16_t *dq_, *dk_, *dv_, *ddo, *dout, *gq, *gk, *gv;
         float *lse, *delta;
         for (uint16_t** ptr : {&dq_, &dk_, &dv_, &ddo, &dout, &gq, &gk, &gv}) CK(hipMalloc(ptr, n * 2));
@@ -88,9 +96,53 @@ int main(int argc, char** argv) {
         a.dq = gq; a.dq_sb = sb; a.dq_sh = sh; a.dq_ss = ss;
         a.dk = gk; a.dk_sb = sb; a.dk_sh = sh; a.dk_ss = ss;
         a.dv = gv; a.dv_sb = sb; a.dv_sh = sh; a.dv_ss = ss;
+        printf("== B %d H %d S %d\n", B, H, S); fflush(stdout);
+        if (getenv("LAB_FWD")) {  // the forward: every configuration against the first (O and lse bit for bit), then interleaved timing rounds
+            std::vector<uint16_t> ro(n), oo(n);
+            std::vector<float> rl((size_t)B * H * S), ol((size_t)B * H * S);
+            for (size_t i = 0; i < cfg.size(); ++i) {
+                CK(hipMemsetAsync(dout, 0xff, n * 2, st)); CK(hipMemsetAsync(lse, 0xff, (size_t)B * H * S * 4, st));
+                setenv("FTMI_ATTN_PL", cfg[i].c_str(), 1);
+                if (ftmi::attn_fwd(a, st) != 0) return 2;
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(oo.data(), dout, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(ol.data(), lse, (size_t)B * H * S * 4, hipMemcpyDeviceToHost));
+                if (i == 0) { ro = oo; rl = ol; }
+                size_t badl = 0; double dl = 0;
+                for (size_t k = 0; k < ol.size(); ++k) { badl += memcmp(&ol[k], &rl[k], 4) != 0; dl = std::max(dl, (double)fabsf(ol[k] - rl[k])); }
+                printf(" forward FTMI_ATTN_PL=%s vs %s:\n", cfg[i].c_str(), cfg[0].c_str());
+                compare("O", oo, ro);
+                printf("   lse mismatching %.3e  max abs diff %.3e\n", (double)badl / ol.size(), dl);
+                fflush(stdout);
+            }
+            hipEvent_t f0, f1;
+            CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+            std::vector<std::vector<float>> res(cfg.size());
+            for (int rnd = 0; rnd < 5; ++rnd)
+                for (size_t i = 0; i < cfg.size(); ++i) {
+                    setenv("FTMI_ATTN_PL", cfg[i].c_str(), 1);
+                    for (int k = 0; k < 5; ++k) ftmi::attn_fwd(a, st);
+                    CK(hipEventRecord(f0, st));
+                    for (int k = 0; k < 20; ++k) ftmi::attn_fwd(a, st);
+                    CK(hipEventRecord(f1, st));
+                    CK(hipEventSynchronize(f1));
+                    float ms; CK(hipEventElapsedTime(&ms, f0, f1));
+                    res[i].push_back(ms / 20);
+                }
+            for (size_t i = 0; i < cfg.size(); ++i) {
+                std::sort(res[i].begin(), res[i].end());
+                printf(" forward        FTMI_ATTN_PL=%-8s median %8.1f us  best %8.1f us  -> %7.1f TF/s\n", cfg[i].c_str(), res[i][2] * 1e3, res[i][0] * 1e3,
+                       4.0 * B * H * (double)S * S * 64 / res[i][2] / 1e9);
+            }
+            fflush(stdout);
+            setenv("FTMI_ATTN_PL", cfg[0].c_str(), 1);
+        }
         if (ftmi::attn_fwd(a, st) != 0) return 2;
         CK(hipStreamSynchronize(st));
-        printf("== B %d H %d S %d  (forward done)\n", B, H, S); fflush(stdout);
+        if (getenv("LAB_FWD_ONLY")) {
+            for (uint16_t* ptr : {dq_, dk_, dv_, ddo, dout, gq, gk, gv}) CK(hipFree(ptr));
+            CK(hipFree(lse)); CK(hipFree(delta));
+            continue;
+        }
         const double flops = 10.0 * B * H * (double)S * S * 64;
         auto run = [&](const std::string& c, int only) {
             setenv("FTMI_ATTN_PL", c.c_str(), 1);

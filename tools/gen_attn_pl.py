@@ -350,6 +350,133 @@ def gen_dkv(name: str, order: str = "roll", drop=()):
     return path
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# forward: a wave owns 64 query rows (qt = 0, 1: 32 each), loops over 64-key tiles; one slot per (tile, qt) = 32 queries x 64 keys.
+# Slot of unit u = (t, qt), parity p = qt:
+#   C(u-1): 12 MFMAs  O[qt'] += V^T . P[p^1]  (8)  and the row sums of P[p^1] through an all-ones A operand (4);
+#   A(u+1):  8 MFMAs  S[p^1] = K . Q[qt']^T  for the two 32-key halves (chains interleaved);
+#   B(u):  102 VALU   the row max of S[p] (22; S[p] was finished by the last MFMAs of the slot before, so this starts two MFMAs into the slot), the
+#                     lazy-reference decision of attn_fwd_kernel (rare rescale of O[qt]: its last products were issued in the slot before, its next
+#                     ones come in the slot after), then P[p] = exp2(S[p] * sl - m) -> bf16 fragments (80).
+# MFMA order  C = rs00 pv000 rs01 pv001 rs10 pv010 rs11 pv011 pv100 pv101 pv110 pv111 | A  (accumulators alternate; per accumulator the order of
+# attn_fwd_kernel: js, hh ascending).  qt == 0 slots reload each V^T fragment for the new tile right behind the MFMA that used it last (the last
+# reload has eight MFMAs to land); qt == 1 slots carry the tile hand-over, the K row fragments of tile t+1 and the DMA of tile t+2.
+# ------------------------------------------------------------------------------------------------------------------------------
+def fwd_valu_ops(par: int):
+    def F(i):
+        js, r = i >> 4, i & 15
+        return ("v_fma_f32 %0, %1, %2, %3", f'"=v"(x[{i}])', f'"v"(S[{par}][{js}][{r}]), "v"(sl), "v"(nm[{par}])')
+
+    def E(i):
+        return ("v_exp_f32 %0, %0", f'"+v"(x[{i}])', "")
+
+    def P(i):  # pair (i, i+1), i even
+        js, r = i >> 4, i & 15
+        hh, e = r >> 3, (r & 7) >> 1
+        return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(pw[{par}][{js}][{hh}][{e}])', f'"v"(x[{i}]), "v"(x[{i + 1}])')
+
+    ops, L = [], 4
+    for s_ in range(32 + L + 2):
+        if s_ < 32:
+            ops.append(F(s_))
+        if 0 <= s_ - L < 32:
+            ops.append(E(s_ - L))
+        r = s_ - L - 1
+        if 0 <= r < 32 and r % 2 == 1:
+            ops.append(P(r - 1))
+    assert len(ops) == 80, len(ops)
+    return ops
+
+
+def fwd_max_ops(parn: int):
+    """row max of the 32 scores of the next unit -> mx (log2 domain), both half-waves: max16 x 2 (chains interleaved), scale, cross-half."""
+    S0, S1 = f"S[{parn}][0]", f"S[{parn}][1]"
+    ops = []
+    for k in range(8):
+        for (S, m) in ((S0, "mxa"), (S1, "mxb")):
+            if k == 0:
+                ops.append(("v_max3_f32 %0, %1, %2, %3", f'"=&v"({m})', f'"v"({S}[0]), "v"({S}[1]), "v"({S}[2])'))
+            elif k < 7:
+                ops.append(("v_max3_f32 %0, %0, %1, %2", f'"+v"({m})', f'"v"({S}[{2 * k + 1}]), "v"({S}[{2 * k + 2}])'))
+            else:
+                ops.append(("v_max_f32 %0, %0, %1", f'"+v"({m})', f'"v"({S}[15])'))
+    ops.append(("v_max_f32 %0, %0, %1", '"+v"(mxa)', '"v"(mxb)'))
+    ops.append(("v_mul_f32 %0, %1, %2", '"=v"(mx)', '"v"(mxa), "v"(sl)'))
+    ops.append(("v_mov_b32 %1, %0\\n\\ts_nop 1\\n\\tv_permlane32_swap_b32 %1, %0\\n\\tv_max_f32 %0, %0, %1", '"+v"(mx), "=&v"(mxb)', ""))
+    return ops
+
+
+def gen_fwd(name: str, drop=()):
+    s = Stream()
+    s.emit(f"// GENERATED by tools/gen_attn_pl.py (fwd_{name}: drop={','.join(drop) or '-'}) -- do not edit")
+    for qt in range(2):
+        par, parn = qt, qt ^ 1
+        s.emit(f"// ---- slot (t, qt {qt}): max + exp2 of S[{par}]; C(u-1) on O[{parn}] with P[{parn}]; A(u+1) into S[{parn}]")
+        s.emit("{")
+        valu = [] if "valu" in drop else fwd_valu_ops(par)
+        vmax = fwd_max_ops(par)
+        def rs(js, hh, first=False):
+            if first:
+                return (f"{MFMA} %0, %1, %2, 0", '"=&v"(lsum)', f'"v"(ones), "v"(PF({parn}, {js}, {hh}))')
+            return (f"{MFMA} %0, %1, %2, %0", '"+v"(lsum)', f'"v"(ones), "v"(PF({parn}, {js}, {hh}))')
+        def pv(js, hh, dt):
+            return (f"{MFMA} %0, %1, %2, %0", f'"+a"(oacc[{parn}][{dt}])', f'"v"(VTF({js}, {hh}, {dt})), "v"(PF({parn}, {js}, {hh}))', (js, hh, dt))
+        def sa(js, c):
+            if c == 0:
+                return (f"{MFMA} %0, %1, %2, 0", f'"=&v"(S[{parn}][{js}])', f'"v"(kf[{js}][{c}]), "v"(qf[{parn}][{c}])')
+            return (f"{MFMA} %0, %1, %2, %0", f'"+v"(S[{parn}][{js}])', f'"v"(kf[{js}][{c}]), "v"(qf[{parn}][{c}])')
+        mf = [rs(0, 0, True), pv(0, 0, 0), rs(0, 1), pv(0, 0, 1), rs(1, 0), pv(0, 1, 0), rs(1, 1), pv(0, 1, 1), pv(1, 0, 0), pv(1, 0, 1), pv(1, 1, 0), pv(1, 1, 1)]
+        mf += [sa(js, c) for c in range(4) for js in range(2)]
+        ngap = len(mf)  # 20
+        # S[par] was finished by the last two MFMAs of the slot before: its row max waits two MFMAs (gaps 2 .. 4), then the (rare) rescale decision,
+        # then the exp2 work in gaps 5 .. 19; the row sums of C(u-1) (MFMAs 0, 2, 4, 6) are taken at gap 10
+        mcounts = [0, 0] + spread(len(vmax), 3) + [0] * 15
+        counts = [0] * 5 + spread(len(valu), 15)
+        if qt == 0:
+            s.emit("RING_ADVANCE_TR();  // transposed-fragment addresses -> ring slot of this tile")
+        else:
+            s.emit("// tile hand-over: my loads of tile t+1 have landed; after the barrier everyone's have, and nobody reads tile t-1 any more")
+            s.asm("s_waitcnt vmcnt(0)\\n\\ts_barrier", "", "", '"memory"')
+            s.emit("RING_ADVANCE_ROW();  // row-fragment addresses -> ring slot of tile t+1")
+        s.asm("s_waitcnt lgkmcnt(0)\\n\\ts_nop 1", "", "", '"memory"')
+        vi = mi = 0
+        for g in range(ngap):
+            if g == 12 and qt == 1 and "lds" not in drop:
+                s.emit("// the K row fragments of tile t+1 must have landed before the first score MFMA")
+                s.asm("s_waitcnt lgkmcnt(0)", "", "", '"memory"')
+            m = mf[g]
+            if "mfma" not in drop:
+                s.asm(m[0], m[1], m[2])
+            if qt == 0 and len(m) == 4 and "lds" not in drop:
+                js, hh, dt = m[3]
+                base = 8192 + js * 4096 + hh * 2048
+                s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(vtlo[{js}][{hh}][{dt}])', f'"v"(tra[{dt}][0])')
+                s.asm(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(vthi[{js}][{hh}][{dt}])', f'"v"(tra[{dt}][1])')
+            if qt == 1 and g < 2 and "lds" not in drop:
+                for c in range(4):
+                    s.asm(f"ds_read_b128 %0, %1 offset:{g * 4096}", f'"=v"(kf[{g}][{c}])', f'"v"(ra[{c}])')
+            if qt == 1 and 6 <= g < 10 and "dma" not in drop:
+                s.emit(f"DMA_PIECE({g - 6});")
+            for _ in range(mcounts[g]):
+                t2, o2, i2 = vmax[mi]
+                s.asm(t2, o2, i2)
+                mi += 1
+            if g == 4:
+                s.emit(f"DECIDE({par});")
+            for _ in range(counts[g]):
+                t2, o2, i2 = valu[vi]
+                s.asm(t2, o2, i2)
+                vi += 1
+            if g == 10:
+                s.emit(f"L_UPDATE({parn});")
+        assert vi == len(valu) and mi == len(vmax)
+        s.emit("}")
+    path = os.path.join(HERE, "experimental", f"attn_pl_fwd_{name}.inc")  # experiment, not shipped (tools/experimental/attention_experimental_6_fwd_pl.hip.h)
+    with open(path, "w") as f:
+        f.write("\n".join(s.lines) + "\n")
+    return path
+
+
 def main():
     made = []
     for nq in (1, 2):
@@ -370,6 +497,9 @@ def main():
     made.append(gen_dkv("v2", order="g4"))
     made.append(gen_dkv("a_novalu", drop=("valu",)))
     made.append(gen_dkv("a_nolds", drop=("lds",)))
+    made.append(gen_fwd("v1"))
+    made.append(gen_fwd("a_novalu", drop=("valu",)))
+    made.append(gen_fwd("a_nolds", drop=("lds",)))
     for p in made:
         print(os.path.relpath(p, os.path.join(HERE, "..")))
 

@@ -10,6 +10,15 @@ case "${1:-}" in
     echo "exit $?" >> gpurun_out/r05_attn_lab_$tag.txt
     tail -40 gpurun_out/r05_attn_lab_$tag.txt
     ;;
+  f)  # attention lab, forward: pipelined forward (FTMI_ATTN_PL bit 2) vs attn_fwd_kernel, bit compare + timing; also with keys that grow along the sequence (rare rescale path)
+    tag="${2:-1}"; shapes="${3:-2x32x2688}"; cfgs="${4:-0,0x4}"
+    LAB_FWD=1 LAB_FWD_ONLY=1 timeout 300 tools/bin/attn_lab "$shapes" "$cfgs" > gpurun_out/r05_attn_fwd_lab_$tag.txt 2>&1
+    echo "exit $?" >> gpurun_out/r05_attn_fwd_lab_$tag.txt
+    echo "# LAB_GROW=1 (keys grow along the sequence)" >> gpurun_out/r05_attn_fwd_lab_$tag.txt
+    LAB_GROW=1 LAB_FWD=1 LAB_FWD_ONLY=1 timeout 300 tools/bin/attn_lab "$shapes" "$cfgs" >> gpurun_out/r05_attn_fwd_lab_$tag.txt 2>&1
+    echo "exit $?" >> gpurun_out/r05_attn_fwd_lab_$tag.txt
+    cat gpurun_out/r05_attn_fwd_lab_$tag.txt
+    ;;
   p)  # the MFMA / VALU issue probe of round 2, whole output
     hipcc --offload-arch=gfx950 -O3 tools/probe_mfma_valu.hip -o /tmp/probe_mfma_valu && timeout 120 /tmp/probe_mfma_valu > gpurun_out/r05_probe_mfma_valu.txt 2>&1
     cat gpurun_out/r05_probe_mfma_valu.txt
