@@ -2095,18 +2095,31 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
     const int li = lane & 31, g = lane >> 5;
 
     const int ntp = a.P / BP, ntq = a.Q / BQ;
-    int bid = blockIdx.x;
-    const int split = bid / (ntp * ntq);
-    bid -= split * ntp * ntq;
-    const int p0 = (bid / ntq) * BP, q0 = (bid % ntq) * BQ;
     const int nsteps_total = a.M / 64;
+    int bid = blockIdx.x, split, batch = blockIdx.y;
+    if (a.xcd_groups > 0) {
+        // XCD-aware order (1-D grid; workgroup w is observed to run on XCD w % 8): all tiles of one (split, batch) group -- they stream the same rows of the
+        // SHORT operand -- go to one XCD, back to back, so that operand comes out of that XCD's L2 instead of being fetched over the fabric once per XCD
+        // (with tiles dealt round-robin the short operand of a 2048 x 64 gradient cost as many fabric bytes as the long one: 8 KB instead of 4.25 KB per token)
+        const int x = bid & 7, s = bid >> 3, nt = ntp * ntq;
+        const int gi = (s / nt) * 8 + x;
+        if (gi >= a.xcd_groups) return;
+        const int nsplit = (nsteps_total + a.msteps_per_split - 1) / a.msteps_per_split;
+        split = gi % nsplit;
+        batch = gi / nsplit;
+        bid = s % nt;
+    } else {
+        split = bid / (ntp * ntq);
+        bid -= split * ntp * ntq;
+    }
+    const int p0 = (bid / ntq) * BP, q0 = (bid % ntq) * BQ;
     const int s_begin = split * a.msteps_per_split;
     const int n = min(nsteps_total, s_begin + a.msteps_per_split) - s_begin;
     if (n <= 0) return;
 
-    const bf16_t* U = a.U + (long)blockIdx.y * a.u_bstride + (a.u_grp_p > 0 ? (long)(p0 / a.u_grp_p) * a.u_grp_stride + p0 % a.u_grp_p : (long)p0);
-    const bf16_t* V = a.V + (long)blockIdx.y * a.v_bstride + q0;
-    float* C = a.C + (long)blockIdx.y * a.c_bstride;
+    const bf16_t* U = a.U + (long)batch * a.u_bstride + (a.u_grp_p > 0 ? (long)(p0 / a.u_grp_p) * a.u_grp_stride + p0 % a.u_grp_p : (long)p0);
+    const bf16_t* V = a.V + (long)batch * a.v_bstride + q0;
+    float* C = a.C + (long)batch * a.c_bstride;
     if (a.v_grp_p > 0) V += (long)(p0 / a.v_grp_p) * a.v_grp_stride;
 
     f32x16 acc[TP][TQ];
@@ -2220,7 +2233,15 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     }
     const bool wideP = (a.P % 128 == 0) && (a.P >= a.Q);
     const bool wideQ = !wideP && (a.Q % 128 == 0);
-    const int bp = wideP ? 128 : 64, bq = wideP ? 64 : (wideQ ? 128 : 64);
+    // Round 5: 256-wide tiles of the long extent for the LoRA weight gradients (2048 x 64 per block and adapter, 28 blocks per launch).  The short operand
+    // (64 columns, two bf16 planes) is re-read by every tile of the long one -- at 128 columns per tile that is as many bytes as the long operand itself;
+    // 256 columns halve it (8 -> 6 KB per token) and put 96 KB instead of 64 KB per CU in flight.  FTMI_TN_WIDE=0: the 128-wide tiles.  Together with the
+    // XCD-aware tile order below: 1.82 -> 1.71 ms per step over the ten launches (rocprofv3, profiles/r05_tn_wgrad.txt) -- these launches already run at
+    // 4.2-5.1 TB/s of unique traffic; the few-token text-side launches (M = 256) keep the old tiles (they got slower: 35 -> 55 us).
+    static const int tn_wide = env_int("FTMI_TN_WIDE", 1), tn_gen = env_int("FTMI_TN_GEN", 2);
+    const bool wide256 = tn_wide && tn_gen == 2 && a.M % 64 == 0 && a.M >= 1024 && ((wideP && a.P % 256 == 0 && a.Q == 64 && (a.v_grp_p == 0 || a.v_grp_p % 256 == 0) && a.u_grp_p == 0) ||
+                                                      (wideQ && a.Q % 256 == 0 && a.v_grp_p == 0));
+    const int bp = wideP ? (wide256 ? 256 : 128) : 64, bq = wideP ? 64 : (wideQ ? (wide256 ? 256 : 128) : 64);
     if (a.v_grp_p > 0 && a.v_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: group width vs tile");
     const int tiles = (a.P / bp) * (a.Q / bq);
     static const int target_wgs = env_int("FTMI_TN_TARGET_WGS", 128) > 0 ? env_int("FTMI_TN_TARGET_WGS", 128) : 128;
@@ -2233,15 +2254,19 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     if (per < 1) per = 1;
     a.msteps_per_split = per;
     const int nsplit = (nsteps + per - 1) / per;
-    const dim3 grid(tiles * nsplit, nb);
+    dim3 grid(tiles * nsplit, nb);
+    static const int tn_xcd = env_int("FTMI_TN_XCD", 1);
+    if (tn_xcd && tn_gen == 2 && a.M % 64 == 0 && a.M >= 1024 && tiles > 1 && nsplit * nb >= 8) {  // the XCD-aware 1-D order of gemm_tn2_kernel
+        a.xcd_groups = nsplit * nb;
+        grid = dim3(8 * ((a.xcd_groups + 7) / 8) * tiles, 1);
+    }
     ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q * nb, st);
-    static const int tn_gen = env_int("FTMI_TN_GEN", 2);
     if (a.u_fold && a.v_fold) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: only one operand may be a (hi, lo) pair");
     if (a.u_grp_p > 0 && a.u_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: U group width vs tile");
     if (tn_gen == 2 && a.M % 64 == 0) {  // DMA-ring kernel (whole 64-token steps only)
         int rc;
-        if (wideP) rc = launch_tn2<128, 64>(a, grid, st);
-        else if (wideQ) rc = launch_tn2<64, 128>(a, grid, st);
+        if (wideP) rc = wide256 ? launch_tn2<256, 64>(a, grid, st) : launch_tn2<128, 64>(a, grid, st);
+        else if (wideQ) rc = wide256 ? launch_tn2<64, 256>(a, grid, st) : launch_tn2<64, 128>(a, grid, st);
         else rc = launch_tn2<64, 64>(a, grid, st);
         return rc ? rc : check_launch("gemm_tn");
     }

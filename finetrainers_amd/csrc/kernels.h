@@ -114,6 +114,7 @@ struct GemmTnArgs {
     // hi^T.other + lo^T.other to the same C (at most one of the two may be folded)
     long u_fold = 0, v_fold = 0;
     int msteps_per_split = 0;  // filled by the launcher
+    int xcd_groups = 0;        // filled by the launcher: > 0 = 1-D grid in the XCD-aware order of gemm_tn2_kernel (number of (split, batch) groups)
     float scale = 1.f;
     // batched form (blockIdx.y = batch index): element strides between consecutive problems (0 = shared operand)
     int batch = 1;
