@@ -417,9 +417,9 @@ static int attn_gen(const char* which, int dflt) {
 }
 #endif
 
-// FTMI_ATTN_PL (re-read every call): bit 0 pipelined dQ, bit 1 pipelined dK / dV, bit 2 pipelined forward (experimental builds only); bits 4-7 dQ stream, bit 8 dQ at 64 rows per wave,
+// FTMI_ATTN_PL (re-read every call): bit 0 pipelined dQ, bit 1 pipelined dK / dV, bit 2 pipelined forward (experimental builds only), bit 3 fused pipelined dK / dV at head_dim 128; bits 4-7 dQ stream, bit 8 dQ at 64 rows per wave,
 // bits 12-15 dK / dV stream, bits 16-19 forward stream (lab)
-static constexpr int kAttnPlDefault = 0x1113;
+static constexpr int kAttnPlDefault = 0x111B;
 #include "attention_pl.hip.h"
 #if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
 #include "../../tools/experimental/attention_experimental_6_fwd_pl.hip.h"  // pipelined forward: bit-identical, 4-7 % slower (EXPERIMENT, not shipped)
@@ -1346,14 +1346,29 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         if (!ok) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
         ProfScope prof(PROF_ATTN_BWD, 10.0 * a.B * a.H * (double)a.Sq * a.Sk * a.d, st);
         const dim3 gq(((a.Sq + 127) / 128) * a.H * a.B), gk(((a.Sk + 127) / 128) * a.H * a.B);
-        if (a.kbias || (a.Sk % 64) != 0)
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 2>), gq, dim3(256), kDq128, st, a);
-        else
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 2>), gq, dim3(256), kDq128, st, a);
-        int rc128 = check_launch("attn_bwd_dq");
-        if (rc128) return rc128;
-        // (one fused dK + dV pass at head_dim 128 needs 256 VGPR + 186 AGPR at one wave per SIMD and measured 11.8 ms against 10.5 ms for the two passes
-        //  at 21 504 tokens x 12 heads -- profiles/r02_attention_experiments.txt)
+#ifdef FTMI_LAB
+        const int lab_only = env_int("FTMI_ATTN_ONLY", 0);  // 1: the dQ kernel alone, 2: the dK / dV kernel(s) alone (delta already in place)
+#else
+        constexpr int lab_only = 0;
+#endif
+        if (lab_only != 2) {
+            if (a.kbias || (a.Sk % 64) != 0)
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 2>), gq, dim3(256), kDq128, st, a);
+            else
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 2>), gq, dim3(256), kDq128, st, a);
+            int rc128 = check_launch("attn_bwd_dq");
+            if (rc128) return rc128;
+        }
+        if (lab_only == 1) return 0;
+        // One fused dK + dV pass: compiler-scheduled it needed 256 VGPR + 186 AGPR at one wave per SIMD and measured 11.8 ms against 10.5 ms for the two passes
+        // at 21 504 tokens x 12 heads (profiles/r02_attention_experiments.txt); as a hand-placed pipeline with single-buffered scores it is what runs
+        // (attention_pl.hip.h, FTMI_ATTN_PL bit 3): same bits, 4 executed matmuls instead of 5.
+        if ((env_int("FTMI_ATTN_PL", kAttnPlDefault) & 8) && a.Sq >= 128 && a.Sk >= 128) {
+            static const bool okp = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_pl128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlDkv128Lds) == hipSuccess;
+            if (!okp) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
+            hipLaunchKernelGGL((attn_bwd_dkdv_pl128_kernel<1>), gk, dim3(256), kPlDkv128Lds, st, a);
+            return check_launch("attn_bwd_dkdv");
+        }
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<2, 0>), gk, dim3(256), kDkv128, st, a);
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<2, 1>), gk, dim3(256), kDkv128, st, a);
         return check_launch("attn_bwd_dkdv");
@@ -1395,7 +1410,8 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         // hand-placed pipelines (attention_pl.hip.h): no key bias (ragged token counts: the DMA zero-fills).  FTMI_ATTN_PL (re-read every call, a getenv, so that one process can compare
         // the kernels): bit 0 = dQ kernel, bits 4-7 = stream variant, bit 8 = 64 query rows per wave at one wave per SIMD (the default; 0: 32 rows, two waves per SIMD)
         const int pl = env_int("FTMI_ATTN_PL", kAttnPlDefault);
-        if ((pl & 1) && !a.kbias && a.Sk >= 128) {
+        // (from 256 keys on: shorter problems keep attn_bwd_dq2_kernel, whose bits the resident few-keys kernel reproduces -- the shipped stream differs by one rounding per score)
+        if ((pl & 1) && !a.kbias && a.Sk >= 256) {
             const int var = (pl >> 4) & 15, nq = (pl & 0x100) ? 2 : 1;
             const dim3 gridp(((a.Sq + 128 * nq - 1) / (128 * nq)) * a.H * a.B);
 #define FTMI_PL_LAUNCH(NQ_, V_)                                                                                                                         \

@@ -321,6 +321,35 @@ def test_pipelined_dkdv_kernel_is_bit_identical_to_the_kernel_it_replaces(B, H, 
             assert torch.equal(x, y), f"FTMI_ATTN_PL={pl} {name}: not bit-identical (max |diff| {(x.float() - y.float()).abs().max().item():.3e})"
 
 
+@pytest.mark.parametrize("B,H,Sq,Sk,biased", [(1, 4, 1024, 1024, False), (2, 3, 1000, 777, False), (1, 2, 2112, 2304, True), (1, 8, 4096, 4096, False), (1, 2, 520, 136, True)])
+def test_fused_head_dim_128_dkdv_kernel_is_bit_identical_to_the_two_passes(B, H, Sq, Sk, biased, monkeypatch):
+    """Round 5: attn_bwd_dkdv_pl128_kernel (head_dim 128: Wan, HunyuanVideo) computes dK and dV in ONE pass over the queries -- 32 keys per wave, one wave per
+    SIMD, single-buffered scores, every instruction placed -- where attn_bwd_dkdv_kernel<2, 0> + <2, 1> make two (4 executed matmuls instead of 5).  Same
+    arithmetic statement for statement, the key bias (HunyuanVideo's text mask, -inf entries included) as the addend of the fma that scales the scores: dK and dV
+    must be the same bits with FTMI_ATTN_PL bit 3 on and off; ragged query and key counts included (zero-filled rows by the bounds-checked DMA)."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    q, k, v = rnd((B, H, Sq, 128), g).to(dev), rnd((B, H, Sk, 128), g).to(dev), rnd((B, H, Sk, 128), g).to(dev)
+    dout = rnd((B, H, Sq, 128), g).to(dev)
+    bias = None
+    if biased:
+        bias = torch.zeros(B, Sk)
+        bias[:, Sk - Sk // 5:] = float("-inf")  # a padded tail, like a text mask
+        bias[:, : Sk // 2] = torch.randn(B, Sk // 2, generator=g) * 0.3
+        bias = bias.to(dev)
+    out, lse = ops.attn_fwd(q, k, v, bias)
+    res = {}
+    for pl in ("0", "0x8"):
+        monkeypatch.setenv("FTMI_ATTN_PL", pl)
+        res[pl] = ops.attn_bwd(q, k, v, out, lse, dout, bias)
+        torch.cuda.synchronize()
+    for name, x, y in zip(("dq", "dk", "dv"), res["0x8"], res["0"]):
+        assert not torch.isnan(x.float()).any(), f"{name}: NaN"
+        assert torch.equal(x, y), f"FTMI_ATTN_PL=0x8 {name}: not bit-identical (max |diff| {(x.float() - y.float()).abs().max().item():.3e})"
+
+
 @pytest.mark.parametrize("M", [5376, 5400, 17776, 2700])
 def test_lora_down_projection_64_row_tiles_are_bit_identical(M, monkeypatch):
     """Round 5: gemm_nt_skinny4_kernel (64-row tiles, one round of workgroups, two-stage 16-KB ring per wave) keeps the K split, the MFMA order per accumulator

@@ -2,7 +2,7 @@
 // seconds).  Compares the hand-placed pipelines (attention_pl.hip.h, FTMI_ATTN_PL) with the compiler-scheduled kernels they replace.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form -DFTMI_LAB -o tools/bin/attn_lab tools/attn_lab.hip
 //   tools/bin/attn_lab "2x32x2688,1x30x17792" "0,0x01,0x11,0x21"
-// Shapes B x H x S (self-attention, head_dim 64, tokens-major [B, S, H, 64] like the DiT's q|k|v buffers); configurations = FTMI_ATTN_PL values
+// Shapes B x H x S (self-attention, head_dim 64 or LAB_D=128, tokens-major [B, S, H, 64] like the DiT's q|k|v buffers); configurations = FTMI_ATTN_PL values
 // (first one = reference).  For every configuration: dQ / dK / dV against the reference (bit mismatches and relative L2), then interleaved
 // timing rounds of the whole backward, of the dQ kernel alone and of the dK/dV kernel alone (FTMI_ATTN_ONLY).
 #include "../finetrainers_amd/csrc/attention.hip"
@@ -67,14 +67,15 @@ int main(int argc, char** argv) {
         int B, H, S;
         if (sscanf(shapes.substr(p, q - p).c_str(), "%dx%dx%d", &B, &H, &S) != 3) { printf("bad shape\n"); return 1; }
         p = q + 1;
-        const size_t n = (size_t)B * S * H * 64;
+        const int D = getenv("LAB_D") ? atoi(getenv("LAB_D")) : 64;  // head_dim (64 | 128)
+        const size_t n = (size_t)B * S * H * D;
         std::vector<uint16_t> hq(n), hk(n), hv(n), hdo(n);
         fill_random(hq, 1, 1.f); fill_random(hk, 2, 1.f); fill_random(hv, 3, 1.f); fill_random(hdo, 4, 1.f);
         if (getenv("LAB_GROW")) {  // keys grow along the sequence: the running row max outgrows the lazy reference by 2^8 several times (the forward's rare path)
             for (int bb = 0; bb < B; ++bb)
                 for (int j = 0; j < S; ++j)
-                    for (int e = 0; e < H * 64; ++e) {
-                        uint16_t& x = hk[((size_t)bb * S + j) * H * 64 + e];
+                    for (int e = 0; e < H * D; ++e) {
+                        uint16_t& x = hk[((size_t)bb * S + j) * H * D + e];
                         x = f2bf_host(bf2f_host(x) * (1.f + 10.f * (float)j / (float)S));
                     }
         }
@@ -85,8 +86,8 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dq_, hq.data(), n * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dk_, hk.data(), n * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dv_, hv.data(), n * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(ddo, hdo.data(), n * 2, hipMemcpyHostToDevice));
         ftmi::AttnArgs a;
-        a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.d = 64; a.scale = 0.125f;
-        const long sb = (long)S * H * 64, sh = 64, ss = (long)H * 64;
+        a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.d = D; a.scale = 1.0f / sqrtf((float)D);
+        const long sb = (long)S * H * D, sh = D, ss = (long)H * D;
         a.q = dq_; a.q_sb = sb; a.q_sh = sh; a.q_ss = ss;
         a.k = dk_; a.k_sb = sb; a.k_sh = sh; a.k_ss = ss;
         a.v = dv_; a.v_sb = sb; a.v_sh = sh; a.v_ss = ss;
@@ -131,7 +132,7 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < cfg.size(); ++i) {
                 std::sort(res[i].begin(), res[i].end());
                 printf(" forward        FTMI_ATTN_PL=%-8s median %8.1f us  best %8.1f us  -> %7.1f TF/s\n", cfg[i].c_str(), res[i][2] * 1e3, res[i][0] * 1e3,
-                       4.0 * B * H * (double)S * S * 64 / res[i][2] / 1e9);
+                       4.0 * B * H * (double)S * S * D / res[i][2] / 1e9);
             }
             fflush(stdout);
             setenv("FTMI_ATTN_PL", cfg[0].c_str(), 1);
@@ -143,7 +144,7 @@ int main(int argc, char** argv) {
             CK(hipFree(lse)); CK(hipFree(delta));
             continue;
         }
-        const double flops = 10.0 * B * H * (double)S * S * 64;
+        const double flops = 10.0 * B * H * (double)S * S * D;
         auto run = [&](const std::string& c, int only) {
             setenv("FTMI_ATTN_PL", c.c_str(), 1);
             setenv("FTMI_ATTN_ONLY", only == 1 ? "1" : only == 2 ? "2" : "0", 1);

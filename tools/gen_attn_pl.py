@@ -477,6 +477,150 @@ def gen_fwd(name: str, drop=()):
     return path
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# dK / dV at head_dim 128 (Wan, HunyuanVideo), ONE pass: a wave owns 32 keys, loops over 64-query tiles (is = 0, 1: 32 query rows each); one slot per
+# unit u = (t, is) = 32 queries x 32 keys:
+#   C(u-1): 16 MFMAs  dV[dt] += dO^T . P,  dK[dt] += Q^T . dS  (dt = 0..3, hh = 0, 1) -- positions 0 .. 15;
+#   A(u+1): 16 MFMAs  S = Q.K^T - lse / sl,  DP = dO.V^T - delta  (chains of 8 over the 128-wide head, interleaved) -- positions 16 .. 31;
+#   B(u):   64 VALU   P = exp2(S * sl + bias_j),  dS = P * DP, both packed to bf16 -- gaps 2 .. 15, i.e. finished BEFORE A(u+1) starts, so S and DP are single
+#                     buffers (the registers that pays for: K and V fragments of the wave's keys stay resident, 64 VGPRs).
+# Every fragment read from LDS is used once: transposed fragments go through an 8-deep rolling buffer (read 8 MFMAs ahead), row fragments through a 4-deep one
+# per operand.  LDS reads return in order, so every consumer waits with a COUNTED lgkmcnt (the number of younger reads in flight, capped at the counter's 15).
+# ------------------------------------------------------------------------------------------------------------------------------
+def gen_dkv128(name: str, drop=()):
+    s = Stream()
+    s.emit(f"// GENERATED by tools/gen_attn_pl.py (dkv128_{name}: drop={','.join(drop) or '-'}) -- do not edit")
+    seq = [0]          # LDS reads issued so far (monotone over the two slots of a tile; relative counts only)
+    issued_at = {}     # name -> sequence number of the read that fills it
+
+    def lds_read(text, outs, ins, key):
+        if "lds" in drop:
+            return
+        s.asm(text, outs, ins)
+        seq[0] += 1
+        issued_at[key] = seq[0]
+
+    landed = [0]       # every read up to this sequence number is known to have landed (by an earlier wait)
+
+    def wait_for(keys):
+        """counted wait: everything up to the youngest of `keys` has landed"""
+        if "lds" in drop:
+            return
+        need = max(issued_at.get(k, -10**9) for k in keys)
+        if need <= landed[0]:
+            return
+        n = min(seq[0] - need, 15)
+        s.asm(f"s_waitcnt lgkmcnt({n})", "", "", '"memory"')
+        landed[0] = max(landed[0], seq[0] - n)
+
+    # reads that the previous tile iteration left in flight (second slot, gaps 8 .. 15: the first eight transposed fragments of unit (t, 0); positions 16 .. 23:
+    # the second halves of the row fragments, all consumed there): model them as issued before everything of this iteration
+    for m in range(8):
+        issued_at[("tr", m)] = -100 + m  # older than anything issued in this iteration: never waited for (the A stage's waits covered them)
+
+    for is_ in range(2):
+        par, parn = is_, is_ ^ 1
+        s.emit(f"// ---- slot (t, is {is_}): C(u-1) with P / dS[{parn}]; B(u) on S / DP -> P / dS[{par}]; A(u+1) into S / DP")
+        s.emit("{")
+        def F(r): return ("v_fma_f32 %0, %1, %2, %3", f'"=v"(x[{r}])', f'"v"(S[{r}]), "v"(sl), "v"(bj)')
+        def E(r): return ("v_exp_f32 %0, %0", f'"+v"(x[{r}])', "")
+        def M2(r): return ("v_mul_f32 %0, %1, %2", f'"=v"(y[{r}])', f'"v"(x[{r}]), "v"(DP[{r}])')
+        def PP(r):
+            hh, e = r >> 3, (r & 7) >> 1
+            return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(pw[{par}][{hh}][{e}])', f'"v"(x[{r}]), "v"(x[{r + 1}])')
+        def PD(r):
+            hh, e = r >> 3, (r & 7) >> 1
+            return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(dsw[{par}][{hh}][{e}])', f'"v"(y[{r}]), "v"(y[{r + 1}])')
+        valu, L = [], 4
+        for s_ in range(16 + 2 * L + 2):
+            if s_ < 16: valu.append(F(s_))
+            if 0 <= s_ - L < 16: valu.append(E(s_ - L))
+            if 0 <= s_ - 2 * L < 16: valu.append(M2(s_ - 2 * L))
+            r = s_ - 2 * L - 1
+            if 0 <= r < 16 and r % 2 == 1:
+                valu.append(PP(r - 1)); valu.append(PD(r - 1))
+        assert len(valu) == 64
+        if "valu" in drop:
+            valu = []
+        counts = [0, 0] + spread(len(valu), 14) + [0] * 16
+
+        def tr_read(m, unit_is):
+            """transposed fragment m (0..15: hh = m >> 3, dt = (m >> 1) & 3, image w = m & 1: 0 = dO^T for dV, 1 = Q^T for dK) of the unit with row half unit_is -> buffer m & 7"""
+            hh, dt, w = m >> 3, (m >> 1) & 3, m & 1
+            base = (16384 if w == 0 else 0) + (dt >> 1) * 8192 + unit_is * 4096 + hh * 2048
+            b = m & 7
+            lds_read(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(trlo[{b}])', f'"v"(tra[{dt & 1}][0])', ("trl", m))
+            lds_read(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(trhi[{b}])', f'"v"(tra[{dt & 1}][1])', ("tr", m))
+
+        if is_ == 1:
+            s.emit("// tile hand-over: my loads of tile t+1 have landed (wave 0 then turns its lse / delta rows into the accumulator inputs, in place);")
+            s.emit("// after the barrier everyone's have, and nobody reads tile t-1 any more")
+            s.emit("HAND_OVER();")
+            s.emit("RING_ADVANCE_ROW();  // row-fragment addresses -> ring slot of tile t+1")
+        isn = is_ ^ 1  # row half of unit u+1
+        for g in range(32):
+            # ---- waits in front of the MFMA at position g
+            if g < 8:
+                wait_for([("tr", g)])
+            elif g < 16:
+                wait_for([("tr", g)])
+            else:
+                k = g - 16
+                c, which = k >> 1, k & 1
+                keys = [("qr" if which == 0 else "dor", c)]
+                if c == 0:
+                    keys += [("lsi", 3)] if which == 0 else [("dli", 3)]
+                wait_for(keys)
+            # ---- the MFMA
+            if g < 16:
+                hh, dt, w = g >> 3, (g >> 1) & 3, g & 1
+                frag = f"TRF({g & 7})"
+                if w == 0:
+                    m_ = (f"{MFMA} %0, %1, %2, %0", f'"+a"(dV[{dt}])', f'"v"({frag}), "v"(PF({parn}, {hh}))')
+                else:
+                    m_ = (f"{MFMA} %0, %1, %2, %0", f'"+a"(dK[{dt}])', f'"v"({frag}), "v"(DSF({parn}, {hh}))')
+            else:
+                k = g - 16
+                c, which = k >> 1, k & 1
+                if which == 0:
+                    m_ = (f"{MFMA} %0, %1, %2, %3", '"=&v"(S)', f'"v"(qr[{c & 3}]), "v"(kf[{c}]), "v"(LSI)') if c == 0 else (f"{MFMA} %0, %1, %2, %0", '"+v"(S)', f'"v"(qr[{c & 3}]), "v"(kf[{c}])')
+                else:
+                    m_ = (f"{MFMA} %0, %1, %2, %3", '"=&v"(DP)', f'"v"(dor[{c & 3}]), "v"(vf[{c}]), "v"(DLI)') if c == 0 else (f"{MFMA} %0, %1, %2, %0", '"+v"(DP)', f'"v"(dor[{c & 3}]), "v"(vf[{c}])')
+            if "mfma" not in drop:
+                s.asm(m_[0], m_[1], m_[2])
+            # ---- LDS reads behind it
+            if g < 8:
+                tr_read(8 + g, parn)            # second half of C(u-1)'s fragments, into the buffer this MFMA just used
+            elif g < 16:
+                if g == 8 and is_ == 0:
+                    s.emit("RING_ADVANCE_TR();  // transposed-fragment addresses -> ring slot of this tile (unit u is its first)")
+                tr_read(g - 8, par)             # first half of C(u)'s fragments (next slot)
+                if 8 <= g < 12:                 # the first four row fragments of unit u+1 and its accumulator-input rows
+                    c = g - 8
+                    lds_read(f"ds_read_b128 %0, %1 offset:{isn * 4096}", f'"=v"(qr[{c}])', f'"v"(ra[{c}])', ("qr", c))
+                    lds_read(f"ds_read_b128 %0, %1 offset:{16384 + isn * 4096}", f'"=v"(dor[{c}])', f'"v"(ra[{c}])', ("dor", c))
+                    lds_read(f"ds_read_b128 %0, %1 offset:{32768 + isn * 128 + c * 32}", f'"=v"(lsi[{c}])', '"v"(la)', ("lsi", c))
+                    lds_read(f"ds_read_b128 %0, %1 offset:{32768 + 256 + isn * 128 + c * 32}", f'"=v"(dli[{c}])', '"v"(la)', ("dli", c))
+            elif g < 24:
+                k = g - 16
+                c, which = k >> 1, k & 1         # this MFMA used row fragment c (< 4) of its operand: reload the buffer with fragment c + 4 (second 64-wide image)
+                if which == 0:
+                    lds_read(f"ds_read_b128 %0, %1 offset:{8192 + isn * 4096}", f'"=v"(qr[{c}])', f'"v"(ra[{c}])', ("qr", c + 4))
+                else:
+                    lds_read(f"ds_read_b128 %0, %1 offset:{16384 + 8192 + isn * 4096}", f'"=v"(dor[{c}])', f'"v"(ra[{c}])', ("dor", c + 4))
+            if is_ == 1 and 16 <= g < 25 and "dma" not in drop:
+                s.emit(f"DMA_PIECE({g - 16});")
+            for _ in range(counts[g]):
+                t2, o2, i2 = valu.pop(0)
+                s.asm(t2, o2, i2)
+        assert not valu
+        s.emit("}")
+    path = os.path.join(OUT, f"attn_pl_dkv128_{name}.inc")
+    with open(path, "w") as f:
+        f.write("\n".join(s.lines) + "\n")
+    return path
+
+
 def main():
     made = []
     for nq in (1, 2):
@@ -497,6 +641,7 @@ def main():
     made.append(gen_dkv("v2", order="g4"))
     made.append(gen_dkv("a_novalu", drop=("valu",)))
     made.append(gen_dkv("a_nolds", drop=("lds",)))
+    made.append(gen_dkv128("v1"))
     made.append(gen_fwd("v1"))
     made.append(gen_fwd("a_novalu", drop=("valu",)))
     made.append(gen_fwd("a_nolds", drop=("lds",)))

@@ -19,6 +19,12 @@ case "${1:-}" in
     echo "exit $?" >> gpurun_out/r05_attn_fwd_lab_$tag.txt
     cat gpurun_out/r05_attn_fwd_lab_$tag.txt
     ;;
+  h)  # attention lab at head_dim 128: the fused pipelined dK / dV kernel (FTMI_ATTN_PL bit 3) vs the two-pass kernels, bit compare + timing
+    tag="${2:-1}"; shapes="${3:-1x12x4096,1x4x1000,1x12x21504}"; cfgs="${4:-0,0x8}"
+    LAB_D=128 LAB_ONLY=02 timeout 600 tools/bin/attn_lab "$shapes" "$cfgs" > gpurun_out/r05_attn128_lab_$tag.txt 2>&1
+    echo "exit $?" >> gpurun_out/r05_attn128_lab_$tag.txt
+    cat gpurun_out/r05_attn128_lab_$tag.txt
+    ;;
   p)  # the MFMA / VALU issue probe of round 2, whole output
     hipcc --offload-arch=gfx950 -O3 tools/probe_mfma_valu.hip -o /tmp/probe_mfma_valu && timeout 120 /tmp/probe_mfma_valu > gpurun_out/r05_probe_mfma_valu.txt 2>&1
     cat gpurun_out/r05_probe_mfma_valu.txt
