@@ -1239,3 +1239,29 @@ def test_bench_two_ranks_rehearsal_emits_the_multi_gpu_schema():
     assert d["buckets_per_step"] == 4.0                 # 28 blocks in ranges of 7, every step (warm-up included in the count and in the divisor)
     assert isinstance(d["exposed_comm_ms"], float) and d["exposed_comm_ms"] >= 0.0
     assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+def test_committed_attention_streams_are_what_the_generator_writes(tmp_path, monkeypatch):
+    """The hand-placed attention kernels #include statement lists written by tools/gen_attn_pl.py (csrc/attn_pl_*.inc, committed: the build does not run the
+    generator).  Regenerate them into a scratch directory and compare byte for byte, so that an edit of the generator without a regenerate -- or a hand edit
+    of a generated file -- cannot ship."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_attn_pl", os.path.join(root, "tools", "gen_attn_pl.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    out, exp = tmp_path / "csrc", tmp_path / "experimental"
+    out.mkdir()
+    exp.mkdir()
+    monkeypatch.setattr(gen, "OUT", str(out))
+    monkeypatch.setattr(gen, "EXP_OUT", str(exp))
+    gen.main()
+    made = sorted(os.listdir(out))
+    committed_dir = os.path.join(root, "finetrainers_amd", "csrc")
+    committed = sorted(f for f in os.listdir(committed_dir) if f.startswith("attn_pl_") and f.endswith(".inc"))
+    assert made == committed, (made, committed)
+    for f in made:
+        assert (out / f).read_bytes() == open(os.path.join(committed_dir, f), "rb").read(), f"{f}: committed stream differs from the generator's output"
+    for f in sorted(os.listdir(exp)):
+        assert (exp / f).read_bytes() == open(os.path.join(root, "tools", "experimental", f), "rb").read(), f"{f}: committed experimental stream differs"

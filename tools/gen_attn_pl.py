@@ -20,7 +20,8 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "..", "finetrainers_amd", "csrc")
+OUT = os.path.join(HERE, "..", "finetrainers_amd", "csrc")   # shipped streams
+EXP_OUT = os.path.join(HERE, "experimental")                 # streams of kernels that exist in lab / experimental builds only
 
 MFMA = "v_mfma_f32_32x32x16_bf16"
 
@@ -471,7 +472,7 @@ def gen_fwd(name: str, drop=()):
                 s.emit(f"L_UPDATE({parn});")
         assert vi == len(valu) and mi == len(vmax)
         s.emit("}")
-    path = os.path.join(HERE, "experimental", f"attn_pl_fwd_{name}.inc")  # experiment, not shipped (tools/experimental/attention_experimental_6_fwd_pl.hip.h)
+    path = os.path.join(EXP_OUT, f"attn_pl_fwd_{name}.inc")  # experiment, not shipped (tools/experimental/attention_experimental_6_fwd_pl.hip.h)
     with open(path, "w") as f:
         f.write("\n".join(s.lines) + "\n")
     return path
