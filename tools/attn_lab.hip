@@ -93,6 +93,12 @@ int main(int argc, char** argv) {
         a.v = dv_; a.v_sb = sb; a.v_sh = sh; a.v_ss = ss;
         a.o = dout; a.o_sb = sb; a.o_sh = sh; a.o_ss = ss;
         a.lse2 = lse; a.delta = delta;
+        float* kbias = nullptr;
+        if (getenv("LAB_BIAS")) {  // an all-zero key bias: the same mathematics through the kernels' bias paths (what HunyuanVideo's text mask costs)
+            CK(hipMalloc(&kbias, (size_t)B * S * 4));
+            CK(hipMemset(kbias, 0, (size_t)B * S * 4));
+            a.kbias = kbias; a.kb_sb = S; a.kb_sh = 0;
+        }
         a.dout = ddo; a.do_sb = sb; a.do_sh = sh; a.do_ss = ss;
         a.dq = gq; a.dq_sb = sb; a.dq_sh = sh; a.dq_ss = ss;
         a.dk = gk; a.dk_sb = sb; a.dk_sh = sh; a.dk_ss = ss;
