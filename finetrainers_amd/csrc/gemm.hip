@@ -2095,7 +2095,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
     const int li = lane & 31, g = lane >> 5;
 
     const int ntp = a.P / BP, ntq = a.Q / BQ;
-    const int nsteps_total = a.M / 64;
+    const int nsteps_total = (a.M + 63) / 64;
+    const bool ragged = (a.M & 63) != 0;  // the last step holds fewer than 64 tokens: bounds-checked loads zero-fill the missing rows (they add nothing)
     int bid = blockIdx.x, split, batch = blockIdx.y;
     if (a.xcd_groups > 0) {
         // XCD-aware order (1-D grid; workgroup w is observed to run on XCD w % 8): all tiles of one (split, batch) group -- they stream the same rows of the
@@ -2131,16 +2132,35 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const TileDma ud = tile_dma_setup(a.ldu, a.M, wave, lane), vd = tile_dma_setup(a.ldv, a.M, wave, lane);
+    // ragged token counts (CogVideoX: 17 776 = 277 x 64 + 48): the same loads as buffer loads with EXACT bounds -- descriptor = the valid bytes from the
+    // sub-tile's first row on, so the rows past the end arrive as zeros (tile_dma_issue clamps them to the last row, which a reduction over tokens cannot use)
+    auto dma_bounded = [&](const TileDma& d, const bf16_t* base, long ld, int step, char* lds) {
+        const long row0 = (long)step * 64;
+        const char* b = (const char*)(base + row0 * ld);
+        const long rem = ((long)a.M - 1 - row0) * ld * 2 + 128;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)b, (short)0, (int)(rem < 0 ? 0 : (rem > 0x7fffffffL ? 0x7fffffffL : rem)), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + (wave * 2 + i) * 1024));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(d.off[i]), "s"(rs) : "memory", "m0");
+        }
+    };
     auto stage = [&](int k) {  // step k of this workgroup -> ring slot k % NS
         char* st = smem + (k % NS) * STAGE;
 #pragma unroll
         for (int f = 0; f < FU; ++f)
 #pragma unroll
-            for (int t = 0; t < NU; ++t) tile_dma_issue(ud, U + t * 64 + f * a.u_fold, a.ldu, s_begin + k, false, st + (f * NU + t) * 8192, wave);
+            for (int t = 0; t < NU; ++t) {
+                if (ragged) dma_bounded(ud, U + t * 64 + f * a.u_fold, a.ldu, s_begin + k, st + (f * NU + t) * 8192);
+                else tile_dma_issue(ud, U + t * 64 + f * a.u_fold, a.ldu, s_begin + k, false, st + (f * NU + t) * 8192, wave);
+            }
 #pragma unroll
         for (int f = 0; f < FV; ++f)
 #pragma unroll
-            for (int t = 0; t < NV; ++t) tile_dma_issue(vd, V + t * 64 + f * a.v_fold, a.ldv, s_begin + k, false, st + (FU * NU + f * NV + t) * 8192, wave);
+            for (int t = 0; t < NV; ++t) {
+                if (ragged) dma_bounded(vd, V + t * 64 + f * a.v_fold, a.ldv, s_begin + k, st + (FU * NU + f * NV + t) * 8192);
+                else tile_dma_issue(vd, V + t * 64 + f * a.v_fold, a.ldv, s_begin + k, false, st + (FU * NU + f * NV + t) * 8192, wave);
+            }
     };
     stage(0);
     if (n > 1) stage(1);
@@ -2239,7 +2259,9 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     // XCD-aware tile order below: 1.82 -> 1.71 ms per step over the ten launches (rocprofv3, profiles/r05_tn_wgrad.txt) -- these launches already run at
     // 4.2-5.1 TB/s of unique traffic; the few-token text-side launches (M = 256) keep the old tiles (they got slower: 35 -> 55 us).
     static const int tn_wide = env_int("FTMI_TN_WIDE", 1), tn_gen = env_int("FTMI_TN_GEN", 2);
-    const bool wide256 = tn_wide && tn_gen == 2 && a.M % 64 == 0 && a.M >= 1024 && ((wideP && a.P % 256 == 0 && a.Q == 64 && (a.v_grp_p == 0 || a.v_grp_p % 256 == 0) && a.u_grp_p == 0) ||
+    static const int tn_ragged = env_int("FTMI_TN_RAGGED", 1);  // 0: ragged token counts on the register-staged kernel (the state before round 5)
+    const bool ring_ok = tn_gen == 2 && (a.M % 64 == 0 || (tn_ragged && a.M >= 256));  // the DMA-ring kernel (a ragged last step through bounds-checked loads)
+    const bool wide256 = tn_wide && ring_ok && a.M >= 1024 && ((wideP && a.P % 256 == 0 && a.Q == 64 && (a.v_grp_p == 0 || a.v_grp_p % 256 == 0) && a.u_grp_p == 0) ||
                                                       (wideQ && a.Q % 256 == 0 && a.v_grp_p == 0));
     const int bp = wideP ? (wide256 ? 256 : 128) : 64, bq = wideP ? 64 : (wideQ ? (wide256 ? 256 : 128) : 64);
     if (a.v_grp_p > 0 && a.v_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: group width vs tile");
@@ -2256,14 +2278,14 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     const int nsplit = (nsteps + per - 1) / per;
     dim3 grid(tiles * nsplit, nb);
     static const int tn_xcd = env_int("FTMI_TN_XCD", 1);
-    if (tn_xcd && tn_gen == 2 && a.M % 64 == 0 && a.M >= 1024 && tiles > 1 && nsplit * nb >= 8) {  // the XCD-aware 1-D order of gemm_tn2_kernel
+    if (tn_xcd && ring_ok && a.M >= 1024 && tiles > 1 && nsplit * nb >= 8) {  // the XCD-aware 1-D order of gemm_tn2_kernel
         a.xcd_groups = nsplit * nb;
         grid = dim3(8 * ((a.xcd_groups + 7) / 8) * tiles, 1);
     }
     ProfScope prof(PROF_GEMM_TN, 2.0 * a.M * a.P * (double)a.Q * nb, st);
     if (a.u_fold && a.v_fold) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: only one operand may be a (hi, lo) pair");
     if (a.u_grp_p > 0 && a.u_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: U group width vs tile");
-    if (tn_gen == 2 && a.M % 64 == 0) {  // DMA-ring kernel (whole 64-token steps only)
+    if (ring_ok) {  // DMA-ring kernel (a ragged last step through bounds-checked loads)
         int rc;
         if (wideP) rc = wide256 ? launch_tn2<256, 64>(a, grid, st) : launch_tn2<128, 64>(a, grid, st);
         else if (wideQ) rc = wide256 ? launch_tn2<64, 256>(a, grid, st) : launch_tn2<64, 128>(a, grid, st);

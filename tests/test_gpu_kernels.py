@@ -154,7 +154,7 @@ def test_linear_lora_bwd(M):
     report("plain dgrad", dx2, (dy.float() @ w.float()).to(bf16), 3e-3)
 
 
-@pytest.mark.parametrize("M,P,Q", [(64, 64, 64), (300, 128, 64), (1000, 64, 2048), (5376, 2048, 64), (333, 192, 2048), (256, 4096, 64), (1024, 64, 2048), (640, 192, 2048)])
+@pytest.mark.parametrize("M,P,Q", [(64, 64, 64), (300, 128, 64), (1000, 64, 2048), (5376, 2048, 64), (333, 192, 2048), (256, 4096, 64), (1024, 64, 2048), (640, 192, 2048), (17776, 1920, 64), (1100, 64, 1920)])
 def test_gemm_tn(M, P, Q):
     from finetrainers_amd import ops
 
