@@ -2270,7 +2270,10 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     // the split-M partials meet in fp32 atomics: more splits = more parallelism but P*Q atomics per split
     const int nb = a.batch > 0 ? a.batch : 1;
     // batched launches already fill the GPU with tiles x batch workgroups: split the token loop only as far as needed
-    int want = nb > 1 ? (4 * target_wgs + tiles * nb - 1) / (tiles * nb) : (target_wgs + tiles - 1) / tiles;
+    // (round 5: a batched launch splits its token loop only until tiles x batch fill 7/8 of the CUs -- every split costs P x Q fp32 atomics per problem and a
+    //  second cold start; measured on the LTX step's ten launches: 1 / 3 / 8 splits of the 2048 x 64 gradients = 1.62 / 1.75 / 1.98 ms, profiles/r05_tn_wgrad.txt)
+    static const int batch_fill = env_int("FTMI_TN_BATCH_FILL", 224) > 0 ? env_int("FTMI_TN_BATCH_FILL", 224) : 224;
+    int want = nb > 1 ? (batch_fill + tiles * nb - 1) / (tiles * nb) : (target_wgs + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int per = (nsteps + want - 1) / want;
     if (per < 1) per = 1;
