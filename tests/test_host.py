@@ -1265,3 +1265,37 @@ def test_committed_attention_streams_are_what_the_generator_writes(tmp_path, mon
         assert (out / f).read_bytes() == open(os.path.join(committed_dir, f), "rb").read(), f"{f}: committed stream differs from the generator's output"
     for f in sorted(os.listdir(exp)):
         assert (exp / f).read_bytes() == open(os.path.join(root, "tools", "experimental", f), "rb").read(), f"{f}: committed experimental stream differs"
+
+
+def test_generated_attention_streams_keep_the_mfma_to_valu_distance():
+    """hipcc inserts no wait states between `asm volatile` statements, so the generator (tools/gen_attn_pl.py) places every VALU instruction that reads an MFMA
+    result at least two MFMAs behind the MFMA that wrote it (the rule the kernels' header states).  Check it statically on the committed streams: walk each
+    loop body twice (the loop wraps around) and, for every VALU statement, look up when each accumulator tile it reads was last written."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dirs = [os.path.join(root, "finetrainers_amd", "csrc"), os.path.join(root, "tools", "experimental")]
+    files = [os.path.join(d, f) for d in dirs for f in sorted(os.listdir(d)) if f.startswith("attn_pl_") and f.endswith(".inc")]
+    assert len(files) >= 12
+    stmt = re.compile(r'asm volatile\("([^"]*)"\s*(?::\s*([^:;]*?))?\s*(?::\s*([^:;]*?))?\s*(?::[^;]*)?\);')
+    operand = re.compile(r'"([^"]+)"\(([^()]*(?:\([^()]*\)[^()]*)*)\)')
+    checked = 0
+    for path in files:
+        if "_nomfma" in path:  # (time-only ablation without the MFMAs)
+            continue
+        body = [m for m in stmt.finditer(open(path).read())]
+        last_write = {}  # accumulator tile -> index (in MFMAs issued) of the MFMA that last wrote it
+        n_mfma = 0
+        for rep in range(2):
+            for m in body:
+                text, outs, ins = m.group(1), m.group(2) or "", m.group(3) or ""
+                if text.startswith("v_mfma"):
+                    n_mfma += 1
+                    for cons, expr in operand.findall(outs):
+                        last_write[expr.strip()] = n_mfma
+                elif text.startswith("v_") and not text.startswith("v_accvgpr"):
+                    for cons, expr in operand.findall(ins):
+                        e = expr.strip()
+                        for tile, when in last_write.items():
+                            if e.startswith(tile + "[") and rep == 1:
+                                checked += 1
+                                assert n_mfma - when >= 2, f"{os.path.basename(path)}: `{text}` reads {e} {n_mfma - when} MFMA(s) behind the MFMA that wrote {tile}"
+    assert checked > 500
