@@ -1299,3 +1299,50 @@ def test_generated_attention_streams_keep_the_mfma_to_valu_distance():
                                 checked += 1
                                 assert n_mfma - when >= 2, f"{os.path.basename(path)}: `{text}` reads {e} {n_mfma - when} MFMA(s) behind the MFMA that wrote {tile}"
     assert checked > 500
+
+
+def test_head_dim_128_stream_waits_for_every_lds_fragment_it_consumes():
+    """attn_bwd_dkdv_pl128_kernel never drains the LDS queue inside a slot: tools/gen_attn_pl.py computes a COUNTED `s_waitcnt lgkmcnt(n)` in front of each consumer
+    from the issue order (LDS reads return in order; the counter saturates at 15).  Replay the committed stream on a model of that queue -- two trips through the
+    loop body, so the reads the previous trip left in flight are covered -- and require that no MFMA is issued while one of the fragment registers it reads is still
+    outstanding, and that no read overwrites a register whose previous content was never consumed."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "finetrainers_amd", "csrc", "attn_pl_dkv128_v1.inc")).read()
+    stmt = re.compile(r'asm volatile\("([^"]*)"\s*(?::\s*([^:;]*?))?\s*(?::\s*([^:;]*?))?\s*(?::[^;]*)?\);|(HAND_OVER\(\);)')
+    operand = re.compile(r'"([^"]+)"\(([^()]*(?:\([^()]*\)[^()]*)*)\)')
+
+    def regs(expr):
+        e = expr.strip()
+        m = re.fullmatch(r"TRF\((\d+)\)", e)
+        if m:
+            return [f"trlo[{m.group(1)}]", f"trhi[{m.group(1)}]"]
+        if e == "LSI":
+            return [f"lsi[{i}]" for i in range(4)]
+        if e == "DLI":
+            return [f"dli[{i}]" for i in range(4)]
+        return [e]
+
+    queue, consumed, n_checked = [], {}, 0  # outstanding reads (oldest first); register -> was its last load consumed by an MFMA
+    for trip in range(2):
+        for m in stmt.finditer(text):
+            if m.group(4):  # HAND_OVER: wave 0 drains the queue inside it, the other waves do not -- model the other waves
+                continue
+            t, outs, ins = m.group(1), m.group(2) or "", m.group(3) or ""
+            if t.startswith("ds_read"):
+                dst = operand.findall(outs)[0][1].strip()
+                if trip == 1:
+                    assert consumed.get(dst, True), f"{dst} is reloaded before its previous content was used"
+                consumed[dst] = False
+                queue.append(dst)  # (pessimistic model: a read retires only when a wait says so)
+            elif t.startswith("s_waitcnt lgkmcnt("):
+                n = int(t[len("s_waitcnt lgkmcnt("):].split(")")[0])
+                while len(queue) > n:
+                    queue.pop(0)
+            elif t.startswith("v_mfma"):
+                for _, expr in operand.findall(ins):
+                    for r in regs(expr):
+                        if r in consumed:
+                            n_checked += 1
+                            assert r not in queue, f"`{t}` reads {r} while its load is still in flight ({len(queue)} outstanding)"
+                            consumed[r] = True
+    assert n_checked >= 2 * (32 + 32 + 16 + 8)  # per trip: 16 + 16 transposed-fragment halves x 2 slots ..., row fragments, accumulator-input rows
