@@ -417,12 +417,13 @@ static int attn_gen(const char* which, int dflt) {
 }
 #endif
 
-// FTMI_ATTN_PL (re-read every call): bit 0 pipelined dQ, bit 1 pipelined dK / dV, bit 2 pipelined forward (experimental builds only), bit 3 fused pipelined dK / dV at head_dim 128; bits 4-7 dQ stream, bit 8 dQ at 64 rows per wave,
+// FTMI_ATTN_PL (re-read every call): bit 0 pipelined dQ, bit 1 pipelined dK / dV, bit 2 pipelined forward (experimental builds only), bit 3 fused pipelined dK / dV at head_dim 128, bit 17 pipelined dQ at head_dim 128 (experimental builds only); bits 4-7 dQ stream, bit 8 dQ at 64 rows per wave,
 // bits 12-15 dK / dV stream, bits 16-19 forward stream (lab)
 static constexpr int kAttnPlDefault = 0x111B;
 #include "attention_pl.hip.h"
 #if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
 #include "../../tools/experimental/attention_experimental_6_fwd_pl.hip.h"  // pipelined forward: bit-identical, 4-7 % slower (EXPERIMENT, not shipped)
+#include "../../tools/experimental/attention_experimental_7_dq128_pl.hip.h"  // pipelined dQ at head_dim 128: bit-identical, no faster (EXPERIMENT, not shipped)
 #endif
 
 int attn_fwd(const AttnArgs& a, hipStream_t st) {
@@ -1351,7 +1352,23 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
 #else
         constexpr int lab_only = 0;
 #endif
-        if (lab_only != 2) {
+#if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
+        const bool dq_pl128 = (env_int("FTMI_ATTN_PL", kAttnPlDefault) & 0x20000) && a.Sq >= 128 && a.Sk >= 128;
+#else
+        constexpr bool dq_pl128 = false;
+#endif
+        if (lab_only != 2 && dq_pl128) {
+#if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
+            // hand-placed dQ pipeline (attention_pl.hip.h, FTMI_ATTN_PL bit 17): same bits as the kernels below
+            static const bool okq = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlDkv128Lds) == hipSuccess &&
+                                    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_pl128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlDkv128Lds) == hipSuccess;
+            if (!okq) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
+            if (a.kbias) hipLaunchKernelGGL((attn_bwd_dq_pl128_kernel<true>), gq, dim3(256), kPlDkv128Lds, st, a);
+            else hipLaunchKernelGGL((attn_bwd_dq_pl128_kernel<false>), gq, dim3(256), kPlDkv128Lds, st, a);
+            int rc128 = check_launch("attn_bwd_dq");
+            if (rc128) return rc128;
+#endif
+        } else if (lab_only != 2) {
             if (a.kbias || (a.Sk % 64) != 0)
                 hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 2>), gq, dim3(256), kDq128, st, a);
             else

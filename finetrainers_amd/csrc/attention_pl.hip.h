@@ -824,3 +824,4 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pl128_kernel(AttnArgs a)
         store_rows_via_lds(smem + wave * 4096, *reinterpret_cast<const f32x16(*)[2]>(&dV[2 * dh]), 1.0f, dvb + 64 * dh, a.dv_ss, key0, a.Sk, lane);
     }
 }
+

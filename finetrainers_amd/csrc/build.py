@@ -34,7 +34,7 @@ if os.environ.get("FTMI_EXPERIMENTAL", "0") not in ("", "0"):
     SOURCES.insert(1, os.path.join(_EXP, "gemm_skinny.hip"))  # the 64 x 128-tile LoRA down-projection kernel (measured slower than the shipped one: profiles/r03_skinny_experiments.txt)
     SOURCES.insert(1, os.path.join(_EXP, "gemm_sk.hip"))      # the persistent stream-K GEMM (5-25 % slower than the shipped kernels: profiles/r03_gemm_streamk.txt)
     HEADERS.append(os.path.join(_EXP, "gemm_experimental.hip.h"))
-    HEADERS += [os.path.join(_EXP, f) for f in sorted(os.listdir(os.path.join(HERE, _EXP))) if f.startswith("attention_experimental_") or f.startswith("attn_pl_fwd_")]
+    HEADERS += [os.path.join(_EXP, f) for f in sorted(os.listdir(os.path.join(HERE, _EXP))) if f.startswith("attention_experimental_") or f.startswith("attn_pl_fwd_") or f.startswith("attn_pl_dq128_")]
 
 
 def _hipcc() -> str:

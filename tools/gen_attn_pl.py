@@ -622,6 +622,135 @@ def gen_dkv128(name: str, drop=()):
     return path
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# dQ at head_dim 128 (Wan, HunyuanVideo): a wave owns 32 query rows (q and dO fragments resident: 64 VGPRs), loops over 64-key tiles (js = 0, 1: 32 keys each);
+# one slot per unit u = (t, js) = 32 queries x 32 keys:
+#   C(u-1):  8 MFMAs  dQ[dt] += K^T . dS  (dt = 0..3, hh = 0, 1)                                          -- positions 0 .. 7
+#   A(u+1): 16 MFMAs  S = K.Q^T,  DP = V.dO^T  (chains of 8 over the 128-wide head, interleaved)             -- positions 8 .. 23
+#   B(u):   88 VALU   bl = bias - lse (gaps 0 .. 1), x = S * sl + bl and y = DP - delta (gaps 2 .. 7: S and DP are free again when A(u+1) starts -- single
+#                     buffers), then exp2, the product and the packs out of x / y under A(u+1) (gaps 8 .. 22).
+# The arithmetic of attn_bwd_dq_kernel<HAS_KB, 2> operation for operation (a zero bias row where there is no bias: 0 - lse = -lse exactly).
+# K / V row fragments through 4-deep rolling buffers, K^T fragments through an 8-deep one (a unit's eight, read a slot ahead), counted lgkmcnt waits.
+# ------------------------------------------------------------------------------------------------------------------------------
+def gen_dq128(name: str, drop=()):
+    s = Stream()
+    s.emit(f"// GENERATED by tools/gen_attn_pl.py (dq128_{name}: drop={','.join(drop) or '-'}) -- do not edit")
+    seq, issued_at, landed = [0], {}, [0]
+
+    def lds_read(text, outs, ins, key):
+        if "lds" in drop:
+            return
+        s.asm(text, outs, ins)
+        seq[0] += 1
+        issued_at[key] = seq[0]
+
+    def wait_for(keys):
+        if "lds" in drop:
+            return
+        need = max(issued_at.get(k, -10**9) for k in keys)
+        if need <= landed[0]:
+            return
+        n = min(seq[0] - need, 15)
+        s.asm(f"s_waitcnt lgkmcnt({n})", "", "", '"memory"')
+        landed[0] = max(landed[0], seq[0] - n)
+
+    for js in range(2):
+        par, parn = js, js ^ 1
+        jsn = js ^ 1  # key half of unit u+1
+        s.emit(f"// ---- slot (t, js {js}): C(u-1) with dS[{parn}]; B(u) on S / DP -> dS[{par}]; A(u+1) into S / DP")
+        s.emit("{")
+        def BS(r): return ("v_sub_f32 %0, %1, %2", f'"=v"(bl[{r}])', f'"v"(b4[{r >> 2}][{r & 3}]), "v"(lse_i)')
+        def F(r): return ("v_fma_f32 %0, %1, %2, %3", f'"=v"(x[{r}])', f'"v"(S[{r}]), "v"(sl), "v"(bl[{r}])')
+        def U(r): return ("v_sub_f32 %0, %1, %2", f'"=v"(y[{r}])', f'"v"(DP[{r}]), "v"(del_i)')
+        def E(r): return ("v_exp_f32 %0, %0", f'"+v"(x[{r}])', "")
+        def M(r): return ("v_mul_f32 %0, %0, %1", f'"+v"(y[{r}])', f'"v"(x[{r}])')
+        def P(r):
+            hh, e = r >> 3, (r & 7) >> 1
+            return ("v_cvt_pk_bf16_f32 %0, %1, %2", f'"=v"(dsw[{par}][{hh}][{e}])', f'"v"(y[{r}]), "v"(y[{r + 1}])')
+        v_bias = [BS(r) for r in range(16)]
+        v_sd = []
+        for r in range(16):
+            v_sd += [F(r), U(r)]
+        v_rest, L = [], 4
+        for s_ in range(16 + L + 2):
+            if s_ < 16: v_rest.append(E(s_))
+            if 0 <= s_ - L < 16: v_rest.append(M(s_ - L))
+            r = s_ - L - 1
+            if 0 <= r < 16 and r % 2 == 1: v_rest.append(P(r - 1))
+        assert len(v_rest) == 40
+        if "valu" in drop:
+            v_bias, v_sd, v_rest = [], [], []
+        plan = {}  # gap -> list of VALU ops
+        for g, k in zip(range(0, 2), spread(len(v_bias), 2)):
+            plan.setdefault(g, []); plan[g] += [v_bias.pop(0) for _ in range(k)]
+        for g, k in zip(range(2, 8), spread(len(v_sd), 6)):
+            plan.setdefault(g, []); plan[g] += [v_sd.pop(0) for _ in range(k)]
+        for g, k in zip(range(8, 23), spread(len(v_rest), 15)):
+            plan.setdefault(g, []); plan[g] += [v_rest.pop(0) for _ in range(k)]
+
+        def tr_read(m, unit_js):
+            """K^T fragment m (hh = m >> 2, dt = m & 3) of the unit with key half unit_js -> buffer m"""
+            hh, dt = m >> 2, m & 3
+            base = (dt >> 1) * 8192 + unit_js * 4096 + hh * 2048
+            lds_read(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(trlo[{m}])', f'"v"(tra[{dt & 1}][0])', ("trl", m))
+            lds_read(f"ds_read_b64_tr_b16 %0, %1 offset:{base}", f'"=v"(trhi[{m}])', f'"v"(tra[{dt & 1}][1])', ("tr", m))
+
+        if js == 1:
+            s.emit("// tile hand-over: my loads of tile t+1 have landed (wave 0 then scales its bias row to the log2 domain, in place); after the barrier everyone's have,")
+            s.emit("// and nobody reads tile t-1 any more")
+            s.emit("HAND_OVER();")
+            s.emit("RING_ADVANCE_ROW();  // row-fragment addresses -> ring slot of tile t+1")
+        for g in range(24):
+            # ---- waits in front of the MFMA at position g
+            if g < 8:
+                wait_for([("tr", g)])
+            else:
+                k = g - 8
+                c, which = k >> 1, k & 1
+                wait_for([("kf" if which == 0 else "vf", c)])
+            # ---- the MFMA
+            if g < 8:
+                hh, dt = g >> 2, g & 3
+                m_ = (f"{MFMA} %0, %1, %2, %0", f'"+a"(dqt[{dt}])', f'"v"(TRF({g})), "v"(DSF({parn}, {hh}))')
+            else:
+                k = g - 8
+                c, which = k >> 1, k & 1
+                if which == 0:
+                    m_ = (f"{MFMA} %0, %1, %2, 0", '"=&v"(S)', f'"v"(kf[{c & 3}]), "v"(qf[{c}])') if c == 0 else (f"{MFMA} %0, %1, %2, %0", '"+v"(S)', f'"v"(kf[{c & 3}]), "v"(qf[{c}])')
+                else:
+                    m_ = (f"{MFMA} %0, %1, %2, 0", '"=&v"(DP)', f'"v"(vf[{c & 3}]), "v"(dof[{c}])') if c == 0 else (f"{MFMA} %0, %1, %2, %0", '"+v"(DP)', f'"v"(vf[{c & 3}]), "v"(dof[{c}])')
+            if "mfma" not in drop:
+                s.asm(m_[0], m_[1], m_[2])
+            # ---- LDS reads behind it
+            if g < 4:   # the first four K / V row fragments of unit u+1
+                lds_read(f"ds_read_b128 %0, %1 offset:{jsn * 4096}", f'"=v"(kf[{g}])', f'"v"(ra[{g}])', ("kf", g))
+                lds_read(f"ds_read_b128 %0, %1 offset:{16384 + jsn * 4096}", f'"=v"(vf[{g}])', f'"v"(ra[{g}])', ("vf", g))
+            if 4 <= g < 8:  # its bias row (the bias subtractions of unit u, gaps 0 .. 1, have read the old one)
+                rq = g - 4
+                lds_read(f"ds_read_b128 %0, %1 offset:{32768 + jsn * 128 + rq * 32}", f'"=v"(b4[{rq}])', '"v"(la)', ("b4", rq))
+            if 8 <= g < 16:
+                if g == 8 and js == 0:
+                    s.emit("RING_ADVANCE_TR();  // transposed-fragment addresses -> ring slot of this tile (unit u is its first)")
+                tr_read(g - 8, par)  # C(u)'s fragments (next slot), into the buffers C(u-1) has released
+                k = g - 8
+                c, which = k >> 1, k & 1  # this MFMA used row fragment c (< 4): reload the buffer with fragment c + 4 (second 64-wide image)
+                if which == 0:
+                    lds_read(f"ds_read_b128 %0, %1 offset:{8192 + jsn * 4096}", f'"=v"(kf[{c}])', f'"v"(ra[{c}])', ("kf", c + 4))
+                else:
+                    lds_read(f"ds_read_b128 %0, %1 offset:{16384 + 8192 + jsn * 4096}", f'"=v"(vf[{c}])', f'"v"(ra[{c}])', ("vf", c + 4))
+            if js == 1 and 12 <= g < 21 and "dma" not in drop:
+                s.emit(f"DMA_PIECE({g - 12});")
+            for (t2, o2, i2) in plan.get(g, []):
+                s.asm(t2, o2, i2)
+            if g == 22:  # the bias row of unit u+1 must have landed: its subtractions open the next slot
+                wait_for([("b4", 3)])
+        s.emit("}")
+    path = os.path.join(EXP_OUT, f"attn_pl_dq128_{name}.inc")  # experiment, not shipped (tools/experimental/attention_experimental_7_dq128_pl.hip.h)
+    with open(path, "w") as f:
+        f.write("\n".join(s.lines) + "\n")
+    return path
+
+
 def main():
     made = []
     for nq in (1, 2):
@@ -643,6 +772,7 @@ def main():
     made.append(gen_dkv("a_novalu", drop=("valu",)))
     made.append(gen_dkv("a_nolds", drop=("lds",)))
     made.append(gen_dkv128("v1"))
+    made.append(gen_dq128("x0"))
     made.append(gen_fwd("v1"))
     made.append(gen_fwd("a_novalu", drop=("valu",)))
     made.append(gen_fwd("a_nolds", drop=("lds",)))
