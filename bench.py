@@ -147,7 +147,7 @@ def cpu_baseline(args):
     dt_32, ts_32 = _cpu_steps(ltx, cfg, args.rank, torch.float32, 1, args.frames, args.height, args.width, 1, 3)
     dt_c1, ts_c1 = _cpu_steps(ltx, ltx.LTXConfig.production(num_layers=28), args.rank, torch.bfloat16, 1, 2, 4, 4, 1, 3)
     scale = 28.0 / nl
-    out["value"] = 1.0 / (dt_bf * scale)  # replaced below by the full-size measurement where it exists (the bounded sample stays as value_bounded_sample)
+    out["value"] = 1.0 / (dt_bf * scale)  # this run's bounded sample (the once-measured full-size figure rides along as full_size_committed)
     out["sample"] = (f"oracle (CPU restatement of the reference step), {cores} threads, 1 warm-up + 3 timed optimisation steps each: cfg 2 clip 49x512x768 "
                      f"(2688 tokens) batch 1 on {nl} of 28 blocks, scaled x{scale:g}: bf16 {dt_bf:.2f} s/step -> {dt_bf * scale:.1f} s per sample-step, "
                      f"fp32 {dt_32:.2f} s/step -> {dt_32 * scale:.1f} s; cfg 1 (9x128x128, 32 tokens, batch 1) at full depth, bf16: {dt_c1 * 1e3:.0f} ms/step")
@@ -155,17 +155,14 @@ def cpu_baseline(args):
     out["cfg2_fp32"] = {"step_s_measured": ts_32, "blocks": nl, "samples_per_s_scaled": 1.0 / (dt_32 * scale), "step_ms_scaled": dt_32 * scale * 1e3}
     out["cfg1_bf16_full_depth"] = {"step_s_measured": ts_c1, "blocks": 28, "samples_per_s": 1.0 / dt_c1, "step_ms": dt_c1 * 1e3}
     full = _profile_json("r04_cpu_baseline_full.json")  # tools/cpu_baseline_full.py: cfg 2 exactly (batch 2, all 28 blocks), measured once, not scaled
+    out["measured_in_this_run"] = True  # `value` and every *_measured list above were timed by THIS process on this box's host cores
     if full:
-        # `value` = the configuration measured at FULL size (cfg 2 exactly: batch 2, 28 blocks -- 7 minutes of host time, measured once and committed);
-        # what this run timed within its bound is the secondary figure (its x7 extrapolation was 6-10 % optimistic)
-        out["measured_full"] = True
-        out["value_bounded_sample"] = out["value"]
-        out["value"] = float(full["samples_per_s"])
-        out["value_source"] = "profiles/r04_cpu_baseline_full.json (tools/cpu_baseline_full.py: oracle step at full size, 1 warm-up + 3 timed steps)"
-        out["cores_full_measurement"] = full.get("cores")
-        out["cfg2_bf16_full_depth_batch2"] = {k: full[k] for k in ("step_s_measured", "step_s", "samples_per_s", "cores", "warmup_steps", "timed_steps") if k in full}
-        out["sample"] = (f"cfg 2 at FULL size (batch 2, 28 blocks, bf16, {full.get('cores')} threads; measured once: profiles/r04_cpu_baseline_full.json): "
-                         f"{full['step_s']:.1f} s/step = {full['samples_per_s']:.4f} samples/s = `value`.  This run's bounded sample (value_bounded_sample): " + out["sample"])
+        # The configuration measured ONCE at FULL size (cfg 2 exactly: batch 2, 28 blocks -- 7 minutes of host time, tools/cpu_baseline_full.py) rides along as a
+        # COMMITTED figure, labelled as such: `value` stays what this run timed within its bound (its x7 extrapolation is 6-10 % optimistic against it).
+        out["full_size_committed"] = {
+            "measured_in_this_run": False, "value": float(full["samples_per_s"]), "unit": "samples/s", "cores": full.get("cores"),
+            "source": "profiles/r04_cpu_baseline_full.json (tools/cpu_baseline_full.py: oracle step at full size, 1 warm-up + 3 timed steps, round-4 box)",
+            **{k: full[k] for k in ("step_s_measured", "step_s", "warmup_steps", "timed_steps") if k in full}}
     return out
 
 
@@ -244,6 +241,8 @@ def _build_cpu_rehearsal(args, par, dev):
     the JSON schema with `exchange` / `exposed_comm_ms` / `buckets_per_step` -- runs end to end on a machine without a GPU (tests/test_host.py)."""
     from finetrainers_amd.parallel import GradBucketReducer
 
+    if args.workload == "wan":
+        return _build_cpu_rehearsal_wan(args, par, dev)
     L, per = 28, 64
     flat = torch.zeros(2 * L * per)
     par.broadcast_(flat, src=0)
@@ -274,6 +273,57 @@ def _build_cpu_rehearsal(args, par, dev):
             "cpu_baseline": lambda: None}
 
 
+def _build_cpu_rehearsal_wan(args, par, dev):
+    """The same rehearsal for `--workload wan` (config 4: parameters sharded over the ranks): the real ParameterSharder walks the schedule of
+    MI355XWanFullFinetuneStep's hooks (wan/trainer.py:62-76) over gloo -- root gathered once, every block gathered before its forward with the next one
+    prefetched, gathered again before its backward (the last two are still resident), its fp32 gradient reduce-scattered (mean) after it -- on 30 small
+    flat units, and checks every rank's shard of every averaged gradient.  No kernels, no measurement; the line carries the sharder's own counters."""
+    from finetrainers_amd.wan.fsdp import ParameterSharder
+
+    nb, n_root, n_blk = 30, 1000, 4104  # Wan2.1-T2V-1.3B has 30 blocks; sizes that do not divide by 8 ranks x 64 (padding path)
+    g = torch.Generator().manual_seed(0)
+    units = [torch.randn(n_root, generator=g).to(torch.bfloat16)] + [torch.randn(n_blk, generator=g).to(torch.bfloat16) for _ in range(nb)]
+    full = [u.clone() for u in units]
+    sh = ParameterSharder(units, ["root"] + [f"blocks.{i}" for i in range(nb)], par.world_size, par.rank, par.backend, force_collectives=par.world_size == 1)
+    W = par.world_size
+
+    def one_step():
+        p0 = sh.acquire(0)
+        if not torch.equal(p0, full[0]):
+            raise RuntimeError(f"rehearsal: rank {par.rank} gathered a wrong root unit")
+        sh.grad_buffer(0).fill_(float(par.rank + 1))
+        for i in range(1, nb + 1):  # forward (_pre_forward)
+            p = sh.acquire(i)
+            sh.prefetch(i + 1)
+            if not torch.equal(p, full[i]):
+                raise RuntimeError(f"rehearsal: rank {par.rank} gathered a wrong unit {i} (forward)")
+        for i in range(nb, 0, -1):  # backward (_pre_backward / _post_backward)
+            p = sh.acquire(i)
+            if i > 1:
+                sh.prefetch(i - 1)
+            if not torch.equal(p, full[i]):
+                raise RuntimeError(f"rehearsal: rank {par.rank} gathered a wrong unit {i} (backward)")
+            sh.grad_buffer(i).fill_(float((par.rank + 1) * i))
+            sh.scatter_grad(i)
+        sh.scatter_grad(0)
+        sh.finish_gradients()
+        mean = (W + 1) / 2.0
+        for i, u in enumerate(sh.units):
+            lo, hi = par.rank * u.k, min((par.rank + 1) * u.k, u.numel)
+            want = mean * (i if i else 1)
+            if hi > lo and not torch.allclose(u.shard_grad[: hi - lo], torch.full((hi - lo,), want)):
+                raise RuntimeError(f"rehearsal: rank {par.rank} unit {i}: averaged gradient shard {float(u.shard_grad[0])} vs {want}")
+        sh.zero_shard_grads()
+        sh.release_all()
+        return {"loss": torch.tensor(0.0)}
+
+    return {"one_step": one_step, "reducer": None, "sharder": sh, "samples_per_step": args.batch, "step_tflop": 0.0,
+            "metric": "train samples/sec (+ step ms) Wan-T2V full fine-tune 81x512x512, parameters sharded over the GPUs",
+            "data": "NONE (CPU rehearsal of the multi-rank harness: no kernels run)",
+            "config": {"workload": "REHEARSAL on CPU over gloo: the parameter sharder's gather / reduce-scatter schedule over 1 + 30 flat units, no step"},
+            "cpu_baseline": lambda: None}
+
+
 def main():
     args = parse()
     cpu_reh = os.environ.get("FTMI_BENCH_REHEARSAL_CPU") == "1"
@@ -300,6 +350,8 @@ def main():
         args.no_prof, args.no_cpu_baseline = True, True
     else:
         par = DataParallelBackend(backend="gloo", device=torch.device("cuda", 0)) if share and args.gpus > 1 else DataParallelBackend()
+    if par.world_size > 1 or cpu_reh:
+        par.gather_rank_devices()  # collective, on every rank: one device record per rank for `exchange.rank_devices`
     if par.world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={par.world_size}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = par.device
@@ -398,6 +450,10 @@ def main():
             "exchange": par.describe() if (par.world_size > 1 or cpu_reh) else None,
             "exposed_comm_ms": exposed,
             "buckets_per_step": (reducer.buckets_issued / max(1, args.steps + args.warmup)) if reducer is not None else None,
+            # parameter sharding (Wan): the sharder's own counters -- all-gathers (bf16 units) and reduce-scatters (fp32 gradients) issued per step
+            **({"sharder": {"units": len(ctx["sharder"].units), "gathers_per_step": ctx["sharder"].gathers_issued / max(1, args.steps + args.warmup),
+                            "scatters_per_step": ctx["sharder"].scatters_issued / max(1, args.steps + args.warmup), "world": ctx["sharder"].world}}
+               if ctx.get("sharder") is not None else {}),
             "step_ms_min_median_max": [round(v, 3) for v in (lambda t: (t[0], t[len(t) // 2], t[-1]))(sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)))],
             # steps that took more than 1.2x the median (index, ms): isolated ~25 ms stalls appear about once in 10 s on the gpurun
             # boxes with and without the in-stream profiler (a box-level pause, not part of the step)
@@ -440,6 +496,7 @@ def main():
                     "unit": "TFLOP/s",
                     "frac": g_["tflops"] / PEAK_BF16_TFLOPS,
                     "traffic": _pmc_traffic("gemm_nt_kernel")[0],
+                    "traffic_measured_in_this_run": False,  # a committed rocprofv3 --pmc pass of this command (counters cannot be collected inside the timed run)
                     "traffic_unit": f"HBM/fabric bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/{_pmc_traffic('gemm_nt_kernel')[1]})",
                     "avg_launch_us": g_["avg_us"],
                     "launches_per_step": g_["launches_per_step"],
@@ -454,9 +511,10 @@ def main():
                 if mf:  # counter-derived figures of the same command (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ..., tools/gpu_profile_r02.sh)
                     keep = ("mfma_util", "valu_issue_share_of_simd_time", "wave_wait_share", "wave_issue_stall_share", "launches_in_trace")
                     res["roofline"]["counters"] = {k: mf.get(NT_CLASS, mf.get("gemm_nt_kernel", {})).get(k) for k in keep}
+                    res["roofline"]["counters"]["measured_in_this_run"] = False
                     res["roofline"]["counters"]["source"] = (f"profiles/{mf_name} (rocprofv3 --pmc passes of this command, tools/gpu_profile_r04.sh): "
                                                              "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
-                    res["mfma_utilisation_counters"] = {"step": mf.get("step", {}).get("mfma_util_over_kernel_time"),
+                    res["mfma_utilisation_counters"] = {"measured_in_this_run": False, "source": f"profiles/{mf_name}", "step": mf.get("step", {}).get("mfma_util_over_kernel_time"),
                                                         **{k: v.get("mfma_util") for k, v in mf.items() if isinstance(v, dict) and v.get("mfma_util")}}
                 if "attn_fwd" in kern and "attn_bwd" in kern:
                     a_ms = kern["attn_fwd"]["ms_per_step"] + kern["attn_bwd"]["ms_per_step"]
@@ -468,7 +526,8 @@ def main():
             # correction of MI355X_MICROARCH.md -- + WRITE_SIZE, separate passes), time from THIS run.
             step_bytes, src = _pmc_step_traffic()
             dom_bytes, dsrc = _pmc_traffic("gemm_nt_kernel")
-            hb = {"peak": PEAK_HBM_GBPS, "unit": "GB/s", "source": f"profiles/{src}" if src else None}
+            hb = {"peak": PEAK_HBM_GBPS, "unit": "GB/s", "source": f"profiles/{src}" if src else None,
+                  "bytes_measured_in_this_run": False, "time_measured_in_this_run": True}  # bytes: committed counter pass; time: this run
             if step_bytes:
                 hb["step"] = step_bytes / (ms * 1e-3) / 1e9
                 hb["step_frac_of_peak"] = hb["step"] / PEAK_HBM_GBPS
@@ -478,13 +537,13 @@ def main():
                 hb["dominant_kernel"] = dom_bytes / (g_["avg_us"] * 1e-6) / 1e9
                 hb["dominant_kernel_frac_of_peak"] = hb["dominant_kernel"] / PEAK_HBM_GBPS
             res["hbm_gbps"] = hb
-            res["hbm_frac_of_peak"] = hb.get("step_frac_of_peak")
+            res["hbm_frac_of_peak_committed_bytes"] = hb.get("step_frac_of_peak")  # (bytes from the committed counter pass / this run's time)
         # the same command with --no-prof on the round's evidence box: the instrument's cost as a stated quantity
         for rr in ("r05", "r04"):
             pr, pd = _profile_json(f"{rr}_bench_noprof.json"), _profile_json(f"{rr}_bench_default.json")
             if prof and pr and pd and args.workload == "ltx":
                 res["ms_per_step_without_event_profiler"] = {
-                    "ms_per_step": pr.get("ms_per_step"), "with_profiler_same_box": pd.get("ms_per_step"),
+                    "measured_in_this_run": False, "ms_per_step": pr.get("ms_per_step"), "with_profiler_same_box": pd.get("ms_per_step"),
                     "source": f"profiles/{rr}_bench_noprof.json vs profiles/{rr}_bench_default.json: python bench.py with and without --no-prof on the round's evidence box "
                               f"({pd.get('ms_per_step', 0):.2f} vs {pr.get('ms_per_step', 0):.2f} ms)"}
                 break

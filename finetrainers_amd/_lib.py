@@ -146,6 +146,7 @@ _SIGS = {
     "ftmi_linear_lora_fwd": (c_int, [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 7 + [c_int, c_void_p]),
     "ftmi_linear_lora_bwd": (c_int, [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 10 + [c_int, c_void_p]),
     "ftmi_gemm_nt_plan": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "ftmi_reload_switches": (c_int, []),
     "ftmi_gemm_nt": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p, c_long, c_int,
                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p]),
     "ftmi_gemm_tn": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_float, c_void_p]),

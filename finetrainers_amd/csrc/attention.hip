@@ -417,9 +417,13 @@ static int attn_gen(const char* which, int dflt) {
 }
 #endif
 
-// FTMI_ATTN_PL (re-read every call): bit 0 pipelined dQ, bit 1 pipelined dK / dV, bit 2 pipelined forward (experimental builds only), bit 3 fused pipelined dK / dV at head_dim 128, bit 17 pipelined dQ at head_dim 128 (experimental builds only); bits 4-7 dQ stream, bit 8 dQ at 64 rows per wave,
+// FTMI_ATTN_PL (read once, see attn_pl_switch): bit 0 pipelined dQ, bit 1 pipelined dK / dV, bit 2 pipelined forward (experimental builds only), bit 3 fused pipelined dK / dV at head_dim 128, bit 17 pipelined dQ at head_dim 128 (experimental builds only); bits 4-7 dQ stream, bit 8 dQ at 64 rows per wave,
 // bits 12-15 dK / dV stream, bits 16-19 forward stream (lab)
 static constexpr int kAttnPlDefault = 0x111B;
+static int attn_pl_switch() {  // read once at the first attention launch (no getenv on the launch path); tests flip it through ftmi_reload_switches()
+    static const EnvSwitch sw("FTMI_ATTN_PL", kAttnPlDefault);
+    return sw.get();
+}
 #include "attention_pl.hip.h"
 #if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
 #include "../../tools/experimental/attention_experimental_6_fwd_pl.hip.h"  // pipelined forward: bit-identical, 4-7 % slower (EXPERIMENT, not shipped)
@@ -496,7 +500,7 @@ int attn_fwd(const AttnArgs& a, hipStream_t st) {
 #if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
     // pipelined forward (experiment: same bits as the kernels below, 4-7 % slower): FTMI_ATTN_PL bit 2
     if (!a.kbias && a.Sk >= 128 && a.Sq >= 128) {
-        const int pl = env_int("FTMI_ATTN_PL", kAttnPlDefault);
+        const int pl = attn_pl_switch();
         if (pl & 4) {
             const dim3 gridp(((a.Sq + 255) / 256) * a.H * a.B);
             const bool ragged = (a.Sk % 64) != 0;
@@ -1353,7 +1357,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         constexpr int lab_only = 0;
 #endif
 #if defined(FTMI_LAB) || defined(FTMI_EXPERIMENTAL)
-        const bool dq_pl128 = (env_int("FTMI_ATTN_PL", kAttnPlDefault) & 0x20000) && a.Sq >= 128 && a.Sk >= 128;
+        const bool dq_pl128 = (attn_pl_switch() & 0x20000) && a.Sq >= 128 && a.Sk >= 128;
 #else
         constexpr bool dq_pl128 = false;
 #endif
@@ -1380,7 +1384,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
         // One fused dK + dV pass: compiler-scheduled it needed 256 VGPR + 186 AGPR at one wave per SIMD and measured 11.8 ms against 10.5 ms for the two passes
         // at 21 504 tokens x 12 heads (profiles/r02_attention_experiments.txt); as a hand-placed pipeline with single-buffered scores it is what runs
         // (attention_pl.hip.h, FTMI_ATTN_PL bit 3): same bits, 4 executed matmuls instead of 5.
-        if ((env_int("FTMI_ATTN_PL", kAttnPlDefault) & 8) && a.Sq >= 128 && a.Sk >= 128) {
+        if ((attn_pl_switch() & 8) && a.Sq >= 128 && a.Sk >= 128) {
             static const bool okp = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_pl128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kPlDkv128Lds) == hipSuccess;
             if (!okp) return set_error(FTMI_ERR_LAUNCH, "attn_bwd: cannot raise the dynamic LDS limit");
             hipLaunchKernelGGL((attn_bwd_dkdv_pl128_kernel<1>), gk, dim3(256), kPlDkv128Lds, st, a);
@@ -1405,10 +1409,11 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     const bool lab_skip_dq = false;
 #endif
     // few keys (LTX cross-attention): resident K / V, row-DMA'd Q / dO / O, one round of workgroups that each walk bpw 128-row query blocks.
-    // FTMI_ATTN_FEWKEYS is re-read every call (a getenv): the bit-identity test switches between the two kernels inside one process.
+    // FTMI_ATTN_FEWKEYS: read once (EnvSwitch); the bit-identity test switches between the two kernels inside one process through ftmi_reload_switches().
     int few_bpw = 1;  // smallest walk that fits every workgroup into one round (one workgroup per CU); its lse rows must fit the staging array
     while ((long)(((a.Sq + 127) / 128 + few_bpw - 1) / few_bpw) * a.H * a.B > 256 && few_bpw <= kDqResMaxBlocks) ++few_bpw;
-    const bool few_keys = env_int("FTMI_ATTN_FEWKEYS", 1) && a.Sk <= 128 && a.Sq >= 512 && few_bpw <= kDqResMaxBlocks;
+    static const EnvSwitch few_keys_sw("FTMI_ATTN_FEWKEYS", 1);
+    const bool few_keys = few_keys_sw.get() && a.Sk <= 128 && a.Sq >= 512 && few_bpw <= kDqResMaxBlocks;
     if (lab_skip_dq) {
     } else if (few_keys) {
         static const bool attr_ok =
@@ -1424,9 +1429,9 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(attn_bwd_dq_res_kernel<false>, gr, dim3(256), kDqResLds, st, a, nblk, bpw);
     } else if (dq_gen == 2) {
         const dim3 grid2(((a.Sq + 255) / 256) * a.H * a.B);
-        // hand-placed pipelines (attention_pl.hip.h): no key bias (ragged token counts: the DMA zero-fills).  FTMI_ATTN_PL (re-read every call, a getenv, so that one process can compare
+        // hand-placed pipelines (attention_pl.hip.h): no key bias (ragged token counts: the DMA zero-fills).  FTMI_ATTN_PL (read once; ftmi_reload_switches() lets one process compare
         // the kernels): bit 0 = dQ kernel, bits 4-7 = stream variant, bit 8 = 64 query rows per wave at one wave per SIMD (the default; 0: 32 rows, two waves per SIMD)
-        const int pl = env_int("FTMI_ATTN_PL", kAttnPlDefault);
+        const int pl = attn_pl_switch();
         // (from 256 keys on: shorter problems keep attn_bwd_dq2_kernel, whose bits the resident few-keys kernel reproduces -- the shipped stream differs by one rounding per score)
         if ((pl & 1) && !a.kbias && a.Sk >= 256) {
             const int var = (pl >> 4) & 15, nq = (pl & 0x100) ? 2 : 1;
@@ -1490,7 +1495,7 @@ int attn_bwd(const AttnArgs& a, hipStream_t st) {
     } else {
         // hand-placed pipeline (attention_pl.hip.h): 64 keys per wave, one wave per SIMD.  FTMI_ATTN_PL bit 1 (value >> 12 = stream variant).  No key bias;
         // a.delta was just written by the dQ kernel.
-        const int plk = env_int("FTMI_ATTN_PL", kAttnPlDefault);
+        const int plk = attn_pl_switch();
         if ((plk & 2) && !a.kbias && a.Sq >= 128 && a.Sk >= 256) {
             const int var = (plk >> 12) & 15;
             const dim3 gridk(((a.Sk + 255) / 256) * a.H * a.B);

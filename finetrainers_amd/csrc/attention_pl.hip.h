@@ -229,15 +229,15 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
             }
 #ifdef FTMI_LAB
             else if constexpr (VAR == 6) {
-#include "attn_pl_dq1_v6.inc"
+#include "../../tools/experimental/attn_pl_dq1_v6.inc"
             } else if constexpr (VAR == 7) {
-#include "attn_pl_dq1_a_mfma16.inc"
+#include "../../tools/experimental/attn_pl_dq1_a_mfma16.inc"
             } else if constexpr (VAR == 3) {
-#include "attn_pl_dq1_a_novalu.inc"
+#include "../../tools/experimental/attn_pl_dq1_a_novalu.inc"
             } else if constexpr (VAR == 4) {
-#include "attn_pl_dq1_a_nolds.inc"
+#include "../../tools/experimental/attn_pl_dq1_a_nolds.inc"
             } else {
-#include "attn_pl_dq1_a_nomfma.inc"
+#include "../../tools/experimental/attn_pl_dq1_a_nomfma.inc"
             }
 #endif
         } else {
@@ -250,15 +250,15 @@ __global__ __launch_bounds__(256, NQ == 1 ? 2 : 1) void attn_bwd_dq_pl_kernel(At
             }
 #ifdef FTMI_LAB
             else if constexpr (VAR == 6) {
-#include "attn_pl_dq2_v6.inc"
+#include "../../tools/experimental/attn_pl_dq2_v6.inc"
             } else if constexpr (VAR == 7) {
-#include "attn_pl_dq2_a_mfma16.inc"
+#include "../../tools/experimental/attn_pl_dq2_a_mfma16.inc"
             } else if constexpr (VAR == 3) {
-#include "attn_pl_dq2_a_novalu.inc"
+#include "../../tools/experimental/attn_pl_dq2_a_novalu.inc"
             } else if constexpr (VAR == 4) {
-#include "attn_pl_dq2_a_nolds.inc"
+#include "../../tools/experimental/attn_pl_dq2_a_nolds.inc"
             } else {
-#include "attn_pl_dq2_a_nomfma.inc"
+#include "../../tools/experimental/attn_pl_dq2_a_nomfma.inc"
             }
 #endif
         }
@@ -506,9 +506,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_pl_kernel(AttnArgs a) {
         }
 #ifdef FTMI_LAB
         else if constexpr (VAR == 3) {
-#include "attn_pl_dkv_a_novalu.inc"
+#include "../../tools/experimental/attn_pl_dkv_a_novalu.inc"
         } else if constexpr (VAR == 4) {
-#include "attn_pl_dkv_a_nolds.inc"
+#include "../../tools/experimental/attn_pl_dkv_a_nolds.inc"
         }
 #endif
         else {

@@ -1797,9 +1797,10 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         if (use_sk3 && gemm_nt_skinny3_eligible(a)) return gemm_nt_skinny3(a, st);
 #endif
         ProfScope prof(PROF_GEMM_SKINNY, 2.0 * a.M * a.N * (double)a.K, st);
-        // 64-row tiles (fourth generation) wherever they fill at least a third of the chip; FTMI_SKINNY4 is re-read every call (a getenv) so that one
-        // process can compare the kernels (they are bit-identical: tests/test_gpu_kernels.py)
-        const int sk4 = env_int("FTMI_SKINNY4", 1);  // 1: 64-deep stages, 2: 32-deep stages
+        // 64-row tiles (fourth generation) wherever they fill at least a third of the chip; FTMI_SKINNY4 is read once (EnvSwitch: one process can still
+        // compare the kernels through ftmi_reload_switches() -- they are bit-identical: tests/test_gpu_kernels.py)
+        static const EnvSwitch sk4_sw("FTMI_SKINNY4", 1);
+        const int sk4 = sk4_sw.get();  // 1: 64-deep stages, 2: 32-deep stages
         if (sk4 && (long)((a.M + 63) / 64) * (a.N / 64) >= 84) {
             constexpr int kSmem4 = 4 * 2 * 16384;
             static const bool attr_ok4 =
@@ -2215,10 +2216,14 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(GemmTnArgs a) {
 template <int BP, int BQ, int FU, int FV>
 static int launch_tn2f(const GemmTnArgs& a, dim3 grid, hipStream_t st) {
     constexpr int kSmem = 3 * ((BP / 64) * FU + (BQ / 64) * FV) * 8192;
+    // a (hi, lo) pair on the 256-wide operand would need 216 KB of LDS: gemm_tn() keeps such launches on the 128-wide tile (the fold must sit on the short operand)
+    if constexpr (kSmem > 163840) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: tile needs more than 160 KB of LDS");
+    else {
     static const bool attr = (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel<BP, BQ, FU, FV>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess);
     if (!attr) return set_error(FTMI_ERR_LAUNCH, "gemm_tn: cannot raise the dynamic LDS limit");
     hipLaunchKernelGGL((gemm_tn2_kernel<BP, BQ, FU, FV>), grid, dim3(256), kSmem, st, a);
     return 0;
+    }
 }
 template <int BP, int BQ>
 static int launch_tn2(const GemmTnArgs& a, dim3 grid, hipStream_t st) {
@@ -2261,8 +2266,9 @@ int gemm_tn(const GemmTnArgs& a0, hipStream_t st) {
     static const int tn_wide = env_int("FTMI_TN_WIDE", 1), tn_gen = env_int("FTMI_TN_GEN", 2);
     static const int tn_ragged = env_int("FTMI_TN_RAGGED", 1);  // 0: ragged token counts on the register-staged kernel (the state before round 5)
     const bool ring_ok = tn_gen == 2 && (a.M % 64 == 0 || (tn_ragged && a.M >= 256));  // the DMA-ring kernel (a ragged last step through bounds-checked loads)
-    const bool wide256 = tn_wide && ring_ok && a.M >= 1024 && ((wideP && a.P % 256 == 0 && a.Q == 64 && (a.v_grp_p == 0 || a.v_grp_p % 256 == 0) && a.u_grp_p == 0) ||
-                                                      (wideQ && a.Q % 256 == 0 && a.v_grp_p == 0));
+    // (the folded (hi, lo) pair must be the SHORT operand: both planes of a 256-wide operand in a three-stage ring are 3 x 9 x 8 KB = 216 KB of LDS)
+    const bool wide256 = tn_wide && ring_ok && a.M >= 1024 && ((wideP && !a.u_fold && a.P % 256 == 0 && a.Q == 64 && (a.v_grp_p == 0 || a.v_grp_p % 256 == 0) && a.u_grp_p == 0) ||
+                                                      (wideQ && !a.v_fold && a.Q % 256 == 0 && a.v_grp_p == 0));
     const int bp = wideP ? (wide256 ? 256 : 128) : 64, bq = wideP ? 64 : (wideQ ? (wide256 ? 256 : 128) : 64);
     if (a.v_grp_p > 0 && a.v_grp_p % bp != 0) return set_error(FTMI_ERR_UNSUPPORTED, "gemm_tn: group width vs tile");
     const int tiles = (a.P / bp) * (a.Q / bq);

@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/ftmi355.h"
 
 namespace ftmi {
@@ -15,6 +17,41 @@ int set_error(int code, const char* msg);
 int check_launch(const char* what);
 // tuning switch from the environment (read once per call site: `static const int v = env_int(...)` is thread-safe)
 int env_int(const char* name, int dflt);
+
+// A switch that tests flip inside one process (FTMI_ATTN_PL, FTMI_ATTN_FEWKEYS, FTMI_SKINNY4: bit-identity tests compare two kernels through the same
+// entry point).  The environment is read ONCE, when the first launch constructs the switch; a launch costs one relaxed atomic load -- no getenv on the launch
+// path.  ftmi_reload_switches() (C ABI; tests call it after changing the environment) re-reads every switch constructed so far.  The stand-alone lab
+// harnesses (tools/*_lab.hip, -DFTMI_LAB) re-read on every call: they drive their variants with setenv().
+class EnvSwitch {
+public:
+    EnvSwitch(const char* name, int dflt) : name_(name), dflt_(dflt), v_(env_int(name, dflt)) {
+        EnvSwitch* head = list().load(std::memory_order_acquire);
+        do next_ = head;
+        while (!list().compare_exchange_weak(head, this, std::memory_order_acq_rel));
+    }
+    int get() const {
+#ifdef FTMI_LAB
+        return env_int(name_, dflt_);
+#else
+        return v_.load(std::memory_order_relaxed);
+#endif
+    }
+    static int reload_all() {
+        int n = 0;
+        for (EnvSwitch* s = list().load(std::memory_order_acquire); s; s = s->next_, ++n) s->v_.store(env_int(s->name_, s->dflt_), std::memory_order_relaxed);
+        return n;
+    }
+
+private:
+    static std::atomic<EnvSwitch*>& list() {
+        static std::atomic<EnvSwitch*> head{nullptr};
+        return head;
+    }
+    const char* name_;
+    int dflt_;
+    std::atomic<int> v_;
+    EnvSwitch* next_ = nullptr;
+};
 
 enum { EPI_STORE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_DGELU = 3 };
 

@@ -35,10 +35,13 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on t
 # tuner is left in charge (it picks among ring / tree / direct by message size and topology) unless FTMI_RCCL_ALGO / FTMI_RCCL_PROTO pin a choice; the
 # protocol default for multi-MB messages is Simple (LL / LL128 trade bandwidth for latency below ~1 MB) and is pinned so that a tuner table tuned for
 # small messages cannot pick LL128 for a 59 MB bucket.  What ran is recorded by `describe()` in every bench line.
+# The Simple default is scoped to multi-rank jobs (WORLD_SIZE > 1 in the launcher's environment): a single-rank process -- whose only collectives are a few
+# bytes of metrics -- keeps RCCL's own choice, and an explicit FTMI_RCCL_* always wins.
+_MULTI_RANK_LAUNCH = int(os.environ.get("WORLD_SIZE", "1") or "1") > 1
 for _var, _dst, _dflt in (("FTMI_RCCL_ALGO", "NCCL_ALGO", None), ("FTMI_RCCL_PROTO", "NCCL_PROTO", "Simple")):
     if os.environ.get(_var):
         os.environ[_dst] = os.environ[_var]
-    elif _dflt is not None:
+    elif _dflt is not None and _MULTI_RANK_LAUNCH:
         os.environ.setdefault(_dst, _dflt)
 
 
@@ -68,11 +71,8 @@ class DataParallelBackend:
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size,
                                     timeout=datetime.timedelta(seconds=timeout_s))
             self._owns_pg = True
-        if (self.world_size > 1 or self.exercise_collectives) and dist.is_initialized():
-            try:
-                self._gather_rank_devices()
-            except Exception:  # diagnostics only: never take the job down
-                self._rank_devices = None
+        # (which device every rank sits on is NOT gathered here: a collective inside a constructor, with its failure swallowed on one rank, can leave the
+        #  other ranks waiting -- callers that want the record in describe() call gather_rank_devices() explicitly, on every rank: bench.py does)
 
     def describe(self) -> Dict[str, object]:
         """What the exchange runs on, for the bench line and the multi-GPU tests' logs."""
@@ -90,13 +90,16 @@ class DataParallelBackend:
         if dist.is_initialized():
             out["group_size"] = dist.get_world_size()
             out["group_rank"] = dist.get_rank()
-            if self._rank_devices is not None:  # gathered ONCE, collectively, when the group was created (describe() itself is rank-local)
+            if self._rank_devices is not None:  # gathered ONCE, collectively, by gather_rank_devices() (describe() itself is rank-local)
                 out["rank_devices"] = self._rank_devices
                 out["distinct_devices"] = len({(d.get("device"), d.get("pci_bus_id"), d.get("uuid")) for d in self._rank_devices})
         return out
 
-    def _gather_rank_devices(self) -> None:
-        """Collective (every rank calls it, right after the group exists): which device each rank of the communicator sits on."""
+    def gather_rank_devices(self) -> None:
+        """COLLECTIVE, opt-in: every rank of the group must call it (once, after construction).  Records which device each rank of the communicator sits on,
+        for describe().  Errors propagate -- a rank that failed here must not let the others run on."""
+        if not dist.is_initialized():
+            return
         mine = {"rank": dist.get_rank(), "local_rank": self.local_rank, "device": str(self.device)}
         if self.device.type == "cuda":
             pr = torch.cuda.get_device_properties(self.device)

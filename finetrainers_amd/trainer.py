@@ -147,7 +147,14 @@ class MI355XSFTStep:
         loss = loss.reshape(()) / gas if gas > 1 else loss.reshape(())
         exchange = self.reducer is not None and (sync or not self.no_sync_accumulation)
         prev_hook, prev_fin = tr._grad_bucket_hook, tr._grad_bucket_finish
-        if not self._model_owns_exchange:  # this step's own reducer (or none): install for the duration of the backward, then put back what was there
+        # Who owns the exchange is decided PER STEP, not at construction: apply_ddp() may be called on the model after this object was built (a step
+        # that then blanked the model's hooks for its backward would leave the replicas to diverge silently).
+        model_owns = prev_hook is not None and prev_fin is not None
+        if model_owns and self.reducer is not None:
+            raise RuntimeError("MI355XSFTStep has its own gradient exchange (parallel=...) and the model now carries apply_ddp()'s hooks as well: the gradients "
+                               "would be averaged twice -- build the step with parallel=None or do not call apply_ddp on this model")
+        self._model_owns_exchange = model_owns
+        if not model_owns:  # this step's own reducer (or none): install for the duration of the backward, then put back what was there
             tr._grad_bucket_hook = self.reducer.bucket_ready if exchange else None
             tr._grad_bucket_finish = None
         try:

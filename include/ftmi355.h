@@ -117,6 +117,10 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
  * (8 waves), 44 = 128 x 128, 2 = a skinny kernel (N <= 256, plain store, no extension, M >= 512: the LDS-ring kernel when K % 256 == 0, else the direct-gather one), 1 = the 128 x 64 kernel of N % 128 != 0,
  * 0 = not a tiled launch (N % 64 or K % 64).  Host tests pin the choice to DESIGN.md. */
 int ftmi_gemm_nt_plan(int M, int N, int K, int K2, int epilogue);
+/* The FTMI_* tuning switches that select between bit-identical kernels (FTMI_ATTN_PL, FTMI_ATTN_FEWKEYS, FTMI_SKINNY4) are read from the environment ONCE,
+ * at the first launch that consults them -- the launch path never calls getenv.  A process that wants to compare kernels (the bit-identity tests do) changes
+ * the environment and calls this: every switch consulted so far is re-read.  Returns how many were. */
+int ftmi_reload_switches(void);
 #ifdef FTMI_EXPERIMENTAL
 /* Research build only (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build): the persistent stream-K GEMM (tools/experimental/gemm_sk.hip, variant 60) --
  * parity-green and 5-25 % slower than the shipped kernels on the step's shapes (profiles/r03_gemm_streamk.txt); not part of the product ABI. */

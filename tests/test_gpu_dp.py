@@ -401,6 +401,37 @@ def test_unmodified_trainer_loop_drives_the_drop_in_classes():
     assert rel < 1e-3
 
 
+def test_apply_ddp_after_the_step_object_was_built_still_exchanges():
+    """Round-5 advice: the owner of the gradient exchange is decided per step.  A MI355XSFTStep built on a plain model (parallel=None) whose model is handed
+    to apply_ddp() AFTERWARDS must exchange through the model's hooks from the next step on (it used to blank them for its backward: replicas diverging in
+    silence); a step that has its own reducer must refuse such a model loudly."""
+    from finetrainers_amd.parallel import MI355XParallelBackend
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    spec, model, cond, latd, _, _ = _model_and_batch(3, 2, 2, 4, 6)
+    os.environ.setdefault("MASTER_PORT", "29539")
+    step = MI355XSFTStep(model, spec, lr=1e-3, parallel=None)  # built BEFORE apply_ddp
+    sig = torch.tensor([0.3, 0.8], device=_dev())
+    step.step(dict(cond), dict(latd), sigmas=sig, force_first_frame_branch=False)
+    backend = MI355XParallelBackend(world_size=1, dp_degree=1, backend="nccl", exercise_collectives=True)
+    try:
+        model = backend.apply_ddp(model, backend.get_mesh())
+        hook, fin = model._grad_bucket_hook, model._grad_bucket_finish
+        before = backend.reducer.buckets_issued
+        out = step.step(dict(cond), dict(latd), sigmas=sig, force_first_frame_branch=False)
+        assert torch.isfinite(out["loss"]) and torch.isfinite(out["grad_norm"])
+        assert backend.reducer.buckets_issued == before + 1 and not backend.reducer._pending
+        assert model._grad_bucket_hook == hook and model._grad_bucket_finish == fin
+        # a step that brought its own reducer, on a model that acquired hooks later: refuse (the gradients would be averaged twice)
+        own = MI355XSFTStep.__new__(MI355XSFTStep)
+        own.__dict__.update(step.__dict__)
+        own.reducer = backend.reducer
+        with pytest.raises(RuntimeError, match="averaged twice"):
+            own.step(dict(cond), dict(latd), sigmas=sig, force_first_frame_branch=False)
+    finally:
+        backend.destroy()
+
+
 def test_fused_step_on_an_apply_ddp_model_keeps_the_models_exchange():
     """Round-4 advice: MI355XCheckpointer wants the MI355XSFTStep, MI355XParallelBackend.apply_ddp() wires the exchange on the MODEL -- mixing the two is
     the documented use.  A fused step on such a model must (a) leave the hooks apply_ddp installed in place, step after step, (b) exchange through them

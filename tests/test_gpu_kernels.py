@@ -11,6 +11,31 @@ pytestmark = pytest.mark.gpu
 bf16 = torch.bfloat16
 
 
+
+@pytest.fixture
+def sw():
+    """Set an FTMI_* kernel switch for the rest of the test.  The library reads its switches from the environment ONCE (no getenv on the launch path);
+    ftmi_reload_switches() makes it look again, here after every change and after the environment has been put back."""
+    import os
+
+    from finetrainers_amd import _lib
+
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = os.environ.get(name)
+        os.environ[name] = value
+        _lib.load().ftmi_reload_switches()
+
+    yield set_
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    _lib.load().ftmi_reload_switches()
+
 def _dev():
     return torch.device("cuda", 0)
 
@@ -154,6 +179,33 @@ def test_linear_lora_bwd(M):
     report("plain dgrad", dx2, (dy.float() @ w.float()).to(bf16), 3e-3)
 
 
+@pytest.mark.parametrize("M,K,N,r", [(1024, 256, 128, 256), (2048, 512, 192, 256), (1024, 256, 64, 256)])
+def test_linear_lora_bwd_fold_on_the_long_operand(M, K, N, r):
+    """Advisor finding of round 5: with rank 256 and a narrow Linear the (hi, lo) pair of the weight-gradient GEMM is the LONG operand (dB: P = out_features
+    128 / 192, Q = rank 256 with the planes of x A^T folded; dA: P = rank 256 folded, Q = in_features 128).  A 256-wide tile of a folded operand would need
+    216 KB of LDS (launch failure); such launches must stay on the 128-wide tile and give the fp32-equivalent gradients."""
+    from finetrainers_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(29)
+    s = 0.5
+    x, w = rnd((M, K), g), rnd((N, K), g, 1 / math.sqrt(K))
+    A = torch.randn(r, K, generator=g) / math.sqrt(K)
+    Bm = torch.randn(N, r, generator=g) * 0.05
+    dy = rnd((M, N), g)
+    xr = x.double().requires_grad_(True)
+    Ar, Br = A.double().requires_grad_(True), Bm.double().requires_grad_(True)
+    y = xr @ w.double().t() + (xr @ Ar.t()) @ Br.t() * s
+    y.backward(dy.double())
+    _, xa = ops.linear_lora_fwd(x.to(dev), w.to(dev), None, A.to(dev), Bm.to(dev), s, variant=8)
+    w_t = ops.transpose_bf16(w.to(dev))
+    dx, ga, gb = ops.linear_lora_bwd(x.to(dev), dy.to(dev), xa, w_t, A.to(dev), Bm.to(dev), s, variant=8)
+    torch.cuda.synchronize()
+    report(f"lora bwd (rank {r}, {K}->{N}) dx", dx, xr.grad.float().to(bf16), 4e-3)
+    report(f"lora bwd (rank {r}, {K}->{N}) dA", ga, Ar.grad.float(), 5e-5)
+    report(f"lora bwd (rank {r}, {K}->{N}) dB", gb, Br.grad.float(), 5e-5)
+
+
 @pytest.mark.parametrize("M,P,Q", [(64, 64, 64), (300, 128, 64), (1000, 64, 2048), (5376, 2048, 64), (333, 192, 2048), (256, 4096, 64), (1024, 64, 2048), (640, 192, 2048), (17776, 1920, 64), (1100, 64, 1920)])
 def test_gemm_tn(M, P, Q):
     from finetrainers_amd import ops
@@ -198,6 +250,10 @@ ATTN_CASES = [
     (1, 1, 1, 1, False),       # a single query and a single key
     (2, 2, 129, 191, True),    # ragged both ways with per-sample masks, keys one short of three tiles
     (1, 3, 64, 4097, False),   # one query tile against many key tiles plus one key
+    # the hand-placed backward pipelines DIRECTLY against fp32 autograd (round-5 review): >= 256 key blocks x heads, no bias, >= 256 keys dispatch to
+    # attn_bwd_dq_pl_kernel + attn_bwd_dkdv_pl_kernel (the cases above mostly stay below that threshold and reach them only through the bit-identity tests)
+    (1, 16, 2688, 2688, False),  # cfg 2 self-attention length, 22 x 16 = 352 key blocks
+    (2, 16, 1000, 1000, False),  # ragged queries and keys (the bounds-checked DMA zero-fills), 8 x 32 = 256 key blocks
 ]
 
 
@@ -232,7 +288,7 @@ def test_attention_fwd_bwd(B, H, Sq, Sk, biased):
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 32, 2688, 128, True), (2, 8, 1000, 128, False), (1, 2, 600, 77, True), (1, 8, 640, 64, False)])
-def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, Sq, Sk, biased, monkeypatch):
+def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, Sq, Sk, biased, sw):
     """LTX cross-attention (128 text keys): the resident-K/V dQ kernel (K / V staged once, Q / dO / O through LDS with the row-contiguous DMA, a walk over
     several 128-row query blocks with counted waits that leave the output stores in flight) does the arithmetic of the general kernel statement for statement --
     dQ, and dK / dV through the delta it publishes, must be the same bits as with FTMI_ATTN_FEWKEYS=0 (the general 64-row dQ kernel).  In an FTMI_EXPERIMENTAL
@@ -240,7 +296,7 @@ def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, S
     from finetrainers_amd import _lib, ops
 
     if hasattr(_lib.load(), "ftmi_gemm_sk_status"):  # (an entry point only the FTMI_EXPERIMENTAL build exports)
-        monkeypatch.setenv("FTMI_ATTN_FEWKEYS_FWD", "1")
+        sw("FTMI_ATTN_FEWKEYS_FWD", "1")
     dev = _dev()
     g = torch.Generator().manual_seed(7)
     q, k, v = rnd((B, H, Sq, 64), g).to(dev), rnd((B, H, Sk, 64), g).to(dev), rnd((B, H, Sk, 64), g).to(dev)
@@ -253,9 +309,9 @@ def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, S
         bias = ((1 - mask.to(bf16)) * -10000.0).float().to(dev)
     res = {}
     for few in ("1", "0"):
-        monkeypatch.setenv("FTMI_ATTN_FEWKEYS", few)
+        sw("FTMI_ATTN_FEWKEYS", few)
         if few == "0":
-            monkeypatch.setenv("FTMI_ATTN_FEWKEYS_FWD", "0")
+            sw("FTMI_ATTN_FEWKEYS_FWD", "0")
         out, lse = ops.attn_fwd(q, k, v, bias)
         dq, dk, dv = ops.attn_bwd(q, k, v, out, lse, dout, bias)
         torch.cuda.synchronize()
@@ -265,7 +321,7 @@ def test_few_keys_resident_kernels_are_bit_identical_to_the_general_ones(B, H, S
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 3, 100, 128), (2, 2, 700, 1024), (1, 2, 129, 192), (1, 1, 2688, 64), (2, 16, 1000, 1000), (1, 4, 300, 1777)])
-def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, monkeypatch):
+def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, sw):
     """Round 5: the hand-placed dQ pipelines (csrc/attention_pl.hip.h: software pipeline over 32 x 32 units, every instruction of the loop an asm statement,
     three-slot K / V ring).  Their `x0` streams do the arithmetic of attn_bwd_dq2_kernel statement for statement -- same MFMA chains, fma / exp2 / sub / mul /
     pack per score -- so dQ (and dK / dV through the delta they publish) must be THE SAME BITS as with FTMI_ATTN_PL=0, for 32 rows x two waves per SIMD
@@ -283,7 +339,7 @@ def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, monkey
     out, lse = ops.attn_fwd(qd, kd, vd, None)
     res = {}
     for pl in ("0", "0x001", "0x101", "0x011", "0x111"):
-        monkeypatch.setenv("FTMI_ATTN_PL", pl)
+        sw("FTMI_ATTN_PL", pl)
         res[pl] = ops.attn_bwd(qd, kd, vd, out, lse, dd, None)
         torch.cuda.synchronize()
     for pl in ("0x001", "0x101"):
@@ -298,7 +354,7 @@ def test_pipelined_dq_kernels_match_the_kernel_they_replace(B, H, Sq, Sk, monkey
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk", [(2, 32, 2688, 2688), (1, 16, 1024, 2048), (1, 16, 1024, 2000), (1, 64, 128, 512), (2, 16, 1000, 1000), (1, 32, 777, 1100)])
-def test_pipelined_dkdv_kernel_is_bit_identical_to_the_kernel_it_replaces(B, H, Sq, Sk, monkeypatch):
+def test_pipelined_dkdv_kernel_is_bit_identical_to_the_kernel_it_replaces(B, H, Sq, Sk, sw):
     """Round 5: attn_bwd_dkdv_pl_kernel (64 keys per wave, one wave per SIMD, the same software pipeline as the dQ kernel; the lse / delta rows arrive by DMA and
     wave 0 turns them into the accumulator inputs -lse / sl and -delta before the tile's hand-over barrier) does the arithmetic of attn_bwd_dkdv_kernel<1, 2>
     statement for statement: dK and dV must be the same bits with FTMI_ATTN_PL bit 1 on and off -- whole and ragged key counts, few and many query tiles.
@@ -313,7 +369,7 @@ def test_pipelined_dkdv_kernel_is_bit_identical_to_the_kernel_it_replaces(B, H, 
     out, lse = ops.attn_fwd(q, k, v, None)
     res = {}
     for pl in ("0x111", "0x1113", "0x2113"):  # same dQ kernel (it publishes delta), dK / dV kernel old | pipelined, rolling order | pipelined, groups of four
-        monkeypatch.setenv("FTMI_ATTN_PL", pl)
+        sw("FTMI_ATTN_PL", pl)
         res[pl] = ops.attn_bwd(q, k, v, out, lse, dout, None)
         torch.cuda.synchronize()
     for pl in ("0x1113", "0x2113"):
@@ -322,7 +378,7 @@ def test_pipelined_dkdv_kernel_is_bit_identical_to_the_kernel_it_replaces(B, H, 
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,biased", [(1, 4, 1024, 1024, False), (2, 3, 1000, 777, False), (1, 2, 2112, 2304, True), (1, 8, 4096, 4096, False), (1, 2, 520, 136, True)])
-def test_fused_head_dim_128_dkdv_kernel_is_bit_identical_to_the_two_passes(B, H, Sq, Sk, biased, monkeypatch):
+def test_fused_head_dim_128_dkdv_kernel_is_bit_identical_to_the_two_passes(B, H, Sq, Sk, biased, sw):
     """Round 5: attn_bwd_dkdv_pl128_kernel (head_dim 128: Wan, HunyuanVideo) computes dK and dV in ONE pass over the queries -- 32 keys per wave, one wave per
     SIMD, single-buffered scores, every instruction placed -- where attn_bwd_dkdv_kernel<2, 0> + <2, 1> make two (4 executed matmuls instead of 5).  Same
     arithmetic statement for statement, the key bias (HunyuanVideo's text mask, -inf entries included) as the addend of the fma that scales the scores: dK and dV
@@ -342,7 +398,7 @@ def test_fused_head_dim_128_dkdv_kernel_is_bit_identical_to_the_two_passes(B, H,
     out, lse = ops.attn_fwd(q, k, v, bias)
     res = {}
     for pl in ("0", "0x8"):
-        monkeypatch.setenv("FTMI_ATTN_PL", pl)
+        sw("FTMI_ATTN_PL", pl)
         res[pl] = ops.attn_bwd(q, k, v, out, lse, dout, bias)
         torch.cuda.synchronize()
     for name, x, y in zip(("dq", "dk", "dv"), res["0x8"], res["0"]):
@@ -351,7 +407,7 @@ def test_fused_head_dim_128_dkdv_kernel_is_bit_identical_to_the_two_passes(B, H,
 
 
 @pytest.mark.parametrize("M", [5376, 5400, 17776, 2700])
-def test_lora_down_projection_64_row_tiles_are_bit_identical(M, monkeypatch):
+def test_lora_down_projection_64_row_tiles_are_bit_identical(M, sw):
     """Round 5: gemm_nt_skinny4_kernel (64-row tiles, one round of workgroups, two-stage 16-KB ring per wave) keeps the K split, the MFMA order per accumulator
     and the cross-wave / cross-plane reduction order of gemm_nt_skinny2_kernel: the fp32-equivalent (hi | lo | hi) down-projection must come out bit for bit
     the same, also with a ragged last row tile (M = 5400, 17776) and where the tile count keeps the launch on the old kernel (M = 2700: both settings equal
@@ -368,7 +424,7 @@ def test_lora_down_projection_64_row_tiles_are_bit_identical(M, monkeypatch):
     Bm = (torch.randn(K, r, generator=g) * 0.05).to(dev)
     got = {}
     for sk4 in ("0", "1"):
-        monkeypatch.setenv("FTMI_SKINNY4", sk4)
+        sw("FTMI_SKINNY4", sk4)
         y, xa = ops.linear_lora_fwd(x, w, None, A, Bm, s, variant=8)
         torch.cuda.synchronize()
         got[sk4] = (y, xa)
@@ -383,8 +439,9 @@ def test_lora_down_projection_64_row_tiles_are_bit_identical(M, monkeypatch):
 @pytest.mark.parametrize("B,H,Sq,Sk,biased", [(2, 3, 300, 257, True), (1, 2, 128, 128, False), (1, 2, 200, 330, False), (1, 4, 2688, 2688, False),
                                               (2, 2, 2688, 512, True)])
 def test_attention_head_dim_128_fwd_bwd(B, H, Sq, Sk, biased):
-    """Head size of Wan / HunyuanVideo: the forward kernel templated on head_dim / 64, the 32-row dQ kernel, and dV / dK in two
-    passes of the key-major loop (the accumulators of both do not fit 256 VGPRs next to the K / V fragments).  Against fp32 softmax attention + autograd."""
+    """Head size of Wan / HunyuanVideo: the forward kernel templated on head_dim / 64, the 32-row dQ kernel, and dK / dV from the fused
+    hand-placed pass attn_bwd_dkdv_pl128_kernel -- every case here has >= 128 queries and keys, which is all that kernel's dispatch asks for (FTMI_ATTN_PL bit 3,
+    on by default), so this IS its direct check against fp32 softmax attention + autograd, with and without a key bias, whole and ragged tiles."""
     from finetrainers_amd import ops
 
     dev = _dev()

@@ -1241,6 +1241,46 @@ def test_bench_two_ranks_rehearsal_emits_the_multi_gpu_schema():
     assert d["value"] > 0 and d["ms_per_step"] > 0
 
 
+def _bench_rehearsal(*argv):
+    import json
+    import subprocess
+
+    env = dict(os.environ, FTMI_BENCH_REHEARSAL_CPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_rehearsal_ltx():
+    """The driver's scaling run is `bench.py --gpus 8` (parallel/ptd.py:462-463 in the reference: replicate() over 8 ranks).  The same harness on 8 gloo ranks
+    on CPU: one line, the communicator reports 8 ranks with 8 distinct rank records, and the 28-block backward is exchanged as 4 buckets per step on every
+    step -- so the first real 8-GPU run cannot trip over anything that only exists at N = 8."""
+    d = _bench_rehearsal("--gpus", "8", "--steps", "2", "--warmup", "1")
+    ex = d["exchange"]
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    assert ex["group_size"] == 8 and ex["world_size"] == 8 and ex["backend"] == "gloo"
+    assert sorted(r["rank"] for r in ex["rank_devices"]) == list(range(8)) and len({r["local_rank"] for r in ex["rank_devices"]}) == 8
+    assert d["buckets_per_step"] == 4.0
+    assert isinstance(d["exposed_comm_ms"], float) and d["value"] > 0
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_rehearsal_wan_parameter_sharding(n):
+    """BASELINE config 4 (`--workload wan`, parallel/ptd.py:466-499: fully_shard per block + root): the real ParameterSharder on n gloo ranks walks the
+    step's gather / reduce-scatter schedule over 1 + 30 flat units and every rank checks its shard of every averaged gradient (bench.py raises otherwise).
+    Per step: the root and 30 blocks are gathered for the forward, 28 blocks again for the backward (the last two are still resident in the two rotating
+    buffers) = 59 all-gathers, and 31 reduce-scatters -- whatever the number of ranks."""
+    d = _bench_rehearsal("--gpus", str(n), "--workload", "wan", "--steps", "2", "--warmup", "1")
+    ex, sh = d["exchange"], d["sharder"]
+    assert d["n_gpus"] == n and d["config"]["parallelism"] == f"fsdp{n}" and ex["group_size"] == n
+    assert sorted(r["rank"] for r in ex["rank_devices"]) == list(range(n))
+    assert sh == {"units": 31, "gathers_per_step": 59.0, "scatters_per_step": 31.0, "world": n}
+
+
 def test_committed_attention_streams_are_what_the_generator_writes(tmp_path, monkeypatch):
     """The hand-placed attention kernels #include statement lists written by tools/gen_attn_pl.py (csrc/attn_pl_*.inc, committed: the build does not run the
     generator).  Regenerate them into a scratch directory and compare byte for byte, so that an edit of the generator without a regenerate -- or a hand edit

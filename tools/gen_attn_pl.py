@@ -23,6 +23,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "..", "finetrainers_amd", "csrc")   # shipped streams
 EXP_OUT = os.path.join(HERE, "experimental")                 # streams of kernels that exist in lab / experimental builds only
 
+
+def _out_dir(name):
+    """Streams that only a -DFTMI_LAB build compiles (the ablations a_*, results wrong on purpose, and the packed-VALU variant v6) are not product source:
+    they live next to the other research code in tools/experimental/."""
+    return EXP_OUT if name.startswith("a_") or name == "v6" else OUT
+
 MFMA = "v_mfma_f32_32x32x16_bf16"
 
 
@@ -213,7 +219,7 @@ def gen_dq(name: str, nq: int, exact: bool, order: str = "roll", weights=None, d
                 vi += 1
         assert vi == len(valu)
         s.emit("}")
-    path = os.path.join(OUT, f"attn_pl_dq{nq}_{name}.inc")
+    path = os.path.join(_out_dir(name), f"attn_pl_dq{nq}_{name}.inc")
     with open(path, "w") as f:
         f.write("\n".join(s.lines) + "\n")
     return path
@@ -345,7 +351,7 @@ def gen_dkv(name: str, order: str = "roll", drop=()):
                 vi += 1
         assert vi == len(valu)
         s.emit("}")
-    path = os.path.join(OUT, f"attn_pl_dkv_{name}.inc")
+    path = os.path.join(_out_dir(name), f"attn_pl_dkv_{name}.inc")
     with open(path, "w") as f:
         f.write("\n".join(s.lines) + "\n")
     return path
