@@ -37,6 +37,14 @@ if os.environ.get("FTMI_EXPERIMENTAL", "0") not in ("", "0"):
     HEADERS += [os.path.join(_EXP, f) for f in sorted(os.listdir(os.path.join(HERE, _EXP))) if f.startswith("attention_experimental_") or f.startswith("attn_pl_fwd_") or f.startswith("attn_pl_dq128_")]
 
 
+# FTMI_TRACE=1: the same sources with the in-kernel phase stamps of the tiled NT GEMMs compiled in (gemm.hip NT_STAMP; tools/nt_trace.py) -- a SEPARATE
+# library (libftmi355_trace.so, objects under build_trace/), never the product one.  Load it with FTMI_LIB=<path>.
+_TRACE = os.environ.get("FTMI_TRACE", "0") not in ("", "0")
+if _TRACE:
+    FLAGS.append("-DFTMI_TRACE")
+    LIB = os.path.join(HERE, "..", "libftmi355_trace.so")
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -67,7 +75,7 @@ def _stamp(target: str, digest: str) -> None:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_trace" if _TRACE else "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
 

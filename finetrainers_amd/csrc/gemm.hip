@@ -22,6 +22,38 @@
 namespace ftmi {
 
 // ------------------------------------------------------------------------------------------------
+// In-kernel phase timeline (FTMI_TRACE=1 builds only: libftmi355_trace.so, driven by tools/nt_trace.py).  Thread 0 of every workgroup of a tiled NT
+// GEMM launch stamps (s_memrealtime: 100 MHz, the same clock on every CU; s_memtime: shader cycles) the boundaries of its phases:
+//   0 kernel entry   1 K loop called (epilogue-input prefetch issued)   2 first stage landed + first fragments read   3 / 4 LoRA mid-round begin / end
+//   5 K loop done (accumulators final)   6 last output store issued   7 = (XCC_ID, HW_ID)
+// so that a launch INSIDE THE STEP can be split into cold start / K loop / epilogue and compared with the stand-alone lab, where the same kernel is
+// 15-25 % faster.  The product library compiles none of this (NT_STAMP expands to nothing).
+// ------------------------------------------------------------------------------------------------
+#ifdef FTMI_TRACE
+#define NT_STAMP(p_, i_)                                                                         \
+    do {                                                                                         \
+        if ((p_).trace && threadIdx.x == 0) {                                                    \
+            unsigned long long* t_ = (p_).trace + (size_t)blockIdx.x * 16 + 2 * (i_);            \
+            t_[0] = wall_clock64();                                                              \
+            t_[1] = __builtin_readcyclecounter();                                                \
+        }                                                                                        \
+    } while (0)
+#define NT_STAMP_HW(p_)                                                                          \
+    do {                                                                                         \
+        if ((p_).trace && threadIdx.x == 0) {                                                    \
+            unsigned xcc_, hw_;                                                                  \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                  \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                    \
+            (p_).trace[(size_t)blockIdx.x * 16 + 14] = xcc_;                                     \
+            (p_).trace[(size_t)blockIdx.x * 16 + 15] = hw_;                                      \
+        }                                                                                        \
+    } while (0)
+#else
+#define NT_STAMP(p_, i_) do { } while (0)
+#define NT_STAMP_HW(p_) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // NT GEMM
 // ------------------------------------------------------------------------------------------------
 
@@ -509,6 +541,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     }
     if (tile_m >= ntm || tile_n >= ntn) return;  // padded grid (whole workgroup exits before any barrier)
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    NT_STAMP(p, 0);
+    NT_STAMP_HW(p);
 
     f32x16 acc[T::TN][T::TM];
 #pragma unroll
@@ -577,6 +611,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
         }
     }
 
+    NT_STAMP(p, 5);
     // ---------------- epilogue ----------------
     // A lane owns output row m and, per accumulator quad rq, 4 consecutive columns; lanes l and l+32 own the two halves of
     // the same 8-column group.  Two quads are exchanged across the half-waves (v_permlane32_swap) so that every lane holds
@@ -717,7 +752,71 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             if (p.out2) flush(scr_in, p.out2, p.ldo2, tm);
         }
     }
+    NT_STAMP(p, 6);
 }
+
+#ifdef FTMI_TRACE
+}  // namespace ftmi
+#include <stdio.h>
+#include <mutex>
+#include <vector>
+namespace ftmi {
+namespace {
+struct NtTraceRec { int bm, bn, mfma16, epi, ext, M, N, K, K2, nwg; size_t off; };
+std::mutex g_tr_mu;
+std::vector<NtTraceRec> g_tr_recs;
+unsigned long long* g_tr_buf = nullptr;  // device
+size_t g_tr_cap = 0, g_tr_used = 0;       // in u64
+bool g_tr_on = false;
+}  // namespace
+// 16 u64 per workgroup of this launch, zeroed; nullptr when tracing is off or the buffer is full
+static unsigned long long* nt_trace_slot(int bm, int bn, int mfma16, const GemmNtArgs& a, int nwg, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_tr_mu);
+    if (!g_tr_on || g_tr_used + (size_t)nwg * 16 > g_tr_cap) return nullptr;
+    unsigned long long* slot = g_tr_buf + g_tr_used;
+    hipMemsetAsync(slot, 0, (size_t)nwg * 16 * 8, st);
+    g_tr_recs.push_back(NtTraceRec{bm, bn, mfma16, a.epi, a.K2 > 0, a.M, a.N, a.K, a.K2, nwg, g_tr_used});
+    g_tr_used += (size_t)nwg * 16;
+    return slot;
+}
+}  // namespace ftmi
+extern "C" int ftmi_trace_enable(long bytes) {  // bytes <= 0: stop tracing (the records stay until the next dump)
+    using namespace ftmi;
+    std::lock_guard<std::mutex> lk(g_tr_mu);
+    if (bytes <= 0) { g_tr_on = false; return 0; }
+    if (!g_tr_buf || g_tr_cap * 8 < (size_t)bytes) {
+        if (g_tr_buf) hipFree(g_tr_buf);
+        if (hipMalloc(&g_tr_buf, (size_t)bytes) != hipSuccess) { g_tr_buf = nullptr; g_tr_cap = 0; return -3; }
+        g_tr_cap = (size_t)bytes / 8;
+    }
+    g_tr_used = 0;
+    g_tr_recs.clear();
+    g_tr_on = true;
+    return 0;
+}
+// writes <path>.meta (one text line per launch: bm bn mfma16 epi ext M N K K2 nwg offset_u64) and <path>.bin (the raw u64 stamps)
+extern "C" int ftmi_trace_dump(const char* path) {
+    using namespace ftmi;
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    std::lock_guard<std::mutex> lk(g_tr_mu);
+    std::vector<unsigned long long> host(g_tr_used);
+    if (g_tr_used && hipMemcpy(host.data(), g_tr_buf, g_tr_used * 8, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    std::string base(path);
+    FILE* f = fopen((base + ".meta").c_str(), "w");
+    if (!f) return -1;
+    for (const NtTraceRec& r : g_tr_recs) fprintf(f, "%d %d %d %d %d %d %d %d %d %d %zu\n", r.bm, r.bn, r.mfma16, r.epi, r.ext, r.M, r.N, r.K, r.K2, r.nwg, r.off);
+    fclose(f);
+    f = fopen((base + ".bin").c_str(), "wb");
+    if (!f) return -1;
+    fwrite(host.data(), 8, host.size(), f);
+    fclose(f);
+    const int n = (int)g_tr_recs.size();
+    g_tr_used = 0;
+    g_tr_recs.clear();
+    return n;
+}
+namespace ftmi {
+#endif  // FTMI_TRACE
 
 template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int MINW, int EPI, bool EXT, int LOOP>
 static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
@@ -755,6 +854,9 @@ static int launch_nt3(const GemmNtArgs& a0, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kl_lds_stages(LOOP) * T::STAGE)) == hipSuccess;
         if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
     }
+#ifdef FTMI_TRACE
+    a.trace = nt_trace_slot(BM, BN, 0, a, 8 * a.map_rm * a.map_rn, st);
+#endif
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, BK, WM, WN, GLDS, MINW, EPI, EXT, LOOP>), dim3(8 * a.map_rm * a.map_rn), dim3(T::NT), smem, st, a);
     return check_launch("gemm_nt");
 }
@@ -813,23 +915,28 @@ FTMI_DEVICE void acc_fence16(f32x4_t (&acc)[8][TMW]) {
     for (int tn = 0; tn < 8; ++tn) {
         if constexpr (TMW == 8)
             asm volatile("s_nop 3" : "+a"(acc[tn][0]), "+a"(acc[tn][1]), "+a"(acc[tn][2]), "+a"(acc[tn][3]), "+a"(acc[tn][4]), "+a"(acc[tn][5]), "+a"(acc[tn][6]), "+a"(acc[tn][7]));
+        else if constexpr (TMW == 7)
+            asm volatile("s_nop 3" : "+a"(acc[tn][0]), "+a"(acc[tn][1]), "+a"(acc[tn][2]), "+a"(acc[tn][3]), "+a"(acc[tn][4]), "+a"(acc[tn][5]), "+a"(acc[tn][6]));
         else
             asm volatile("s_nop 3" : "+a"(acc[tn][0]), "+a"(acc[tn][1]), "+a"(acc[tn][2]), "+a"(acc[tn][3]), "+a"(acc[tn][4]), "+a"(acc[tn][5]));
     }
 }
 
-// TMW = 16-row tiles per wave along the token dimension: 8 -> 256 x 256 tiles, 6 -> 192 x 256 (M = 5376 = 28 x 192: 224 tiles at N = 2048)
+// TMW = 16-row tiles per wave along the token dimension: 8 -> 256 x 256 tiles, 6 -> 192 x 256 (M = 5376 = 28 x 192: 224 tiles at N = 2048),
+// 7 -> 224 x 256 (round 6; M = 5376 = 24 x 224: the 768 tiles of an N = 8192 launch are exactly three rounds of the 256 CUs, where 672 tiles of 256 rows
+// or 896 of 192 both quantise to the time of 768 rows per CU -- 12.5 % more)
 // DBG (tools/gemm_lab.hip only; results wrong on purpose): 1 = no loads inside the loop, 2 = no rendezvous, 3 = no fragment reads
-template <int TMW, bool EXT, int DBG = 0, class MID>
+struct NoStamp { FTMI_DEVICE void operator()(int) const {} };
+template <int TMW, bool EXT, int DBG = 0, class MID, class STAMP = NoStamp>
 FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
-                                 int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid) {
+                                 int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid, STAMP stamp = STAMP()) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int XI = TMW;           // 1-KiB loads per wave and stage: (32 TMW rows x 128 B) / 4 waves of X ...
     constexpr int LPT = XI + 8;       // ... then 8 of W
     constexpr int NMF = 8 * TMW;      // MFMAs per k-slice of 32
     constexpr int NRD = 8 + TMW;      // fragment reads per k-slice
     constexpr int RG = NMF / NRD;     // one read (and one load) every RG-th MFMA: 4 (TMW 8), 3 (TMW 6)
-    static_assert(TMW == 8 || TMW == 6, "192- or 256-row tiles");
+    static_assert(TMW == 8 || TMW == 7 || TMW == 6, "192-, 224- or 256-row tiles");
     static_assert(NMF / RG >= NRD && NMF / RG >= LPT, "gaps");
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -898,13 +1005,16 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
 #pragma unroll
     for (int q = 0; q < NRD; ++q) rd(0, q, 0, 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(2);
 
     uint32_t so = 0;
     for (int s = 0; s < S; ++s) {
         if constexpr (EXT) {
             if (s == nk1) {
                 acc_fence16<TMW>(acc);
+                stamp(3);
                 mid();
+                stamp(4);
             }
         }
 #pragma unroll
@@ -1082,6 +1192,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     }
     if (tile_m >= ntm || tile_n >= ntn) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    NT_STAMP(p, 0);
+    NT_STAMP_HW(p);
 
     f32x4_t acc[8][TMW];
 #pragma unroll
@@ -1145,10 +1257,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
             if (p.x2_grp_n > 0) X2 += (long)(n0 / p.x2_grp_n) * p.x2_grp_stride;
             W2t = p.w2_grp_n > 0 ? p.W2 + (long)(n0 / p.w2_grp_n) * p.w2_grp_stride + (long)(n0 % p.w2_grp_n) * p.ldw2 : p.W2 + (long)n0 * p.ldw2;
         }
+        NT_STAMP(p, 1);
+        auto stamp = [&](int i) { NT_STAMP(p, i); (void)i; };
         if constexpr (RING)
             nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
         else
-            nt_run_k_pipe16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round);
+            nt_run_k_pipe16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp);
+        NT_STAMP(p, 5);
     }
 
     // ---------------- epilogue ----------------
@@ -1163,9 +1278,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4*>(scr_in + scr_off(it * 4 + srow, schunk)) = pre[HAS_IN ? it : 0];
     };
+    constexpr int NBLK = (TMW + 1) / 2;  // 32-row blocks of the wave's rows; with an odd TMW (224-row tiles) the last block holds 16 rows
     auto flush = [&](const char* from, bf16_t* dst, long ld, int blk) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+            if (blk * 32 + it * 4 + 3 >= WROWS) continue;  // (compile time after unrolling: the upper half of an odd tile's last block belongs to nobody)
             const int row = it * 4 + srow;
             const u32x4 w = *reinterpret_cast<const u32x4*>(from + scr_off(row, schunk));
             const int mm = m0 + wm * WROWS + blk * 32 + row;
@@ -1175,13 +1292,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     float bv[8][4];
     if constexpr (!EXT) load_bias(bv);
 #pragma unroll
-    for (int blk = 0; blk < TMW / 2; ++blk) {
+    for (int blk = 0; blk < NBLK; ++blk) {
         if constexpr (HAS_IN) {
             fetch_put();
-            if (blk + 1 < TMW / 2) fetch_regs(blk + 1);
+            if (blk + 1 < NBLK) fetch_regs(blk + 1);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (blk * 2 + h >= TMW) continue;
             const int tm = blk * 2 + h, rl = h * 16 + l15;
             const int m = min(m0 + wm * WROWS + blk * 32 + rl, p.M - 1);  // rows past M compute on row M-1 and are dropped by flush()
             const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
@@ -1251,6 +1369,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
             if (p.out2) flush(scr_in, p.out2, p.ldo2, blk);
         }
     }
+    NT_STAMP(p, 6);
 }
 
 // tile -> XCD rasterisation shared by the tiled kernels: choose the XCD grid gm x gn = 8 by predicted fabric->L2 operand traffic
@@ -1284,6 +1403,9 @@ static int launch_nt16_3(const GemmNtArgs& a0, hipStream_t st) {
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * ((double)a.K + (double)a.K2 / 3.0), st);
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
     if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
+#ifdef FTMI_TRACE
+    a.trace = nt_trace_slot(32 * TMW, 256, 1, a, 8 * a.map_rm * a.map_rn, st);
+#endif
     hipLaunchKernelGGL((gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING>), dim3(8 * a.map_rm * a.map_rn), dim3(256), kSmem, st, a);
     return check_launch("gemm_nt16");
 }
@@ -1724,6 +1846,10 @@ static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
     const int cls = multi_short ? ((a.epi == EPI_DGELU || a.epi == EPI_RESID) ? 2 : 1) : 4;
     if ((use16 & cls) && ok256 && a.M >= 1024 && !one_round_short) {
         variant = c192 < c256 ? 86 : 80;
+        // round 6: 224-row tiles where they save a whole share of a round (N = 8192 at M = 5376: 768 tiles = 3.0 rounds instead of 2.625 -> 3 of 256 rows)
+        static const int use224 = env_int("FTMI_NT224", 1);
+        const long t224 = (long)((a.M + 223) / 224) * (a.N / 256), c224 = ((t224 + 255) / 256) * 224;
+        if (use224 && c224 < std::min(c256, c192)) variant = 87;
     } else if (a.M < 1024 || n192 < few192) {
         variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
     } else {
@@ -1860,6 +1986,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 190: return launch_nt16<8, 1, true>(a, st);
             case 290: return launch_nt16<8, 2, true>(a, st);
             case 86: return launch_nt16<6>(a, st);   // ... 192 x 256 tiles
+            case 87: return launch_nt16<7>(a, st);   // ... 224 x 256 tiles
             case 180: return launch_nt16<8, 1>(a, st);
             case 280: return launch_nt16<8, 2>(a, st);
             case 380: return launch_nt16<8, 3>(a, st);
@@ -1877,6 +2004,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         switch (variant) {
             case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
+            case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
@@ -1927,6 +2055,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
         switch (variant) {
             case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
+            case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
@@ -1940,7 +2069,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
 }
 
 // Which kernel the automatic choice takes for a plain [M, K] x [N, K]^T launch with an optional K-extension and epilogue (no groups): the variant numbers of
-// gemm_nt()'s switch -- 80 / 86 = gemm_nt16_kernel with 256- / 192-row tiles, 42 = 192 x 128 (two workgroups per CU), 47 = 256 x 256 (8 waves), 44 = 128 x 128,
+// gemm_nt()'s switch -- 80 / 86 / 87 = gemm_nt16_kernel with 256- / 192- / 224-row tiles, 42 = 192 x 128 (two workgroups per CU), 47 = 256 x 256 (8 waves), 44 = 128 x 128,
 // 1 = the 128 x 64 kernel for N % 128 != 0, 0 = a launch the tiled kernels do not take (N % 64, K % 64).  No launch, no device: host tests pin the rule.
 int gemm_nt_plan(int M, int N, int K, int K2, int epi) {
     if (M <= 0 || N <= 0 || K % 64 != 0 || K2 % 64 != 0 || N % 64 != 0) return 0;

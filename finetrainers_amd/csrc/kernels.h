@@ -120,6 +120,10 @@ struct GemmNtArgs {
     // tile -> XCD rasterisation (filled by the launcher): the 8 XCDs form a map_gm x map_gn grid, each owning a
     // map_rm x map_rn rectangle of output tiles, so the tiles resident on one XCD share few operand panels in its L2
     int map_gm = 1, map_gn = 8, map_rm = 0, map_rn = 0;
+#ifdef FTMI_TRACE
+    // FTMI_TRACE=1 builds only (libftmi355_trace.so, tools/nt_trace.py): per-workgroup phase stamps, 16 x u64 per workgroup -- see NT_STAMP in gemm.hip
+    unsigned long long* trace = nullptr;
+#endif
 };
 int gemm_nt(const GemmNtArgs& a, hipStream_t st);
 int gemm_nt_plan(int M, int N, int K, int K2, int epi);  // the automatic kernel choice as a pure host function (tests)
