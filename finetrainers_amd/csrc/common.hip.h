@@ -126,28 +126,31 @@ FTMI_DEVICE float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e2x);
 }
 
+// GELU (tanh form) through the logistic function: 0.5 (1 + tanh u) = 1 / (1 + e^{-2u}) =: s, so gelu(x) = x s with u = sqrt(2/pi) (x + 0.044715 x^3).
+// Round 6: the GELU / GELU' GEMM epilogues were 33-36 k cycles per 224 x 256 tile in the step (profiles/r06_nt_trace_*.txt), about half of it VALU issue: this
+// form needs 5 plain + 2 transcendental instructions per element instead of 11 + 2 (the constants -2 log2(e) sqrt(2/pi) {1, 0.044715} are folded into the
+// polynomial).  Same function to ~1e-7 relative; results are rounded to bf16 right after.  Saturates correctly (e -> inf gives s = 0, e -> 0 gives s = 1).
+FTMI_DEVICE float gelu_sigmoid_arg(float x, float x_sq) {  // -2 log2(e) u
+    const float c1 = -2.0f * 1.4426950408889634f * 0.7978845608028654f;
+    const float c3 = c1 * 0.044715f;
+    return x * __builtin_fmaf(c3, x_sq, c1);
+}
 FTMI_DEVICE float gelu_tanh_f(float x) {
-    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
-    const float kKappa = 0.044715f;
-    float inner = kBeta * (x + kKappa * x * x * x);
-    return 0.5f * x * (1.0f + fast_tanh(inner));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gelu_sigmoid_arg(x, x * x)));
+    return x * s;
 }
 
 // torch's gelu_backward(approximate="tanh") in fp32
+// (with s as above: 1 + tanh u = 2 s and 1 - tanh^2 u = 4 s (1 - s), so d gelu / dx = s + 2 x s (1 - s) u' = s (1 + 2 x (1 - s) u'),
+//  u' = sqrt(2/pi) (1 + 3 * 0.044715 x^2): 10 plain + 2 transcendental instructions instead of 21 + 2)
 FTMI_DEVICE float gelu_tanh_grad_f(float x) {
     const float kBeta = 0.7978845608028654f;
     const float kKappa = 0.044715f;
-    float x_sq = x * x;
-    float x_cube = x_sq * x;
-    float inner = kBeta * (x + kKappa * x_cube);
-    float tanh_inner = fast_tanh(inner);
-    float left = 0.5f * x;
-    float right = 1.0f + tanh_inner;
-    float left_derivative = 0.5f * right;
-    float tanh_derivative = 1.0f - tanh_inner * tanh_inner;
-    float inner_derivative = kBeta * (1.0f + 3.0f * kKappa * x_sq);
-    float right_derivative = left * tanh_derivative * inner_derivative;
-    return left_derivative + right_derivative;
+    const float x_sq = x * x;
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gelu_sigmoid_arg(x, x_sq)));
+    const float du = __builtin_fmaf(3.0f * kKappa * kBeta, x_sq, kBeta);
+    const float w = (x * (1.0f - s)) * du;
+    return s * __builtin_fmaf(2.0f, w, 1.0f);
 }
 
 FTMI_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }

@@ -629,14 +629,6 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
     // the row-wise epilogue inputs (residual, GELU pre-activation) come in the same way: whole-line loads into a second scratch block,
     // then every lane picks its 8-byte pieces out of LDS
     char* scr_in = smem + T::NW * (32 * CPW * 16) + wave * (32 * CPW * 16);
-    auto fetch = [&](const bf16_t* src, long ld, int tm) {  // global -> scratch, whole lines
-#pragma unroll
-        for (int it = 0; it < NSI; ++it) {
-            const int row = it * RPS + srow;
-            const int mm = min(m0 + (wm * T::TM + tm) * 32 + row, p.M - 1);
-            *reinterpret_cast<u32x4*>(scr_in + scr_off(row, schunk)) = *reinterpret_cast<const u32x4*>(src + (long)mm * ld + n0 + wn * T::TN * 32 + schunk * 8);
-        }
-    };
     auto flush = [&](const char* from, bf16_t* dst, long ld, int tm) {  // scratch -> global, whole lines
 #pragma unroll
         for (int it = 0; it < NSI; ++it) {
@@ -646,12 +638,29 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void gemm_nt_kernel(GemmNtArgs 
             if (mm < p.M) *reinterpret_cast<u32x4*>(dst + (long)mm * ld + n0 + wn * T::TN * 32 + schunk * 8) = w;
         }
     };
+    // (round 6: every block's row-wise input is requested up front, into registers -- the fragment registers are free -- instead of one synchronous
+    //  global -> LDS copy per block: in the step these rows come from HBM and three round trips in a row were 8.0 us of a 50 us launch)
+    constexpr bool HAS_IN32 = EPI == EPI_RESID || EPI == EPI_DGELU;
+    u32x4 pre_in[HAS_IN32 ? T::TM : 1][HAS_IN32 ? NSI : 1];
+    if constexpr (HAS_IN32) {
+        const bf16_t* src = EPI == EPI_RESID ? p.resid : p.aux;
+        const long ld = EPI == EPI_RESID ? p.ldr : p.ldaux;
+#pragma unroll
+        for (int tm = 0; tm < T::TM; ++tm)
+#pragma unroll
+            for (int it = 0; it < NSI; ++it) {
+                const int mm = min(m0 + (wm * T::TM + tm) * 32 + it * RPS + srow, p.M - 1);
+                pre_in[tm][it] = *reinterpret_cast<const u32x4*>(src + (long)mm * ld + n0 + wn * T::TN * 32 + schunk * 8);
+            }
+    }
 #pragma unroll
     for (int tm = 0; tm < T::TM; ++tm) {
         const int m = min(m0 + (wm * T::TM + tm) * 32 + li, p.M - 1);  // rows past M compute on row M-1 and are dropped by flush()
         const int b = p.rows_per_batch > 0 ? m / p.rows_per_batch : 0;
-        if constexpr (EPI == EPI_RESID) fetch(p.resid, p.ldr, tm);
-        if constexpr (EPI == EPI_DGELU) fetch(p.aux, p.ldaux, tm);
+        if constexpr (HAS_IN32) {
+#pragma unroll
+            for (int it = 0; it < NSI; ++it) *reinterpret_cast<u32x4*>(scr_in + scr_off(it * RPS + srow, schunk)) = pre_in[tm][it];
+        }
 #pragma unroll
         for (int tn = 0; tn < T::TN; ++tn) {
             u32x2 pk[4], pkz[4];
@@ -927,9 +936,15 @@ FTMI_DEVICE void acc_fence16(f32x4_t (&acc)[8][TMW]) {
 // or 896 of 192 both quantise to the time of 768 rows per CU -- 12.5 % more)
 // DBG (tools/gemm_lab.hip only; results wrong on purpose): 1 = no loads inside the loop, 2 = no rendezvous, 3 = no fragment reads
 struct NoStamp { FTMI_DEVICE void operator()(int) const {} };
-template <int TMW, bool EXT, int DBG = 0, class MID, class STAMP = NoStamp>
+// NPRE / pre(): `pre` issues NPRE further vector loads (the epilogue's first row-wise input block) right BEHIND the prologue's direct-to-LDS loads, and the
+// prologue then waits for stage 0 ONLY -- vmcnt(LPT + NPRE): stage 1 and the epilogue input keep flying while the first slice computes, P_0 (vmcnt(0)) collects
+// them.  (Round 6: the in-step timeline showed 2.8-4.4 us between a workgroup's entry and its first MFMA, the longer figure where the row-wise input had been
+// requested first and the whole of stages 0 and 1 was waited for.)
+struct NoPre { FTMI_DEVICE void operator()() const {} };
+template <int TMW, bool EXT, int DBG = 0, int NPRE = 0, class MID, class STAMP = NoStamp, class PRE = NoPre>
 FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
-                                 int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid, STAMP stamp = STAMP()) {
+                                 int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid, STAMP stamp = STAMP(),
+                                 PRE pre = PRE()) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int XI = TMW;           // 1-KiB loads per wave and stage: (32 TMW rows x 128 B) / 4 waves of X ...
     constexpr int LPT = XI + 8;       // ... then 8 of W
@@ -1001,6 +1016,9 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
     for (int i = 0; i < LPT; ++i) dma(i, 0);
 #pragma unroll
     for (int i = 0; i < LPT; ++i) dma(i, 1);
+    pre();
+    // (round 6, measured: waiting for stage 0 only -- vmcnt(LPT + NPRE) -- and letting stage 1 and the epilogue input land behind the first slice is no faster
+    //  in the step: 63.53 / 63.74 ms before, 63.66 / 63.79 after, profiles/r06_instep_ab_prologue_stage0.txt; the first rendezvous then waits instead)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int q = 0; q < NRD; ++q) rd(0, q, 0, 0u);
@@ -1019,15 +1037,15 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
         }
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            if (sl == 1 && DBG != 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
+            if (sl == 1 && DBG != 2 && DBG != 6) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
 #pragma unroll
             for (int m = 0; m < NMF; ++m) {
-                pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
+                if constexpr (DBG != 5) pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
                 if (m % RG == 0 && m / RG < NRD && DBG != 3) {  // fragment reads of the next slice
                     if (sl == 0) rd(1, m / RG, 1, so);
                     else rd(0, m / RG, 0, so ^ 65536u);
                 }
-                if (sl == 1 && m % RG == RG / 2 && m / RG < LPT && DBG != 1) dma(m / RG, s + 2);  // the loads of stage s+2, right after P_s
+                if (sl == 1 && m % RG == RG / 2 && m / RG < LPT && DBG != 1 && DBG != 6) dma(m / RG, s + 2);  // the loads of stage s+2, right after P_s
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -1241,15 +1259,19 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     const int ncol0 = n0 + wn * 128;  // first column of the wave
     const bf16_t* in_src = EPI == EPI_RESID ? p.resid : p.aux;
     const long in_ld = EPI == EPI_RESID ? p.ldr : p.ldaux;
-    u32x4 pre[HAS_IN ? 8 : 1];
+    // (round 6: the phase timeline of the step -- profiles/r06_nt_trace_1_before.txt -- shows the residual epilogue at 16.5 us per workgroup in the step against 8.7 us
+    //  stand-alone and 3.3 us for a plain store: one block ahead is not enough when the row-wise input comes from HBM, every block waited for its own round trip.
+    //  Now block 0 is read before the K loop as before and ALL the other blocks right after it, together -- the fragment registers are free by then -- so one
+    //  round trip is exposed at most, behind the arithmetic of block 0.)
+    constexpr int NBLK_IN = (TMW + 1) / 2;
+    u32x4 pre[HAS_IN ? NBLK_IN : 1][HAS_IN ? 8 : 1];
     auto fetch_regs = [&](int blk) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int mm = min(m0 + wm * WROWS + blk * 32 + it * 4 + srow, p.M - 1);
-            pre[HAS_IN ? it : 0] = *reinterpret_cast<const u32x4*>(in_src + (long)mm * in_ld + ncol0 + schunk * 8);
+            pre[HAS_IN ? blk : 0][HAS_IN ? it : 0] = *reinterpret_cast<const u32x4*>(in_src + (long)mm * in_ld + ncol0 + schunk * 8);
         }
     };
-    if constexpr (HAS_IN) fetch_regs(0);
     {
         const bf16_t* X2 = p.X2;
         const bf16_t* W2t = p.W2;
@@ -1259,10 +1281,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
         }
         NT_STAMP(p, 1);
         auto stamp = [&](int i) { NT_STAMP(p, i); (void)i; };
-        if constexpr (RING)
+        auto pre_in = [&]() { if constexpr (HAS_IN) fetch_regs(0); };
+        if constexpr (RING) {
+            pre_in();
             nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
-        else
-            nt_run_k_pipe16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp);
+        } else
+            nt_run_k_pipe16<TMW, EXT, DBG, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
+                                                         pre_in);
         NT_STAMP(p, 5);
     }
 
@@ -1274,9 +1299,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     char* scr = smem + wave * 8192;
     char* scr_in = smem + 4 * 8192 + wave * 8192;
     auto scr_off = [&](int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); };
-    auto fetch_put = [&]() {  // the block read ahead -> second scratch block
+    auto fetch_put = [&](int blk) {  // a block read ahead -> second scratch block
 #pragma unroll
-        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4*>(scr_in + scr_off(it * 4 + srow, schunk)) = pre[HAS_IN ? it : 0];
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<u32x4*>(scr_in + scr_off(it * 4 + srow, schunk)) = pre[HAS_IN ? blk : 0][HAS_IN ? it : 0];
     };
     constexpr int NBLK = (TMW + 1) / 2;  // 32-row blocks of the wave's rows; with an odd TMW (224-row tiles) the last block holds 16 rows
     auto flush = [&](const char* from, bf16_t* dst, long ld, int blk) {
@@ -1291,12 +1316,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     };
     float bv[8][4];
     if constexpr (!EXT) load_bias(bv);
+    if constexpr (HAS_IN) {
+#pragma unroll
+        for (int blk = 1; blk < NBLK; ++blk) fetch_regs(blk);
+    }
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
-        if constexpr (HAS_IN) {
-            fetch_put();
-            if (blk + 1 < NBLK) fetch_regs(blk + 1);
-        }
+        if constexpr (HAS_IN) fetch_put(blk);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (blk * 2 + h >= TMW) continue;
@@ -1844,7 +1870,9 @@ static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
     const bool one_round_short = std::min(c256, c192) <= 256 && a.K + a.K2 <= 2304;
     const bool multi_short = std::min(c256, c192) > 256 && a.K + a.K2 <= 2304;
     const int cls = multi_short ? ((a.epi == EPI_DGELU || a.epi == EPI_RESID) ? 2 : 1) : 4;
-    if ((use16 & cls) && ok256 && a.M >= 1024 && !one_round_short) {
+    static const int short16 = env_int("FTMI_NT16_SHORT", 0);  // 1: the single-round short-K launches (N = K = 2048) take the 192 x 256 pipeline too.  Round 6, in the step, two boxes:
+    // 66.58 -> 66.23 ms on one (the GEMM class 0.2 ms slower, the attention backward behind it 0.5 ms faster), 63.39 -> 63.72 on the other: no decision, the default stays
+    if ((use16 & cls) && ok256 && a.M >= 1024 && (!one_round_short || short16)) {
         variant = c192 < c256 ? 86 : 80;
         // round 6: 224-row tiles where they save a whole share of a round (N = 8192 at M = 5376: 768 tiles = 3.0 rounds instead of 2.625 -> 3 of 256 rows)
         static const int use224 = env_int("FTMI_NT224", 1);
@@ -1987,6 +2015,12 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 290: return launch_nt16<8, 2, true>(a, st);
             case 86: return launch_nt16<6>(a, st);   // ... 192 x 256 tiles
             case 87: return launch_nt16<7>(a, st);   // ... 224 x 256 tiles
+            case 186: return launch_nt16<6, 1>(a, st);
+            case 286: return launch_nt16<6, 2>(a, st);
+            case 386: return launch_nt16<6, 3>(a, st);
+            case 586: return launch_nt16<6, 5>(a, st);   // no MFMAs (memory side alone)
+            case 686: return launch_nt16<6, 6>(a, st);   // no loads, no rendezvous
+            case 580: return launch_nt16<8, 5>(a, st);
             case 180: return launch_nt16<8, 1>(a, st);
             case 280: return launch_nt16<8, 2>(a, st);
             case 380: return launch_nt16<8, 3>(a, st);

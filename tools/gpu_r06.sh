@@ -27,6 +27,11 @@ case "${1:-}" in
     bash tools/ab_env.sh "$var" "$vals" "$rounds" > gpurun_out/r06_instep_ab_$tag.txt 2>&1
     cat gpurun_out/r06_instep_ab_$tag.txt
     ;;
+  l)  # in-step A/B of two library builds: tag "libA libB" [rounds]
+    tag="${2:-1}"; libs="${3:-finetrainers_amd/libftmi355_prev.so finetrainers_amd/libftmi355.so}"; rounds="${4:-2}"
+    bash tools/ab_lib.sh "$libs" "$rounds" > gpurun_out/r06_lib_ab_$tag.txt 2>&1
+    cat gpurun_out/r06_lib_ab_$tag.txt
+    ;;
   k)  # GPU kernel tests (GEMM + attention files)
     timeout 1500 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -15
     ;;
