@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--width", type=int, default=24, help="latent width  (768 / 32)")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("FTMI_GEMM_VARIANT", "8")))
     ap.add_argument("--gradient-checkpointing", action="store_true",
-                    help="hunyuan only: every block keeps its input and recomputes its forward inside the backward (the reference's --gradient_checkpointing)")
+                    help="ltx / hunyuan: every block keeps its input and recomputes its forward inside the backward (the reference's --gradient_checkpointing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=["full", "quick"], default="full",
                     help="full: SURVEY 8d protocol (1 warm-up + 3 timed steps; cfg 2 on --cpu-baseline-layers blocks in bf16 and fp32, cfg 1 at full depth); "
@@ -63,8 +63,8 @@ def parse():
         a.steps = 30 if a.workload == "ltx" else 10
     if a.workload == "ltx" and a.layers <= 0:
         a.layers = 28
-    if a.gradient_checkpointing and a.workload != "hunyuan":
-        ap.error("--gradient-checkpointing: only the hunyuan workload recomputes (the other three keep their activations: 10 / 63 / 74 GiB of 288)")
+    if a.gradient_checkpointing and a.workload not in ("ltx", "hunyuan"):
+        ap.error("--gradient-checkpointing: the ltx and hunyuan workloads recompute (cogvideox and wan keep their activations: 45 / 74 GiB of 288)")
     return a
 
 
@@ -192,6 +192,8 @@ def _build_ltx(args, par, dev):
     spec = MI355XLTXVideoModelSpecification(transformer_config=tcfg, gemm_variant=args.gemm_variant)
     model = spec.load_diffusion_models(device=dev, random_init_seed=0)["transformer"]  # identical weights on every rank
     model.add_adapter(r=args.rank, lora_alpha=float(args.rank))
+    if args.gradient_checkpointing:
+        model.enable_gradient_checkpointing()
     with torch.no_grad():  # same LoRA init on every rank; B != 0 so every gradient path carries real data
         g = torch.Generator(device=dev).manual_seed(1)
         model.lora_flat.copy_(torch.randn(model.lora_flat.shape, generator=g, device=dev) * 0.01)
@@ -226,7 +228,7 @@ def _build_ltx(args, par, dev):
                         "(BASELINE configs[1])" if full_shape else f"REDUCED: layers={args.layers} tokens={S} rank={args.rank}",
             "model": "LTX-Video DiT 28 blocks, width 2048, 32x64 heads, 1.923B frozen bf16 params + 58.7M fp32 LoRA params",
             "seq_len": S,
-            "activation_checkpointing": False,
+            "activation_checkpointing": bool(args.gradient_checkpointing),
             "optimizer": "AdamW(lr 5e-5, betas (0.9,0.99), wd 1e-4) + clip 1.0, fused",
             "gemm_variant": args.gemm_variant,
         },

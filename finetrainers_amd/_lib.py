@@ -45,6 +45,7 @@ class LtxConfig(Structure):
         ("r", c_int),
         ("lora_scale", c_float), ("eps_norm", c_float), ("eps_qk", c_float),
         ("gemm_variant", c_int),
+        ("checkpoint", c_int),
     ]
 
 

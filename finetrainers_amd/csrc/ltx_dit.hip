@@ -28,6 +28,7 @@ struct WsLayout {
     size_t g_o2, g_q2, g_o, g_qkv, dxa_o2, dxa_q2, dxa_o, dxa_qkv;
     // scratch
     size_t s_n2, s_g, s_ln, s_dh0, s_dh1, s_d1, s_d2, s_d3, s_dqr, s_dkr, s_dbig, s_delta;
+    size_t blk_slot;  // bytes of one block slot (blk_stride is 0 under gradient checkpointing: every block uses the same slot)
 };
 
 struct Bump {
@@ -85,8 +86,11 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.dxa_q2 = b.take(M * 3 * r * e2);
     w.dxa_o = b.take(M * 3 * r * e2);
     w.dxa_qkv = b.take(M * 9 * r * e2);
-    w.blk_stride = b.off;
-    w.blk0 = g.take(w.blk_stride * c.L);
+    // gradient checkpointing (cfg.checkpoint, the reference's --gradient_checkpointing: utils/activation_checkpoint.py:24-49 wraps every block): ONE block slot
+    // instead of L -- a block keeps only its input (the residual stream hs[l], kept for every block either way) and its forward runs again inside its backward
+    w.blk_slot = b.off;
+    w.blk_stride = c.checkpoint ? 0 : b.off;
+    w.blk0 = g.take(w.blk_slot * (c.checkpoint ? 1 : c.L));
     w.s_n2 = g.take(M * D * e2);
     w.s_g = g.take(M * (size_t)c.D_ff * e2);
     w.s_ln = g.take(M * D * e2);
@@ -182,55 +186,14 @@ int ltx_workspace_offset(const ftmi_ltx_config& c, const char* name, int layer, 
     return set_error(FTMI_ERR_INVALID, "workspace_offset: unknown name");
 }
 
-int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* x_t, const bf16_t* text, const float* key_bias,
-                const float* sigma, bf16_t* pred, void* ws, size_t ws_bytes, hipStream_t st) {
-    FTMI_TRY(check_cfg(c));
-    const WsLayout L = make_layout(c);
-    if (ws_bytes < L.total) return set_error(FTMI_ERR_INVALID, "ltx_forward: workspace too small");
-    const int M = c.B * c.S, Mt = c.B * c.T, D = c.D, r = c.r, V = c.gemm_variant;
+// One transformer block of the forward (steps 1-13 of patches/models/ltx_video/patch.py:82-123 + the upstream block): reads hs[l], writes hs[l+1] and the
+// block's activations into its slot.  Called by the forward for every block and -- under gradient checkpointing -- again by the backward right before a
+// block's gradient computation (deterministic kernels: the recomputed activations are the forward's, bit for bit).
+static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const WsLayout& L, void* ws, int l, const float* key_bias, hipStream_t st) {
+    const int M = c.B * c.S, D = c.D, r = c.r, V = c.gemm_variant;
     const long D2 = (long)D * D;
     const float s = c.lora_scale;
-
-    // ---- conditioning (one row per sample: every token of a sample shares its timestep) ----
-    FTMI_TRY(timestep_sinusoid(sigma, W(ws, L.tsin), c.B, st));
-    FTMI_TRY(small_linear(W(ws, L.tsin), P(w.time_l1_w, 0), P(w.time_l1_b, 0), W(ws, L.t1), c.B, D, 256, 0, 0, st));
-    FTMI_TRY(small_linear(W(ws, L.t1), P(w.time_l2_w, 0), P(w.time_l2_b, 0), W(ws, L.emb), c.B, D, D, 1, 0, st));
-    FTMI_TRY(small_linear(W(ws, L.emb), P(w.time_lin_w, 0), P(w.time_lin_b, 0), W(ws, L.temb), c.B, 6 * D, D, 1, 0, st));
-    FTMI_TRY(ada_prep(P(w.tables, 0), W(ws, L.temb), W(ws, L.ada), c.L, c.B, D, st));
-    FTMI_TRY(ada_out_prep(P(w.table_out, 0), W(ws, L.emb), W(ws, L.ada_out), c.B, D, st));
-
-    // ---- proj_in, caption projection ----
-    FTMI_TRY(linear(x_t, c.C_in, M, P(w.proj_in_w, 0), c.C_in, D, c.C_in, P(w.proj_in_b, 0), W(ws, L.hs), D, V, st));
     {
-        GemmNtArgs a;
-        a.X = text; a.ldx = c.D_cap; a.W = P(w.cap_l1_w, 0); a.ldw = c.D_cap; a.M = Mt; a.N = D; a.K = c.D_cap;
-        a.bias = P(w.cap_l1_b, 0); a.out = W(ws, L.cap_h); a.ldo = D; a.epi = EPI_GELU; a.variant = V;
-        FTMI_TRY(gemm_nt(a, st));
-        FTMI_TRY(linear(W(ws, L.cap_h), D, Mt, P(w.cap_l2_w, 0), D, D, D, P(w.cap_l2_b, 0), W(ws, L.e), D, V, st));
-    }
-    const bf16_t* e = W(ws, L.e);
-
-    // ---- cross-attention keys/values of EVERY block (the text stream does not change across blocks) ----
-    {
-        const long ldkv = (long)c.L * 2 * D;
-        GemmNtArgs a;
-        a.X = e; a.ldx = D; a.W = P(w.w_kv2, 0); a.ldw = D; a.M = Mt; a.N = c.L * 2 * D; a.K = D;
-        a.bias = P(w.b_kv2, 0); a.out = W(ws, L.kv2_all); a.ldo = ldkv; a.variant = V;
-        if (r > 0) {
-            GemmNtArgs x;  // XA[:, (l,k|v)] = s * e A_{l,k|v}^T : adapters 5,6 of block l are 2 * 2r consecutive plane rows, blocks 8 * 2r * D apart
-            x.X = e; x.ldx = D; x.W = P(w.lora_a_sp, 5L * 2 * r * D); x.ldw = D; x.w_grp_n = 4 * r; x.w_grp_stride = 16L * r * D;
-            x.M = Mt; x.N = c.L * 4 * r; x.K = D; x.alpha = s; x.split_r = r; x.out = W(ws, L.xa_kv2_all); x.ldo = (long)c.L * 6 * r; x.variant = V;
-            FTMI_TRY(gemm_nt(x, st));
-            a.X2 = W(ws, L.xa_kv2_all); a.ldx2 = (long)c.L * 6 * r; a.x2_grp_n = D; a.x2_grp_stride = 3 * r; a.K2 = 3 * r;
-            a.W2 = P(w.lora_b_ext, 5L * D * 3 * r); a.ldw2 = 3 * r; a.w2_grp_n = 2 * D; a.w2_grp_stride = 8L * D * 3 * r;
-        }
-        FTMI_TRY(gemm_nt(a, st));
-        // k2 = norm_k(k2raw): rows ordered (token, block): row i = t * L + l reads kv2_all + i * 2D, weight row l
-        FTMI_TRY(qknorm_rope_fwd(W(ws, L.kv2_all), 2 * D, P(w.norm_k2, 0), nullptr, nullptr, W(ws, L.k2n_all), D, Mt * c.L, Mt * c.L, D,
-                                 c.eps_qk, st, c.L));
-    }
-
-    for (int l = 0; l < c.L; ++l) {
         char* blk = reinterpret_cast<char*>(ws) + L.blk0 + L.blk_stride * l;
         const bf16_t* h0 = W(ws, L.hs) + (size_t)l * M * D;
         bf16_t* hout = W(ws, L.hs) + (size_t)(l + 1) * M * D;
@@ -333,6 +296,58 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
             FTMI_TRY(gemm_nt(a, st));
         }
     }
+    return 0;
+}
+
+int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* x_t, const bf16_t* text, const float* key_bias,
+                const float* sigma, bf16_t* pred, void* ws, size_t ws_bytes, hipStream_t st) {
+    FTMI_TRY(check_cfg(c));
+    const WsLayout L = make_layout(c);
+    if (ws_bytes < L.total) return set_error(FTMI_ERR_INVALID, "ltx_forward: workspace too small");
+    const int M = c.B * c.S, Mt = c.B * c.T, D = c.D, r = c.r, V = c.gemm_variant;
+    const long D2 = (long)D * D;
+    const float s = c.lora_scale;
+
+    // ---- conditioning (one row per sample: every token of a sample shares its timestep) ----
+    FTMI_TRY(timestep_sinusoid(sigma, W(ws, L.tsin), c.B, st));
+    FTMI_TRY(small_linear(W(ws, L.tsin), P(w.time_l1_w, 0), P(w.time_l1_b, 0), W(ws, L.t1), c.B, D, 256, 0, 0, st));
+    FTMI_TRY(small_linear(W(ws, L.t1), P(w.time_l2_w, 0), P(w.time_l2_b, 0), W(ws, L.emb), c.B, D, D, 1, 0, st));
+    FTMI_TRY(small_linear(W(ws, L.emb), P(w.time_lin_w, 0), P(w.time_lin_b, 0), W(ws, L.temb), c.B, 6 * D, D, 1, 0, st));
+    FTMI_TRY(ada_prep(P(w.tables, 0), W(ws, L.temb), W(ws, L.ada), c.L, c.B, D, st));
+    FTMI_TRY(ada_out_prep(P(w.table_out, 0), W(ws, L.emb), W(ws, L.ada_out), c.B, D, st));
+
+    // ---- proj_in, caption projection ----
+    FTMI_TRY(linear(x_t, c.C_in, M, P(w.proj_in_w, 0), c.C_in, D, c.C_in, P(w.proj_in_b, 0), W(ws, L.hs), D, V, st));
+    {
+        GemmNtArgs a;
+        a.X = text; a.ldx = c.D_cap; a.W = P(w.cap_l1_w, 0); a.ldw = c.D_cap; a.M = Mt; a.N = D; a.K = c.D_cap;
+        a.bias = P(w.cap_l1_b, 0); a.out = W(ws, L.cap_h); a.ldo = D; a.epi = EPI_GELU; a.variant = V;
+        FTMI_TRY(gemm_nt(a, st));
+        FTMI_TRY(linear(W(ws, L.cap_h), D, Mt, P(w.cap_l2_w, 0), D, D, D, P(w.cap_l2_b, 0), W(ws, L.e), D, V, st));
+    }
+    const bf16_t* e = W(ws, L.e);
+
+    // ---- cross-attention keys/values of EVERY block (the text stream does not change across blocks) ----
+    {
+        const long ldkv = (long)c.L * 2 * D;
+        GemmNtArgs a;
+        a.X = e; a.ldx = D; a.W = P(w.w_kv2, 0); a.ldw = D; a.M = Mt; a.N = c.L * 2 * D; a.K = D;
+        a.bias = P(w.b_kv2, 0); a.out = W(ws, L.kv2_all); a.ldo = ldkv; a.variant = V;
+        if (r > 0) {
+            GemmNtArgs x;  // XA[:, (l,k|v)] = s * e A_{l,k|v}^T : adapters 5,6 of block l are 2 * 2r consecutive plane rows, blocks 8 * 2r * D apart
+            x.X = e; x.ldx = D; x.W = P(w.lora_a_sp, 5L * 2 * r * D); x.ldw = D; x.w_grp_n = 4 * r; x.w_grp_stride = 16L * r * D;
+            x.M = Mt; x.N = c.L * 4 * r; x.K = D; x.alpha = s; x.split_r = r; x.out = W(ws, L.xa_kv2_all); x.ldo = (long)c.L * 6 * r; x.variant = V;
+            FTMI_TRY(gemm_nt(x, st));
+            a.X2 = W(ws, L.xa_kv2_all); a.ldx2 = (long)c.L * 6 * r; a.x2_grp_n = D; a.x2_grp_stride = 3 * r; a.K2 = 3 * r;
+            a.W2 = P(w.lora_b_ext, 5L * D * 3 * r); a.ldw2 = 3 * r; a.w2_grp_n = 2 * D; a.w2_grp_stride = 8L * D * 3 * r;
+        }
+        FTMI_TRY(gemm_nt(a, st));
+        // k2 = norm_k(k2raw): rows ordered (token, block): row i = t * L + l reads kv2_all + i * 2D, weight row l
+        FTMI_TRY(qknorm_rope_fwd(W(ws, L.kv2_all), 2 * D, P(w.norm_k2, 0), nullptr, nullptr, W(ws, L.k2n_all), D, Mt * c.L, Mt * c.L, D,
+                                 c.eps_qk, st, c.L));
+    }
+
+    for (int l = 0; l < c.L; ++l) FTMI_TRY(ltx_block_forward(c, w, L, ws, l, key_bias, st));
 
     // ---- tail: LayerNorm + modulate + proj_out ----
     const bf16_t* hL = W(ws, L.hs) + (size_t)c.L * M * D;
@@ -426,6 +441,7 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
         const bf16_t* h1 = W(blk, L.h1);
         const bf16_t* h2 = W(blk, L.h2);
         const bf16_t* dhin = dh[cur];
+        if (c.checkpoint) FTMI_TRY(ltx_block_forward(c, w, L, ws, l, key_bias, st));  // the block's activations again, into the one slot
 
         // ---- feed-forward ----
         // (dO holds bf(dhin * gate_mlp): written by the kernel that produced dhin)
@@ -510,8 +526,9 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
             FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st, ada_prev + 5 * D, ab, dO));
             cur ^= 1;
         }
+        if (c.checkpoint && r > 0) FTMI_TRY(lora_wgrad(l, 1, st));  // the slot is about to be reused: this block's weight gradients now
     }
-    if (r > 0) FTMI_TRY(lora_wgrad(l_lo, l_hi - l_lo, st));
+    if (r > 0 && !c.checkpoint) FTMI_TRY(lora_wgrad(l_lo, l_hi - l_lo, st));
     const int nb = l_hi - l_lo;
 
     // ---- text side of the cross-attention, all blocks at once (nothing upstream of `e` needs a gradient) ----

@@ -103,7 +103,8 @@ class _LTXDiTFunction(torch.autograd.Function):
     def forward(ctx, module, x_t, text, key_bias, tvals, cos, sin, lora_a, lora_b):
         B, S, _ = x_t.shape
         T = text.shape[1]
-        cfg = module._c_config(B, S, T)
+        # gradient checkpointing only where a backward will follow (a forward under no_grad keeps every activation readable for the tests / tools)
+        cfg = module._c_config(B, S, T, checkpoint=module.gradient_checkpointing and any(ctx.needs_input_grad) and module.lora_A is not None)
         weights = module._c_weights(cos, sin)
         lib = _lib.load()
         ws_bytes = lib.ftmi_ltx_workspace_bytes(ctypes.byref(cfg))
@@ -192,7 +193,10 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         if c.inner_dim != 2048 or c.attention_head_dim != 64 or c.patch_size != 1 or c.patch_size_t != 1:
             raise ValueError("the MI355X kernels are built for LTX-Video's production geometry: width 2048 = 32 heads x 64, patch size 1")
         self.gemm_variant = gemm_variant
-        self.gradient_checkpointing = False  # accepted for interface parity; activations fit HBM, nothing is recomputed
+        # --gradient_checkpointing (trainer/sft_trainer/trainer.py:155-157; the reference's own LTX example sets it): off by default -- the activations of
+        # BASELINE config 2 are 10.4 GB of 288 -- but implemented: one block slot instead of 28, every block's forward re-run inside its backward (bit-identical
+        # gradients; see enable_gradient_checkpointing)
+        self.gradient_checkpointing = False
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         D, L, Dff, Dcap, Cin, Cout = c.inner_dim, c.num_layers, c.inner_dim * c.ff_mult, c.caption_channels, c.in_channels, c.out_channels
         shapes = {
@@ -346,6 +350,28 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
             self.load_lora_state_dict({k: v for k, v in sd.items() if "lora_" in k})
 
     # ------------------------------------------------------------------ LoRA (peft-compatible surface)
+    # ---- --gradient_checkpointing (trainer/sft_trainer/trainer.py:155-157 -> utils/activation_checkpoint.py:24-49) ---------------------------------------
+    def apply_activation_checkpointing(self, checkpointing_type: str = "full", n_layer: int = 1) -> "MI355XLTXVideoTransformer3DModel":
+        """The reference wraps every transformer block ("full"; the trainer passes nothing else).  Here: the activation workspace holds one block slot
+        instead of ``num_layers`` (10.4 GB -> 1.3 GB at BASELINE config 2), the forward keeps only the residual stream and ``ftmi_ltx_backward_range`` runs a
+        block's forward kernels again right before its gradient kernels.  Gradients are bit-identical to the un-checkpointed step (deterministic kernels);
+        the price is one extra forward per step (``bench.py --gradient-checkpointing``).  "block_skip" would mix kept and recomputed blocks in one
+        workspace: not offered for this model (HunyuanVideo, where memory matters, has it)."""
+        if checkpointing_type != "full":
+            raise ValueError(f"LTX-Video: checkpointing_type {checkpointing_type!r} is not supported (only 'full', what the reference trainer uses)")
+        self.gradient_checkpointing = True
+        return self
+
+    def enable_gradient_checkpointing(self) -> None:  # diffusers ModelMixin spelling
+        self.apply_activation_checkpointing("full")
+
+    def disable_gradient_checkpointing(self) -> None:
+        self.gradient_checkpointing = False
+
+    @property
+    def is_gradient_checkpointing(self) -> bool:
+        return bool(self.gradient_checkpointing)
+
     def add_adapter(self, adapter_config=None, adapter_name: str = "default", *, r: Optional[int] = None, lora_alpha: Optional[float] = None,
                     target_modules=None) -> None:
         """Mirror of diffusers ``PeftAdapterMixin.add_adapter(LoraConfig(r, lora_alpha, init_lora_weights=True,
@@ -512,12 +538,12 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         self._lora_versions = ver
 
     # ------------------------------------------------------------------ C structs
-    def _c_config(self, B: int, S: int, T: int) -> LtxConfig:
+    def _c_config(self, B: int, S: int, T: int, checkpoint: bool = False) -> LtxConfig:
         c = self.config
         return LtxConfig(B=B, S=S, T=T, D=c.inner_dim, H=c.num_attention_heads, L=c.num_layers, C_in=c.in_channels, C_out=c.out_channels,
                          D_ff=c.inner_dim * c.ff_mult, D_cap=c.caption_channels, r=self.lora_rank_padded,
                          lora_scale=(self.lora_alpha / self.lora_rank) if self.lora_rank else 0.0, eps_norm=c.norm_eps, eps_qk=c.qk_norm_eps,
-                         gemm_variant=self.gemm_variant)
+                         gemm_variant=self.gemm_variant, checkpoint=int(bool(checkpoint)))
 
     def _c_weights(self, cos: torch.Tensor, sin: torch.Tensor) -> LtxWeights:
         w = LtxWeights()

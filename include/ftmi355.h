@@ -184,6 +184,11 @@ typedef struct {
     float eps_norm;   /* 1e-6 (norm1 / norm2 / norm_out) */
     float eps_qk;     /* 1e-5 (norm_q / norm_k) */
     int gemm_variant; /* 8 = automatic tile / K-loop choice (production); other ids select one fixed kernel (A/B partners, gemm.hip) */
+    /* 1 = gradient checkpointing (the reference's --gradient_checkpointing, trainer/sft_trainer/trainer.py:155-157 -> utils/activation_checkpoint.py:24-49,
+     * every block wrapped): the workspace holds ONE block's activations instead of L (ftmi_ltx_workspace_bytes shrinks accordingly), the forward keeps only
+     * the residual stream, and the backward runs every block's forward kernels again right before its gradient kernels.  Gradients are bit-identical to
+     * checkpoint = 0 (deterministic kernels).  Forward and backward of one step must use the same value. */
+    int checkpoint;
 } ftmi_ltx_config;
 
 /* All weights bf16 unless noted.  Per-block tensors are stacked along a leading L dimension.  "*_t" are

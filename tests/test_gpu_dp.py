@@ -53,6 +53,43 @@ def _grads(spec, model, cond, latd, sig, noise, hook=None, bucket=0):
     return model.lora_A.grad.detach().clone(), model.lora_B.grad.detach().clone()
 
 
+def test_gradient_checkpointing_gives_the_same_gradients_from_one_block_slot():
+    """--gradient_checkpointing (the reference's own LTX example sets it: examples/training/sft/ltx_video/crush_smol_lora/train.sh:79; trainer.py:155-157 ->
+    utils/activation_checkpoint.py:24-49 wraps every block).  Here the workspace then holds ONE block slot instead of L, the forward keeps the residual stream
+    only and the backward re-runs a block's forward kernels before its gradient kernels: the prediction is bit-identical, the LoRA gradients agree to the
+    fp32-atomics order of the weight-gradient GEMMs (batched over the range without checkpointing, per block with it), the workspace is the smaller one, and
+    the block-range backward (bucketed exchange) works on top of it."""
+    import ctypes
+
+    from finetrainers_amd import _lib
+
+    spec, model, cond, latd, sig, noise = _model_and_batch(5, 2, 2, 4, 6)
+    ga0, gb0 = _grads(spec, model, cond, latd, sig, noise)
+    pred0, _, _ = spec.forward(transformer=model, condition_model_conditions=dict(cond), latent_model_conditions=dict(latd), sigmas=sig, noise=noise,
+                               force_first_frame_branch=False)
+    full = _lib.load().ftmi_ltx_workspace_bytes(ctypes.byref(model._c_config(2, 2688, 128)))  # (sized at config 2's token count; this model has 5 blocks)
+    one = _lib.load().ftmi_ltx_workspace_bytes(ctypes.byref(model._c_config(2, 2688, 128, checkpoint=True)))
+    print(f"[ckpt] workspace at 2 x 2688 tokens, 5 blocks: {full / 2**30:.2f} GiB kept, {one / 2**30:.2f} GiB checkpointed")
+    assert one < 0.5 * full, (one, full)  # 5 block slots -> 1 (the rest: the residual stream, the all-block text-side arrays, the backward's scratch)
+    model.enable_gradient_checkpointing()
+    assert model.is_gradient_checkpointing
+    ga1, gb1 = _grads(spec, model, cond, latd, sig, noise)
+    pred1, _, _ = spec.forward(transformer=model, condition_model_conditions=dict(cond), latent_model_conditions=dict(latd), sigmas=sig, noise=noise,
+                               force_first_frame_branch=False)
+    assert torch.equal(pred0, pred1)
+    for name, a, b in (("A", ga0, ga1), ("B", gb0, gb1)):
+        rel = ((a - b).norm() / a.norm()).item()
+        print(f"[ckpt] lora_{name}.grad checkpointed vs kept: rel {rel:.2e}")
+        assert rel < 2e-6, (name, rel)
+    seen = []
+    ga2, gb2 = _grads(spec, model, cond, latd, sig, noise, hook=lambda lo, hi, a, b: seen.append((lo, hi)), bucket=2)
+    assert seen == [(3, 5), (1, 3), (0, 1)]
+    assert ((ga2 - ga1).norm() / ga1.norm()).item() < 2e-6 and ((gb2 - gb1).norm() / gb1.norm()).item() < 2e-6
+    model.disable_gradient_checkpointing()
+    with pytest.raises(ValueError):
+        model.apply_activation_checkpointing("block_skip", 2)
+
+
 def test_block_range_backward_matches_single_call():
     """ftmi_ltx_backward_range over [3,5) [1,3) [0,1) == one ftmi_ltx_backward over [0,5): same gradients (fp32 atomics order aside),
     ranges reported in backward order, each exactly once."""
