@@ -941,10 +941,13 @@ struct NoStamp { FTMI_DEVICE void operator()(int) const {} };
 // them.  (Round 6: the in-step timeline showed 2.8-4.4 us between a workgroup's entry and its first MFMA, the longer figure where the row-wise input had been
 // requested first and the whole of stages 0 and 1 was waited for.)
 struct NoPre { FTMI_DEVICE void operator()() const {} };
-template <int TMW, bool EXT, int DBG = 0, int NPRE = 0, class MID, class STAMP = NoStamp, class PRE = NoPre>
+// early(): called once at the top of stage 1 -- the kernel requests the REST of its row-wise epilogue input there (round 6: in the step the residual rows come
+// from HBM and an epilogue that asks for them after the K loop sits through the round trip with every other workgroup of the single round: 16 us against 3.7 us
+// for a plain store; requested here they arrive under the K loop -- the rendezvous of stage 2 waits for them once, vmcnt retires in order).
+template <int TMW, bool EXT, int DBG = 0, int NPRE = 0, class MID, class STAMP = NoStamp, class PRE = NoPre, class EARLY = NoPre>
 FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
                                  int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid, STAMP stamp = STAMP(),
-                                 PRE pre = PRE()) {
+                                 PRE pre = PRE(), EARLY early = EARLY()) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int XI = TMW;           // 1-KiB loads per wave and stage: (32 TMW rows x 128 B) / 4 waves of X ...
     constexpr int LPT = XI + 8;       // ... then 8 of W
@@ -1027,6 +1030,7 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
 
     uint32_t so = 0;
     for (int s = 0; s < S; ++s) {
+        if (s == 1) early();
         if constexpr (EXT) {
             if (s == nk1) {
                 acc_fence16<TMW>(acc);
@@ -1264,6 +1268,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     //  Now block 0 is read before the K loop as before and ALL the other blocks right after it, together -- the fragment registers are free by then -- so one
     //  round trip is exposed at most, behind the arithmetic of block 0.)
     constexpr int NBLK_IN = (TMW + 1) / 2;
+    // 192-row tiles have 188 registers to spare: their whole row-wise input (96 registers) is requested at stage 1 of the K loop and arrives under it
+    constexpr bool EARLY_IN = HAS_IN && !RING && TMW <= 6 && !EXT;  // (with a K-extension the second set of load offsets takes the spare registers)
     u32x4 pre[HAS_IN ? NBLK_IN : 1][HAS_IN ? 8 : 1];
     auto fetch_regs = [&](int blk) {
 #pragma unroll
@@ -1282,12 +1288,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
         NT_STAMP(p, 1);
         auto stamp = [&](int i) { NT_STAMP(p, i); (void)i; };
         auto pre_in = [&]() { if constexpr (HAS_IN) fetch_regs(0); };
+        auto early_in = [&]() {
+            if constexpr (EARLY_IN) {
+#pragma unroll
+                for (int blk = 1; blk < NBLK_IN; ++blk) fetch_regs(blk);
+            }
+        };
         if constexpr (RING) {
             pre_in();
             nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
         } else
             nt_run_k_pipe16<TMW, EXT, DBG, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
-                                                         pre_in);
+                                                         pre_in, early_in);
         NT_STAMP(p, 5);
     }
 
@@ -1316,7 +1328,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     };
     float bv[8][4];
     if constexpr (!EXT) load_bias(bv);
-    if constexpr (HAS_IN) {
+    if constexpr (HAS_IN && !EARLY_IN) {  // (taller tiles have no registers to hold the whole input across the K loop: requested here, all blocks together)
 #pragma unroll
         for (int blk = 1; blk < NBLK; ++blk) fetch_regs(blk);
     }
