@@ -79,8 +79,8 @@ def _profile_json(name: str):
 NT_CLASS = "gemm_nt (all NT GEMM kernels)"
 
 
-PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json", "r02_a_pmc_traffic.json", "r01_pmc_traffic.json")
-PMC_MFMA_FILES = ("r05_pmc_mfma.json", "r04_pmc_mfma.json", "r03_pmc_mfma.json", "r02_b_pmc_mfma.json", "r02_a_pmc_mfma.json")
+PMC_TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_b_pmc_traffic.json", "r02_a_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_MFMA_FILES = ("r06_pmc_mfma.json", "r05_pmc_mfma.json", "r04_pmc_mfma.json", "r03_pmc_mfma.json", "r02_b_pmc_mfma.json", "r02_a_pmc_mfma.json")
 PEAK_HBM_GBPS = 8000.0  # HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s is what a streaming copy reaches)
 
 
@@ -451,6 +451,8 @@ def main():
             # `exchange.group_size` / `rank_devices` / `distinct_devices` come from the communicator itself: N ranks on N distinct GPUs is checkable from the line
             "exchange": par.describe() if (par.world_size > 1 or cpu_reh) else None,
             "exposed_comm_ms": exposed,
+            # True: the buckets went through the library's own RCCL communicator (ftmi_allreduce_bucket / _wait, FTMI_NATIVE_ALLREDUCE=1); False: torch.distributed's
+            "exchange_in_library": (bool(getattr(reducer, "native", False)) if reducer is not None else None),
             "buckets_per_step": (reducer.buckets_issued / max(1, args.steps + args.warmup)) if reducer is not None else None,
             # parameter sharding (Wan): the sharder's own counters -- all-gathers (bf16 units) and reduce-scatters (fp32 gradients) issued per step
             **({"sharder": {"units": len(ctx["sharder"].units), "gathers_per_step": ctx["sharder"].gathers_issued / max(1, args.steps + args.warmup),
@@ -541,7 +543,7 @@ def main():
             res["hbm_gbps"] = hb
             res["hbm_frac_of_peak_committed_bytes"] = hb.get("step_frac_of_peak")  # (bytes from the committed counter pass / this run's time)
         # the same command with --no-prof on the round's evidence box: the instrument's cost as a stated quantity
-        for rr in ("r05", "r04"):
+        for rr in ("r06", "r05", "r04"):
             pr, pd = _profile_json(f"{rr}_bench_noprof.json"), _profile_json(f"{rr}_bench_default.json")
             if prof and pr and pd and args.workload == "ltx":
                 res["ms_per_step_without_event_profiler"] = {

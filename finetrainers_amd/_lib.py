@@ -148,6 +148,13 @@ _SIGS = {
     "ftmi_linear_lora_bwd": (c_int, [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 10 + [c_int, c_void_p]),
     "ftmi_gemm_nt_plan": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "ftmi_reload_switches": (c_int, []),
+    "ftmi_allreduce_unique_id": (c_int, [c_void_p]),
+    "ftmi_allreduce_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "ftmi_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "ftmi_allreduce_wait": (c_int, [c_void_p, c_void_p]),
+    "ftmi_allreduce_buckets_issued": (c_long, [c_void_p]),
+    "ftmi_allreduce_version": (c_int, []),
+    "ftmi_allreduce_destroy": (c_int, [c_void_p]),
     "ftmi_gemm_nt": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_float, c_void_p, c_long, c_int,
                              c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int, c_void_p]),
     "ftmi_gemm_tn": (c_int, [c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_float, c_void_p]),

@@ -9,7 +9,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "cast.hip", "cogvideox.hip", "ltx_dit.hip", "cog_dit.hip", "hy_dit.hip", "wan.hip", "wan_dit.hip", "api.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "cast.hip", "cogvideox.hip", "ltx_dit.hip", "cog_dit.hip", "hy_dit.hip", "wan.hip", "wan_dit.hip", "collective.hip", "api.hip"]
 HEADERS = ["common.hip.h", "kernels.h", os.path.join("..", "..", "include", "ftmi355.h"), "attention_pl.hip.h"]
 HEADERS += sorted(f for f in os.listdir(HERE) if f.startswith("attn_pl_") and f.endswith(".inc"))  # generated statement lists (tools/gen_attn_pl.py)
 LIB = os.path.join(HERE, "..", "libftmi355.so")
@@ -97,7 +97,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     lib = os.path.abspath(LIB)
     dg = _digest(objs)
     if force or _stale(lib, dg):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -183,7 +183,40 @@ class DataParallelBackend:
             else:
                 dist.barrier()
 
+    # ---- the in-library exchange (include/ftmi355.h: ftmi_allreduce_*) ----------------------------------------------------------------------------
+    def native_exchange(self):
+        """COLLECTIVE, opt-in (``FTMI_NATIVE_ALLREDUCE=1`` or an explicit call on every rank): a communicator owned by libftmi355.so -- RCCL looked up
+        with dlopen, its own communication stream, event hand-over with the compute stream -- instead of ``torch.distributed``'s.  Rank 0 obtains the
+        rendezvous id, the process group carries its 128 bytes to the other ranks.  Returns the ``ftmi_exchange`` handle (cached); GradBucketReducer
+        then issues its buckets through ``ftmi_allreduce_bucket`` / ``ftmi_allreduce_wait``.  GPU ranks only."""
+        if getattr(self, "_native_ex", None) is not None:
+            return self._native_ex
+        if self.device.type != "cuda":
+            raise RuntimeError("the in-library exchange runs on RCCL: GPU ranks only (CPU ranks use gloo through torch.distributed)")
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.load()
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.ftmi_allreduce_unique_id(ident), "ftmi_allreduce_unique_id")
+        if self.world_size > 1:
+            box = [ident.raw if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        ex = ctypes.c_void_p()
+        torch.cuda.set_device(self.device)
+        _lib.check(lib.ftmi_allreduce_init(ident, self.rank, self.world_size, ctypes.byref(ex)), "ftmi_allreduce_init")
+        self._native_ex = ex
+        return ex
+
     def destroy(self) -> None:
+        if getattr(self, "_native_ex", None) is not None:
+            from . import _lib
+
+            _lib.load().ftmi_allreduce_destroy(self._native_ex)
+            self._native_ex = None
         if self._owns_pg and dist.is_initialized():
             dist.destroy_process_group()
             self._owns_pg = False
@@ -198,10 +231,17 @@ class GradBucketReducer:
     ~3 ms against a ~60 ms step, and only the last bucket (the first blocks) is exposed.  Every rank issues the same collectives in
     the same order by construction (the bucket schedule is a function of L alone)."""
 
-    def __init__(self, backend: DataParallelBackend):
+    def __init__(self, backend: DataParallelBackend, native: Optional[bool] = None):
         self.backend = backend
         self._pending = []
         self.buckets_issued = 0
+        # native: the buckets go through the library's own communicator (ftmi_allreduce_bucket / _wait: RCCL on the library's communication stream) instead
+        # of torch.distributed's process group.  Default: FTMI_NATIVE_ALLREDUCE=1 on GPU ranks of an RCCL job; every rank must make the same choice.
+        if native is None:
+            native = os.environ.get("FTMI_NATIVE_ALLREDUCE", "0") not in ("", "0") and backend.active and backend.backend == "nccl" and backend.device.type == "cuda"
+        self.native = bool(native)
+        self._ex = backend.native_exchange() if self.native else None
+        self._native_pending = False
         # measure_exposed: bracket finish() with events on the compute stream -- the time the step actually WAITS for the exchange (what the
         # backward did not cover); read with exposed_ms().  Off by default (two event records per step).
         self.measure_exposed = False
@@ -209,6 +249,17 @@ class GradBucketReducer:
 
     def bucket_ready(self, l_lo: int, l_hi: int, grad_a: torch.Tensor, grad_b: torch.Tensor) -> None:
         """Hook signature of ``MI355XLTXVideoTransformer3DModel._grad_bucket_hook``."""
+        if self.native:
+            from . import _lib
+
+            lib, st = _lib.load(), torch.cuda.current_stream().cuda_stream
+            for t in (grad_a, grad_b):
+                if not (t.is_contiguous() and t.dtype == torch.float32):
+                    raise ValueError("the in-library exchange reduces contiguous fp32 slices of the flat gradient buffer in place")
+                _lib.check(lib.ftmi_allreduce_bucket(self._ex, t.data_ptr(), t.numel(), 1, st), "ftmi_allreduce_bucket")
+            self._native_pending = True
+            self.buckets_issued += 1
+            return
         for t in (grad_a, grad_b):
             h = self.backend.all_reduce_mean_async(t)
             if h is not None:
@@ -218,6 +269,19 @@ class GradBucketReducer:
     def finish(self) -> None:
         """Make the current stream wait for every outstanding bucket (device-side wait on RCCL; gloo: host wait + divide)."""
         ev = t_host = None
+        if self.native:
+            if self._native_pending:
+                from . import _lib
+
+                if self.measure_exposed:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                _lib.check(_lib.load().ftmi_allreduce_wait(self._ex, torch.cuda.current_stream().cuda_stream), "ftmi_allreduce_wait")
+                self._native_pending = False
+                if ev is not None:
+                    ev[1].record()
+                    self._exposed.append(ev)
+            return
         if self.measure_exposed and self._pending:
             if torch.cuda.is_available() and self.backend.device.type == "cuda":
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -250,6 +314,11 @@ class GradBucketReducer:
     def abort(self) -> None:
         """A backward that raised after issuing some buckets: wait for the collectives already in flight (every rank issued them, so they
         complete) and forget them -- the next step must neither wait on stale handles nor re-divide their tensors."""
+        if self.native and self._native_pending:
+            from . import _lib
+
+            _lib.load().ftmi_allreduce_wait(self._ex, torch.cuda.current_stream().cuda_stream)  # the buckets already on the wire complete (every rank issued them)
+            self._native_pending = False
         for work, _ in self._pending:
             try:
                 work.wait()

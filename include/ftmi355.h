@@ -117,6 +117,28 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
  * (8 waves), 44 = 128 x 128, 2 = a skinny kernel (N <= 256, plain store, no extension, M >= 512: the LDS-ring kernel when K % 256 == 0, else the direct-gather one), 1 = the 128 x 64 kernel of N % 128 != 0,
  * 0 = not a tiled launch (N % 64 or K % 64).  Host tests pin the choice to DESIGN.md. */
 int ftmi_gemm_nt_plan(int M, int N, int K, int K2, int epilogue);
+/* ---- in-library gradient exchange (replaces what replicate(model, bucket_cap_mb=100) does for the LoRA gradients: finetrainers/parallel/ptd.py:462-463) ----
+ * One process per GPU; the collectives are RCCL's (xGMI inside a node), looked up with dlopen at the first call -- libftmi355.so has no link-time dependency on
+ * librccl and these entry points return FTMI_ERR_UNSUPPORTED where it cannot be found.
+ *   ftmi_allreduce_unique_id : rank 0 obtains the 128-byte rendezvous id; the host side hands the bytes to every rank (any channel: torch.distributed's store,
+ *                              a file, MPI).
+ *   ftmi_allreduce_init      : COLLECTIVE -- every rank calls it with the same id, its rank and the world size; creates the communicator, the library's
+ *                              communication stream and its events.  The handle is owned by the caller (ftmi_allreduce_destroy).
+ *   ftmi_allreduce_bucket    : all-reduce (mean if average != 0, else sum) of count fp32 values IN PLACE, ordered after everything already queued on
+ *                              compute_stream (event hand-over, no host sync), running on the communication stream: the caller goes on queueing the
+ *                              backward of the earlier blocks while the bucket is on the wire.  Every rank must issue the same buckets in the same order
+ *                              (the block-range schedule of ftmi_ltx_backward_range is a function of L alone).
+ *   ftmi_allreduce_wait      : compute_stream waits (device side) for every bucket issued so far -- call before clip + AdamW.
+ * Thread-safe per handle (a mutex); no thread-local state. */
+typedef void* ftmi_exchange;
+int ftmi_allreduce_unique_id(void* id128);
+int ftmi_allreduce_init(const void* id128, int rank, int world, ftmi_exchange* out);
+int ftmi_allreduce_bucket(ftmi_exchange ex, float* grad, size_t count, int average, ftmi_stream compute_stream);
+int ftmi_allreduce_wait(ftmi_exchange ex, ftmi_stream compute_stream);
+long ftmi_allreduce_buckets_issued(ftmi_exchange ex);
+int ftmi_allreduce_version(void); /* RCCL's version code, -1 if librccl could not be loaded */
+int ftmi_allreduce_destroy(ftmi_exchange ex);
+
 /* The FTMI_* tuning switches that select between bit-identical kernels (FTMI_ATTN_PL, FTMI_ATTN_FEWKEYS, FTMI_SKINNY4) are read from the environment ONCE,
  * at the first launch that consults them -- the launch path never calls getenv.  A process that wants to compare kernels (the bit-identity tests do) changes
  * the environment and calls this: every switch consulted so far is re-read.  Returns how many were. */

@@ -145,6 +145,51 @@ def test_dp_step_on_rccl_single_rank():
         par.destroy()
 
 
+def test_dp_step_through_the_in_library_exchange_single_rank(monkeypatch):
+    """SURVEY 8(b)'s ftmi_allreduce_{init,bucket,wait}: the gradient exchange of replicate(bucket_cap_mb=100) (parallel/ptd.py:462-463) INSIDE the library --
+    its own RCCL communicator (dlopen), its own communication stream, event hand-over with the compute stream.  On this one-GPU box a one-rank communicator:
+    the step that sends its buckets through ftmi_allreduce_bucket / _wait must reproduce the step that sends them through torch.distributed, bucket count
+    included, and a mean all-reduce over one rank must leave the data untouched."""
+    import ctypes
+
+    from finetrainers_amd import _lib
+    from finetrainers_amd.parallel import DataParallelBackend, GradBucketReducer
+    from finetrainers_amd.trainer import MI355XSFTStep
+
+    lib = _lib.load()
+    assert lib.ftmi_allreduce_version() > 20000, "librccl not found by dlopen"
+    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 90))
+    par = DataParallelBackend(backend="nccl", exercise_collectives=True)
+    try:
+        ex = par.native_exchange()
+        assert par.native_exchange() is ex  # cached
+        buf = torch.randn(1 << 20, device=_dev())
+        ref = buf.clone()
+        st = torch.cuda.current_stream().cuda_stream
+        assert lib.ftmi_allreduce_bucket(ex, buf.data_ptr(), buf.numel(), 1, st) == 0
+        assert lib.ftmi_allreduce_wait(ex, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(buf, ref) and lib.ftmi_allreduce_buckets_issued(ex) == 1
+        outs = []
+        for native in (False, True):
+            spec, model, cond, latd, sig, noise = _model_and_batch(4, 2, 2, 4, 4)
+            step = MI355XSFTStep(model, spec, lr=5e-5, betas=(0.9, 0.99), parallel=par, grad_bucket_blocks=1)
+            if native:
+                step.reducer = GradBucketReducer(par, native=True)
+                step.reducer.measure_exposed = True
+            for _ in range(2):
+                o = step.step(cond, latd, sigmas=sig, noise=noise, force_first_frame_branch=False)
+            torch.cuda.synchronize()
+            outs.append((o["loss"].item(), o["grad_norm"].item(), model.lora_flat.detach().clone(), step.reducer))
+        (l0, g0, p0, r0), (l1, g1, p1, r1) = outs
+        print(f"[dp-native] loss {l0:.6f} / {l1:.6f} grad_norm {g0:.6e} / {g1:.6e} buckets {r0.buckets_issued} / {r1.buckets_issued} exposed {r1.exposed_ms()}")
+        assert r1.native and r0.buckets_issued == r1.buckets_issued == 8
+        assert lib.ftmi_allreduce_buckets_issued(ex) == 1 + 2 * 8  # two slices (A, B) per bucket
+        assert abs(l0 - l1) <= 2e-4 * abs(l0) and abs(g0 - g1) <= 1e-3 * g0 and ((p0 - p1).norm() / p0.norm()).item() < 1e-4
+    finally:
+        par.destroy()
+
+
 def test_gradient_accumulation_matches_oracle():
     """gradient_accumulation_steps = 2 (trainer.py:476-503): two micro-batches, each loss / 2, gradients summed, ONE clip + AdamW.  The
     accumulated LoRA gradient is compared with the oracle's; the scale must be 1/gas, not 1/gas^2."""

@@ -35,5 +35,25 @@ case "${1:-}" in
   k)  # GPU kernel tests (GEMM + attention files)
     timeout 1500 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu 2>&1 | tail -15
     ;;
+  e)  # evidence run: default bench line (with the CPU baseline), the driver's command, --no-prof, the checkpointing line, rocprofv3 stats + counter passes
+    python bench.py > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err; echo "bench default rc=$?"; cut -c1-400 gpurun_out/r06_bench_default.json
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r06_bench_driver_cmd.json 2>/dev/null; cut -c1-300 gpurun_out/r06_bench_driver_cmd.json
+    python bench.py --no-prof --no-cpu-baseline > gpurun_out/r06_bench_noprof.json 2>/dev/null; cut -c1-300 gpurun_out/r06_bench_noprof.json
+    python bench.py --no-cpu-baseline --gradient-checkpointing > gpurun_out/r06_bench_ckpt.json 2>/dev/null; cut -c1-300 gpurun_out/r06_bench_ckpt.json
+    bash tools/gpu_profile_r06.sh r06 2>&1 | tail -70
+    ;;
+  w)  # the other three workloads, plain bench lines (after the last kernel change)
+    for wl in cogvideox wan hunyuan; do
+      python bench.py --workload $wl --no-cpu-baseline > gpurun_out/r06_${wl}_bench.json 2> gpurun_out/r06_${wl}_bench.err; echo "$wl rc=$?"; cut -c1-330 gpurun_out/r06_${wl}_bench.json
+    done
+    ;;
+  u)  # the whole -m gpu suite, one process per file
+    shift
+    bash tools/gpu_suite.sh r06 "$@" 2>&1 | tail -60
+    ;;
+  p)  # full-depth parity at config 2 (28 blocks, batch 2) against the bf16 oracle and the committed fp32 sample
+    timeout 2400 python -m pytest tests/test_gpu_dit.py -m gpu -q -s -k "full_depth" -p no:cacheprovider > gpurun_out/r06_parity_full_cfg2.log 2>&1
+    echo "rc=$?"; grep -E "parity|passed|failed|rel|floor" gpurun_out/r06_parity_full_cfg2.log | tail -20
+    ;;
   *) echo "unknown visit"; exit 1;;
 esac
