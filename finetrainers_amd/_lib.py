@@ -148,6 +148,7 @@ _SIGS = {
     "ftmi_linear_lora_bwd": (c_int, [c_int, c_int, c_int, c_int, c_float] + [c_void_p] * 10 + [c_int, c_void_p]),
     "ftmi_gemm_nt_plan": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "ftmi_reload_switches": (c_int, []),
+    "ftmi_fused_status": (c_int, []),
     "ftmi_allreduce_unique_id": (c_int, [c_void_p]),
     "ftmi_allreduce_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "ftmi_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),

@@ -228,6 +228,8 @@ int ftmi_gemm_nt_plan(int M, int N, int K, int K2, int epilogue) { return gemm_n
 
 int ftmi_reload_switches(void) { return EnvSwitch::reload_all(); }
 
+int ftmi_fused_status(void) { return gemm_fused_status(); }
+
 int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, long ldw, const void* bias, float alpha, void* out, long ldo,
                  int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch, const void* aux, long ld_side, int variant,
                  ftmi_stream stream) {

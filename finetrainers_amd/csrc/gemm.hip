@@ -944,10 +944,12 @@ struct NoPre { FTMI_DEVICE void operator()() const {} };
 // early(): called once at the top of stage 1 -- the kernel requests the REST of its row-wise epilogue input there (round 6: in the step the residual rows come
 // from HBM and an epilogue that asks for them after the K loop sits through the round trip with every other workgroup of the single round: 16 us against 3.7 us
 // for a plain store; requested here they arrive under the K loop -- the rendezvous of stage 2 waits for them once, vmcnt retires in order).
-template <int TMW, bool EXT, int DBG = 0, int NPRE = 0, class MID, class STAMP = NoStamp, class PRE = NoPre, class EARLY = NoPre>
+// ext_rdy(): called once at the top of stage nk1 - 2, i.e. before the first load of the K-extension's operands is issued (P_{nk1-2}): the fused launch waits
+// there for the down-projection workgroups that write X2.
+template <int TMW, bool EXT, int DBG = 0, int NPRE = 0, class MID, class STAMP = NoStamp, class PRE = NoPre, class EARLY = NoPre, class EXTRDY = NoPre>
 FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
                                  int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid, STAMP stamp = STAMP(),
-                                 PRE pre = PRE(), EARLY early = EARLY()) {
+                                 PRE pre = PRE(), EARLY early = EARLY(), EXTRDY ext_rdy = EXTRDY()) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int XI = TMW;           // 1-KiB loads per wave and stage: (32 TMW rows x 128 B) / 4 waves of X ...
     constexpr int LPT = XI + 8;       // ... then 8 of W
@@ -1032,6 +1034,7 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
     for (int s = 0; s < S; ++s) {
         if (s == 1) early();
         if constexpr (EXT) {
+            if (s == nk1 - 2) ext_rdy();
             if (s == nk1) {
                 acc_fence16<TMW>(acc);
                 stamp(3);
@@ -1191,9 +1194,11 @@ FTMI_DEVICE void nt_run_k_ring16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
 #endif
 }
 
-template <int TMW, int EPI, bool EXT, int DBG, bool RING = false>
-__global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// (the kernel's body as a function of the block index: gemm_nt16_kernel calls it with blockIdx.x, the fused launch of round 6 -- gemm_nt16_fused_kernel -- with the
+//  index behind its leading down-projection workgroups and an `ext_ready` hook that waits for their output two stages before the K-extension)
+struct NoHook { FTMI_DEVICE void operator()(int, int) const {} };
+template <int TMW, int EPI, bool EXT, int DBG, bool RING, class READY = NoHook>
+FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY ext_ready = READY()) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -1203,7 +1208,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     const int ntm = (p.M + BM - 1) / BM, ntn = p.N / BN;
     int tile_m, tile_n;
     {  // tile -> XCD rasterisation: as gemm_nt_kernel
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = bid & 7, idx = bid >> 3;
         const int xm = xcd / p.map_gn, xn = xcd % p.map_gn;
         constexpr int GN = 4;
         const int gsz = p.map_rm * GN;
@@ -1299,7 +1304,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
             nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
         } else
             nt_run_k_pipe16<TMW, EXT, DBG, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
-                                                         pre_in, early_in);
+                                                         pre_in, early_in, [&]() { ext_ready(m0, BM); });
         NT_STAMP(p, 5);
     }
 
@@ -1408,6 +1413,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
         }
     }
     NT_STAMP(p, 6);
+}
+
+template <int TMW, int EPI, bool EXT, int DBG, bool RING = false>
+__global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    nt16_body<TMW, EPI, EXT, DBG, RING>(p, smem, blockIdx.x);
 }
 
 // tile -> XCD rasterisation shared by the tiled kernels: choose the XCD grid gm x gn = 8 by predicted fabric->L2 operand traffic
@@ -1715,15 +1726,15 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny2_kernel(GemmNtArgs p) {
 // the same reduction order across the four waves and the two planes: outputs are bit-identical to gemm_nt_skinny2_kernel.
 #ifdef FTMI_LAB
 __device__ unsigned long long g_sk4_trace[512 * 8];  // tools/skinny_lab.hip: s_memtime at the phase boundaries of wave 0 of every workgroup
-#define SK4_T(i) do { if (tid == 0) g_sk4_trace[((blockIdx.y * gridDim.x + blockIdx.x) & 511) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define SK4_T(i) do { if (tid == 0) g_sk4_trace[((bid_y * gridDim.x + bid_x) & 511) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SK4_T(i) do { } while (0)
 #endif
 // (measured and dropped, profiles/r05_skinny_lab_*.txt: 32-deep stages in a four-stage ring -- half-line loads, 15.8 vs 13.1 us; every workgroup starting its K
 // quarters at a different chunk so that the 4-KB-strided rows do not all hit one 128-byte column at a time -- 13.1 vs 13.5 us for the loss of bit identity)
-template <int BK>  // K depth of a ring stage: 64 (two 16-KB stages per wave) or 32 (four 8-KB stages: three loads in flight behind the one being multiplied)
-__global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <int BK, bool WT = false>  // K depth of a ring stage: 64 (two 16-KB stages per wave) or 32 (four 8-KB stages: three loads in flight behind the one being multiplied)
+                                    // WT: the outputs leave as write-through stores (sc0 sc1: straight to the memory side) -- what a consumer on another XCD inside the SAME launch needs
+FTMI_DEVICE int skinny4_body(const GemmNtArgs& p, char* smem, const int bid_x, const int bid_y) {  // returns the 64-row tile it computed (-1: a surplus block)
     constexpr int CH = 256 * BK, NST = 128 / BK;  // bytes per chunk (64 x BK X + 64 x BK W), stages per wave (32 KB per wave either way)
     constexpr int RPI = 1024 / (BK * 2), NPI = 64 / RPI;  // rows per 1-KiB wave load, loads per operand and chunk
     constexpr int CPR = BK / 8, KK = BK / 16;
@@ -1734,11 +1745,11 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
     // 64-row slice of X (x = j * 8 + xcd) meet in one L2 -- the numbering of gemm_nt_skinny2_kernel without its integer divisions (the prologue of
     // this kernel was 5 000 cycles of its 25 000: four dependent scalar-load round trips and eight divisions in front of the first load)
     const int ntm = (p.M + 63) / 64;
-    const int grp = blockIdx.y, lid = blockIdx.x;
+    const int grp = bid_y, lid = bid_x;
     const int in_grp = min(8, ntm - grp * 8);  // row tiles of this group (the last group may be short: its surplus blocks leave)
     int mt, nt_;
     if (in_grp == 8) { mt = lid & 7; nt_ = lid >> 3; }
-    else { mt = lid % in_grp; nt_ = lid / in_grp; if (nt_ >= p.N / 64) return; }
+    else { mt = lid % in_grp; nt_ = lid / in_grp; if (nt_ >= p.N / 64) return -1; }
     const int m0 = (grp * 8 + mt) * 64, n0 = nt_ * 64;
     const bf16_t* X = p.X;
     if (p.xk_grp_n > 0) X += (long)(n0 / p.xk_grp_n) * p.xk_grp_stride;
@@ -1846,12 +1857,97 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
         lo[0] = pack2bf(t[0] - h0, t[1] - h1); lo[1] = pack2bf(t[2] - h2, t[3] - h3);
         const int o = n0 / 2 + wave * 8 + 4 * g;  // output index (32 per tile)
         bf16_t* dst = p.out + (long)m * p.ldo + (long)(o / p.split_r) * 3 * p.split_r + o % p.split_r;
-        *reinterpret_cast<u32x2*>(dst) = hi;
-        *reinterpret_cast<u32x2*>(dst + p.split_r) = lo;
-        *reinterpret_cast<u32x2*>(dst + 2 * p.split_r) = hi;
+        if constexpr (WT) {
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(hi) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst + p.split_r), "v"(lo) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst + 2 * p.split_r), "v"(hi) : "memory");
+        } else {
+            *reinterpret_cast<u32x2*>(dst) = hi;
+            *reinterpret_cast<u32x2*>(dst + p.split_r) = lo;
+            *reinterpret_cast<u32x2*>(dst + 2 * p.split_r) = hi;
+        }
     }
     SK4_T(5);
+    return grp * 8 + mt;
 }
+template <int BK>
+__global__ __launch_bounds__(256) void gemm_nt_skinny4_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    skinny4_body<BK>(p, smem, blockIdx.x, blockIdx.y);
+}
+
+// (FTMI_EXPERIMENTAL builds only.  Measured in the step, profiles/r06_instep_ab_fused_down_*.txt: as written -- release fence in the producers, acquire in the consumers
+//  -- 62.7 -> 64.6 ms; the acquire alone costs 5-10 us per launch (four waves invalidating the L1 in the middle of the K loop), the producers' buffer_wbl2 the rest;
+//  with write-through output stores and NO fences 61.79 -> 61.68 ms: the 4.1 ms of down-projection launches disappear and the GEMM class grows by 3.2 ms, because
+//  the 168 leading workgroups delay 136 of the 224 tiles of a single-round launch by their own 8-10 us and the N = K = 2048 launches have to leave the
+//  two-per-CU kernel.  Break-even at best, with a hand-off that leans on first-touch semantics: not shipped.)
+#ifdef FTMI_EXPERIMENTAL
+// ------------------------------------------------------------------------------------------------
+// Round 6: the LoRA down-projection INSIDE the launch of the GEMM that consumes it.  x A^T (or dY B) used to be its own launch of 168 workgroups in front of
+// every projection GEMM -- 226 launches of 13-22 us per step at 7 % matrix-pipe duty, each a serial position on the stream -- although the GEMM needs its
+// result only for the last three of its 35 K stages.  Here the first n_down workgroups of the grid run the down-projection (skinny4_body, unchanged: the bits
+// are those of the separate launch), every other workgroup a GEMM tile (nt16_body, unchanged); a tile starts its base K loop at once and, two stages before its
+// K-extension, checks the counters of the 64-row tiles its rows span (`flags[mt]` counts the down-projection workgroups of row tile mt that have published).
+//   publish:  every wave drains its stores (s_waitcnt vmcnt(0) inside __syncthreads), thread 0 releases at agent scope (buffer_wbl2: the XCD's L2 writes the
+//             rows back), waits for that, and adds 1 to the counter with a relaxed agent-scope atomic          (MI355X_MICROARCH.md: "producer: plain stores ->
+//   consume:  every wave polls the counters it needs with relaxed agent-scope loads (bounded: a poll that       __syncthreads -> lane-0 fence(release, agent) ->
+//             gives up raises g_fused_timeout and goes on), then one agent-scope acquire (L1 invalidate)          s_waitcnt vmcnt(0) -> relaxed agent flag";
+//             before it issues the extension's loads                                                            consumer: poll -> ONE acquire -> plain loads")
+// No deadlock by construction: the down-projection workgroups wait for nobody, have the LOWEST block indices (dispatched first; they need no CU a GEMM tile
+// could be holding for ever: a tile that polls gives up after ~40 ms), and the counters only grow (`expect` = the running total the host passes in).
+// ------------------------------------------------------------------------------------------------
+__device__ int g_fused_timeout;  // set when a poll gave up (read back by ftmi_fused_status: tests assert 0)
+
+struct FusedArgs {
+    GemmNtArgs g;   // the GEMM (K-extension operand X2 = the down-projection's output)
+    GemmNtArgs d;   // the down-projection (split hi/lo mode)
+    int* flags;     // one counter per 64-row tile of d
+    int expect;     // counter value that means "this launch's down-projection of the row tile is complete"
+    int no_acquire; // (lab: FTMI_FUSE_DOWN bit 2 -- skip the consumer's agent-scope acquire, to price it)
+    int n_down;     // leading workgroups that run the down-projection: d's grid, 8 * ntn wide, linearised (a multiple of 8: block b still runs on XCD b % 8)
+    int down_gx;    // d's grid width (8 * ntn)
+};
+
+template <int TMW, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt16_fused_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < a.n_down) {
+        if (a.no_acquire & 2) {  // (lab: write-through outputs, no L2 write-back)
+            const int mt = skinny4_body<64, true>(a.d, smem, blockIdx.x % a.down_gx, blockIdx.x / a.down_gx);
+            if (mt < 0) return;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged by the memory side
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(a.flags + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const int mt = skinny4_body<64>(a.d, smem, blockIdx.x % a.down_gx, blockIdx.x / a.down_gx);
+        if (mt < 0) return;  // (surplus block of a short last group: it left before any barrier)
+        __syncthreads();     // every wave's stores have been issued and acknowledged (the barrier's s_waitcnt vmcnt(0))
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md "Compiler hazard")
+            __hip_atomic_fetch_add(a.flags + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    auto ext_ready = [&](int m0, int bm) {
+        const int mt0 = m0 >> 6, mt1 = min(m0 + bm - 1, a.g.M - 1) >> 6;
+        for (int mt = mt0; mt <= mt1; ++mt) {
+            int spins = 0;
+            while (__hip_atomic_load(a.flags + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.expect) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 17)) {  // ~40 ms: never in a healthy launch (the down-projection finishes ~10 us into it)
+                    g_fused_timeout = 1;
+                    break;
+                }
+            }
+        }
+        if (!(a.no_acquire & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    };
+    nt16_body<TMW, EPI, true, 0, false>(a.g, smem, (int)blockIdx.x - a.n_down, ext_ready);
+}
+
+#endif  // FTMI_EXPERIMENTAL (fused down-projection + GEMM launch)
 
 // The automatic kernel choice for a "wide" NT launch (N % 128 == 0), as a pure function of the launch description (and of the FTMI_NT* switches, read once):
 // what gemm_nt() runs for variant 8 / 61, and what ftmi_gemm_nt_plan reports to the host tests.  Returns a variant number of the switch in gemm_nt().
@@ -2113,6 +2209,80 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
 #endif
     return launch_nt<128, 64, 64, 2, 2, true, 1, KL_GEN2_BUF>(a, st);  // N % 128 != 0
 }
+
+#ifdef FTMI_EXPERIMENTAL
+// ---- fused launch: LoRA down-projection + the GEMM that consumes it (gemm_nt16_fused_kernel) ----
+template <int TMW, int EPI>
+static int launch_fused(const GemmNtArgs& g0, const GemmNtArgs& d, int* flags, int expect, hipStream_t st, int no_acquire) {
+    FusedArgs a;
+    a.no_acquire = no_acquire;
+    a.g = g0;
+    a.d = d;
+    choose_xcd_map(a.g, 32 * TMW, 256);
+    a.flags = flags;
+    a.expect = expect;
+    a.down_gx = 8 * (d.N / 64);
+    a.n_down = a.down_gx * (((d.M + 63) / 64 + 7) / 8);
+    constexpr int kSmem = 131072;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_fused_kernel<TMW, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
+    if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
+    ProfScope prof(PROF_GEMM_NT, 2.0 * a.g.M * a.g.N * ((double)a.g.K + (double)a.g.K2 / 3.0), st);  // (the down-projection's 2 M N K rides along: < 3 % of the launch)
+    hipLaunchKernelGGL((gemm_nt16_fused_kernel<TMW, EPI>), dim3(a.n_down + 8 * a.g.map_rm * a.g.map_rn), dim3(256), kSmem, st, a);
+    return check_launch("gemm_nt16_fused");
+}
+
+int gemm_nt_lora_fused(const GemmNtArgs& g, const GemmNtArgs& d, int* flags, int* expect, hipStream_t st) {
+    static const EnvSwitch fuse_sw("FTMI_FUSE_DOWN", 0);  // (read once; ftmi_reload_switches() lets one process compare the fused launch with the two launches)
+    const int fuse = fuse_sw.get();
+    auto g256 = [](int x) { return x <= 0 || x % 256 == 0; };
+    const bool ok256 = g.N % 256 == 0 && g256(g.w_grp_n) && g256(g.w2_grp_n) && g256(g.xk_grp_n) && g256(g.x2_grp_n);
+    bool ok = fuse && flags && expect && g.K2 > 0 && g.K >= 128 && g.K % 64 == 0 && g.K2 % 64 == 0 && ok256 && g.M >= 1024 && g.variant == 8 && g.M == d.M &&
+              // the down-projection must be one the 64-row kernel takes (gemm_nt(): split mode, >= 84 tiles) and must write exactly the GEMM's X2
+              d.split_r > 0 && d.K2 == 0 && d.epi == EPI_STORE && !d.bias && d.K >= 256 && d.K % 64 == 0 && d.split_r % 64 == 0 && (d.N / 2) % d.split_r == 0 &&
+              (long)((d.M + 63) / 64) * (d.N / 64) >= 84 && (d.w_grp_n % 64) == 0 && (d.xk_grp_n % 64) == 0 && (const void*)d.out == (const void*)g.X2;
+    int variant = 0;
+    if (ok) {
+        variant = nt_auto_variant(g, ok256);
+        // FTMI_FUSE_DOWN bit 0: the launches that run the 16 x 16 x 32 pipeline anyway (several rounds of tiles or a long K); bit 1: also the single-round short-K
+        // launches (N = K = 2048), which move from the 192 x 128 two-per-CU kernel to 192 x 256 tiles for it
+        if (variant == 42 && (fuse & 2)) variant = 86;
+        else if (!(fuse & 1)) variant = 0;
+        ok = variant == 80 || variant == 86 || variant == 87;
+    }
+    if (!ok) {
+        const int rc = gemm_nt(d, st);
+        return rc ? rc : gemm_nt(g, st);
+    }
+    *expect += d.N / 64;  // every row tile's counter grows by the number of its column tiles
+    const int ex = *expect;
+#define FTMI_FUSED_EPI(TMW_)                                                                       \
+    switch (g.epi) {                                                                               \
+        case EPI_STORE: return launch_fused<TMW_, EPI_STORE>(g, d, flags, ex, st, (fuse >> 2) & 3);                 \
+        case EPI_RESID: return launch_fused<TMW_, EPI_RESID>(g, d, flags, ex, st, (fuse >> 2) & 3);                 \
+        default: break;                                                                            \
+    }
+    if (variant == 80) { FTMI_FUSED_EPI(8) }
+    else if (variant == 86) { FTMI_FUSED_EPI(6) }
+    else { FTMI_FUSED_EPI(7) }
+#undef FTMI_FUSED_EPI
+    *expect -= d.N / 64;  // (an epilogue the fused kernel is not built for: GELU / GELU' never carry a K-extension in these models)
+    const int rc = gemm_nt(d, st);
+    return rc ? rc : gemm_nt(g, st);
+}
+
+int gemm_fused_status() {  // 1 if a poll of a fused launch ever gave up (tests)
+    int v = 0;
+    hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fused_timeout), sizeof(int));
+    return v;
+}
+
+#else
+int gemm_nt_lora_fused(const GemmNtArgs& g, const GemmNtArgs& d, int*, int*, hipStream_t st) {  // the product library: the two launches
+    const int rc = gemm_nt(d, st);
+    return rc ? rc : gemm_nt(g, st);
+}
+int gemm_fused_status() { return 0; }
+#endif
 
 // Which kernel the automatic choice takes for a plain [M, K] x [N, K]^T launch with an optional K-extension and epilogue (no groups): the variant numbers of
 // gemm_nt()'s switch -- 80 / 86 / 87 = gemm_nt16_kernel with 256- / 192- / 224-row tiles, 42 = 192 x 128 (two workgroups per CU), 47 = 256 x 256 (8 waves), 44 = 128 x 128,

@@ -126,6 +126,12 @@ struct GemmNtArgs {
 #endif
 };
 int gemm_nt(const GemmNtArgs& a, hipStream_t st);
+// Round 6: a LoRA down-projection (split hi/lo mode: `down.out` is `gemm.X2`) and the GEMM that consumes it through its K-extension as ONE launch -- the
+// down-projection's workgroups lead the grid, the GEMM's tiles wait (once, two K stages before their extension) on per-row-tile counters in `flags`
+// (ints, >= ceil(M / 64) of them, owned by the caller: zero them once, then pass `*expect` back in for every following launch on the same flags).
+// Falls back to the two launches (down-projection, then GEMM) wherever the pair is not eligible or FTMI_FUSE_DOWN=0.
+int gemm_nt_lora_fused(const GemmNtArgs& gemm, const GemmNtArgs& down, int* flags, int* expect, hipStream_t st);
+int gemm_fused_status();  // 1 if a poll inside a fused launch ever gave up (synchronises the device: tests only)
 int gemm_nt_plan(int M, int N, int K, int K2, int epi);  // the automatic kernel choice as a pure host function (tests)
 // persistent 256 x 256 stream-K form of the same contract (gemm_sk.hip); gemm_nt() routes eligible launches to it
 bool gemm_nt_sk_eligible(const GemmNtArgs& a);

@@ -28,6 +28,7 @@ struct WsLayout {
     size_t g_o2, g_q2, g_o, g_qkv, dxa_o2, dxa_q2, dxa_o, dxa_qkv;
     // scratch
     size_t s_n2, s_g, s_ln, s_dh0, s_dh1, s_d1, s_d2, s_d3, s_dqr, s_dkr, s_dbig, s_delta;
+    size_t sk_flags;
     size_t blk_slot;  // bytes of one block slot (blk_stride is 0 under gradient checkpointing: every block uses the same slot)
 };
 
@@ -60,6 +61,7 @@ WsLayout make_layout(const ftmi_ltx_config& c) {
     w.g_kv2_all = g.take(Mt * (size_t)c.L * 2 * D * e2);
     w.g_k2n_all = g.take(Mt * (size_t)c.L * D * e2);
     w.dxa_kv2_all = g.take(Mt * (size_t)c.L * 2 * 3 * r * e2);
+    w.sk_flags = g.take(4096);  // 1024 int counters: one per 64-row tile of the token dimension (fused down-projection + GEMM launches, gemm_nt_lora_fused)
     Bump b;
     w.n1 = b.take(M * D * e2);
     w.qkv = b.take(M * 3 * D * e2);
@@ -139,13 +141,22 @@ int linear(const bf16_t* X, long ldx, int M, const bf16_t* Wt, long ldw, int N, 
 // LoRA down-projection at fp32-equivalent precision: t = alpha * X . Wf^T for an fp32 matrix Wf given as interleaved bf16 (hi, lo) row
 // planes `w_sp` ([2 nout, K], kernels.h LoraSplitArgs), t kept as bf16 planes (hi | lo | hi) per group of r outputs: out [M, 3 nout].
 // The reference runs this product in fp32 (trainer/sft_trainer/trainer.py:132-136 casts the LoRA parameters to fp32).
-int lora_down(const bf16_t* X, long ldx, int M, const bf16_t* w_sp, int nout, int K, int r, float alpha, bf16_t* out, hipStream_t st,
-              int xk_grp_stride = 0) {
+GemmNtArgs lora_down_args(const bf16_t* X, long ldx, int M, const bf16_t* w_sp, int nout, int K, int r, float alpha, bf16_t* out, int xk_grp_stride = 0) {
     GemmNtArgs a;
     a.X = X; a.ldx = ldx; a.W = w_sp; a.ldw = K; a.M = M; a.N = 2 * nout; a.K = K; a.alpha = alpha;
     if (xk_grp_stride > 0) { a.xk_grp_n = 2 * r; a.xk_grp_stride = xk_grp_stride; }  // output group g (one adapter) reads X columns g * stride ...
     a.split_r = r; a.out = out; a.ldo = 3L * nout; a.variant = 8;
-    return gemm_nt(a, st);
+    return a;
+}
+int lora_down(const bf16_t* X, long ldx, int M, const bf16_t* w_sp, int nout, int K, int r, float alpha, bf16_t* out, hipStream_t st,
+              int xk_grp_stride = 0) {
+    return gemm_nt(lora_down_args(X, ldx, M, w_sp, nout, K, r, alpha, out, xk_grp_stride), st);
+}
+// A projection with its LoRA: the down-projection `dn` (writes a.X2) and the GEMM `a` (K-extension over X2) -- one fused launch where the pair is eligible
+// (gemm_nt_lora_fused: FTMI_FUSE_DOWN=1), else the two launches of rounds 1-5.  `fx` = the workspace's row-tile counters + the running expectation of this call.
+struct FuseCtx { int* flags; int expect; };
+int lora_gemm(const GemmNtArgs& a, const GemmNtArgs& dn, FuseCtx& fx, hipStream_t st) {
+    return gemm_nt_lora_fused(a, dn, (a.M + 63) / 64 <= 1024 ? fx.flags : nullptr, &fx.expect, st);
 }
 
 AttnArgs attn_args(const ftmi_ltx_config& c, int Sq, int Sk) {
@@ -189,7 +200,7 @@ int ltx_workspace_offset(const ftmi_ltx_config& c, const char* name, int layer, 
 // One transformer block of the forward (steps 1-13 of patches/models/ltx_video/patch.py:82-123 + the upstream block): reads hs[l], writes hs[l+1] and the
 // block's activations into its slot.  Called by the forward for every block and -- under gradient checkpointing -- again by the backward right before a
 // block's gradient computation (deterministic kernels: the recomputed activations are the forward's, bit for bit).
-static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const WsLayout& L, void* ws, int l, const float* key_bias, hipStream_t st) {
+static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const WsLayout& L, void* ws, int l, const float* key_bias, hipStream_t st, FuseCtx& fx) {
     const int M = c.B * c.S, D = c.D, r = c.r, V = c.gemm_variant;
     const long D2 = (long)D * D;
     const float s = c.lora_scale;
@@ -211,11 +222,12 @@ static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w
             GemmNtArgs a;
             a.X = n1; a.ldx = D; a.W = P(w.w_qkv, (size_t)l * 3 * D2); a.ldw = D; a.M = M; a.N = 3 * D; a.K = D;
             a.bias = P(w.b_qkv, (size_t)l * 3 * D); a.out = qkv; a.ldo = 3 * D; a.variant = V;
+            GemmNtArgs dn;
             if (r > 0) {
-                FTMI_TRY(lora_down(n1, D, M, la, 3 * r, D, r, s, W(blk, L.xa_qkv), st));
+                dn = lora_down_args(n1, D, M, la, 3 * r, D, r, s, W(blk, L.xa_qkv));
                 a.X2 = W(blk, L.xa_qkv); a.ldx2 = 9 * r; a.W2 = lb; a.ldw2 = 3 * r; a.K2 = 3 * r; a.x2_grp_n = D; a.x2_grp_stride = 3 * r;
             }
-            FTMI_TRY(gemm_nt(a, st));
+            FTMI_TRY(r > 0 ? lora_gemm(a, dn, fx, st) : gemm_nt(a, st));
         }
         // 4. QK RMSNorm across heads + RoPE
         FTMI_TRY(qknorm_rope_fwd(qkv, 3 * D, P(w.norm_q, (size_t)l * D), w.rope_cos, w.rope_sin, W(blk, L.qrot), D, M, c.S, D, c.eps_qk, st, 1,
@@ -236,11 +248,12 @@ static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w
             a.X = W(blk, L.o1); a.ldx = D; a.W = P(w.w_o, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D;
             a.bias = P(w.b_o, (size_t)l * D); a.out = W(blk, L.h1); a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = h0; a.ldr = D; a.gate = ada + 2 * D; a.gate_bstride = ab; a.rows_per_batch = c.S;
+            GemmNtArgs dn;
             if (r > 0) {
-                FTMI_TRY(lora_down(W(blk, L.o1), D, M, la + 3L * 2 * r * D, r, D, r, s, W(blk, L.xa_o), st));
+                dn = lora_down_args(W(blk, L.o1), D, M, la + 3L * 2 * r * D, r, D, r, s, W(blk, L.xa_o));
                 a.X2 = W(blk, L.xa_o); a.ldx2 = 3 * r; a.W2 = lb + 3L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r;
             }
-            FTMI_TRY(gemm_nt(a, st));
+            FTMI_TRY(r > 0 ? lora_gemm(a, dn, fx, st) : gemm_nt(a, st));
         }
         const bf16_t* h1 = W(blk, L.h1);
         // 7. cross-attention query (no pre-norm, no RoPE)
@@ -248,11 +261,12 @@ static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w
             GemmNtArgs a;
             a.X = h1; a.ldx = D; a.W = P(w.w_q2, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D;
             a.bias = P(w.b_q2, (size_t)l * D); a.out = W(blk, L.q2raw); a.ldo = D; a.variant = V;
+            GemmNtArgs dn;
             if (r > 0) {
-                FTMI_TRY(lora_down(h1, D, M, la + 4L * 2 * r * D, r, D, r, s, W(blk, L.xa_q2), st));
+                dn = lora_down_args(h1, D, M, la + 4L * 2 * r * D, r, D, r, s, W(blk, L.xa_q2));
                 a.X2 = W(blk, L.xa_q2); a.ldx2 = 3 * r; a.W2 = lb + 4L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r;
             }
-            FTMI_TRY(gemm_nt(a, st));
+            FTMI_TRY(r > 0 ? lora_gemm(a, dn, fx, st) : gemm_nt(a, st));
             FTMI_TRY(qknorm_rope_fwd(W(blk, L.q2raw), D, P(w.norm_q2, (size_t)l * D), nullptr, nullptr, W(blk, L.q2n), D, M, c.S, D, c.eps_qk, st));
         }
         // 9. cross-attention with the text-mask bias
@@ -272,11 +286,12 @@ static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w
             a.X = W(blk, L.o2); a.ldx = D; a.W = P(w.w_o2, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D;
             a.bias = P(w.b_o2, (size_t)l * D); a.out = W(blk, L.h2); a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = h1; a.ldr = D;
+            GemmNtArgs dn;
             if (r > 0) {
-                FTMI_TRY(lora_down(W(blk, L.o2), D, M, la + 7L * 2 * r * D, r, D, r, s, W(blk, L.xa_o2), st));
+                dn = lora_down_args(W(blk, L.o2), D, M, la + 7L * 2 * r * D, r, D, r, s, W(blk, L.xa_o2));
                 a.X2 = W(blk, L.xa_o2); a.ldx2 = 3 * r; a.W2 = lb + 7L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r;
             }
-            FTMI_TRY(gemm_nt(a, st));
+            FTMI_TRY(r > 0 ? lora_gemm(a, dn, fx, st) : gemm_nt(a, st));
         }
         const bf16_t* h2 = W(blk, L.h2);
         // 11-13. norm2 + modulate, feed-forward, gate * residual
@@ -347,7 +362,9 @@ int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_
                                  c.eps_qk, st, c.L));
     }
 
-    for (int l = 0; l < c.L; ++l) FTMI_TRY(ltx_block_forward(c, w, L, ws, l, key_bias, st));
+    FuseCtx fx{reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + L.sk_flags), 0};
+    if (hipMemsetAsync(fx.flags, 0, 4096, st) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "ltx_forward: memset of the row-tile counters failed");
+    for (int l = 0; l < c.L; ++l) FTMI_TRY(ltx_block_forward(c, w, L, ws, l, key_bias, st, fx));
 
     // ---- tail: LayerNorm + modulate + proj_out ----
     const bf16_t* hL = W(ws, L.hs) + (size_t)c.L * M * D;
@@ -397,10 +414,12 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
     // LoRA adapter backward, critical-path half: dXA = s * dY B (needed at once by the dgrad K-extension).  The weight
     // gradients dB += dY^T XA and dA += dXA^T X only feed the gradient buffer, so dY / dXA are kept per block and all 28
     // blocks of one adapter are reduced by ONE batched launch after the loop (fills the GPU instead of 28 latency-bound ones).
-    auto lora_dxa = [&](const bf16_t* dY, long lddy, int rows, int nadp, int adp, int l, bf16_t* dxa_out) -> int {
+    auto lora_dxa = [&](const bf16_t* dY, long lddy, int rows, int nadp, int adp, int l, bf16_t* dxa_out) -> GemmNtArgs {
         const bf16_t* lbt = P(w.lora_bt_sp, ((size_t)l * 8 + adp) * 2 * r * D);  // [nadp * 2r][D]: (hi, lo) planes of B^T
-        return lora_down(dY, lddy, rows, lbt, nadp * r, D, r, s, dxa_out, st, nadp > 1 ? D : 0);
+        return lora_down_args(dY, lddy, rows, lbt, nadp * r, D, r, s, dxa_out, nadp > 1 ? D : 0);
     };
+    FuseCtx fx{reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + L.sk_flags), 0};  // row-tile counters of the fused down-projection + GEMM launches of this call
+    if (r > 0 && hipMemsetAsync(fx.flags, 0, 4096, st) != hipSuccess) return set_error(FTMI_ERR_LAUNCH, "ltx_backward: memset of the row-tile counters failed");
 
     // LoRA weight gradients dB += dY^T XA, dA += dXA^T X only feed the gradient buffer: ONE batched launch per adapter group over all
     // blocks of this call's range, after its block loop (fills the GPU instead of 28 latency-bound launches per adapter).
@@ -441,7 +460,7 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
         const bf16_t* h1 = W(blk, L.h1);
         const bf16_t* h2 = W(blk, L.h2);
         const bf16_t* dhin = dh[cur];
-        if (c.checkpoint) FTMI_TRY(ltx_block_forward(c, w, L, ws, l, key_bias, st));  // the block's activations again, into the one slot
+        if (c.checkpoint) FTMI_TRY(ltx_block_forward(c, w, L, ws, l, key_bias, st, fx));  // the block's activations again, into the one slot
 
         // ---- feed-forward ----
         // (dO holds bf(dhin * gate_mlp): written by the kernel that produced dhin)
@@ -456,12 +475,11 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
         FTMI_TRY(norm_modulate_bwd(h2, d2, ada + 7 * D, ab, dhin, d3, M, c.S, D, c.eps_norm, 0, st));
 
         // ---- cross-attention ----
-        if (r > 0) FTMI_TRY(lora_dxa(d3, D, M, 1, 7, l, W(blk, L.dxa_o2)));
         {
             GemmNtArgs a;
             a.X = d3; a.ldx = D; a.W = P(w.w_o2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d1; a.ldo = D; a.variant = V;
             if (r > 0) { a.X2 = W(blk, L.dxa_o2); a.ldx2 = 3 * r; a.W2 = lat + 7L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r; }
-            FTMI_TRY(gemm_nt(a, st));  // d1 = dO2
+            FTMI_TRY(r > 0 ? lora_gemm(a, lora_dxa(d3, D, M, 1, 7, l, W(blk, L.dxa_o2)), fx, st) : gemm_nt(a, st));  // d1 = dO2
         }
         {
             AttnArgs a = attn_args(c, c.S, c.T);
@@ -479,24 +497,22 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
         }
         bf16_t* gq2 = W(blk, L.g_q2);  // dq2raw
         FTMI_TRY(qknorm_rope_bwd(W(blk, L.q2raw), D, P(w.norm_q2, (size_t)l * D), nullptr, nullptr, d2, D, gq2, D, M, c.S, D, c.eps_qk, st));
-        if (r > 0) FTMI_TRY(lora_dxa(gq2, D, M, 1, 4, l, W(blk, L.dxa_q2)));
         {
             GemmNtArgs a;
             a.X = gq2; a.ldx = D; a.W = P(w.w_q2_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = d2; a.ldo = D; a.variant = V;
             a.epi = EPI_RESID; a.resid = d3; a.ldr = D;
             a.out2 = W(blk, L.g_o); a.ldo2 = D; a.gate2 = ada + 2 * D; a.gate2_bstride = ab; a.rows_per_batch = c.S;  // go = bf(dh1 * gate_msa), fused
             if (r > 0) { a.X2 = W(blk, L.dxa_q2); a.ldx2 = 3 * r; a.W2 = lat + 4L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r; }
-            FTMI_TRY(gemm_nt(a, st));  // d2 = dh1
+            FTMI_TRY(r > 0 ? lora_gemm(a, lora_dxa(gq2, D, M, 1, 4, l, W(blk, L.dxa_q2)), fx, st) : gemm_nt(a, st));  // d2 = dh1
         }
 
         // ---- self-attention ----
         bf16_t* go = W(blk, L.g_o);  // d(attn1.to_out output)
-        if (r > 0) FTMI_TRY(lora_dxa(go, D, M, 1, 3, l, W(blk, L.dxa_o)));
         {
             GemmNtArgs a;
             a.X = go; a.ldx = D; a.W = P(w.w_o_t, (size_t)l * D2); a.ldw = D; a.M = M; a.N = D; a.K = D; a.out = dO; a.ldo = D; a.variant = V;
             if (r > 0) { a.X2 = W(blk, L.dxa_o); a.ldx2 = 3 * r; a.W2 = lat + 3L * D * 3 * r; a.ldw2 = 3 * r; a.K2 = 3 * r; }
-            FTMI_TRY(gemm_nt(a, st));
+            FTMI_TRY(r > 0 ? lora_gemm(a, lora_dxa(go, D, M, 1, 3, l, W(blk, L.dxa_o)), fx, st) : gemm_nt(a, st));
         }
         bf16_t* dqkv = W(blk, L.g_qkv);
         const bf16_t* qkv = W(blk, L.qkv);
@@ -516,12 +532,12 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
         }
         FTMI_TRY(qknorm_rope_bwd(qkv, 3 * D, P(w.norm_q, (size_t)l * D), w.rope_cos, w.rope_sin, W(ws, L.s_dqr), D, dqkv, 3 * D, M, c.S, D, c.eps_qk, st, 1,
                                  qkv + D, P(w.norm_k, (size_t)l * D), W(ws, L.s_dkr), dqkv + D));  // q and k in one launch
-        if (r > 0) FTMI_TRY(lora_dxa(dqkv, 3 * D, M, 3, 0, l, W(blk, L.dxa_qkv)));
+        if (r > 0 && l == 0) FTMI_TRY(gemm_nt(lora_dxa(dqkv, 3 * D, M, 3, 0, l, W(blk, L.dxa_qkv)), st));  // (block 0 has no input gradient: the dXA alone, for dA)
         if (l > 0) {
             GemmNtArgs a;
             a.X = dqkv; a.ldx = 3 * D; a.W = P(w.w_qkv_t, (size_t)l * 3 * D2); a.ldw = 3 * D; a.M = M; a.N = D; a.K = 3 * D; a.out = d1; a.ldo = D; a.variant = V;
             if (r > 0) { a.X2 = W(blk, L.dxa_qkv); a.ldx2 = 9 * r; a.W2 = P(w.lora_at_qkv_ext, (size_t)l * D * 9 * r); a.ldw2 = 9 * r; a.K2 = 9 * r; }
-            FTMI_TRY(gemm_nt(a, st));  // d1 = dn1
+            FTMI_TRY(r > 0 ? lora_gemm(a, lora_dxa(dqkv, 3 * D, M, 3, 0, l, W(blk, L.dxa_qkv)), fx, st) : gemm_nt(a, st));  // d1 = dn1
             const bf16_t* ada_prev = W(ws, L.ada) + (size_t)(l - 1) * c.B * 8 * D;  // the next block processed is l - 1
             FTMI_TRY(norm_modulate_bwd(h0, d1, ada + 6 * D, ab, d2, dh[cur ^ 1], M, c.S, D, c.eps_norm, 0, st, ada_prev + 5 * D, ab, dO));
             cur ^= 1;

@@ -113,7 +113,7 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
                  void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
                  const void* aux, long ld_side, int variant, ftmi_stream stream);
 /* Which kernel variant 8 takes for a plain launch of this shape (K2 = depth of a fused LoRA K-extension or 0; epilogue as above), as a pure host function
- * (no device, no launch): 80 / 86 = the 16 x 16 x 32 pipeline with 256- / 192-row tiles, 42 = 192 x 128 tiles (two workgroups per CU), 47 = 256 x 256
+ * (no device, no launch): 80 / 86 / 87 = the 16 x 16 x 32 pipeline with 256- / 192- / 224-row tiles, 42 = 192 x 128 tiles (two workgroups per CU), 47 = 256 x 256
  * (8 waves), 44 = 128 x 128, 2 = a skinny kernel (N <= 256, plain store, no extension, M >= 512: the LDS-ring kernel when K % 256 == 0, else the direct-gather one), 1 = the 128 x 64 kernel of N % 128 != 0,
  * 0 = not a tiled launch (N % 64 or K % 64).  Host tests pin the choice to DESIGN.md. */
 int ftmi_gemm_nt_plan(int M, int N, int K, int K2, int epilogue);
@@ -143,6 +143,11 @@ int ftmi_allreduce_destroy(ftmi_exchange ex);
  * at the first launch that consults them -- the launch path never calls getenv.  A process that wants to compare kernels (the bit-identity tests do) changes
  * the environment and calls this: every switch consulted so far is re-read.  Returns how many were. */
 int ftmi_reload_switches(void);
+/* FTMI_FUSE_DOWN=1 (round 6): a LoRA down-projection and the GEMM that consumes it run as ONE launch -- the down-projection's workgroups lead the grid, the GEMM's
+ * tiles wait for the rows they need on per-row-tile counters two K stages before their K-extension (csrc/gemm.hip: gemm_nt16_fused_kernel; results are the bits of
+ * the two separate launches).  A wait is bounded: a poll that gives up raises a device-side status word and goes on.  This returns that word (0 = every wait of
+ * every fused launch so far was satisfied); it synchronises the device -- tests only. */
+int ftmi_fused_status(void);
 #ifdef FTMI_EXPERIMENTAL
 /* Research build only (FTMI_EXPERIMENTAL=1 python -m finetrainers_amd.csrc.build): the persistent stream-K GEMM (tools/experimental/gemm_sk.hip, variant 60) --
  * parity-green and 5-25 % slower than the shipped kernels on the step's shapes (profiles/r03_gemm_streamk.txt); not part of the product ABI. */

@@ -90,6 +90,39 @@ def test_gradient_checkpointing_gives_the_same_gradients_from_one_block_slot():
         model.apply_activation_checkpointing("block_skip", 2)
 
 
+def test_fused_down_projection_launch_gives_the_bits_of_the_two_launches():
+    """Round 6 (FTMI_FUSE_DOWN=1): x A^T / dY B computed by the leading workgroups of the projection GEMM's own launch, the GEMM's tiles waiting on per-row-tile
+    counters two K stages before their K-extension.  Same kernels' arithmetic, so with 192- / 256-row tiles on both sides the prediction and every activation
+    gradient are THE SAME BITS as with the two launches; the single-round launches move from the 192 x 128 kernel to the 192 x 256 pipeline when fused (bit-
+    identical GEMM kernels by construction), so the LoRA gradients agree to the fp32 atomic order of the weight-gradient GEMMs.  No wait may time out."""
+    import ctypes
+
+    from finetrainers_amd import _lib
+
+    lib = _lib.load()
+    if not hasattr(lib, "ftmi_gemm_sk_status"):  # (an entry point only the FTMI_EXPERIMENTAL build exports)
+        pytest.skip("the fused down-projection launch is compiled in FTMI_EXPERIMENTAL builds only (measured break-even: profiles/r06_instep_ab_fused_down_*.txt)")
+    spec, model, cond, latd, sig, noise = _model_and_batch(3, 2, 7, 16, 24)  # config 2's token count: the fused launch needs >= 84 row tiles x column tiles
+    res = {}
+    for fuse in ("0", "3"):
+        os.environ["FTMI_FUSE_DOWN"] = fuse
+        lib.ftmi_reload_switches()
+        try:
+            ga, gb = _grads(spec, model, cond, latd, sig, noise)
+            pred, _, _ = spec.forward(transformer=model, condition_model_conditions=dict(cond), latent_model_conditions=dict(latd), sigmas=sig, noise=noise,
+                                      force_first_frame_branch=False)
+            res[fuse] = (pred.detach().clone(), ga, gb)
+        finally:
+            os.environ.pop("FTMI_FUSE_DOWN", None)
+            lib.ftmi_reload_switches()
+    assert lib.ftmi_fused_status() == 0, "a fused launch gave up waiting for its down-projection"
+    assert torch.equal(res["0"][0], res["3"][0]), f"prediction differs: {(res['0'][0].float() - res['3'][0].float()).abs().max().item():.3e}"
+    for name, a, b in (("A", res["0"][1], res["3"][1]), ("B", res["0"][2], res["3"][2])):
+        rel = ((a - b).norm() / a.norm()).item()
+        print(f"[fused] lora_{name}.grad fused vs two launches: rel {rel:.2e}")
+        assert rel < 2e-6, (name, rel)
+
+
 def test_block_range_backward_matches_single_call():
     """ftmi_ltx_backward_range over [3,5) [1,3) [0,1) == one ftmi_ltx_backward over [0,5): same gradients (fp32 atomics order aside),
     ranges reported in backward order, each exactly once."""

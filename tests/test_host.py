@@ -1050,14 +1050,14 @@ def test_spec_classes_subclass_the_reference_when_it_is_importable():
 
 def test_gemm_dispatch_rule_matches_the_design(lib):
     """The automatic NT-GEMM kernel choice as a pure host function (ftmi_gemm_nt_plan; no device): pinned to what DESIGN.md section 3 / 6 state for the
-    LTX step's shapes (M = 2 x 2688 tokens) -- the 16 x 16 x 32 pipeline (80 = 256-row tiles, 86 = 192-row tiles) on every launch with several rounds of tiles or a
-    long K, 192 x 128 two-per-CU tiles (42) on the single-round N = 2048 / K = 2048 launches, 128 x 128 (44) for few rows or few tiles."""
+    LTX step's shapes (M = 2 x 2688 tokens) -- the 16 x 16 x 32 pipeline (80 = 256-row tiles, 86 = 192-row tiles, 87 = 224-row tiles where they save a share of a
+    round) on every launch with several rounds of tiles or a long K, 192 x 128 two-per-CU tiles (42) on the single-round N = 2048 / K = 2048 launches, 128 x 128 (44) for few rows or few tiles."""
     M = 2 * 2688
     EPI_STORE, EPI_GELU, EPI_RESID, EPI_DGELU = 0, 1, 2, 3
     plan = lambda *a: lib.ftmi_gemm_nt_plan(*a)
     assert plan(M, 6144, 2048, 192, EPI_STORE) == 80     # fused q|k|v forward with the LoRA K-extension: 21 x 24 tiles of 256 x 256, two rounds
-    assert plan(M, 8192, 2048, 0, EPI_GELU) == 80        # ff1 forward (GELU + stash)
-    assert plan(M, 8192, 2048, 0, EPI_DGELU) == 80       # ff2 input gradient (GELU')
+    assert plan(M, 8192, 2048, 0, EPI_GELU) == 87        # ff1 forward (GELU + stash): 24 x 32 tiles of 224 x 256 = exactly three rounds of the 256 CUs (round 6)
+    assert plan(M, 8192, 2048, 0, EPI_DGELU) == 87       # ff2 input gradient (GELU')
     assert plan(M, 2048, 8192, 0, EPI_RESID) == 86       # ff2 forward: K = 8192, 28 x 8 tiles of 192 x 256 in one round
     assert plan(M, 2048, 8192, 0, EPI_STORE) == 86       # ff1 input gradient
     assert plan(M, 2048, 6144, 192, EPI_STORE) == 86     # fused q|k|v input gradient
@@ -1071,8 +1071,8 @@ def test_gemm_dispatch_rule_matches_the_design(lib):
     assert plan(M, 192, 2048, 192, EPI_STORE) == 1       # a K-extension keeps it off the skinny route
     assert plan(M, 2048, 100, 0, EPI_STORE) == 0 and plan(M, 100, 2048, 0, EPI_STORE) == 0
     # Wan-1.3B's widths (1536, 4608, 8960 = 35 x 256) take the same pipeline; CogVideoX-2b's 1920 = 7.5 x 256 keeps the 32 x 32 x 16 kernels
-    assert plan(21504, 4608, 1536, 0, EPI_STORE) in (80, 86) and plan(21504, 8960, 1536, 0, EPI_GELU) in (80, 86)
-    assert plan(17776, 1920, 1920, 0, EPI_STORE) not in (80, 86) and plan(17776, 7680, 1920, 0, EPI_GELU) in (80, 86)
+    assert plan(21504, 4608, 1536, 0, EPI_STORE) in (80, 86, 87) and plan(21504, 8960, 1536, 0, EPI_GELU) in (80, 86, 87)
+    assert plan(17776, 1920, 1920, 0, EPI_STORE) not in (80, 86, 87) and plan(17776, 7680, 1920, 0, EPI_GELU) in (80, 86, 87)
 
 
 def test_parallel_backend_has_the_reference_surface():
