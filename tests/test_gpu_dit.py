@@ -527,6 +527,21 @@ def test_full_depth_config2_parity():
     assert w32 < 1.25 * y["bf16_vs_fp32_worst_adapter_sampled"]
 
 
+def test_north_star_gradient_tolerance_1e3_is_reported_not_claimed():
+    """north_star states "grads within 1e-3 rel of reference".  The full-depth test above asserts the tolerance this project CLAIMS (2.0e-3 global /
+    1.0e-2 worst adapter at config 2, 1.5 x the bf16 graph's own summation-order floor of 1.17e-3) -- this test keeps the north-star number itself visible: it
+    reads what that test measured in this session and is an EXPECTED FAILURE with the measured figure wherever 1e-3 is not met (it cannot be met by two bf16
+    evaluations of this graph: the oracle moves by 1.17e-3 against itself), a pass if it ever is."""
+    path = os.path.join(os.environ.get("FTMI_REPORT_DIR", "gpurun_out"), "parity_full_cfg2_yardsticks.json")
+    if not os.path.exists(path):
+        pytest.skip("the full-depth cfg-2 parity did not run in this session (no report to read)")
+    rec = json.load(open(path))
+    glob, floor = rec["kernel_vs_bf16_oracle"][0], rec["floor"][0]
+    print(f"[dit] north star: LoRA gradients {glob:.3e} from the bf16 oracle at config 2 (target 1e-3; floor of the bf16 graph {floor:.3e})")
+    if glob > 1e-3:
+        pytest.xfail(f"north_star's 1e-3 is not met and not claimed: measured {glob:.3e} (the reference's own bf16 graph moves by {floor:.3e} under a pure fp32 reordering)")
+
+
 def test_full_step_matches_oracle_step():
     """forward + loss + backward + clip + AdamW: updated LoRA parameters vs the oracle's torch.optim.AdamW step."""
     from finetrainers_amd.trainer import MI355XSFTStep
