@@ -1044,10 +1044,10 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
         }
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            if (sl == 1 && DBG != 2 && DBG != 6) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
+            if (sl == 1 && DBG != 2 && DBG != 6 && DBG != 10) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // P_s
 #pragma unroll
             for (int m = 0; m < NMF; ++m) {
-                if constexpr (DBG != 5) pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
+                if constexpr (DBG != 5 && DBG != 10) pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
                 if (m % RG == 0 && m / RG < NRD && DBG != 3) {  // fragment reads of the next slice
                     if (sl == 0) rd(1, m / RG, 1, so);
                     else rd(0, m / RG, 0, so ^ 65536u);
@@ -1060,6 +1060,219 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     acc_fence16<TMW>(acc);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the same stream with a REGISTER-STAGED prefetch (RS = 2 or 3 register sets) instead of the direct-to-LDS loads.
+// Why: the lab's ablations (profiles/r06_gemm_lab_ablations_*.txt) show that the 192-row loop's memory side alone -- no MFMA -- takes 142 of the kernel's 153 us,
+// but only 94 us once the rendezvous is taken out as well: the L2s can deliver the operands 1.5 x faster than the two-slot ring asks for them.  With two LDS slots
+// the loads of stage s+2 cannot be issued before stage s has been read (P_s) and must have landed by P_{s+1}: at most ONE stage is ever in flight, for at most one
+// stage period, and the period cannot be shorter than a load's round trip (~1.1 us under this load).  A third LDS slot does not fit (3 x 56 KB > 160 KB) -- but the
+// 192-row tile leaves 188 registers per lane unused.  So the operands of stage s+1+RS are requested in the first slice of stage s into a register set (plain
+// buffer_load_dwordx4, the addresses of the direct-to-LDS path: 1 KiB per instruction, whole 128-byte lines), wait there for RS - 0.5 stage periods, and are
+// stored into the LDS slot that P_{s'} frees with ds_write_b128 (lane-linear, conflict-free: the XOR swizzle sits on the source address as before) during the second
+// slice of stage s' = s+RS-1... in the numbering below: at P_s the set (s+2) % RS holds stage s+2 (vmcnt leaves the (RS-1) younger stages in flight), its
+// ds_writes go into slot s & 1 between the MFMAs of slice 1, the fragment reads of stage s+2 start after P_{s+1} as before.  RS = 2: 1.5 periods of flight
+// time and 2 x 56 registers; RS = 3: 2.5 periods, 168 registers.  Same products, same fp32 order per output element: bit-identical.
+// ------------------------------------------------------------------------------------------------
+// compile-time loop: f(integral_constant<int, I>) for I = 0 .. N-1 -- the statement lists of nt_run_k_rs16 are two to three stages long, beyond what
+// `#pragma unroll` will flatten (the unroller's size threshold then leaves a loop, the accumulator indices stop being constants and the arrays go to scratch)
+template <int I, int N, class F>
+FTMI_DEVICE void cfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cfor<I + 1, N>(f);
+    }
+}
+
+// (the same store with its data in the accumulator file: on gfx950 LDS and vector-memory instructions take AGPR data operands, which is what lets half of the
+//  prefetch registers live next to the accumulators -- only 256 of a wave's 512 registers can be architectural VGPRs)
+FTMI_DEVICE void pl_ds_write16a(uint32_t a, const u32x4& d, int t) {
+    switch (t) {
+        case 0: asm volatile("ds_write_b128 %0, %1" ::"v"(a), "a"(d) : "memory"); break;
+        case 1: asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(a), "a"(d) : "memory"); break;
+        case 2: asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(a), "a"(d) : "memory"); break;
+        case 3: asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(a), "a"(d) : "memory"); break;
+        case 4: asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "a"(d) : "memory"); break;
+        case 5: asm volatile("ds_write_b128 %0, %1 offset:5120" ::"v"(a), "a"(d) : "memory"); break;
+        case 6: asm volatile("ds_write_b128 %0, %1 offset:6144" ::"v"(a), "a"(d) : "memory"); break;
+        default: asm volatile("ds_write_b128 %0, %1 offset:7168" ::"v"(a), "a"(d) : "memory"); break;
+    }
+}
+FTMI_DEVICE void pl_ds_write16(uint32_t a, const u32x4& d, int t) {  // t * 1024 = immediate offset (a constant after unrolling)
+    switch (t) {
+        case 0: asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(d) : "memory"); break;
+        case 1: asm volatile("ds_write_b128 %0, %1 offset:1024" ::"v"(a), "v"(d) : "memory"); break;
+        case 2: asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"(a), "v"(d) : "memory"); break;
+        case 3: asm volatile("ds_write_b128 %0, %1 offset:3072" ::"v"(a), "v"(d) : "memory"); break;
+        case 4: asm volatile("ds_write_b128 %0, %1 offset:4096" ::"v"(a), "v"(d) : "memory"); break;
+        case 5: asm volatile("ds_write_b128 %0, %1 offset:5120" ::"v"(a), "v"(d) : "memory"); break;
+        case 6: asm volatile("ds_write_b128 %0, %1 offset:6144" ::"v"(a), "v"(d) : "memory"); break;
+        default: asm volatile("ds_write_b128 %0, %1 offset:7168" ::"v"(a), "v"(d) : "memory"); break;
+    }
+}
+
+template <int TMW, bool EXT, int RS, int NPRE = 0, class MID, class STAMP = NoStamp, class PRE = NoPre, class EARLY = NoPre, class EXTRDY = NoPre>
+FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
+                               int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid, STAMP stamp = STAMP(),
+                               PRE pre = PRE(), EARLY early = EARLY(), EXTRDY ext_rdy = EXTRDY()) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int XI = TMW, LPT = XI + 8, NMF = 8 * TMW, NRD = 8 + TMW, RG = NMF / NRD;
+    static_assert(RS == 2 || RS == 3, "two or three register sets");
+    static_assert(NMF / RG >= NRD && NMF / RG >= LPT, "gaps");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int S = nk1 + (EXT ? nk2 : 0);
+
+    uint32_t off[LPT], off2[EXT ? LPT : 1];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const bool isx = i < XI;
+        const int blk = isx ? wave * XI + i : wave * 8 + (i - XI);
+        const int row = blk * 8 + (lane >> 3), cs = lane & 7;
+        const int c = cs ^ ((row >> 1) & 7);
+        off[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx + c * 8) * 2) : (uint32_t)(((long)row * ldw + c * 8) * 2);
+        if constexpr (EXT) off2[i] = isx ? (uint32_t)(((long)min(m0 + row, M - 1) * ldx2 + c * 8) * 2) : (uint32_t)(((long)row * ldw2 + c * 8) * 2);
+    }
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, (short)0, 0x7fffffff, 0x00020000);
+    const auto xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? X2 : X), (short)0, 0x7fffffff, 0x00020000);
+    const auto wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(EXT ? W2 : W), (short)0, 0x7fffffff, 0x00020000);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+
+    // prologue only: stages 0 and 1 straight into the LDS (the direct-to-LDS path of nt_run_k_pipe16)
+    auto dma = [&](int i, int t) {
+        const bool isx = i < XI;
+        const uint32_t dst = lds0 + (uint32_t)(t & 1) * 65536u + (isx ? (uint32_t)(wave * XI + i) * 1024u : 32768u + (uint32_t)(wave * 8 + (i - XI)) * 1024u);
+        const int tt = min(t, S - 1);
+        const bool seg2 = EXT && tt >= nk1;
+        const int soff = (seg2 ? tt - nk1 : tt) * 128;
+        const uint32_t vo = seg2 ? off2[EXT ? i : 0] : off[i];
+        const auto rs = isx ? (seg2 ? xrs2 : xrs) : (seg2 ? wrs2 : wrs);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(vo), "s"(rs), "s"(soff) : "memory");
+    };
+    // The prefetch registers: the X blocks of a set in VGPRs, the W blocks in the ACCUMULATOR file (AW of the 8: a wave owns 512 registers but only 256 of them
+    // can be architectural VGPRs -- fragments 2 x (8 + TMW) x 4 and a whole set already fill those; what hipcc then does with the overflow is copy "values" between
+    // the files right behind the asm statement that defines them, i.e. copy a load destination before the load has returned.  Vector-memory loads and LDS stores
+    // take AGPR data operands directly, and the 192-row tile leaves 64 AGPRs beside its accumulators.)
+    constexpr int AW = TMW == 6 ? 8 : 0;  // W blocks kept in AGPRs
+    u32x4 R[RS][LPT];
+    // load i of stage t (stages past the end: the last one again, nobody stores it) into register set `set` (a constant after unrolling)
+    auto gld = [&](int i, int t, int set) {
+        const bool isx = i < XI;
+        const int tt = min(t, S - 1);
+        const bool seg2 = EXT && tt >= nk1;
+        const int soff = (seg2 ? tt - nk1 : tt) * 128;
+        const uint32_t vo = seg2 ? off2[EXT ? i : 0] : off[i];
+        const auto rs = isx ? (seg2 ? xrs2 : xrs) : (seg2 ? wrs2 : wrs);
+        if (i >= XI && i - XI < AW) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(R[set][i]) : "v"(vo), "s"(rs), "s"(soff) : "memory");
+        else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(R[set][i]) : "v"(vo), "s"(rs), "s"(soff) : "memory");
+    };
+    // the same 1-KiB block into the slot at byte offset so: lane-linear (block base + 16 B per lane), X image at +0, W image at +32 KB
+    const uint32_t wax = lds0 + (uint32_t)(wave * XI) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t waw = lds0 + 32768u + (uint32_t)(wave * 8) * 1024u + (uint32_t)lane * 16u;
+    auto lst = [&](int i, int set, uint32_t so) {
+        if (i < XI) pl_ds_write16(wax + so, R[set][i], i);
+        else if (i - XI < AW) pl_ds_write16a(waw + so, R[set][i], i - XI);
+        else pl_ds_write16(waw + so, R[set][i], i - XI);
+    };
+    uint32_t raw[2], rax[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int ch = (kk * 4 + grp) ^ ((l15 >> 1) & 7);
+        raw[kk] = lds0 + 32768u + (uint32_t)((wn * 128 + l15) * 128 + (ch << 4));
+        rax[kk] = lds0 + (uint32_t)((wm * 16 * TMW + l15) * 128 + (ch << 4));
+    }
+    s16x8 F[2][NRD];
+    auto rd = [&](int par, int q, int kk, uint32_t so) {
+        const int r = q == 0 ? 0 : (q <= TMW ? 7 + q : q - TMW);
+        if (r < 8) pl_ds_read16(F[par][r], raw[kk] + so, r);
+        else pl_ds_read16(F[par][r], rax[kk] + so, r - 8);
+    };
+
+    // prologue: stages 0, 1 -> LDS; stages 2 .. RS -> register sets 2 % RS .. RS % RS (stage 1 + RS follows in the first slice of stage 0)
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) dma(i, 0);
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) dma(i, 1);
+#pragma unroll
+    for (int t = 2; t <= RS; ++t)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) gld(i, t, t % RS);
+    pre();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 1) * LPT + NPRE) : "memory");  // stages 0 and 1 have landed (loads retire in order)
+#pragma unroll
+    for (int q = 0; q < NRD; ++q) rd(0, q, 0, 0u);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(2);
+
+    uint32_t so = 0;
+    // one stage; PH = s % RS (a constant: it names the register sets)
+    auto stage = [&](int s, auto PH) __attribute__((always_inline)) {
+        constexpr int ph = decltype(PH)::value;
+        constexpr int set_in = (ph + 1) % RS;   // receives stage s + 1 + RS (the set that stage s + 1 left during the second slice of stage s - 1)
+        constexpr int set_out = (ph + 2) % RS;  // holds stage s + 2: stored into the slot of stage s behind P_s
+        if (s == 1) early();
+        if constexpr (EXT) {
+            if (s == nk1 - 2) ext_rdy();
+            if (s == nk1) {
+                acc_fence16<TMW>(acc);
+                stamp(3);
+                mid();
+                stamp(4);
+            }
+        }
+        cfor<0, 2>([&](auto SL) __attribute__((always_inline)) {
+            constexpr int sl = decltype(SL)::value;
+            // P_s: stage s + 2 has landed in its registers (the RS - 1 younger stages stay in flight), everyone has read all of stage s
+            if constexpr (sl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 1) * LPT) : "memory");
+            cfor<0, NMF>([&](auto MM) __attribute__((always_inline)) {
+                constexpr int m = decltype(MM)::value;
+                pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
+                if constexpr (m % RG == 0 && m / RG < NRD) {  // fragment reads of the next slice
+                    if constexpr (sl == 0) rd(1, m / RG, 1, so);
+                    else rd(0, m / RG, 0, so ^ 65536u);
+                }
+                if constexpr (m % RG == RG / 2 && m / RG < LPT) {
+                    if constexpr (sl == 0) gld(m / RG, s + 1 + RS, set_in);  // request stage s + 1 + RS
+                    else lst(m / RG, set_out, so);                            // stage s + 2: registers -> the slot stage s has just left
+                }
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+        so ^= 65536u;
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    int s = 0;
+    if constexpr (RS == 2) {
+        for (; s + 1 < S; s += 2) {
+            stage(s, P0{});
+            stage(s + 1, P1{});
+        }
+        if (s < S) stage(s, P0{});
+    } else {
+        for (; s + 2 < S; s += 3) {
+            stage(s, P0{});
+            stage(s + 1, P1{});
+            stage(s + 2, P2{});
+        }
+        if (s < S) { stage(s, P0{}); ++s; }
+        if (s < S) stage(s, P1{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    acc_fence16<TMW>(acc);
+    // the register sets stay allocated until every load has returned
+#pragma unroll
+    for (int t = 0; t < RS; ++t)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            if (i >= XI && i - XI < AW) asm volatile("" ::"a"(R[t][i]));
+            else asm volatile("" ::"v"(R[t][i]));
+        }
 #endif
 }
 
@@ -1197,7 +1410,7 @@ FTMI_DEVICE void nt_run_k_ring16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
 // (the kernel's body as a function of the block index: gemm_nt16_kernel calls it with blockIdx.x, the fused launch of round 6 -- gemm_nt16_fused_kernel -- with the
 //  index behind its leading down-projection workgroups and an `ext_ready` hook that waits for their output two stages before the K-extension)
 struct NoHook { FTMI_DEVICE void operator()(int, int) const {} };
-template <int TMW, int EPI, bool EXT, int DBG, bool RING, class READY = NoHook>
+template <int TMW, int EPI, bool EXT, int DBG, bool RING, class READY = NoHook, int RS = 0>
 FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY ext_ready = READY()) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1274,7 +1487,7 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
     //  round trip is exposed at most, behind the arithmetic of block 0.)
     constexpr int NBLK_IN = (TMW + 1) / 2;
     // 192-row tiles have 188 registers to spare: their whole row-wise input (96 registers) is requested at stage 1 of the K loop and arrives under it
-    constexpr bool EARLY_IN = HAS_IN && !RING && TMW <= 6 && !EXT;  // (with a K-extension the second set of load offsets takes the spare registers)
+    constexpr bool EARLY_IN = HAS_IN && !RING && TMW <= 6 && !EXT && RS == 0;  // (the register-staged loop keeps its prefetch in those registers)  // (with a K-extension the second set of load offsets takes the spare registers)
     u32x4 pre[HAS_IN ? NBLK_IN : 1][HAS_IN ? 8 : 1];
     auto fetch_regs = [&](int blk) {
 #pragma unroll
@@ -1302,7 +1515,10 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
         if constexpr (RING) {
             pre_in();
             nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
-        } else
+        } else if constexpr (RS > 0)
+            nt_run_k_rs16<TMW, EXT, RS, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
+                                                      pre_in, early_in, [&]() { ext_ready(m0, BM); });
+        else
             nt_run_k_pipe16<TMW, EXT, DBG, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
                                                          pre_in, early_in, [&]() { ext_ready(m0, BM); });
         NT_STAMP(p, 5);
@@ -1415,10 +1631,10 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
     NT_STAMP(p, 6);
 }
 
-template <int TMW, int EPI, bool EXT, int DBG, bool RING = false>
+template <int TMW, int EPI, bool EXT, int DBG, bool RING = false, int RS = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt16_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    nt16_body<TMW, EPI, EXT, DBG, RING>(p, smem, blockIdx.x);
+    nt16_body<TMW, EPI, EXT, DBG, RING, NoHook, RS>(p, smem, blockIdx.x);
 }
 
 // tile -> XCD rasterisation shared by the tiled kernels: choose the XCD grid gm x gn = 8 by predicted fabric->L2 operand traffic
@@ -1444,32 +1660,32 @@ static void choose_xcd_map(GemmNtArgs& a, int BM, int BN) {
     }
 }
 
-template <int TMW, int EPI, bool EXT, int DBG, bool RING>
+template <int TMW, int EPI, bool EXT, int DBG, bool RING, int RS = 0>
 static int launch_nt16_3(const GemmNtArgs& a0, hipStream_t st) {
     GemmNtArgs a = a0;
     choose_xcd_map(a, 32 * TMW, 256);
     constexpr int kSmem = RING ? 163840 : 131072;
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * ((double)a.K + (double)a.K2 / 3.0), st);
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING, RS>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
     if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
 #ifdef FTMI_TRACE
     a.trace = nt_trace_slot(32 * TMW, 256, 1, a, 8 * a.map_rm * a.map_rn, st);
 #endif
-    hipLaunchKernelGGL((gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING>), dim3(8 * a.map_rm * a.map_rn), dim3(256), kSmem, st, a);
+    hipLaunchKernelGGL((gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING, RS>), dim3(8 * a.map_rm * a.map_rn), dim3(256), kSmem, st, a);
     return check_launch("gemm_nt16");
 }
-template <int TMW, int DBG = 0, bool RING = false>
+template <int TMW, int DBG = 0, bool RING = false, int RS = 0>
 static int launch_nt16(const GemmNtArgs& a, hipStream_t st) {
 #ifdef FTMI_LAB
-    return launch_nt16_3<TMW, EPI_STORE, false, DBG, RING>(a, st);
+    return launch_nt16_3<TMW, EPI_STORE, false, DBG, RING, RS>(a, st);
 #else
     static_assert(DBG == 0, "ablation builds exist in tools/gemm_lab.hip only");
     const bool ext = a.K2 > 0;
     switch (a.epi) {
-        case EPI_STORE: return ext ? launch_nt16_3<TMW, EPI_STORE, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_STORE, false, 0, RING>(a, st);
-        case EPI_GELU: return ext ? launch_nt16_3<TMW, EPI_GELU, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_GELU, false, 0, RING>(a, st);
-        case EPI_RESID: return ext ? launch_nt16_3<TMW, EPI_RESID, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_RESID, false, 0, RING>(a, st);
-        default: return ext ? launch_nt16_3<TMW, EPI_DGELU, true, 0, RING>(a, st) : launch_nt16_3<TMW, EPI_DGELU, false, 0, RING>(a, st);
+        case EPI_STORE: return ext ? launch_nt16_3<TMW, EPI_STORE, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_STORE, false, 0, RING, RS>(a, st);
+        case EPI_GELU: return ext ? launch_nt16_3<TMW, EPI_GELU, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_GELU, false, 0, RING, RS>(a, st);
+        case EPI_RESID: return ext ? launch_nt16_3<TMW, EPI_RESID, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_RESID, false, 0, RING, RS>(a, st);
+        default: return ext ? launch_nt16_3<TMW, EPI_DGELU, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_DGELU, false, 0, RING, RS>(a, st);
     }
 #endif
 }
@@ -1983,6 +2199,9 @@ static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
     if ((use16 & cls) && ok256 && a.M >= 1024 && (!one_round_short || short16)) {
         variant = c192 < c256 ? 86 : 80;
         // round 6: 224-row tiles where they save a whole share of a round (N = 8192 at M = 5376: 768 tiles = 3.0 rounds instead of 2.625 -> 3 of 256 rows)
+        // round 6: 192-row tiles with the register-staged prefetch (nt_run_k_rs16, two register sets); FTMI_NT16_RS=0: the direct-to-LDS loop
+        static const int use_rs = env_int("FTMI_NT16_RS", 1);
+        if (variant == 86 && use_rs) variant = 2286;
         static const int use224 = env_int("FTMI_NT224", 1);
         const long t224 = (long)((a.M + 223) / 224) * (a.N / 256), c224 = ((t224 + 255) / 256) * 224;
         if (use224 && c224 < std::min(c256, c192)) variant = 87;
@@ -2126,7 +2345,13 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 186: return launch_nt16<6, 1>(a, st);
             case 286: return launch_nt16<6, 2>(a, st);
             case 386: return launch_nt16<6, 3>(a, st);
+            case 2286: return launch_nt16<6, 0, false, 2>(a, st);  // register-staged prefetch, two / three register sets
+            case 3286: return launch_nt16<6, 0, false, 3>(a, st);
+            case 2287: return launch_nt16<7, 0, false, 2>(a, st);
+            case 2280: return launch_nt16<8, 0, false, 2>(a, st);
             case 586: return launch_nt16<6, 5>(a, st);   // no MFMAs (memory side alone)
+            case 1086: return launch_nt16<6, 10>(a, st); // no MFMAs, no rendezvous: the loads as fast as they issue
+            case 1080: return launch_nt16<8, 10>(a, st);
             case 686: return launch_nt16<6, 6>(a, st);   // no loads, no rendezvous
             case 580: return launch_nt16<8, 5>(a, st);
             case 180: return launch_nt16<8, 1>(a, st);
@@ -2147,6 +2372,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
+            case 2286: if (ok256) return launch_nt16<6, 0, false, 2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, register-staged prefetch
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
@@ -2198,6 +2424,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
+            case 2286: if (ok256) return launch_nt16<6, 0, false, 2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, register-staged prefetch
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)

@@ -60,7 +60,7 @@ def report(name, got, ref, rel_tol, max_ulp_frac=None):
 # the tiled-GEMM kernels the product library ships: 8 = automatic choice (production), 42 / 44 / 47 pin 192x128 / 128x128 / 256x256 tiles,
 # 70 = the hand-placed 4-wave pipeline (128 x 128 per wave, accumulators in AGPRs), 80 / 86 = that pipeline on 16 x 16 x 32 MFMAs (256 x 256 / 192 x 256 tiles), 72 = the 32 x 32
 # stream on 8 waves (the research variants of tools/experimental/gemm_experimental.hip.h are not in the product build)
-SHIPPED_VARIANTS = [8, 42, 44, 47, 70, 72, 80, 86, 87]
+SHIPPED_VARIANTS = [8, 42, 44, 47, 70, 72, 80, 86, 87, 2286]
 
 
 def rnd(shape, gen, scale=1.0, dtype=bf16):
