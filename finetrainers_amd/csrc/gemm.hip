@@ -1157,7 +1157,8 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
     // can be architectural VGPRs -- fragments 2 x (8 + TMW) x 4 and a whole set already fill those; what hipcc then does with the overflow is copy "values" between
     // the files right behind the asm statement that defines them, i.e. copy a load destination before the load has returned.  Vector-memory loads and LDS stores
     // take AGPR data operands directly, and the 192-row tile leaves 64 AGPRs beside its accumulators.)
-    constexpr int AW = TMW == 6 ? 8 : 0;  // W blocks kept in AGPRs
+    constexpr int AFREE = 64 - 8 * TMW;  // 16-byte entries that fit beside the accumulators: 16 (192 rows: the W blocks of both sets), 8 (224 rows: those of set 0)
+    auto in_agpr = [](int i, int set) constexpr { return i >= XI && set * 8 + (i - XI) < AFREE; };
     u32x4 R[RS][LPT];
     // load i of stage t (stages past the end: the last one again, nobody stores it) into register set `set` (a constant after unrolling)
     auto gld = [&](int i, int t, int set) {
@@ -1167,7 +1168,7 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
         const int soff = (seg2 ? tt - nk1 : tt) * 128;
         const uint32_t vo = seg2 ? off2[EXT ? i : 0] : off[i];
         const auto rs = isx ? (seg2 ? xrs2 : xrs) : (seg2 ? wrs2 : wrs);
-        if (i >= XI && i - XI < AW) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(R[set][i]) : "v"(vo), "s"(rs), "s"(soff) : "memory");
+        if (in_agpr(i, set)) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(R[set][i]) : "v"(vo), "s"(rs), "s"(soff) : "memory");
         else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(R[set][i]) : "v"(vo), "s"(rs), "s"(soff) : "memory");
     };
     // the same 1-KiB block into the slot at byte offset so: lane-linear (block base + 16 B per lane), X image at +0, W image at +32 KB
@@ -1175,7 +1176,7 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
     const uint32_t waw = lds0 + 32768u + (uint32_t)(wave * 8) * 1024u + (uint32_t)lane * 16u;
     auto lst = [&](int i, int set, uint32_t so) {
         if (i < XI) pl_ds_write16(wax + so, R[set][i], i);
-        else if (i - XI < AW) pl_ds_write16a(waw + so, R[set][i], i - XI);
+        else if (in_agpr(i, set)) pl_ds_write16a(waw + so, R[set][i], i - XI);
         else pl_ds_write16(waw + so, R[set][i], i - XI);
     };
     uint32_t raw[2], rax[2];
@@ -1270,7 +1271,7 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
     for (int t = 0; t < RS; ++t)
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            if (i >= XI && i - XI < AW) asm volatile("" ::"a"(R[t][i]));
+            if (in_agpr(i, t)) asm volatile("" ::"a"(R[t][i]));
             else asm volatile("" ::"v"(R[t][i]));
         }
 #endif
@@ -1505,7 +1506,10 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
         }
         NT_STAMP(p, 1);
         auto stamp = [&](int i) { NT_STAMP(p, i); (void)i; };
-        auto pre_in = [&]() { if constexpr (HAS_IN) fetch_regs(0); };
+        // (block 0 of the row-wise input before the K loop -- except where the register-staged loop has no 32 architectural VGPRs to spare for it: 224-row tiles and
+        //  K-extension launches request it after the loop with the other blocks; a spill there would copy load destinations that have not arrived)
+        constexpr bool PRE_IN = HAS_IN && !(RS > 0 && (EXT || TMW > 6));
+        auto pre_in = [&]() { if constexpr (PRE_IN) fetch_regs(0); };
         auto early_in = [&]() {
             if constexpr (EARLY_IN) {
 #pragma unroll
@@ -1516,7 +1520,7 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
             pre_in();
             nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
         } else if constexpr (RS > 0)
-            nt_run_k_rs16<TMW, EXT, RS, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
+            nt_run_k_rs16<TMW, EXT, RS, PRE_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
                                                       pre_in, early_in, [&]() { ext_ready(m0, BM); });
         else
             nt_run_k_pipe16<TMW, EXT, DBG, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
@@ -1550,8 +1554,9 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
     float bv[8][4];
     if constexpr (!EXT) load_bias(bv);
     if constexpr (HAS_IN && !EARLY_IN) {  // (taller tiles have no registers to hold the whole input across the K loop: requested here, all blocks together)
+        constexpr bool PRE_DONE = !(RS > 0 && (EXT || TMW > 6));
 #pragma unroll
-        for (int blk = 1; blk < NBLK; ++blk) fetch_regs(blk);
+        for (int blk = PRE_DONE ? 1 : 0; blk < NBLK; ++blk) fetch_regs(blk);
     }
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
@@ -2194,17 +2199,18 @@ static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
     const bool one_round_short = std::min(c256, c192) <= 256 && a.K + a.K2 <= 2304;
     const bool multi_short = std::min(c256, c192) > 256 && a.K + a.K2 <= 2304;
     const int cls = multi_short ? ((a.epi == EPI_DGELU || a.epi == EPI_RESID) ? 2 : 1) : 4;
-    static const int short16 = env_int("FTMI_NT16_SHORT", 0);  // 1: the single-round short-K launches (N = K = 2048) take the 192 x 256 pipeline too.  Round 6, in the step, two boxes:
-    // 66.58 -> 66.23 ms on one (the GEMM class 0.2 ms slower, the attention backward behind it 0.5 ms faster), 63.39 -> 63.72 on the other: no decision, the default stays
-    if ((use16 & cls) && ok256 && a.M >= 1024 && (!one_round_short || short16)) {
+    static const int short16 = env_int("FTMI_NT16_SHORT", 1);  // the single-round short-K launches (N = K = 2048) take the 192 x 256 pipeline too (0: the 192 x 128 two-per-CU
+    // kernel of rounds 1-5).  Round 6, in the step: with the direct-to-LDS loop undecided (66.58 -> 66.23 ms on one box, 63.39 -> 63.72 on another); with the register-staged
+    // prefetch 64.15 -> 63.75 ms, four interleaved rounds (the GEMM class +0.15 ms, the attention backward behind the output-projection input gradient -0.55 ms)
+    if ((use16 & cls) && ok256 && a.M >= 1024 && (!one_round_short || (short16 && t192 >= 192))) {  // (a single round must at least fill three quarters of the CUs: batch 1 keeps 128 x 128 tiles)
         variant = c192 < c256 ? 86 : 80;
         // round 6: 224-row tiles where they save a whole share of a round (N = 8192 at M = 5376: 768 tiles = 3.0 rounds instead of 2.625 -> 3 of 256 rows)
         // round 6: 192-row tiles with the register-staged prefetch (nt_run_k_rs16, two register sets); FTMI_NT16_RS=0: the direct-to-LDS loop
-        static const int use_rs = env_int("FTMI_NT16_RS", 1);
-        if (variant == 86 && use_rs) variant = 2286;
+        static const int use_rs = env_int("FTMI_NT16_RS", 1);  // bit 0: 192-row tiles; bit 1: 224-row tiles without a K-extension (measured slower: 146.6 -> 153.2 us, default off)
+        if (variant == 86 && (use_rs & 1)) variant = 2286;  // (bit 1: the 224-row tiles too)
         static const int use224 = env_int("FTMI_NT224", 1);
         const long t224 = (long)((a.M + 223) / 224) * (a.N / 256), c224 = ((t224 + 255) / 256) * 224;
-        if (use224 && c224 < std::min(c256, c192)) variant = 87;
+        if (use224 && c224 < std::min(c256, c192)) variant = ((use_rs & 2) && a.K2 == 0) ? 2287 : 87;  // (with a K-extension the 224-row register-staged kernel would spill: never)
     } else if (a.M < 1024 || n192 < few192) {
         variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
     } else {
@@ -2373,6 +2379,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
             case 2286: if (ok256) return launch_nt16<6, 0, false, 2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, register-staged prefetch
+            case 2287: if (ok256 && a.K2 == 0) return launch_nt16<7, 0, false, 2>(a, st); else if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256, register-staged prefetch
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)
@@ -2425,6 +2432,7 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
             case 2286: if (ok256) return launch_nt16<6, 0, false, 2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, register-staged prefetch
+            case 2287: if (ok256 && a.K2 == 0) return launch_nt16<7, 0, false, 2>(a, st); else if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256, register-staged prefetch
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
             case 71: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE3>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // ... loads spread over 3 slices
             case 72: if (ok256) return launch_nt<256, 256, 64, 2, 4, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // the same pipeline, 8 waves x (128 x 64)

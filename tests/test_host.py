@@ -1061,8 +1061,8 @@ def test_gemm_dispatch_rule_matches_the_design(lib):
     assert plan(M, 2048, 8192, 0, EPI_RESID) == 2286     # ff2 forward: K = 8192, 28 x 8 tiles of 192 x 256 in one round -- with the register-staged prefetch (round 6)
     assert plan(M, 2048, 8192, 0, EPI_STORE) == 2286     # ff1 input gradient
     assert plan(M, 2048, 6144, 192, EPI_STORE) == 2286   # fused q|k|v input gradient
-    assert plan(M, 2048, 2048, 192, EPI_RESID) == 42     # to_out forward: one round, short K -> two workgroups per CU
-    assert plan(M, 2048, 2048, 192, EPI_STORE) == 42     # attn2.to_q forward
+    assert plan(M, 2048, 2048, 192, EPI_RESID) == 2286   # to_out forward: one round, short K -- 192 x 256 tiles with the register-staged prefetch since round 6
+    assert plan(M, 2048, 2048, 192, EPI_STORE) == 2286   # attn2.to_q forward   (FTMI_NT16_SHORT=0: 42, the 192 x 128 two-per-CU kernel of rounds 1-5)
     assert plan(2688, 2048, 2048, 0, EPI_STORE) == 44    # batch 1: 224 tiles of 192 x 128 would half-fill the machine
     assert plan(256, 4096, 2048, 192, EPI_STORE) == 44   # the text side (few rows)
     assert plan(M, 192, 2048, 0, EPI_STORE) == 2         # narrow plain store over many rows: the LDS-ring skinny kernel, whatever N % 128 is
