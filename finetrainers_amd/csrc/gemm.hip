@@ -365,6 +365,9 @@ FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char
     // hipcc does not know what the MFMA statements write or when: every accumulator passes through this statement (so no ordinary read of
     // one can be scheduled above it) and the wait states of the last MFMAs' results sit inside it
     auto acc_fence = [&]() {
+        // (12 wait states first: an 8-pass MFMA's result may be read 11 wait states after its issue -- the statements below release a row of tiles after 8 each,
+        //  which the order of the last slice's MFMAs covers in the default placement but not in every lab placement: tools/mfma_hazard_lint.py)
+        asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             if constexpr (AG) {
@@ -437,6 +440,9 @@ FTMI_DEVICE void nt_run_k_pipe(f32x16 (&acc)[256 / WN / 32][256 / WM / 32], char
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         so ^= 65536u;
+        // (hipcc may split an accumulator tile's live range at the loop exit and copy it right behind the branch, a handful of instructions after the last MFMA,
+        //  whose result an ordinary instruction may read 11 wait states after its issue at the earliest: tools/mfma_hazard_lint.py)
+        if (s + 1 == S) asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     acc_fence();
@@ -1113,13 +1119,14 @@ FTMI_DEVICE void pl_ds_write16(uint32_t a, const u32x4& d, int t) {  // t * 1024
     }
 }
 
-template <int TMW, bool EXT, int RS, int NPRE = 0, class MID, class STAMP = NoStamp, class PRE = NoPre, class EARLY = NoPre, class EXTRDY = NoPre>
+template <int TMW, bool EXT, int RS, int NPRE = 0, int DBG = 0, int HY = 0, class MID, class STAMP = NoStamp, class PRE = NoPre, class EARLY = NoPre, class EXTRDY = NoPre>
 FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t* __restrict__ X, long ldx, int m0, int M, const bf16_t* __restrict__ W, long ldw,
                                int nk1, const bf16_t* __restrict__ X2, long ldx2, const bf16_t* __restrict__ W2, long ldw2, int nk2, int tid, MID mid, STAMP stamp = STAMP(),
                                PRE pre = PRE(), EARLY early = EARLY(), EXTRDY ext_rdy = EXTRDY()) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int XI = TMW, LPT = XI + 8, NMF = 8 * TMW, NRD = 8 + TMW, RG = NMF / NRD;
     static_assert(RS == 2 || RS == 3, "two or three register sets");
+    static_assert(!HY || RS == 2, "the hybrid ring stages X through two register sets");
     static_assert(NMF / RG >= NRD && NMF / RG >= LPT, "gaps");
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -1143,9 +1150,10 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
 
     // prologue only: stages 0 and 1 straight into the LDS (the direct-to-LDS path of nt_run_k_pipe16)
-    auto dma = [&](int i, int t) {
+    // (HY: the W image of stage t sits in slot t % 3 of a THREE-slot ring at +32 KB, +96 KB, +128 KB -- `wo` = its offset relative to +32 KB; X keeps two slots)
+    auto dma = [&](int i, int t, uint32_t wo) {
         const bool isx = i < XI;
-        const uint32_t dst = lds0 + (uint32_t)(t & 1) * 65536u + (isx ? (uint32_t)(wave * XI + i) * 1024u : 32768u + (uint32_t)(wave * 8 + (i - XI)) * 1024u);
+        const uint32_t dst = lds0 + (isx ? (uint32_t)(t & 1) * 65536u + (uint32_t)(wave * XI + i) * 1024u : wo + 32768u + (uint32_t)(wave * 8 + (i - XI)) * 1024u);
         const int tt = min(t, S - 1);
         const bool seg2 = EXT && tt >= nk1;
         const int soff = (seg2 ? tt - nk1 : tt) * 128;
@@ -1159,7 +1167,7 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
     // take AGPR data operands directly, and the 192-row tile leaves 64 AGPRs beside its accumulators.)
     constexpr int AFREE = 64 - 8 * TMW;  // 16-byte entries that fit beside the accumulators: 16 (192 rows: the W blocks of both sets), 8 (224 rows: those of set 0)
     auto in_agpr = [](int i, int set) constexpr { return i >= XI && set * 8 + (i - XI) < AFREE; };
-    u32x4 R[RS][LPT];
+    u32x4 R[RS][HY ? XI : LPT];
     // load i of stage t (stages past the end: the last one again, nobody stores it) into register set `set` (a constant after unrolling)
     auto gld = [&](int i, int t, int set) {
         const bool isx = i < XI;
@@ -1187,32 +1195,45 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
         rax[kk] = lds0 + (uint32_t)((wm * 16 * TMW + l15) * 128 + (ch << 4));
     }
     s16x8 F[2][NRD];
-    auto rd = [&](int par, int q, int kk, uint32_t so) {
+    auto rd = [&](int par, int q, int kk, uint32_t so, uint32_t wo) {
         const int r = q == 0 ? 0 : (q <= TMW ? 7 + q : q - TMW);
-        if (r < 8) pl_ds_read16(F[par][r], raw[kk] + so, r);
+        if (r < 8) pl_ds_read16(F[par][r], raw[kk] + wo, r);
         else pl_ds_read16(F[par][r], rax[kk] + so, r - 8);
     };
 
     // prologue: stages 0, 1 -> LDS; stages 2 .. RS -> register sets 2 % RS .. RS % RS (stage 1 + RS follows in the first slice of stage 0)
+    // (HY: X of stage 2 -> register set 0, then W of stage 2 -> ring slot 2, the order the loop issues them in)
 #pragma unroll
-    for (int i = 0; i < LPT; ++i) dma(i, 0);
+    for (int i = 0; i < LPT; ++i) dma(i, 0, 0u);
 #pragma unroll
-    for (int i = 0; i < LPT; ++i) dma(i, 1);
+    for (int i = 0; i < LPT; ++i) dma(i, 1, 65536u);
+    if constexpr (HY) {
+        if constexpr (HY == 1) {
 #pragma unroll
-    for (int t = 2; t <= RS; ++t)
+            for (int i = 0; i < XI; ++i) gld(i, 2, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) gld(i, t, t % RS);
+        for (int i = XI; i < LPT; ++i) dma(i, 2, 98304u);
+    } else {
+#pragma unroll
+        for (int t = 2; t <= RS; ++t)
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) gld(i, t, t % RS);
+    }
     pre();
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 1) * LPT + NPRE) : "memory");  // stages 0 and 1 have landed (loads retire in order)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((HY == 2 ? 8 : (RS - 1) * LPT) + NPRE) : "memory");  // stages 0 and 1 have landed (loads retire in order)
 #pragma unroll
-    for (int q = 0; q < NRD; ++q) rd(0, q, 0, 0u);
+    for (int q = 0; q < NRD; ++q) rd(0, q, 0, 0u, 0u);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stamp(2);
 
     uint32_t so = 0;
+    uint32_t w0 = 0u, w1 = 65536u, w2 = 98304u;  // HY: W ring offsets of stages s, s + 1, s + 2 (wave-uniform: scalar registers)
     // one stage; PH = s % RS (a constant: it names the register sets)
-    auto stage = [&](int s, auto PH) __attribute__((always_inline)) {
+    // (LAST: the stage S - 1 behind the unrolled loop where S is not a multiple of RS -- nothing is left to request or to store, its rendezvous collects everything)
+    auto stage = [&](int s, auto PH, auto LAST) __attribute__((always_inline)) {
         constexpr int ph = decltype(PH)::value;
+        constexpr bool last = decltype(LAST)::value;
         constexpr int set_in = (ph + 1) % RS;   // receives stage s + 1 + RS (the set that stage s + 1 left during the second slice of stage s - 1)
         constexpr int set_out = (ph + 2) % RS;  // holds stage s + 2: stored into the slot of stage s behind P_s
         if (s == 1) early();
@@ -1228,41 +1249,69 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
         cfor<0, 2>([&](auto SL) __attribute__((always_inline)) {
             constexpr int sl = decltype(SL)::value;
             // P_s: stage s + 2 has landed in its registers (the RS - 1 younger stages stay in flight), everyone has read all of stage s
-            if constexpr (sl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((RS - 1) * LPT) : "memory");
+            // (HY: the same count -- the XI register loads of stage s + 3 and the 8 direct-to-LDS loads of W stage s + 2 stay in flight; X of stage s + 2 is in its
+            //  registers and W of stage s + 1 in its slot)
+            if constexpr (sl == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(last ? 0 : HY == 2 ? 8 : (RS - 1) * LPT) : "memory");
             cfor<0, NMF>([&](auto MM) __attribute__((always_inline)) {
                 constexpr int m = decltype(MM)::value;
-                pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
-                if constexpr (m % RG == 0 && m / RG < NRD) {  // fragment reads of the next slice
-                    if constexpr (sl == 0) rd(1, m / RG, 1, so);
-                    else rd(0, m / RG, 0, so ^ 65536u);
+                // (DBG, tools/gemm_lab.hip only, results wrong on purpose: 5 = no MFMAs, 12 = no MFMAs and no LDS stores, 13 = no MFMAs, no stores, no fragment reads)
+                if constexpr (DBG != 5 && DBG != 12 && DBG != 13) pl_mfma16(acc[m / TMW][m % TMW], F[sl][m / TMW], F[sl][8 + m % TMW]);
+                if constexpr (m % RG == 0 && m / RG < NRD && DBG != 13) {  // fragment reads of the next slice
+                    // (not behind the last stage: a fragment nobody multiplies is a DEAD asm output to hipcc -- it hands the register to the next value while the
+                    //  LDS read is still in flight.  Seen as a memory fault: the address register of a load was such a register, launches with a K-extension and an odd
+                    //  number of stages only.  Inside the loop the fragments stay live around the back edge.)
+                    if constexpr (sl == 0) rd(1, m / RG, 1, so, HY ? w0 : so);
+                    else if constexpr (!last) rd(0, m / RG, 0, so ^ 65536u, HY ? w1 : so ^ 65536u);
                 }
-                if constexpr (m % RG == RG / 2 && m / RG < LPT) {
-                    if constexpr (sl == 0) gld(m / RG, s + 1 + RS, set_in);  // request stage s + 1 + RS
-                    else lst(m / RG, set_out, so);                            // stage s + 2: registers -> the slot stage s has just left
+                if constexpr (m % RG == RG / 2 && m / RG < LPT && !last) {
+                    constexpr int j = m / RG;
+                    if constexpr (HY) {
+                        // X of stage s + 3 -> registers (first slice); behind P_s: X of stage s + 2 registers -> the X slot stage s has left, W of stage s + 3
+                        // straight into the ring slot stage s has left (needed by P_{s+2}: two periods of flight)
+                        // (HY == 2, lab: X direct-to-LDS as well, two slots, one period of flight -- X of stage s + 2 first, then W of stage s + 3)
+                        if constexpr (sl == 0) { if constexpr (j < XI && HY == 1) gld(j, s + 3, set_in); }
+                        else if constexpr (j < XI) { if constexpr (HY == 2) dma(j, s + 2, 0u); else if constexpr (DBG != 12 && DBG != 13) lst(j, set_out, so); }
+                        else dma(j, s + 3, w0);
+                    } else {
+                        if constexpr (sl == 0) gld(j, s + 1 + RS, set_in);  // request stage s + 1 + RS
+                        else if constexpr (DBG != 12 && DBG != 13) lst(j, set_out, so);  // stage s + 2: registers -> the slot stage s has just left
+                    }
                 }
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         });
         so ^= 65536u;
+        if constexpr (HY) { const uint32_t t = w0; w0 = w1; w1 = w2; w2 = t; }
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     using P2 = std::integral_constant<int, 2>;
+    // settle(): twelve wait states on every path that LEAVES the unrolled loop.  The MFMAs sit inside asm statements, so hipcc's hazard recogniser does not know
+    // that the accumulators are matrix-pipe results (gfx950 has no interlock: passes + 3 = 7 wait states between a 16 x 16 x 32 MFMA and an ordinary read of its result) -- and where
+    // its register allocator splits an accumulator tile's live range at the loop exit it puts the copy (v_accvgpr_mov_b32) right behind the branch, five
+    // instructions after the last MFMA.  Seen as ONE wrong register (a220 <- a224) in the 224-row GELU' instantiation of the three-slot loop; the copies of a phi
+    // are placed at the end of the predecessor block, i.e. behind this statement.  tools/mfma_hazard_lint.py checks every built kernel for the distance.
+    auto settle = [&]() { asm volatile("s_nop 7\n\ts_nop 3" ::: "memory"); };
     int s = 0;
     if constexpr (RS == 2) {
         for (; s + 1 < S; s += 2) {
-            stage(s, P0{});
-            stage(s + 1, P1{});
+            stage(s, P0{}, std::false_type{});
+            stage(s + 1, P1{}, std::false_type{});
+            if (s + 3 >= S) settle();
         }
-        if (s < S) stage(s, P0{});
+        if (s < S) {
+            stage(s, P0{}, std::true_type{});
+            settle();
+        }
     } else {
         for (; s + 2 < S; s += 3) {
-            stage(s, P0{});
-            stage(s + 1, P1{});
-            stage(s + 2, P2{});
+            stage(s, P0{}, std::false_type{});
+            stage(s + 1, P1{}, std::false_type{});
+            stage(s + 2, P2{}, std::false_type{});
+            if (s + 5 >= S) settle();
         }
-        if (s < S) { stage(s, P0{}); ++s; }
-        if (s < S) stage(s, P1{});
+        if (s < S) { stage(s, P0{}, std::false_type{}); ++s; settle(); }
+        if (s < S) { stage(s, P1{}, std::false_type{}); settle(); }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     acc_fence16<TMW>(acc);
@@ -1270,7 +1319,7 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
 #pragma unroll
     for (int t = 0; t < RS; ++t)
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
+        for (int i = 0; i < (HY ? XI : LPT); ++i) {
             if (in_agpr(i, t)) asm volatile("" ::"a"(R[t][i]));
             else asm volatile("" ::"v"(R[t][i]));
         }
@@ -1488,7 +1537,8 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
     //  round trip is exposed at most, behind the arithmetic of block 0.)
     constexpr int NBLK_IN = (TMW + 1) / 2;
     // 192-row tiles have 188 registers to spare: their whole row-wise input (96 registers) is requested at stage 1 of the K loop and arrives under it
-    constexpr bool EARLY_IN = HAS_IN && !RING && TMW <= 6 && !EXT && RS == 0;  // (the register-staged loop keeps its prefetch in those registers)  // (with a K-extension the second set of load offsets takes the spare registers)
+    constexpr bool REGS_STAGED = RS > 0 && RS != 13;  // (RS 13 = the three-slot W ring with X direct-to-LDS: no prefetch registers, the budget of the two-slot loop)
+    constexpr bool EARLY_IN = HAS_IN && !RING && TMW <= 6 && !EXT && !REGS_STAGED;  // (the register-staged loop keeps its prefetch in those registers)  // (with a K-extension the second set of load offsets takes the spare registers)
     u32x4 pre[HAS_IN ? NBLK_IN : 1][HAS_IN ? 8 : 1];
     auto fetch_regs = [&](int blk) {
 #pragma unroll
@@ -1508,7 +1558,7 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
         auto stamp = [&](int i) { NT_STAMP(p, i); (void)i; };
         // (block 0 of the row-wise input before the K loop -- except where the register-staged loop has no 32 architectural VGPRs to spare for it: 224-row tiles and
         //  K-extension launches request it after the loop with the other blocks; a spill there would copy load destinations that have not arrived)
-        constexpr bool PRE_IN = HAS_IN && !(RS > 0 && (EXT || TMW > 6));
+        constexpr bool PRE_IN = HAS_IN && !(REGS_STAGED && (EXT || TMW > 6));
         auto pre_in = [&]() { if constexpr (PRE_IN) fetch_regs(0); };
         auto early_in = [&]() {
             if constexpr (EARLY_IN) {
@@ -1520,7 +1570,7 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
             pre_in();
             nt_run_k_ring16<TMW, EXT, DBG>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 32, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 32 : 0, tid, mid_round);
         } else if constexpr (RS > 0)
-            nt_run_k_rs16<TMW, EXT, RS, PRE_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
+            nt_run_k_rs16<TMW, EXT, RS >= 12 ? 2 : RS, PRE_IN ? 8 : 0, DBG, RS == 12 ? 1 : RS == 13 ? 2 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
                                                       pre_in, early_in, [&]() { ext_ready(m0, BM); });
         else
             nt_run_k_pipe16<TMW, EXT, DBG, HAS_IN ? 8 : 0>(acc, smem, X1, p.ldx, m0, p.M, Wt, p.ldw, p.K / 64, X2, p.ldx2, W2t, p.ldw2, EXT ? p.K2 / 64 : 0, tid, mid_round, stamp,
@@ -1554,7 +1604,7 @@ FTMI_DEVICE void nt16_body(const GemmNtArgs& p, char* smem, const int bid, READY
     float bv[8][4];
     if constexpr (!EXT) load_bias(bv);
     if constexpr (HAS_IN && !EARLY_IN) {  // (taller tiles have no registers to hold the whole input across the K loop: requested here, all blocks together)
-        constexpr bool PRE_DONE = !(RS > 0 && (EXT || TMW > 6));
+        constexpr bool PRE_DONE = !(REGS_STAGED && (EXT || TMW > 6));
 #pragma unroll
         for (int blk = PRE_DONE ? 1 : 0; blk < NBLK; ++blk) fetch_regs(blk);
     }
@@ -1669,7 +1719,7 @@ template <int TMW, int EPI, bool EXT, int DBG, bool RING, int RS = 0>
 static int launch_nt16_3(const GemmNtArgs& a0, hipStream_t st) {
     GemmNtArgs a = a0;
     choose_xcd_map(a, 32 * TMW, 256);
-    constexpr int kSmem = RING ? 163840 : 131072;
+    constexpr int kSmem = (RING || RS >= 12) ? 163840 : 131072;  // RS 12 = the hybrid loop: two X slots + a three-slot W ring
     ProfScope prof(PROF_GEMM_NT, 2.0 * a.M * a.N * ((double)a.K + (double)a.K2 / 3.0), st);
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<TMW, EPI, EXT, DBG, RING, RS>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem) == hipSuccess;
     if (!attr_ok) return set_error(FTMI_ERR_LAUNCH, "gemm_nt: cannot raise the dynamic LDS limit");
@@ -2211,6 +2261,17 @@ static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
         static const int use224 = env_int("FTMI_NT224", 1);
         const long t224 = (long)((a.M + 223) / 224) * (a.N / 256), c224 = ((t224 + 255) / 256) * 224;
         if (use224 && c224 < std::min(c256, c192)) variant = ((use_rs & 2) && a.K2 == 0) ? 2287 : 87;  // (with a K-extension the 224-row register-staged kernel would spill: never)
+        // round 6, last: the W operand on a THREE-slot direct-to-LDS ring (two stage periods of flight instead of one; X keeps two slots: 2 x 32 TMW rows + 3 x 256 rows of
+        // 128 B <= 160 KB for every tile height), X direct-to-LDS as before: the registers of the two-slot loop.  (X through the register sets on top of it -- 1.5 periods
+        // for X as well -- measures the same and exists in the lab only: variants 128x of tools/gemm_lab.hip.)
+        // In the step (profiles/r06_instep_ab_w3_*.txt): 192-row tiles 62.8 -> 61.3 ms; 224- and 256-row tiles as well 61.5 (their launches gain 1-4 % in the lab and
+        // nothing here; the 256-row kernel with a K-extension spills 72 bytes).  Default: the 192-row launches.
+        static const int use_w3 = env_int("FTMI_NT16_W3", 1);  // bit 0: 192-row tiles, bit 1: 224-row, bit 2: 256-row
+        {
+            const int tmw = variant % 10;  // 86 / 2286 -> 6, 87 / 2287 -> 7, 80 -> 0
+            const int bit = tmw == 6 ? 1 : tmw == 7 ? 2 : 4;
+            if (use_w3 & bit) variant = 1380 + tmw;
+        }
     } else if (a.M < 1024 || n192 < few192) {
         variant = 44;  // few rows (the text side) or few tiles: 128 x 128 tiles
     } else {
@@ -2356,6 +2417,22 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 2287: return launch_nt16<7, 0, false, 2>(a, st);
             case 2280: return launch_nt16<8, 0, false, 2>(a, st);
             case 586: return launch_nt16<6, 5>(a, st);   // no MFMAs (memory side alone)
+            case 1386: return launch_nt16<6, 0, false, 13>(a, st);
+            case 1387: return launch_nt16<7, 0, false, 13>(a, st);
+            case 1380: return launch_nt16<8, 0, false, 13>(a, st);
+            case 1286: return launch_nt16<6, 0, false, 12>(a, st);
+            case 1287: return launch_nt16<7, 0, false, 12>(a, st);
+            case 1280: return launch_nt16<8, 0, false, 12>(a, st);
+            case 12086: return launch_nt16<6, 0, false, 12>(a, st);  // hybrid: X register-staged, W on a three-slot direct-to-LDS ring
+            case 12087: return launch_nt16<7, 0, false, 12>(a, st);
+            case 13086: return launch_nt16<6, 0, false, 13>(a, st);  // X direct-to-LDS too (two slots), W three-slot ring
+            case 13087: return launch_nt16<7, 0, false, 13>(a, st);
+            case 13080: return launch_nt16<8, 0, false, 13>(a, st);
+            case 12080: return launch_nt16<8, 0, false, 12>(a, st);
+            case 12586: return launch_nt16<6, 5, false, 12>(a, st);  // ... without MFMAs
+            case 5286: return launch_nt16<6, 5, false, 2>(a, st);   // register-staged loop: no MFMAs
+            case 12286: return launch_nt16<6, 12, false, 2>(a, st); // ... and no LDS stores
+            case 13286: return launch_nt16<6, 13, false, 2>(a, st); // ... and no fragment reads
             case 1086: return launch_nt16<6, 10>(a, st); // no MFMAs, no rendezvous: the loads as fast as they issue
             case 1080: return launch_nt16<8, 10>(a, st);
             case 686: return launch_nt16<6, 6>(a, st);   // no loads, no rendezvous
@@ -2378,6 +2455,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
+            case 1386: if (ok256) return launch_nt16<6, 0, false, 13>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, W on the three-slot ring
+            case 1387: if (ok256) return launch_nt16<7, 0, false, 13>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
+            case 1380: if (ok256) return launch_nt16<8, 0, false, 13>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256
             case 2286: if (ok256) return launch_nt16<6, 0, false, 2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, register-staged prefetch
             case 2287: if (ok256 && a.K2 == 0) return launch_nt16<7, 0, false, 2>(a, st); else if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256, register-staged prefetch
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline
@@ -2431,6 +2511,9 @@ int gemm_nt(const GemmNtArgs& a, hipStream_t st) {
             case 80: if (ok256) return launch_nt16<8>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256 on 16 x 16 x 32 MFMAs
             case 86: if (ok256) return launch_nt16<6>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256
             case 87: if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
+            case 1386: if (ok256) return launch_nt16<6, 0, false, 13>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, W on the three-slot ring
+            case 1387: if (ok256) return launch_nt16<7, 0, false, 13>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256
+            case 1380: if (ok256) return launch_nt16<8, 0, false, 13>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 256 x 256
             case 2286: if (ok256) return launch_nt16<6, 0, false, 2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 192 x 256, register-staged prefetch
             case 2287: if (ok256 && a.K2 == 0) return launch_nt16<7, 0, false, 2>(a, st); else if (ok256) return launch_nt16<7>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 224 x 256, register-staged prefetch
             case 70: if (ok256) return launch_nt<256, 256, 64, 2, 2, true, 1, KL_PIPE2>(a, st); else return launch_nt<192, 128, 64, 2, 2, true, 2, KL_GEN2_BUF>(a, st);  // 4 waves x (128 x 128), hand-placed pipeline

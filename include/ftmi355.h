@@ -113,7 +113,7 @@ int ftmi_gemm_nt(int M, int N, int K, const void* x, long ldx, const void* w, lo
                  void* out, long ldo, int epilogue, void* out2, const void* resid, const void* gate, int rows_per_batch,
                  const void* aux, long ld_side, int variant, ftmi_stream stream);
 /* Which kernel variant 8 takes for a plain launch of this shape (K2 = depth of a fused LoRA K-extension or 0; epilogue as above), as a pure host function
- * (no device, no launch): 80 / 86 / 87 = the 16 x 16 x 32 pipeline with 256- / 192- / 224-row tiles (2286 = 192-row tiles with the register-staged operand prefetch), 42 = 192 x 128 tiles (two workgroups per CU), 47 = 256 x 256
+ * (no device, no launch): 80 / 86 / 87 = the 16 x 16 x 32 pipeline with 256- / 192- / 224-row tiles (1386 = 192-row tiles with the W operand on a three-slot direct-to-LDS ring: the default of the 192-row launches; 2286 = 192-row tiles with the register-staged operand prefetch, FTMI_NT16_W3=0), 42 = 192 x 128 tiles (two workgroups per CU), 47 = 256 x 256
  * (8 waves), 44 = 128 x 128, 2 = a skinny kernel (N <= 256, plain store, no extension, M >= 512: the LDS-ring kernel when K % 256 == 0, else the direct-gather one), 1 = the 128 x 64 kernel of N % 128 != 0,
  * 0 = not a tiled launch (N % 64 or K % 64).  Host tests pin the choice to DESIGN.md. */
 int ftmi_gemm_nt_plan(int M, int N, int K, int K2, int epilogue);

@@ -60,7 +60,7 @@ def report(name, got, ref, rel_tol, max_ulp_frac=None):
 # the tiled-GEMM kernels the product library ships: 8 = automatic choice (production), 42 / 44 / 47 pin 192x128 / 128x128 / 256x256 tiles,
 # 70 = the hand-placed 4-wave pipeline (128 x 128 per wave, accumulators in AGPRs), 80 / 86 = that pipeline on 16 x 16 x 32 MFMAs (256 x 256 / 192 x 256 tiles), 72 = the 32 x 32
 # stream on 8 waves (the research variants of tools/experimental/gemm_experimental.hip.h are not in the product build)
-SHIPPED_VARIANTS = [8, 42, 44, 47, 70, 72, 80, 86, 87, 2286]
+SHIPPED_VARIANTS = [8, 42, 44, 47, 70, 72, 80, 86, 87, 2286, 1386, 1387, 1380]
 
 
 def rnd(shape, gen, scale=1.0, dtype=bf16):
@@ -118,6 +118,36 @@ def _split_ref(t):
     hi = t.to(bf16)
     lo = (t - hi.float()).to(bf16)
     return hi, lo
+
+
+@pytest.mark.parametrize("base,others", [(86, (2286, 1386)), (87, (1387,)), (80, (1380,))])
+@pytest.mark.parametrize("M,N,K", [(5376, 2048, 2048), (1100, 512, 8192), (1024, 256, 64), (1024, 256, 128), (1024, 256, 192), (1024, 256, 256), (1024, 256, 320)])
+def test_nt16_k_loops_are_bit_identical(M, N, K, base, others):
+    """The K loops of gemm_nt16_kernel (round 6: register-staged prefetch 22xx, W on a three-slot direct-to-LDS ring 13xx) issue the same MFMAs on the
+    same fragments in the same order as the two-slot loop: every epilogue and the LoRA K-extension must agree bit for bit -- including K of one, two and three
+    stages, where the prologue's loads are all there is."""
+    from finetrainers_amd import _lib, ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = rnd((M, K), g).to(dev), rnd((N, K), g, 1 / math.sqrt(K)).to(dev), rnd((N,), g).to(dev)
+    resid, z = rnd((M, N), g).to(dev), rnd((M, N), g).to(dev)
+    A = (torch.randn(64, K, generator=g) / math.sqrt(K)).to(dev)
+    Bm = (torch.randn(N, 64, generator=g) * 0.05).to(dev)
+
+    def run(v):
+        outs = [ops.gemm_nt(x, w, b, variant=v), ops.gemm_nt(x, w, b, epilogue=_lib.EPI_RESID, resid=resid, variant=v),
+                ops.gemm_nt(x, w, b, epilogue=_lib.EPI_DGELU, aux=z, variant=v)]
+        y, pre = ops.gemm_nt(x, w, b, epilogue=_lib.EPI_GELU, want_out2=True, variant=v)
+        outs += [y, pre]
+        if K >= 256:  # (the down-projection kernel's minimum)
+            outs.append(ops.linear_lora_fwd(x, w, b, A, Bm, 0.5, variant=v)[0])
+        return outs
+
+    ref = run(base)
+    for v in others:
+        for i, (a, r) in enumerate(zip(run(v), ref)):
+            assert torch.equal(a, r), f"variant {v} differs from {base} in output {i}"
 
 
 @pytest.mark.parametrize("variant", SHIPPED_VARIANTS)

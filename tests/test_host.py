@@ -1058,11 +1058,11 @@ def test_gemm_dispatch_rule_matches_the_design(lib):
     assert plan(M, 6144, 2048, 192, EPI_STORE) == 80     # fused q|k|v forward with the LoRA K-extension: 21 x 24 tiles of 256 x 256, two rounds
     assert plan(M, 8192, 2048, 0, EPI_GELU) == 87        # ff1 forward (GELU + stash): 24 x 32 tiles of 224 x 256 = exactly three rounds of the 256 CUs (round 6)
     assert plan(M, 8192, 2048, 0, EPI_DGELU) == 87       # ff2 input gradient (GELU')
-    assert plan(M, 2048, 8192, 0, EPI_RESID) == 2286     # ff2 forward: K = 8192, 28 x 8 tiles of 192 x 256 in one round -- with the register-staged prefetch (round 6)
-    assert plan(M, 2048, 8192, 0, EPI_STORE) == 2286     # ff1 input gradient
-    assert plan(M, 2048, 6144, 192, EPI_STORE) == 2286   # fused q|k|v input gradient
-    assert plan(M, 2048, 2048, 192, EPI_RESID) == 2286   # to_out forward: one round, short K -- 192 x 256 tiles with the register-staged prefetch since round 6
-    assert plan(M, 2048, 2048, 192, EPI_STORE) == 2286   # attn2.to_q forward   (FTMI_NT16_SHORT=0: 42, the 192 x 128 two-per-CU kernel of rounds 1-5)
+    assert plan(M, 2048, 8192, 0, EPI_RESID) == 1386     # ff2 forward: K = 8192, 28 x 8 tiles of 192 x 256 in one round -- W on the three-slot direct-to-LDS ring (round 6)
+    assert plan(M, 2048, 8192, 0, EPI_STORE) == 1386     # ff1 input gradient
+    assert plan(M, 2048, 6144, 192, EPI_STORE) == 1386   # fused q|k|v input gradient
+    assert plan(M, 2048, 2048, 192, EPI_RESID) == 1386   # to_out forward: one round, short K -- 192 x 256 tiles since round 6
+    assert plan(M, 2048, 2048, 192, EPI_STORE) == 1386   # attn2.to_q forward   (FTMI_NT16_SHORT=0: 42, the 192 x 128 two-per-CU kernel of rounds 1-5)
     assert plan(2688, 2048, 2048, 0, EPI_STORE) == 44    # batch 1: 224 tiles of 192 x 128 would half-fill the machine
     assert plan(256, 4096, 2048, 192, EPI_STORE) == 44   # the text side (few rows)
     assert plan(M, 192, 2048, 0, EPI_STORE) == 2         # narrow plain store over many rows: the LDS-ring skinny kernel, whatever N % 128 is
@@ -1071,8 +1071,8 @@ def test_gemm_dispatch_rule_matches_the_design(lib):
     assert plan(M, 192, 2048, 192, EPI_STORE) == 1       # a K-extension keeps it off the skinny route
     assert plan(M, 2048, 100, 0, EPI_STORE) == 0 and plan(M, 100, 2048, 0, EPI_STORE) == 0
     # Wan-1.3B's widths (1536, 4608, 8960 = 35 x 256) take the same pipeline; CogVideoX-2b's 1920 = 7.5 x 256 keeps the 32 x 32 x 16 kernels
-    assert plan(21504, 4608, 1536, 0, EPI_STORE) in (80, 86, 87, 2286) and plan(21504, 8960, 1536, 0, EPI_GELU) in (80, 86, 87, 2286)
-    assert plan(17776, 1920, 1920, 0, EPI_STORE) not in (80, 86, 87, 2286) and plan(17776, 7680, 1920, 0, EPI_GELU) in (80, 86, 87, 2286)
+    assert plan(21504, 4608, 1536, 0, EPI_STORE) in (80, 86, 87, 2286, 1386, 1387, 1380) and plan(21504, 8960, 1536, 0, EPI_GELU) in (80, 86, 87, 2286, 1386, 1387, 1380)
+    assert plan(17776, 1920, 1920, 0, EPI_STORE) not in (80, 86, 87, 2286, 1386, 1387, 1380) and plan(17776, 7680, 1920, 0, EPI_GELU) in (80, 86, 87, 2286, 1386, 1387, 1380)
 
 
 def test_parallel_backend_has_the_reference_surface():
@@ -1386,3 +1386,22 @@ def test_head_dim_128_stream_waits_for_every_lds_fragment_it_consumes():
                             assert r not in queue, f"`{t}` reads {r} while its load is still in flight ({len(queue)} outstanding)"
                             consumed[r] = True
     assert n_checked >= 2 * (32 + 32 + 16 + 8)  # per trip: 16 + 16 transposed-fragment halves x 2 slots ..., row fragments, accumulator-input rows
+
+
+def test_no_accumulator_is_read_before_the_matrix_pipe_has_written_it():
+    """tools/mfma_hazard_lint.py on the built code objects: the MFMAs of the hand-placed kernels sit inside asm statements, so hipcc's hazard recogniser does not
+    know their results are matrix-pipe results -- a copy it inserts at a loop exit (live-range split of an accumulator tile) can come passes + 3 wait states too
+    early.  Round 6 met exactly that (one accumulator register of the 224-row GELU' kernel wrong); the kernels now settle on every exit path and this test
+    proves the distance on every kernel whose MFMAs are asm, for whatever register allocation this build produced."""
+    import importlib.util
+
+    build = os.path.join(ROOT, "finetrainers_amd", "csrc", "build")
+    objs = [os.path.join(build, f) for f in ("gemm.hip.o", "attention.hip.o")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("no object files: run __graft_entry__.build() first")
+    spec = importlib.util.spec_from_file_location("mfma_hazard_lint", os.path.join(ROOT, "tools", "mfma_hazard_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    for o in objs:
+        early = [x for x in lint.lint(lint.disassemble(o)) if any(k in x[0] for k in lint.ASM_KERNELS)]
+        assert not early, f"{o}: {len(early)} early accumulator reads, first: {early[0]}"
