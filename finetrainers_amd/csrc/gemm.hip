@@ -1038,7 +1038,7 @@ FTMI_DEVICE void nt_run_k_pipe16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_
 
     uint32_t so = 0;
     for (int s = 0; s < S; ++s) {
-        if (s == 1) early();
+        if (s == (S > 1 ? 1 : 0)) early();  // (a single-stage launch has no stage 1)
         if constexpr (EXT) {
             if (s == nk1 - 2) ext_rdy();
             if (s == nk1) {
@@ -1236,7 +1236,7 @@ FTMI_DEVICE void nt_run_k_rs16(f32x4_t (&acc)[8][TMW], char* smem, const bf16_t*
         constexpr bool last = decltype(LAST)::value;
         constexpr int set_in = (ph + 1) % RS;   // receives stage s + 1 + RS (the set that stage s + 1 left during the second slice of stage s - 1)
         constexpr int set_out = (ph + 2) % RS;  // holds stage s + 2: stored into the slot of stage s behind P_s
-        if (s == 1) early();
+        if (s == (S > 1 ? 1 : 0)) early();  // (a single-stage launch has no stage 1)
         if constexpr (EXT) {
             if (s == nk1 - 2) ext_rdy();
             if (s == nk1) {
