@@ -2249,10 +2249,13 @@ static int nt_auto_variant(const GemmNtArgs& a, bool ok256) {
     const bool one_round_short = std::min(c256, c192) <= 256 && a.K + a.K2 <= 2304;
     const bool multi_short = std::min(c256, c192) > 256 && a.K + a.K2 <= 2304;
     const int cls = multi_short ? ((a.epi == EPI_DGELU || a.epi == EPI_RESID) ? 2 : 1) : 4;
-    static const int short16 = env_int("FTMI_NT16_SHORT", 1);  // the single-round short-K launches (N = K = 2048) take the 192 x 256 pipeline too (0: the 192 x 128 two-per-CU
+    static const int short16 = env_int("FTMI_NT16_SHORT", 3);  // the single-round short-K launches (N = K = 2048) take the 192 x 256 pipeline too (0: the 192 x 128 two-per-CU
     // kernel of rounds 1-5).  Round 6, in the step: with the direct-to-LDS loop undecided (66.58 -> 66.23 ms on one box, 63.39 -> 63.72 on another); with the register-staged
     // prefetch 64.15 -> 63.75 ms, four interleaved rounds (the GEMM class +0.15 ms, the attention backward behind the output-projection input gradient -0.55 ms)
-    if ((use16 & cls) && ok256 && a.M >= 1024 && (!one_round_short || (short16 && t192 >= 192))) {  // (a single round must at least fill three quarters of the CUs: batch 1 keeps 128 x 128 tiles)
+    // (bit 0: launches whose epilogue has no row-wise input; bit 1: residual / GELU' launches too -- their epilogue reads and writes its tile in one burst per CU where the
+    //  two-per-CU kernel hides one workgroup's epilogue behind the other's K loop: 61.4 against 56.6 us in the step)
+    const int short_bit = (a.epi == EPI_RESID || a.epi == EPI_DGELU) ? 2 : 1;
+    if ((use16 & cls) && ok256 && a.M >= 1024 && (!one_round_short || ((short16 & short_bit) && t192 >= 192))) {  // (a single round must at least fill three quarters of the CUs: batch 1 keeps 128 x 128 tiles)
         variant = c192 < c256 ? 86 : 80;
         // round 6: 224-row tiles where they save a whole share of a round (N = 8192 at M = 5376: 768 tiles = 3.0 rounds instead of 2.625 -> 3 of 256 rows)
         // round 6: 192-row tiles with the register-staged prefetch (nt_run_k_rs16, two register sets); FTMI_NT16_RS=0: the direct-to-LDS loop
