@@ -46,6 +46,8 @@ class LtxConfig(Structure):
         ("lora_scale", c_float), ("eps_norm", c_float), ("eps_qk", c_float),
         ("gemm_variant", c_int),
         ("checkpoint", c_int),
+        ("d_valid", c_int),
+        ("head_dim_valid", c_int),
     ]
 
 

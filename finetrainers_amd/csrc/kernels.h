@@ -210,6 +210,7 @@ int ada_prep(const bf16_t* tables, const bf16_t* temb, bf16_t* ada, int L, int B
 int ada_out_prep(const bf16_t* table2, const bf16_t* emb, bf16_t* ada_out, int B, int D, hipStream_t st);
 
 // y = bf(bf(norm(x)) * onep[b]) + shift[b]   (norm = RMS (no affine) or LayerNorm (no affine))
+void rowwise_set_valid_width(int dv);  // zero-padded narrow rows: over how many channels norm_modulate / qknorm_rope take their mean (0 = all; thread-local)
 int norm_modulate_fwd(const bf16_t* x, const bf16_t* shift, const bf16_t* onep, long mod_bstride, bf16_t* y, int rows,
                       int rows_per_batch, int D, float eps, int layernorm, hipStream_t st);
 // dx_out = (dres ? dres : 0) + norm_bwd(x, bf(dy * onep[b]))

@@ -116,6 +116,8 @@ int check_cfg(const ftmi_ltx_config& c) {
     if (c.r < 0 || (c.r % 64) != 0) return set_error(FTMI_ERR_UNSUPPORTED, "ltx: LoRA rank must be 0 or a multiple of 64");
     if ((c.C_in % 64) || (c.C_out % 64) || (c.D_ff % 128) || (c.D_cap % 64))
         return set_error(FTMI_ERR_UNSUPPORTED, "ltx: channel counts must be multiples of 64");
+    if (c.d_valid < 0 || c.d_valid > c.D || c.head_dim_valid < 0 || c.head_dim_valid > 64)
+        return set_error(FTMI_ERR_INVALID, "ltx: d_valid / head_dim_valid describe a model narrower than the layout (0 = full width)");
     return 0;
 }
 
@@ -162,7 +164,7 @@ int lora_gemm(const GemmNtArgs& a, const GemmNtArgs& dn, FuseCtx& fx, hipStream_
 AttnArgs attn_args(const ftmi_ltx_config& c, int Sq, int Sk) {
     AttnArgs a;
     a.B = c.B; a.H = c.H; a.Sq = Sq; a.Sk = Sk;
-    a.scale = 0.125f;
+    a.scale = (c.head_dim_valid > 0 && c.head_dim_valid < 64) ? 1.0f / sqrtf((float)c.head_dim_valid) : 0.125f;  // (a zero-padded narrow head: the scale of its true width)
     return a;
 }
 inline void set3(long& sb, long& sh, long& ss, long rows_per_batch, long ld) {
@@ -317,6 +319,10 @@ static int ltx_block_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w
 int ltx_forward(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, const bf16_t* x_t, const bf16_t* text, const float* key_bias,
                 const float* sigma, bf16_t* pred, void* ws, size_t ws_bytes, hipStream_t st) {
     FTMI_TRY(check_cfg(c));
+    struct ValidWidth {  // (normalisations of a zero-padded narrow model take their mean over d_valid channels; reset when the pass has queued its launches)
+        explicit ValidWidth(int dv) { rowwise_set_valid_width(dv); }
+        ~ValidWidth() { rowwise_set_valid_width(0); }
+    } valid_width_guard(c.d_valid);
     const WsLayout L = make_layout(c);
     if (ws_bytes < L.total) return set_error(FTMI_ERR_INVALID, "ltx_forward: workspace too small");
     const int M = c.B * c.S, Mt = c.B * c.T, D = c.D, r = c.r, V = c.gemm_variant;
@@ -382,6 +388,10 @@ int ltx_backward_range(const ftmi_ltx_config& c, const ftmi_ltx_weights& w, cons
                        float* grad_a, float* grad_b, void* ws, size_t ws_bytes, int l_hi, int l_lo, int accumulate, hipStream_t st) {
     (void)text;
     FTMI_TRY(check_cfg(c));
+    struct ValidWidth {  // (normalisations of a zero-padded narrow model take their mean over d_valid channels; reset when the pass has queued its launches)
+        explicit ValidWidth(int dv) { rowwise_set_valid_width(dv); }
+        ~ValidWidth() { rowwise_set_valid_width(0); }
+    } valid_width_guard(c.d_valid);
     const WsLayout L = make_layout(c);
     if (ws_bytes < L.total) return set_error(FTMI_ERR_INVALID, "ltx_backward: workspace too small");
     if (l_lo < 0 || l_hi > c.L || l_lo >= l_hi) return set_error(FTMI_ERR_INVALID, "ltx_backward: bad block range");

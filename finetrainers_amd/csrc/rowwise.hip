@@ -73,11 +73,19 @@ int ada_out_prep(const bf16_t* table2, const bf16_t* emb, bf16_t* ada_out, int B
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Valid width of a zero-padded row (round 6: the reference's DUMMY model -- 4 heads x 8, tests/models/ltx_video/base_specification.py:47-58 -- runs through these
+// kernels embedded in the 2048-wide layout: every weight zero-padded, so every padded channel carries exact zeros; what a normalisation must still know is how many
+// channels the mean is taken over).  Set by the DiT pass around its launches (one process per GPU, one pass at a time per thread); 0 = the whole row.
+static thread_local int g_valid_width = 0;
+void rowwise_set_valid_width(int dv) { g_valid_width = dv; }
+static inline int valid_width(int D) { return g_valid_width > 0 && g_valid_width < D ? g_valid_width : D; }
+
 template <bool LN>
 __global__ __launch_bounds__(256) void norm_modulate_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ shift,
                                                                 const bf16_t* __restrict__ onep, long mod_bstride,
-                                                                bf16_t* __restrict__ y, int rows, int rows_per_batch, float eps) {
+                                                                bf16_t* __restrict__ y, int rows, int rows_per_batch, float eps, int Dv) {
     constexpr int D = kNch * 512;
+    const float invD = 1.0f / Dv;  // (Dv = D unless the row is a zero-padded narrow one)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void norm_modulate_fwd_kernel(const bf16_t* __
     }
     float mean = 0.f, rstd;
     if (LN) {
-        mean = wave_sum(s1) * (1.0f / D);
+        mean = wave_sum(s1) * invD;
         float v = 0.f;
 #pragma unroll
         for (int it = 0; it < kNch; ++it)
@@ -106,9 +114,11 @@ __global__ __launch_bounds__(256) void norm_modulate_fwd_kernel(const bf16_t* __
                 float c = xv[it][e] - mean;
                 v += c * c;
             }
-        rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
+        v = wave_sum(v);
+        if (Dv < D) v -= (float)(D - Dv) * mean * mean;  // the padded zeros are not part of the row
+        rstd = rsqrtf(v * invD + eps);
     } else {
-        rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+        rstd = rsqrtf(wave_sum(s2) * invD + eps);
     }
     const bf16_t* sp = shift + (long)b * mod_bstride;
     const bf16_t* op = onep + (long)b * mod_bstride;
@@ -123,6 +133,7 @@ __global__ __launch_bounds__(256) void norm_modulate_fwd_kernel(const bf16_t* __
         for (int e = 0; e < 8; ++e) {
             float n = rbf((xv[it][e] - mean) * rstd);
             o[e] = rbf(n * ov[e]) + sv[e];
+            if (LN && off + e >= Dv) o[e] = 0.f;
         }
         *reinterpret_cast<s16x8*>(yp + off) = pack8(o);
     }
@@ -132,9 +143,9 @@ int norm_modulate_fwd(const bf16_t* x, const bf16_t* shift, const bf16_t* onep, 
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "norm_modulate: row width must be 2048");
     dim3 grid((rows + 3) / 4);
     if (layernorm)
-        hipLaunchKernelGGL(norm_modulate_fwd_kernel<true>, grid, dim3(256), 0, st, x, shift, onep, mod_bstride, y, rows, rows_per_batch, eps);
+        hipLaunchKernelGGL(norm_modulate_fwd_kernel<true>, grid, dim3(256), 0, st, x, shift, onep, mod_bstride, y, rows, rows_per_batch, eps, valid_width(D));
     else
-        hipLaunchKernelGGL(norm_modulate_fwd_kernel<false>, grid, dim3(256), 0, st, x, shift, onep, mod_bstride, y, rows, rows_per_batch, eps);
+        hipLaunchKernelGGL(norm_modulate_fwd_kernel<false>, grid, dim3(256), 0, st, x, shift, onep, mod_bstride, y, rows, rows_per_batch, eps, valid_width(D));
     return check_launch("norm_modulate_fwd");
 }
 
@@ -143,8 +154,9 @@ __global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ onep, long mod_bstride,
                                                                 const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, int rows,
                                                                 int rows_per_batch, float eps, const bf16_t* __restrict__ gate2, long gate2_bstride,
-                                                                bf16_t* __restrict__ dx2) {
+                                                                bf16_t* __restrict__ dx2, int Dv) {
     constexpr int D = kNch * 512;
+    const float invD = 1.0f / Dv;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __
     }
     float mean = 0.f, rstd;
     if (LN) {
-        mean = wave_sum(s1) * (1.0f / D);
+        mean = wave_sum(s1) * invD;
         float v = 0.f;
 #pragma unroll
         for (int it = 0; it < kNch; ++it)
@@ -179,9 +191,11 @@ __global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __
                 float c = xv[it][e] - mean;
                 v += c * c;
             }
-        rstd = rsqrtf(wave_sum(v) * (1.0f / D) + eps);
+        v = wave_sum(v);
+        if (Dv < D) v -= (float)(D - Dv) * mean * mean;
+        rstd = rsqrtf(v * invD + eps);
     } else {
-        rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+        rstd = rsqrtf(wave_sum(s2) * invD + eps);
     }
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -192,8 +206,10 @@ __global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __
             c1 += gv[it][e];
             c2 += gv[it][e] * xh;
         }
-    c1 = LN ? wave_sum(c1) * (1.0f / D) : 0.f;
-    c2 = wave_sum(c2) * (1.0f / D);
+    // (padded channels: their upstream gradient is an exact zero -- zero weight columns -- so they add nothing to c1 / c2; what LayerNorm's mean would hand back to them
+    //  is masked below: a padded channel does not exist)
+    c1 = LN ? wave_sum(c1) * invD : 0.f;
+    c2 = wave_sum(c2) * invD;
     bf16_t* dxp = dx + (long)row * D;
 #pragma unroll
     for (int it = 0; it < kNch; ++it) {
@@ -205,6 +221,7 @@ __global__ __launch_bounds__(256) void norm_modulate_bwd_kernel(const bf16_t* __
             float xh = (xv[it][e] - mean) * rstd;
             float d = rstd * (gv[it][e] - c1 - xh * c2);
             o[e] = dres ? rv[e] + rbf(d) : d;
+            if (LN && off + e >= Dv) o[e] = 0.f;
         }
         *reinterpret_cast<s16x8*>(dxp + off) = pack8(o);
         if (dx2) {  // the consumer's first op, bf(dx * gate[b]) (a gate multiply), done here while dx is in registers: one pass and one launch less
@@ -222,9 +239,9 @@ int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, lon
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "norm_modulate: row width must be 2048");
     dim3 grid((rows + 3) / 4);
     if (layernorm)
-        hipLaunchKernelGGL(norm_modulate_bwd_kernel<true>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps, gate2, gate2_bstride, dx2);
+        hipLaunchKernelGGL(norm_modulate_bwd_kernel<true>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps, gate2, gate2_bstride, dx2, valid_width(D));
     else
-        hipLaunchKernelGGL(norm_modulate_bwd_kernel<false>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps, gate2, gate2_bstride, dx2);
+        hipLaunchKernelGGL(norm_modulate_bwd_kernel<false>, grid, dim3(256), 0, st, x, dy, onep, mod_bstride, dres, dx, rows, rows_per_batch, eps, gate2, gate2_bstride, dx2, valid_width(D));
     return check_launch("norm_modulate_bwd");
 }
 
@@ -232,7 +249,7 @@ int norm_modulate_bwd(const bf16_t* x, const bf16_t* dy, const bf16_t* onep, lon
 __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                               bf16_t* __restrict__ y, long ldy, int rows, int rows_per_batch, float eps, int w_rows,
-                                                              const bf16_t* __restrict__ x2, const bf16_t* __restrict__ w2, bf16_t* __restrict__ y2) {
+                                                              const bf16_t* __restrict__ x2, const bf16_t* __restrict__ w2, bf16_t* __restrict__ y2, int Dv) {
     constexpr int D = kNch * 512;
     if (blockIdx.y == 1) {  // pair launch (q and k of one projection): same strides and RoPE rows, second tensor set
         x = x2; w = w2; y = y2;
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const bf16_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) s2 += xv[it][e] * xv[it][e];
     }
-    const float rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+    const float rstd = rsqrtf(wave_sum(s2) * (1.0f / Dv) + eps);
     bf16_t* yp = y + (long)row * ldy;
 #pragma unroll
     for (int it = 0; it < kNch; ++it) {
@@ -280,7 +297,7 @@ int qknorm_rope_fwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
     if ((ldx % 8) || (ldy % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
     hipLaunchKernelGGL(qknorm_rope_fwd_kernel, dim3((rows + 3) / 4, x2 ? 2 : 1), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, y, ldy, rows, rows_per_batch, eps, w_rows,
-                       x2, w2, y2);
+                       x2, w2, y2, valid_width(D));
     return check_launch("qknorm_rope_fwd");
 }
 
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ dy, long lddy, bf16_t* __restrict__ dx, long lddx,
                                                               int rows, int rows_per_batch, float eps, int w_rows, const bf16_t* __restrict__ x2,
                                                               const bf16_t* __restrict__ w2, const bf16_t* __restrict__ dy2, bf16_t* __restrict__ dx2,
-                                                              int row_grp, int row_grp_span) {
+                                                              int row_grp, int row_grp_span, int Dv) {
     constexpr int D = kNch * 512;
     if (blockIdx.y == 1) {
         x = x2; w = w2; dy = dy2; dx = dx2;
@@ -332,13 +349,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const bf16_t* __re
             s2 += xv[it][e] * xv[it][e];
         }
     }
-    const float rstd = rsqrtf(wave_sum(s2) * (1.0f / D) + eps);
+    const float rstd = rsqrtf(wave_sum(s2) * (1.0f / Dv) + eps);
     float c2 = 0.f;
 #pragma unroll
     for (int it = 0; it < kNch; ++it)
 #pragma unroll
         for (int e = 0; e < 8; ++e) c2 += gv[it][e] * (xv[it][e] * rstd);
-    c2 = wave_sum(c2) * (1.0f / D);
+    c2 = wave_sum(c2) * (1.0f / Dv);
     bf16_t* dxp = dx + mrow * lddx;
 #pragma unroll
     for (int it = 0; it < kNch; ++it) {
@@ -354,7 +371,7 @@ int qknorm_rope_bwd(const bf16_t* x, long ldx, const bf16_t* w, const float* cos
     if (D != kNch * 512) return set_error(FTMI_ERR_UNSUPPORTED, "qknorm_rope: row width must be 2048");
     if ((ldx % 8) || (lddy % 8) || (lddx % 8)) return set_error(FTMI_ERR_INVALID, "qknorm_rope: row strides must keep 16-byte alignment");
     hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((rows + 3) / 4, x2 ? 2 : 1), dim3(256), 0, st, x, ldx, w, cos_t, sin_t, dy, lddy, dx, lddx, rows, rows_per_batch, eps, w_rows,
-                       x2, w2, dy2, dx2, row_grp, row_grp_span);
+                       x2, w2, dy2, dx2, row_grp, row_grp_span, valid_width(D));
     return check_launch("qknorm_rope_bwd");
 }
 

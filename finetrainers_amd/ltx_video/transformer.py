@@ -543,7 +543,9 @@ class MI355XLTXVideoTransformer3DModel(nn.Module):
         return LtxConfig(B=B, S=S, T=T, D=c.inner_dim, H=c.num_attention_heads, L=c.num_layers, C_in=c.in_channels, C_out=c.out_channels,
                          D_ff=c.inner_dim * c.ff_mult, D_cap=c.caption_channels, r=self.lora_rank_padded,
                          lora_scale=(self.lora_alpha / self.lora_rank) if self.lora_rank else 0.0, eps_norm=c.norm_eps, eps_qk=c.qk_norm_eps,
-                         gemm_variant=self.gemm_variant, checkpoint=int(bool(checkpoint)))
+                         gemm_variant=self.gemm_variant, checkpoint=int(bool(checkpoint)),
+                         # (a narrow model embedded by zero padding -- ltx_video/narrow.py -- tells the kernels its true width and head width; 0 = this geometry)
+                         d_valid=getattr(self, "_narrow", (0, 0))[0], head_dim_valid=getattr(self, "_narrow", (0, 0))[1])
 
     def _c_weights(self, cos: torch.Tensor, sin: torch.Tensor) -> LtxWeights:
         w = LtxWeights()

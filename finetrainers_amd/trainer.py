@@ -143,7 +143,7 @@ class MI355XSFTStep:
         # that gradient directly (what loss.backward() would hand it, without the unit-seed multiply)
         per_sample_sigma = sig.reshape(B, -1)[:, 0].float()
         weights = diffusion_utils.compute_loss_weighting_for_sd3(self.scheme, per_sample_sigma).float().contiguous()
-        loss, dpred = ops.mse_loss(pred.detach(), target, weights, want_grad=True, grad_scale=1.0 / gas)
+        loss, dpred = ops.mse_loss(pred.detach().contiguous(), target.contiguous(), weights, want_grad=True, grad_scale=1.0 / gas)
         loss = loss.reshape(()) / gas if gas > 1 else loss.reshape(())
         exchange = self.reducer is not None and (sync or not self.no_sync_accumulation)
         prev_hook, prev_fin = tr._grad_bucket_hook, tr._grad_bucket_finish

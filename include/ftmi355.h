@@ -216,6 +216,12 @@ typedef struct {
      * the residual stream, and the backward runs every block's forward kernels again right before its gradient kernels.  Gradients are bit-identical to
      * checkpoint = 0 (deterministic kernels).  Forward and backward of one step must use the same value. */
     int checkpoint;
+    /* A NARROW model embedded in this layout by zero padding (round 6: the reference's dummy fixture, tests/models/ltx_video/base_specification.py:47-58 -- 4 heads x 8,
+     * one block -- through the production kernels): every weight / bias / table zero-padded to D = 2048 (head h of the narrow model occupies channels [64 h, 64 h + hd)),
+     * channel counts and the LoRA rank padded to multiples of 64 (finetrainers_amd/ltx_video/padded.py builds the image).  Padded channels then carry exact zeros
+     * everywhere; what the kernels must be told is over how many channels a normalisation takes its mean (d_valid) and the true head width for the softmax scale
+     * 1 / sqrt(head_dim_valid).  0 = the full width (2048 / 64). */
+    int d_valid, head_dim_valid;
 } ftmi_ltx_config;
 
 /* All weights bf16 unless noted.  Per-block tensors are stacked along a leading L dimension.  "*_t" are

@@ -1405,3 +1405,42 @@ def test_no_accumulator_is_read_before_the_matrix_pipe_has_written_it():
     for o in objs:
         early = [x for x in lint.lint(lint.disassemble(o)) if any(k in x[0] for k in lint.ASM_KERNELS)]
         assert not early, f"{o}: {len(early)} early accumulator reads, first: {early[0]}"
+
+
+def test_narrow_ltx_layout_embeds_the_reference_dummy_in_the_wide_one():
+    """finetrainers_amd/ltx_video/narrow.py, host logic: every parameter of the reference's dummy transformer (tests/models/ltx_video/base_specification.py:47-58; the
+    oracle builds the same module tree) has a layout rule, widening is zero padding (same sum of magnitudes, narrow entries recovered exactly), heads land on 64-channel
+    strides, RoPE pairs follow their channels, and geometries the embedding cannot hold are refused."""
+    from finetrainers_amd.ltx_video import LTXTransformerConfig, NarrowLayout
+    from finetrainers_amd.ltx_video.narrow import is_native
+    from oracle import ltx
+
+    cfg = ltx.LTXConfig.dummy()
+    tcfg = LTXTransformerConfig(in_channels=8, out_channels=8, num_attention_heads=4, attention_head_dim=8, cross_attention_dim=32, num_layers=1, caption_channels=32)
+    assert not is_native(tcfg) and is_native(LTXTransformerConfig())
+    lay = NarrowLayout(tcfg)
+    assert (lay.wide.inner_dim, lay.wide.in_channels, lay.wide.caption_channels) == (2048, 64, 64)
+    assert lay.idx_h.tolist()[:10] == [0, 1, 2, 3, 4, 5, 6, 7, 64, 65] and lay.idx_pair.tolist()[:5] == [0, 1, 2, 3, 32]
+    model = ltx.build_model(cfg, seed=0, rank=4, alpha=4.0)
+    n = 0
+    for k, v in model.state_dict().items():
+        if "lora_" in k:
+            continue
+        sp = lay.spaces_of(k)
+        w = lay.widen(v, *sp)
+        assert torch.equal(lay.narrow(w, *sp), v) and w.float().abs().sum() == v.float().abs().sum(), k
+        n += 1
+    assert n == 15 + 25  # 15 top-level tensors, 25 of the block
+    w = lay.widen(model.state_dict()["transformer_blocks.0.attn1.to_q.base_layer.weight"], "h", "d")
+    assert w.shape == (2048, 2048) and w[8:64].abs().sum() == 0 and w[:, 32:].abs().sum() == 0 and w[64:72, :32].abs().sum() > 0
+    cos, sin = torch.rand(5, 16), torch.rand(5, 16)
+    wc, ws = lay.rope_wide(cos, sin)
+    assert wc.shape == (5, 1024) and torch.equal(wc[:, lay.idx_pair], cos) and torch.equal(ws[:, lay.idx_pair], sin)
+    rest = torch.ones(1024, dtype=torch.bool)
+    rest[lay.idx_pair] = False
+    assert bool((wc[:, rest] == 1).all()) and bool((ws[:, rest] == 0).all())  # the identity rotation on every padded pair
+    assert lay.lora_spaces(3) == ("h", "d") and lay.lora_spaces(0) == ("d", "h") and lay.lora_spaces(5) == ("d", "h")
+    for bad in (dict(num_attention_heads=4, attention_head_dim=7, cross_attention_dim=28), dict(num_attention_heads=40, attention_head_dim=8, cross_attention_dim=320),
+                dict(num_attention_heads=4, attention_head_dim=10, cross_attention_dim=40)):
+        with pytest.raises(ValueError):
+            NarrowLayout(LTXTransformerConfig(in_channels=8, out_channels=8, num_layers=1, caption_channels=32, **bad))
