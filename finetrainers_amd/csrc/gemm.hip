@@ -1736,11 +1736,23 @@ static int launch_nt16(const GemmNtArgs& a, hipStream_t st) {
 #else
     static_assert(DBG == 0, "ablation builds exist in tools/gemm_lab.hip only");
     const bool ext = a.K2 > 0;
-    switch (a.epi) {
-        case EPI_STORE: return ext ? launch_nt16_3<TMW, EPI_STORE, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_STORE, false, 0, RING, RS>(a, st);
-        case EPI_GELU: return ext ? launch_nt16_3<TMW, EPI_GELU, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_GELU, false, 0, RING, RS>(a, st);
-        case EPI_RESID: return ext ? launch_nt16_3<TMW, EPI_RESID, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_RESID, false, 0, RING, RS>(a, st);
-        default: return ext ? launch_nt16_3<TMW, EPI_DGELU, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_DGELU, false, 0, RING, RS>(a, st);
+    // (224-row tiles with the register-staged prefetch AND a K-extension do not fit 256 architectural registers: hipcc would spill load destinations that are still
+    //  in flight -- tools/inflight_reg_lint.py flags exactly that in such a build -- so the combination is not even instantiated: the direct-to-LDS loop takes it)
+    if constexpr (TMW == 7 && RS == 2) {
+        if (ext) return launch_nt16<7, DBG, RING, 0>(a, st);
+        switch (a.epi) {
+            case EPI_STORE: return launch_nt16_3<TMW, EPI_STORE, false, 0, RING, RS>(a, st);
+            case EPI_GELU: return launch_nt16_3<TMW, EPI_GELU, false, 0, RING, RS>(a, st);
+            case EPI_RESID: return launch_nt16_3<TMW, EPI_RESID, false, 0, RING, RS>(a, st);
+            default: return launch_nt16_3<TMW, EPI_DGELU, false, 0, RING, RS>(a, st);
+        }
+    } else {
+        switch (a.epi) {
+            case EPI_STORE: return ext ? launch_nt16_3<TMW, EPI_STORE, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_STORE, false, 0, RING, RS>(a, st);
+            case EPI_GELU: return ext ? launch_nt16_3<TMW, EPI_GELU, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_GELU, false, 0, RING, RS>(a, st);
+            case EPI_RESID: return ext ? launch_nt16_3<TMW, EPI_RESID, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_RESID, false, 0, RING, RS>(a, st);
+            default: return ext ? launch_nt16_3<TMW, EPI_DGELU, true, 0, RING, RS>(a, st) : launch_nt16_3<TMW, EPI_DGELU, false, 0, RING, RS>(a, st);
+        }
     }
 #endif
 }

@@ -1444,3 +1444,31 @@ def test_narrow_ltx_layout_embeds_the_reference_dummy_in_the_wide_one():
                 dict(num_attention_heads=4, attention_head_dim=10, cross_attention_dim=40)):
         with pytest.raises(ValueError):
             NarrowLayout(LTXTransformerConfig(in_channels=8, out_channels=8, num_layers=1, caption_channels=32, **bad))
+
+
+def test_no_register_is_reused_while_its_load_is_in_flight():
+    """tools/inflight_reg_lint.py: the second hazard class of asm-load kernels that round 6 met (a dead fragment read handed its register to a load's address while
+    the LDS read was still in flight: memory fault).  The replay of the in-order wait counters must (a) flag that pattern in a hand-written listing and accept it once
+    the wait is there, (b) find nothing in the built GEMM and attention code objects -- which also proves that no instantiation that spills in-flight load destinations
+    (224-row register-staged tiles with a K-extension) is in the library at all."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("inflight_reg_lint", os.path.join(ROOT, "tools", "inflight_reg_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    bad = ("0000 <k1>:\n\tds_read_b128 v[2:5], v210 offset:2048\n\tv_mfma_f32_16x16x32_bf16 a[0:3], v[38:41], v[6:9], a[0:3]\n"
+           "\tv_cndmask_b32_e32 v2, v104, v102, vcc\n\tbuffer_load_dwordx4 v2, s[0:3], s4 offen lds\n\ts_waitcnt lgkmcnt(0)\n")
+    found = lint.lint(bad)
+    assert found and found[0][2] == "writes" and found[0][3] == "v2"
+    assert lint.lint(bad.replace("\tv_cndmask", "\ts_waitcnt lgkmcnt(0)\n\tv_cndmask")) == []
+    counted = ("0000 <k2>:\n\tbuffer_load_dwordx4 a[0:3], v0, s[8:11], s20 offen\n\tbuffer_load_dwordx4 v[8:11], v1, s[8:11], s20 offen\n\ts_waitcnt vmcnt(1)\n"
+               "\tds_write_b128 v20, a[0:3]\n\tds_write_b128 v20, v[8:11]\n")
+    found = lint.lint(counted)  # vmcnt(1) retires the older load only: the first store is fine, the second reads a destination still in flight
+    assert len(found) == 1 and "v[8:11]" in found[0][1]
+    build = os.path.join(ROOT, "finetrainers_amd", "csrc", "build")
+    objs = [os.path.join(build, f) for f in ("gemm.hip.o", "attention.hip.o")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("no object files: run __graft_entry__.build() first")
+    for o in objs:
+        pr = lint.lint(lint.disassemble(o))
+        assert not pr, f"{o}: {len(pr)} uses of a register whose load is in flight, first: {pr[0]}"
