@@ -281,6 +281,37 @@ class MI355XNarrowLTXVideoTransformer3DModel(nn.Module):
                 self.inner.lora_B[l, i].copy_(lay.widen(sd[f"{p}.lora_B.weight"].float().cpu(), b_sp, "-"))
         self.inner._lora_versions = None
 
+    # ---- the reference's save / resume paths (trainer.py:279-306, parallel/ptd.py:313-321) read and write state dicts: NARROW shapes, the production class's keys ----
+    def state_dict(self, *args, destination=None, prefix: str = "", keep_vars: bool = False, **kwargs) -> Dict[str, torch.Tensor]:
+        lay = self.layout
+        out = destination if destination is not None else {}
+        for k, v in self.inner._base_views().items():
+            out[prefix + k] = lay.narrow(v.detach(), *lay.spaces_of(k))
+        if self.inner.lora_A is not None:
+            for k, v in self.lora_state_dict(adapter_name="default").items():
+                out[prefix + k] = v.detach()
+        return out
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True, assign: bool = False):
+        if assign:
+            raise ValueError("load_state_dict(assign=True) is not supported: the parameters are views of one flat buffer of the wide layout")
+        sd = {k.replace(".base_layer.", "."): v for k, v in state_dict.items()}
+        base = {k: v for k, v in sd.items() if "lora_" not in k}
+        lora = {k: v for k, v in sd.items() if "lora_" in k}
+        missing = []
+        if base:
+            want = {k.replace(".base_layer.", ".") for k in self.inner._base_views()}
+            missing = sorted(want - set(base))
+            if strict and (missing or set(base) - want):
+                raise RuntimeError(f"load_state_dict: missing {missing[:5]}, unexpected {sorted(set(base) - want)[:5]}")
+            if not missing:
+                self.load_diffusers_state_dict(base)
+        if lora:
+            if self.inner.lora_A is None:
+                raise RuntimeError("load_state_dict: LoRA tensors given but no adapter attached (call add_adapter first)")
+            self.load_lora_state_dict(lora)
+        return nn.modules.module._IncompatibleKeys(missing, [])
+
     def enable_gradient_checkpointing(self) -> None:
         self.inner.enable_gradient_checkpointing()
 

@@ -656,6 +656,14 @@ def test_reference_dummy_model_runs_on_the_production_kernels():
     assert torch.equal(target.cpu(), target_ref)
     assert pred_err < 2e-2 and loss_rel < 2e-3
     assert glob < 3e-2 and worst < 6e-2
+    # state dict in the reference's (narrow) shapes and names, both ways: what the save / resume paths read and write
+    osd = omodel.state_dict()
+    gsd = gmodel.state_dict()
+    assert set(gsd) == set(osd)
+    for k, v in osd.items():
+        assert gsd[k].shape == v.shape and torch.equal(gsd[k].float().cpu(), v.float() if "lora_" in k else v.to(bf16).float()), k
+    gmodel.load_state_dict(gsd)
+    assert all(torch.equal(a.cpu(), gsd[k].cpu()) for k, a in gmodel.state_dict().items())
     # the padding stays padding: gradients of every padded LoRA entry are exact zeros, activations of padded channels too
     lay = gmodel.layout
     ga, gb = gmodel.inner.lora_A.grad.clone(), gmodel.inner.lora_B.grad.clone()
